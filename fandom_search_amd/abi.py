@@ -1,0 +1,104 @@
+"""ctypes mirrors of include/fandom_search.h (structs, constants, dtypes)."""
+
+import ctypes as C
+
+import numpy as np
+
+FS_OK = 0
+FS_E_INVALID = -1
+FS_E_NOMEM = -2
+FS_E_DEVICE = -3
+FS_E_CAPACITY = -4
+FS_E_UNSUPPORTED = -5
+FS_E_UNPROVEN = -6
+
+FS_MODE_AUTO = 0
+FS_MODE_GENERAL = 1
+FS_MODE_EXACT = 2
+
+FS_OOV_FLAG = 0x80000000
+
+
+class FsConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32),
+                ("window_size", C.c_uint32),
+                ("number_of_hashes", C.c_uint32),
+                ("hash_dimensions", C.c_uint32),
+                ("emb_dim", C.c_uint32),
+                ("nearest_n", C.c_uint32),
+                ("unique_filter", C.c_uint32),
+                ("mode", C.c_uint32),
+                ("device", C.c_int32),
+                ("reserved", C.c_uint32),
+                ("distance_threshold", C.c_double)]
+
+
+class FsStats(C.Structure):
+    _fields_ = [("windows_processed", C.c_uint64),
+                ("candidates", C.c_uint64),
+                ("matches", C.c_uint64),
+                ("rows", C.c_uint64),
+                ("scan_ms", C.c_double),
+                ("total_ms", C.c_double),
+                ("path", C.c_uint32),
+                ("scan_launches", C.c_uint32)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class FsIndexInfo(C.Structure):
+    _fields_ = [("path", C.c_uint32),
+                ("proof_ok", C.c_uint32),
+                ("c_max", C.c_double),
+                ("cos_bound", C.c_double),
+                ("norm_min", C.c_double),
+                ("norm_max", C.c_double),
+                ("n_script", C.c_uint64),
+                ("n_windows", C.c_uint64),
+                ("n_grams", C.c_uint64),
+                ("filter_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+# fs_row: 32 bytes
+ROW_DTYPE = np.dtype([("work", np.uint32), ("fan_ix", np.uint32),
+                      ("orig_ix", np.uint32), ("lev", np.uint32),
+                      ("dist", np.float64), ("comb", np.float64)])
+assert ROW_DTYPE.itemsize == 32
+
+
+def make_config(window_size=6, number_of_hashes=15, hash_dimensions=14,
+                distance_threshold=0.1, emb_dim=300, nearest_n=10,
+                unique_filter=True, mode=FS_MODE_AUTO, device=0):
+    """Defaults are the keyword defaults of the reference's analyze()
+    (/root/reference/search.py:336-341) and NearPy's Engine defaults."""
+    cfg = FsConfig()
+    cfg.struct_size = C.sizeof(FsConfig)
+    cfg.window_size = window_size
+    cfg.number_of_hashes = number_of_hashes
+    cfg.hash_dimensions = hash_dimensions
+    cfg.emb_dim = emb_dim
+    cfg.nearest_n = nearest_n
+    cfg.unique_filter = 1 if unique_filter else 0
+    cfg.mode = mode
+    cfg.device = device
+    cfg.distance_threshold = distance_threshold
+    return cfg
+
+
+def ptr(arr, ctype):
+    """Typed pointer to a C-contiguous numpy array (None -> NULL)."""
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def as_u32(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def as_u64(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)

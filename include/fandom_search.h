@@ -1,0 +1,173 @@
+/* fandom_search.h -- C ABI of the MI355X 6-gram text-reuse search library
+ * (libfandomsearch_hip.so).
+ *
+ * The reference (senderle/fandom-search) is pure Python and has no FFI; its
+ * seams for this path are Python call sites.  Each entry point below names the
+ * reference interface it stands behind (file:line in the reference tree):
+ *
+ *   fs_index_create      AnnIndexSearch.__init__ + build_lsh_engine
+ *                        (search.py:131-154, 86-124): script tokens -> LSH index
+ *   fs_corpus_create     the per-work read + tokenise + mk_vectors step of
+ *                        AnnIndexSearch.search (search.py:164-173), batched:
+ *                        packed vector-id / string-id buffers for many works
+ *   fs_search_corpus     AnnIndexSearch.search (search.py:163-226) over every
+ *                        work of a corpus, i.e. one pool.map batch
+ *                        (search.py:381-386) in a single call
+ *   fs_search            convenience: fs_corpus_create + fs_search_corpus +
+ *                        fs_corpus_destroy on host buffers
+ *   fs_stats             AnnIndexSearch.windows_processed / reset_stats
+ *                        (search.py:156-161) plus kernel timings
+ *
+ * Conventions: every function returns FS_OK (0) or a negative FS_E_* code and
+ * never throws across the boundary; the caller owns every buffer it passes,
+ * the library owns only the opaque handles; a handle is bound to one device
+ * and is not thread-safe (use one handle per device / per rank).  Rows come
+ * back sorted by (work, fan_ix) -- the order of `sorted(values)` at
+ * search.py:226 followed by the in-order concatenation of search.py:386.
+ *
+ * Data model
+ *   vector id   uint32.  id < n_vec: row of the embedding matrix `emb`.
+ *               id & FS_OOV_FLAG: out-of-vocabulary 3-hot vector of
+ *               search.py:79-83, low 31 bits = (a*D + b)*D + c, a <= b <= c.
+ *               Two tokens have equal vector ids iff they have equal vectors.
+ *   string      UTF-32 code points in a string table: chars[off[i]..off[i+1])
+ *   work        tokens [work_off[w], work_off[w+1]) of the packed buffers
+ */
+#ifndef FANDOM_SEARCH_H
+#define FANDOM_SEARCH_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS_ABI_VERSION 1
+#define FS_OOV_FLAG 0x80000000u
+
+enum {
+  FS_OK = 0,
+  FS_E_INVALID = -1,      /* bad argument / inconsistent sizes                */
+  FS_E_NOMEM = -2,        /* host or device allocation failed                 */
+  FS_E_DEVICE = -3,       /* HIP runtime error (fs_last_error has the text)   */
+  FS_E_CAPACITY = -4,     /* rows buffer too small; *n_rows = rows required   */
+  FS_E_UNSUPPORTED = -5,  /* parameter outside what the kernels are built for */
+  FS_E_UNPROVEN = -6      /* mode FS_MODE_EXACT but the prefilter proof fails */
+};
+
+/* which device pipeline produced (or will produce) the rows */
+enum {
+  FS_MODE_AUTO = 0,     /* exact n-gram scan when the index proves it sound,
+                           otherwise the general LSH pipeline                 */
+  FS_MODE_GENERAL = 1,  /* always the LSH pipeline (A6/A12 of SURVEY 8(a))    */
+  FS_MODE_EXACT = 2     /* exact scan or FS_E_UNPROVEN                        */
+};
+
+typedef struct fs_config {
+  uint32_t struct_size;        /* sizeof(fs_config), for ABI growth           */
+  uint32_t window_size;        /* n            search.py:337  default 6       */
+  uint32_t number_of_hashes;   /* H            search.py:338  default 15      */
+  uint32_t hash_dimensions;    /* B <= 24      search.py:339  default 14      */
+  uint32_t emb_dim;            /* D            300 for en_core_web_md         */
+  uint32_t nearest_n;          /* NearPy NearestFilter(N) default 10          */
+  uint32_t unique_filter;      /* NearPy UniqueFilter on fetch, default 1     */
+  uint32_t mode;               /* FS_MODE_*                                   */
+  int32_t  device;             /* HIP device ordinal                          */
+  uint32_t reserved;
+  double   distance_threshold; /*              search.py:340  default 0.1     */
+} fs_config;
+
+/* One output record = the numeric half of a row of new_record_structure
+ * (search.py:20-37); the host joins file name, words, orth ids, character and
+ * scene by (work, fan_ix, orig_ix). */
+typedef struct fs_row {
+  uint32_t work;     /* index into work_off                                   */
+  uint32_t fan_ix;   /* FAN_WORK_WORD_INDEX                                   */
+  uint32_t orig_ix;  /* ORIGINAL_SCRIPT_WORD_INDEX                            */
+  uint32_t lev;      /* BEST_LEVENSHTEIN_DISTANCE                             */
+  double   dist;     /* BEST_MATCH_DISTANCE                                   */
+  double   comb;     /* BEST_COMBINED_DISTANCE = dist * lev                   */
+} fs_row;            /* 32 bytes                                              */
+
+typedef struct fs_stats {
+  uint64_t windows_processed;  /* search.py:177 counter, summed over works     */
+  uint64_t candidates;         /* scan: filter positives; LSH: bucket entries */
+  uint64_t matches;            /* (window, script window) pairs kept          */
+  uint64_t rows;               /* records after per-word dedupe               */
+  double   scan_ms;            /* dominant kernel, HIP-event time, last call  */
+  double   total_ms;           /* all device work of the call, HIP events     */
+  uint32_t path;               /* FS_MODE_GENERAL or FS_MODE_EXACT            */
+  uint32_t scan_launches;      /* launches of the dominant kernel in the call */
+} fs_stats;
+
+typedef struct fs_index_info {
+  uint32_t path;            /* pipeline fs_search_corpus will run             */
+  uint32_t proof_ok;        /* exact-n-gram prefilter proven sound            */
+  double   c_max;           /* max cosine between distinct vectors            */
+  double   cos_bound;       /* upper bound on cos(F,S) with >= 1 mismatch     */
+  double   norm_min, norm_max;
+  uint64_t n_script;        /* script tokens                                  */
+  uint64_t n_windows;       /* script windows                                 */
+  uint64_t n_grams;         /* distinct script n-grams (by vector id)         */
+  uint64_t filter_bytes;    /* size of the LDS-resident n-gram filter         */
+} fs_index_info;
+
+typedef struct fs_index fs_index;
+typedef struct fs_corpus fs_corpus;
+
+int fs_version(void);
+const char* fs_strerror(int code);
+/* text of the last FS_E_DEVICE / FS_E_INVALID on this thread */
+const char* fs_last_error(void);
+
+/* Build the script index on cfg->device.
+ *   script_vec[n_script]        vector id of each (lower-cased) script word
+ *   script_chars/script_off     text of each script word: word i is
+ *                               script_chars[script_off[i]..script_off[i+1])
+ *   emb[n_vec][D] float32       vector table (spaCy vectors.data)
+ *   normals[H][B][D*n] float64  LSH hyperplanes (NearPy draws them unseeded,
+ *                               search.py:114-115; here they are an input)   */
+int fs_index_create(const fs_config* cfg,
+                    const uint32_t* script_vec,
+                    const uint32_t* script_chars, const uint64_t* script_off,
+                    uint64_t n_script,
+                    const float* emb, uint64_t n_vec,
+                    const double* normals,
+                    fs_index** out);
+int fs_index_info_get(const fs_index* ix, fs_index_info* info);
+void fs_index_destroy(fs_index* ix);
+
+/* Upload a batch of works (host buffers) to the index's device.
+ *   tok_vec[n_tok]   vector id per fan token (what the kernels scan)
+ *   tok_str[n_tok]   string id per fan token, or NULL when string id ==
+ *                    vector id (synthetic corpora)
+ *   str_chars/str_off/n_str   string table of the fan side
+ *   work_off[n_works+1]       token offsets, work_off[0] == 0               */
+int fs_corpus_create(fs_index* ix,
+                     const uint32_t* tok_vec, const uint32_t* tok_str,
+                     const uint64_t* work_off, uint64_t n_works,
+                     const uint32_t* str_chars, const uint64_t* str_off,
+                     uint64_t n_str,
+                     fs_corpus** out);
+void fs_corpus_destroy(fs_corpus* c);
+
+/* Search every work of `c`.  `rows` is a host buffer of `cap` records, or,
+ * when rows_on_device != 0, a device pointer on the index's device (for a
+ * collective gather without a host round trip).  On FS_E_CAPACITY *n_rows is
+ * the number required.  `st` may be NULL. */
+int fs_search_corpus(fs_index* ix, fs_corpus* c,
+                     fs_row* rows, uint64_t cap, int rows_on_device,
+                     uint64_t* n_rows, fs_stats* st);
+
+/* fs_corpus_create + fs_search_corpus + fs_corpus_destroy. */
+int fs_search(fs_index* ix,
+              const uint32_t* tok_vec, const uint32_t* tok_str,
+              const uint64_t* work_off, uint64_t n_works,
+              const uint32_t* str_chars, const uint64_t* str_off,
+              uint64_t n_str,
+              fs_row* rows, uint64_t cap, uint64_t* n_rows, fs_stats* st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FANDOM_SEARCH_H */
