@@ -1,0 +1,97 @@
+"""Loader of libfandomsearch_hip.so (the C ABI of include/fandom_search.h).
+
+There is no CPU fallback: if the library is missing or cannot be loaded the
+import of anything that needs it fails with a clear error.
+"""
+
+import ctypes as C
+import os
+import subprocess
+
+from . import abi
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libfandomsearch_hip.so"
+_LIB = None
+
+SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
+           "fs_index_info_get", "fs_index_destroy", "fs_corpus_create",
+           "fs_corpus_destroy", "fs_search_corpus", "fs_search")
+
+
+class FsError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = "%s failed: %d" % (where, code)
+        if detail:
+            msg += " (%s)" % detail
+        RuntimeError.__init__(self, msg)
+
+
+def lib_path():
+    return os.path.join(_PKG, LIB_NAME)
+
+
+def build(verbose=False):
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles
+    without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_PKG, "csrc")]
+    if not verbose:
+        cmd.insert(1, "-s")
+    subprocess.check_call(cmd)
+    return lib_path()
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is not built; run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C fandom_search_amd/csrc`. There is no CPU "
+            "fallback for the search path." % path)
+    L = C.CDLL(path)
+    u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+    L.fs_version.restype = C.c_int
+    L.fs_strerror.restype = C.c_char_p
+    L.fs_strerror.argtypes = [C.c_int]
+    L.fs_last_error.restype = C.c_char_p
+    L.fs_index_create.restype = C.c_int
+    L.fs_index_create.argtypes = [
+        C.POINTER(abi.FsConfig), u32p, u32p, u64p, C.c_uint64,
+        C.POINTER(C.c_float), C.c_uint64, C.POINTER(C.c_double),
+        C.POINTER(C.c_void_p)]
+    L.fs_index_info_get.restype = C.c_int
+    L.fs_index_info_get.argtypes = [C.c_void_p, C.POINTER(abi.FsIndexInfo)]
+    L.fs_index_destroy.restype = None
+    L.fs_index_destroy.argtypes = [C.c_void_p]
+    L.fs_corpus_create.restype = C.c_int
+    L.fs_corpus_create.argtypes = [
+        C.c_void_p, u32p, u32p, u64p, C.c_uint64, u32p, u64p, C.c_uint64,
+        C.POINTER(C.c_void_p)]
+    L.fs_corpus_destroy.restype = None
+    L.fs_corpus_destroy.argtypes = [C.c_void_p]
+    L.fs_search_corpus.restype = C.c_int
+    L.fs_search_corpus.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, u64p,
+        C.POINTER(abi.FsStats)]
+    L.fs_search.restype = C.c_int
+    L.fs_search.argtypes = [
+        C.c_void_p, u32p, u32p, u64p, C.c_uint64, u32p, u64p, C.c_uint64,
+        C.c_void_p, C.c_uint64, u64p, C.POINTER(abi.FsStats)]
+    if L.fs_version() != 1:
+        raise RuntimeError("ABI version mismatch in %s" % path)
+    _LIB = L
+    return L
+
+
+def check(rc, where):
+    if rc != abi.FS_OK:
+        L = load()
+        detail = L.fs_strerror(rc).decode()
+        last = L.fs_last_error().decode()
+        if last:
+            detail += ": " + last
+        raise FsError(rc, where, detail)

@@ -1,0 +1,483 @@
+// fs_api.hip -- C ABI of libfandomsearch_hip.so (include/fandom_search.h): host
+// side index build and the orchestration of the device pipeline.
+#include "fs_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <numeric>
+
+static thread_local char g_err[512];
+
+void fs_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* fs_last_error(void) { return g_err; }
+extern "C" int fs_version(void) { return FS_ABI_VERSION; }
+
+extern "C" const char* fs_strerror(int code) {
+  switch (code) {
+    case FS_OK: return "ok";
+    case FS_E_INVALID: return "invalid argument";
+    case FS_E_NOMEM: return "out of memory";
+    case FS_E_DEVICE: return "HIP runtime error";
+    case FS_E_CAPACITY: return "row buffer too small";
+    case FS_E_UNSUPPORTED: return "unsupported parameter";
+    case FS_E_UNPROVEN: return "exact n-gram prefilter not proven for this vector table";
+    default: return "unknown error";
+  }
+}
+
+GramIndexDev fs_index::gram_dev() const {
+  GramIndexDev g;
+  g.stok = d_stok.p; g.filter = d_filter.p; g.table = d_table.p; g.gpos = d_gpos.p;
+  g.gcnt = d_gcnt.p; g.selfdist = d_selfdist.p; g.schars = d_schars.p; g.soff = d_soff.p;
+  g.log2_words = log2_words; g.log2_slots = log2_slots;
+  g.n = (int)cfg.window_size; g.nn = (int)cfg.nearest_n; g.n_grams = n_grams;
+  return g;
+}
+
+CorpusDev fs_corpus::dev() const {
+  CorpusDev c;
+  c.tok = d_tok.p; c.str = has_str ? d_str.p : nullptr; c.work_off = d_work_off.p;
+  c.chars = d_chars.p; c.coff = d_coff.p;
+  c.n_tok = (uint32_t)n_tok; c.n_works = (uint32_t)n_works; c.n_str = (uint32_t)n_str;
+  return c;
+}
+
+fs_index::~fs_index() {
+  if (ev_begin) (void)hipEventDestroy(ev_begin);
+  if (ev_scan0) (void)hipEventDestroy(ev_scan0);
+  if (ev_scan1) (void)hipEventDestroy(ev_scan1);
+  if (ev_end) (void)hipEventDestroy(ev_end);
+  if (h_status) (void)hipHostFree(h_status);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+static int ceil_log2(uint64_t x) {
+  int l = 0;
+  while ((1ull << l) < x) ++l;
+  return l;
+}
+
+// Group the script's windows by their n vector ids; per distinct n-gram keep the
+// first `nn` positions in ascending order (what a stable NearestFilter keeps when
+// every candidate has the same distance).  Then build the Bloom filter and the
+// exact open-addressing table the kernels use.
+static int build_gram_index(fs_index* ix, const uint32_t* stok) {
+  const uint32_t n = ix->cfg.window_size, nn = ix->cfg.nearest_n;
+  const uint64_t W = ix->n_windows;
+  std::vector<uint32_t> order(W);
+  std::iota(order.begin(), order.end(), 0u);
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    const int c = memcmp(stok + a, stok + b, n * sizeof(uint32_t));
+    return c != 0 ? c < 0 : a < b;
+  });
+  std::vector<uint32_t> gpos, gcnt;
+  for (uint64_t i = 0; i < W;) {
+    uint64_t j = i;
+    while (j < W && memcmp(stok + order[i], stok + order[j], n * sizeof(uint32_t)) == 0) ++j;
+    const uint32_t cnt = (uint32_t)std::min<uint64_t>(j - i, nn);
+    gcnt.push_back(cnt);
+    for (uint32_t r = 0; r < nn; ++r) gpos.push_back(r < cnt ? order[i + r] : 0u);
+    i = j;
+  }
+  const uint32_t G = (uint32_t)gcnt.size();
+  ix->n_grams = G;
+
+  // filter: about one 32-bit word per n-gram, 4 KiB .. 128 KiB (it lives in LDS)
+  int lw = ceil_log2(std::max<uint64_t>(1, (uint64_t)G * 3 / 4));
+  if (const char* e = getenv("FS_FILTER_LOG2_WORDS")) lw = atoi(e);
+  lw = std::min(15, std::max(10, lw));
+  ix->log2_words = lw;
+  ix->log2_slots = std::max(4, ceil_log2((uint64_t)G * 2 + 1));
+  if (ix->log2_slots > 31) { fs_set_error("script too large"); return FS_E_UNSUPPORTED; }
+  std::vector<uint32_t> filter(1u << lw, 0u), table(1u << ix->log2_slots, 0u);
+  const uint32_t slot_mask = (1u << ix->log2_slots) - 1;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t h = fs_gram_hash(stok + gpos[(size_t)g * nn], (int)n);
+    filter[fs_bloom_word(h, lw)] |= fs_bloom_mask(h);
+    uint32_t slot = fs_table_slot(h, ix->log2_slots);
+    while (table[slot]) slot = (slot + 1) & slot_mask;
+    table[slot] = g + 1;
+  }
+  FS_TRY(ix->d_filter.upload(filter.data(), filter.size(), ix->stream));
+  FS_TRY(ix->d_table.upload(table.data(), table.size(), ix->stream));
+  FS_TRY(ix->d_gpos.upload(gpos.data(), gpos.size(), ix->stream));
+  FS_TRY(ix->d_gcnt.upload(gcnt.data(), gcnt.size(), ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));   // the vectors above die with this scope
+  ix->info.n_grams = G;
+  ix->info.filter_bytes = (uint64_t)4 << lw;
+  return FS_OK;
+}
+
+// Soundness of the exact n-gram prefilter (DESIGN.md "proof"): a record needs
+// cos(F, S) > 1 - threshold.  If F and S differ in at least one slot,
+//   cos(F,S) <= ((n-1) a_max^2 + c a_min^2) / ((n-1) a_max^2 + a_min^2)
+// with a_min/a_max the extreme vector norms of the table and c the largest
+// cosine between a script vector and any other table vector.  When that bound
+// is below 1 - threshold only id-identical windows can produce records.
+static int prove_exact(fs_index* ix, const uint32_t* stok) {
+  fs_index_info& inf = ix->info;
+  inf.proof_ok = 0; inf.c_max = 1.0; inf.cos_bound = 1.0; inf.norm_min = 0; inf.norm_max = 0;
+  const uint64_t V = ix->n_vec;
+  const int D = (int)ix->cfg.emb_dim;
+  if (V == 0 || ix->n_windows == 0) {   // nothing can match; the scan finds nothing
+    inf.proof_ok = 1; inf.c_max = 0; inf.cos_bound = 0;
+    return FS_OK;
+  }
+  std::vector<uint32_t> rows_u;
+  {
+    std::vector<uint8_t> seen(V, 0);
+    for (uint64_t i = 0; i < ix->n_script; ++i) {
+      const uint32_t id = stok[i];
+      if (id & FS_OOV_FLAG) return FS_OK;   // 3-hot vectors: norms differ, no proof
+      if (!seen[id]) { seen[id] = 1; rows_u.push_back(id); }
+    }
+  }
+  std::vector<double> q(V);
+  FS_HIP(hipMemcpyAsync(q.data(), ix->d_q.p, V * sizeof(double), hipMemcpyDeviceToHost, ix->stream));
+  DBuf<float> embT;
+  DBuf<uint32_t> d_rows_u;
+  DBuf<int> d_bits;
+  FS_TRY(embT.reserve((size_t)V * D));
+  FS_TRY(d_rows_u.upload(rows_u.data(), rows_u.size(), ix->stream));
+  FS_TRY(d_bits.reserve(1));
+  FS_HIP(hipMemsetAsync(d_bits.p, 0, sizeof(int), ix->stream));
+  FS_TRY(fs_launch_cmax(ix->d_emb.p, V, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p, embT.p,
+                        d_bits.p, ix->stream));
+  int bits = 0;
+  FS_HIP(hipMemcpyAsync(&bits, d_bits.p, sizeof(int), hipMemcpyDeviceToHost, ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  float cmaxf;
+  memcpy(&cmaxf, &bits, sizeof cmaxf);
+  double qmin = q[0], qmax = q[0];
+  for (uint64_t v = 1; v < V; ++v) { qmin = std::min(qmin, q[v]); qmax = std::max(qmax, q[v]); }
+  inf.norm_min = sqrt(qmin); inf.norm_max = sqrt(qmax);
+  inf.c_max = cmaxf;
+  if (!(qmin > 0.0)) return FS_OK;
+  const double c = std::min(1.0, (double)cmaxf + 1e-4);     // float32 accumulation slack
+  const double n1 = (double)ix->cfg.window_size - 1.0;
+  inf.cos_bound = (n1 * qmax + c * qmin) / (n1 * qmax + qmin);
+  inf.proof_ok = inf.cos_bound < 1.0 - ix->cfg.distance_threshold - 1e-6 ? 1u : 0u;
+  return FS_OK;
+}
+
+extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
+                               const uint32_t* script_chars, const uint64_t* script_off,
+                               uint64_t n_script, const float* emb, uint64_t n_vec,
+                               const double* normals, fs_index** out) {
+  if (!cfg || !out || cfg->struct_size != sizeof(fs_config)) {
+    fs_set_error("fs_config missing or of a different ABI size");
+    return FS_E_INVALID;
+  }
+  *out = nullptr;
+  if ((n_script && (!script_vec || !script_off)) || (n_vec && !emb)) {
+    fs_set_error("null input buffer");
+    return FS_E_INVALID;
+  }
+  if (cfg->window_size < 1 || cfg->window_size > FS_MAX_WINDOW || cfg->nearest_n < 1 ||
+      cfg->nearest_n > 64 || cfg->emb_dim < 1 || cfg->emb_dim > 1024 ||
+      cfg->hash_dimensions < 1 || cfg->hash_dimensions > 24 || cfg->number_of_hashes < 1 ||
+      cfg->number_of_hashes > 64) {
+    fs_set_error("window_size 1..%d, nearest_n 1..64, emb_dim 1..1024, hash_dimensions 1..24, "
+                 "number_of_hashes 1..64", FS_MAX_WINDOW);
+    return FS_E_UNSUPPORTED;
+  }
+  if (n_script >= (1ull << 31) || n_vec >= (1ull << 31) ||
+      (uint64_t)cfg->emb_dim * cfg->emb_dim * cfg->emb_dim >= (1ull << 31)) {
+    fs_set_error("script or vector table too large");
+    return FS_E_UNSUPPORTED;
+  }
+  for (uint64_t i = 0; i < n_script; ++i) {
+    const uint32_t id = script_vec[i];
+    if (!(id & FS_OOV_FLAG) && id >= n_vec) {
+      fs_set_error("script_vec[%llu] = %u is outside the vector table", (unsigned long long)i, id);
+      return FS_E_INVALID;
+    }
+    if (script_off[i + 1] < script_off[i]) { fs_set_error("script_off not monotone"); return FS_E_INVALID; }
+  }
+  int ndev = 0;
+  FS_HIP(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) {
+    fs_set_error("device %d of %d", cfg->device, ndev);
+    return FS_E_INVALID;
+  }
+  FS_HIP(hipSetDevice(cfg->device));
+  fs_index* ix = new (std::nothrow) fs_index();
+  if (!ix) return FS_E_NOMEM;
+  struct Guard { fs_index* p; ~Guard() { delete p; } } guard{ix};
+  ix->cfg = *cfg;
+  ix->device = cfg->device;
+  ix->n_script = n_script; ix->n_vec = n_vec;
+  ix->n_windows = n_script >= cfg->window_size ? n_script - cfg->window_size + 1 : 0;
+  hipDeviceProp_t prop;
+  FS_HIP(hipGetDeviceProperties(&prop, cfg->device));
+  ix->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  FS_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  FS_HIP(hipEventCreate(&ix->ev_begin));
+  FS_HIP(hipEventCreate(&ix->ev_scan0));
+  FS_HIP(hipEventCreate(&ix->ev_scan1));
+  FS_HIP(hipEventCreate(&ix->ev_end));
+  FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
+  FS_TRY(ix->d_status.reserve(1));
+  FS_TRY(ix->w_bsum.reserve(256));
+
+  // script ids padded by n so that device code may read a full window anywhere
+  std::vector<uint32_t> stok(n_script + cfg->window_size + 1, 0u);
+  if (n_script) memcpy(stok.data(), script_vec, n_script * sizeof(uint32_t));
+  FS_TRY(ix->d_stok.upload(stok.data(), stok.size(), ix->stream));
+  const uint64_t n_chars = n_script ? script_off[n_script] : 0;
+  FS_TRY(ix->d_schars.upload(script_chars, n_chars, ix->stream));
+  {
+    std::vector<uint64_t> soff(n_script + 1, 0);
+    if (n_script) memcpy(soff.data(), script_off, (n_script + 1) * sizeof(uint64_t));
+    FS_TRY(ix->d_soff.upload(soff.data(), soff.size(), ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+  }
+  FS_TRY(ix->d_emb.upload(emb, (size_t)n_vec * cfg->emb_dim, ix->stream));
+  if (normals) {
+    const size_t nn = (size_t)cfg->number_of_hashes * cfg->hash_dimensions * cfg->emb_dim *
+                      cfg->window_size;
+    FS_TRY(ix->d_normals.upload(normals, nn, ix->stream));
+  }
+  FS_TRY(ix->d_q.reserve(n_vec));
+  FS_TRY(ix->d_selfdist.reserve(ix->n_windows));
+  FS_TRY(fs_launch_rownorms(ix->d_emb.p, n_vec, (int)cfg->emb_dim, ix->d_q.p, ix->stream));
+  FS_TRY(fs_launch_selfdist(ix->d_stok.p, ix->n_windows, (int)cfg->window_size, (int)cfg->emb_dim,
+                            n_vec, ix->d_q.p, ix->d_selfdist.p, ix->stream));
+  FS_TRY(build_gram_index(ix, stok.data()));
+  FS_TRY(prove_exact(ix, stok.data()));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+
+  ix->info.n_script = n_script;
+  ix->info.n_windows = ix->n_windows;
+  const bool exact = ix->info.proof_ok && cfg->mode != FS_MODE_GENERAL;
+  if (cfg->mode == FS_MODE_EXACT && !ix->info.proof_ok) {
+    fs_set_error("exact mode requested but cos bound %.6f >= 1 - threshold (c_max %.6f)",
+                 ix->info.cos_bound, ix->info.c_max);
+    return FS_E_UNPROVEN;
+  }
+  ix->info.path = exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
+  if (!exact) {
+    fs_set_error("the general LSH pipeline is not built yet: this vector table does not admit "
+                 "the exact n-gram prefilter (cos bound %.6f, c_max %.6f) or FS_MODE_GENERAL "
+                 "was requested", ix->info.cos_bound, ix->info.c_max);
+    return FS_E_UNSUPPORTED;
+  }
+  guard.p = nullptr;
+  *out = ix;
+  return FS_OK;
+}
+
+extern "C" int fs_index_info_get(const fs_index* ix, fs_index_info* info) {
+  if (!ix || !info) return FS_E_INVALID;
+  *info = ix->info;
+  return FS_OK;
+}
+
+extern "C" void fs_index_destroy(fs_index* ix) {
+  if (!ix) return;
+  (void)hipSetDevice(ix->device);
+  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  delete ix;
+}
+
+extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uint32_t* tok_str,
+                                const uint64_t* work_off, uint64_t n_works,
+                                const uint32_t* str_chars, const uint64_t* str_off, uint64_t n_str,
+                                fs_corpus** out) {
+  if (!ix || !out || !work_off || (n_str && (!str_chars || !str_off))) {
+    fs_set_error("null argument");
+    return FS_E_INVALID;
+  }
+  *out = nullptr;
+  if (work_off[0] != 0) { fs_set_error("work_off[0] must be 0"); return FS_E_INVALID; }
+  const uint64_t T = work_off[n_works];
+  if (T && !tok_vec) { fs_set_error("null token buffer"); return FS_E_INVALID; }
+  if (T >= (1ull << 32) - 65536 || n_works >= (1ull << 32) - 1 || n_str >= (1ull << 32)) {
+    fs_set_error("one corpus batch holds fewer than 2^32 tokens; split the batch");
+    return FS_E_UNSUPPORTED;
+  }
+  const uint32_t n = ix->cfg.window_size;
+  uint64_t windows = 0;
+  for (uint64_t w = 0; w < n_works; ++w) {
+    if (work_off[w + 1] < work_off[w]) { fs_set_error("work_off not monotone"); return FS_E_INVALID; }
+    const uint64_t len = work_off[w + 1] - work_off[w];
+    if (len >= n) windows += len - n + 1;
+  }
+  bool oov = false;
+  for (uint64_t i = 0; i < T; ++i) {
+    const uint32_t id = tok_vec[i];
+    if (id & FS_OOV_FLAG) oov = true;
+    else if (id >= ix->n_vec) {
+      fs_set_error("tok_vec[%llu] = %u is outside the vector table", (unsigned long long)i, id);
+      return FS_E_INVALID;
+    }
+  }
+  if (!tok_str && n_str < ix->n_vec && T) {
+    // string id == vector id: every id must have a string
+    uint32_t mx = 0;
+    for (uint64_t i = 0; i < T; ++i) mx = std::max(mx, tok_vec[i]);
+    if (mx >= n_str) { fs_set_error("string table smaller than the largest token id"); return FS_E_INVALID; }
+  }
+  if (oov && ix->info.path == FS_MODE_EXACT) {
+    fs_set_error("corpus holds out-of-vocabulary vector ids; the exact n-gram path is not proven "
+                 "for them and the general LSH pipeline is not built yet");
+    return FS_E_UNSUPPORTED;
+  }
+  FS_HIP(hipSetDevice(ix->device));
+  fs_corpus* c = new (std::nothrow) fs_corpus();
+  if (!c) return FS_E_NOMEM;
+  struct Guard { fs_corpus* p; ~Guard() { delete p; } } guard{c};
+  c->ix = ix; c->n_tok = T; c->n_works = n_works; c->n_str = n_str; c->windows = windows;
+  c->has_oov = oov; c->has_str = tok_str != nullptr;
+  const size_t pad = fs_scan_pad_tokens();
+  FS_TRY(c->d_tok.reserve(T + pad));
+  FS_HIP(hipMemsetAsync(c->d_tok.p + T, 0, pad * sizeof(uint32_t), ix->stream));
+  if (T) FS_HIP(hipMemcpyAsync(c->d_tok.p, tok_vec, T * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+  if (tok_str) {
+    FS_TRY(c->d_str.reserve(T + n + 1));
+    FS_HIP(hipMemsetAsync(c->d_str.p, 0, (T + n + 1) * sizeof(uint32_t), ix->stream));
+    if (T) FS_HIP(hipMemcpyAsync(c->d_str.p, tok_str, T * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+  }
+  FS_TRY(c->d_work_off.upload(work_off, n_works + 1, ix->stream));
+  FS_TRY(c->d_chars.upload(str_chars, n_str ? str_off[n_str] : 0, ix->stream));
+  {
+    std::vector<uint64_t> coff(n_str + 1, 0);
+    if (n_str) memcpy(coff.data(), str_off, (n_str + 1) * sizeof(uint64_t));
+    FS_TRY(c->d_coff.upload(coff.data(), coff.size(), ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+  }
+  if (!c->has_str) {
+    // string id == vector id: Levenshtein per (n-gram, rank) once per corpus
+    FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), ix->stream));
+    FS_TRY(fs_launch_levtab(ix, c, ix->stream));
+    FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    if (ix->h_status->bad_string) { fs_set_error("script vector id without a string"); return FS_E_INVALID; }
+    if (ix->h_status->lev_overflow) {
+      fs_set_error("an n-gram text exceeds %d code points", FS_LEV_MAX);
+      return FS_E_UNSUPPORTED;
+    }
+    c->levtab_ready = true;
+  }
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  guard.p = nullptr;
+  *out = c;
+  return FS_OK;
+}
+
+extern "C" void fs_corpus_destroy(fs_corpus* c) {
+  if (!c) return;
+  if (c->ix) { (void)hipSetDevice(c->ix->device); (void)hipStreamSynchronize(c->ix->stream); }
+  delete c;
+}
+
+extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap,
+                                int rows_on_device, uint64_t* n_rows, fs_stats* st) {
+  if (!ix || !c || c->ix != ix || !n_rows || (cap && !rows)) {
+    fs_set_error("null or mismatched handle");
+    return FS_E_INVALID;
+  }
+  FS_HIP(hipSetDevice(ix->device));
+  hipStream_t s = ix->stream;
+  const uint64_t T = c->n_tok;
+  const uint32_t n_bm = (uint32_t)((T + 255) / 256);
+  const uint32_t nn = ix->cfg.nearest_n;
+  // capacities: grown from the device totals when a stage overflows
+  uint64_t qcap = std::max<uint64_t>(4096, T / 8);
+  uint64_t hcap = std::max<uint64_t>(4096, T / 8);
+  uint64_t mcap = c->has_str ? std::max<uint64_t>(4096, T / 4) : 1;
+  uint64_t rcap = rows_on_device ? cap : std::max<uint64_t>(4096, T / 8);
+  qcap = std::max<uint64_t>(qcap, ix->w_qpos.n);
+  hcap = std::max<uint64_t>(hcap, ix->w_hit_p.n);
+  if (c->has_str) mcap = std::max<uint64_t>(mcap, ix->w_mlev.n);
+  if (!rows_on_device) rcap = std::max<uint64_t>(rcap, ix->w_rows.n);
+
+  float scan_ms = 0, total_ms = 0;
+  uint32_t launches = 0;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    FS_TRY(ix->w_qbm.reserve(n_bm));
+    FS_TRY(ix->w_off1.reserve(n_bm));
+    FS_TRY(ix->w_qpos.reserve(qcap));
+    FS_TRY(ix->w_hg.reserve(qcap * 4));
+    FS_TRY(ix->w_hw.reserve(qcap * 4));
+    FS_TRY(ix->w_hoff.reserve(qcap * 4));
+    FS_TRY(ix->w_hit_p.reserve(hcap));
+    FS_TRY(ix->w_hit_g.reserve(hcap));
+    FS_TRY(ix->w_hit_w.reserve(hcap));
+    FS_TRY(ix->w_roff.reserve(hcap));
+    FS_TRY(ix->w_moff.reserve(c->has_str ? hcap : 1));
+    FS_TRY(ix->w_mlev.reserve(mcap));
+    fs_row* d_rows = rows;
+    if (!rows_on_device) { FS_TRY(ix->w_rows.reserve(rcap)); d_rows = ix->w_rows.p; }
+
+    FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
+    FS_HIP(hipEventRecord(ix->ev_begin, s));
+    FS_HIP(hipEventRecord(ix->ev_scan0, s));
+    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, n_bm, s));
+    FS_HIP(hipEventRecord(ix->ev_scan1, s));
+    ++launches;
+    FS_TRY(fs_launch_post(ix, c, n_bm, (uint32_t)qcap, (uint32_t)hcap, (uint32_t)mcap,
+                          (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFull), d_rows, s));
+    FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipEventRecord(ix->ev_end, s));
+    FS_HIP(hipStreamSynchronize(s));
+    FS_HIP(hipEventElapsedTime(&scan_ms, ix->ev_scan0, ix->ev_scan1));
+    FS_HIP(hipEventElapsedTime(&total_ms, ix->ev_begin, ix->ev_end));
+    const fs_status& hs = *ix->h_status;
+    if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }
+    if (hs.lev_overflow) {
+      fs_set_error("an n-gram text exceeds %d code points", FS_LEV_MAX);
+      return FS_E_UNSUPPORTED;
+    }
+    bool again = false;
+    if (hs.n_quads > qcap) { qcap = (uint64_t)hs.n_quads + hs.n_quads / 8; again = true; }
+    else if (hs.n_hits > hcap) { hcap = (uint64_t)hs.n_hits + hs.n_hits / 8; again = true; }
+    else if (c->has_str && hs.n_matches > mcap) { mcap = hs.n_matches; again = true; }
+    else if (!rows_on_device && hs.n_rows > rcap && hs.n_rows <= cap) { rcap = hs.n_rows; again = true; }
+    if (!again) break;
+    if (attempt == 7) { fs_set_error("workspace growth did not converge"); return FS_E_DEVICE; }
+  }
+  const fs_status hs = *ix->h_status;
+  *n_rows = hs.n_rows;
+  if (st) {
+    memset(st, 0, sizeof *st);
+    st->windows_processed = c->windows;
+    st->candidates = hs.n_cand_windows;
+    st->matches = hs.n_matches;
+    st->rows = hs.n_rows;
+    st->scan_ms = scan_ms;
+    st->total_ms = total_ms;
+    st->path = FS_MODE_EXACT;
+    st->scan_launches = launches;
+  }
+  if (hs.n_rows > cap) return FS_E_CAPACITY;
+  if (!rows_on_device && hs.n_rows) {
+    FS_HIP(hipMemcpyAsync(rows, ix->w_rows.p, (size_t)hs.n_rows * sizeof(fs_row), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+  }
+  (void)nn;
+  return FS_OK;
+}
+
+extern "C" int fs_search(fs_index* ix, const uint32_t* tok_vec, const uint32_t* tok_str,
+                         const uint64_t* work_off, uint64_t n_works, const uint32_t* str_chars,
+                         const uint64_t* str_off, uint64_t n_str, fs_row* rows, uint64_t cap,
+                         uint64_t* n_rows, fs_stats* st) {
+  fs_corpus* c = nullptr;
+  FS_TRY(fs_corpus_create(ix, tok_vec, tok_str, work_off, n_works, str_chars, str_off, n_str, &c));
+  const int rc = fs_search_corpus(ix, c, rows, cap, 0, n_rows, st);
+  fs_corpus_destroy(c);
+  return rc;
+}

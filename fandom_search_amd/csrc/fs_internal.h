@@ -1,0 +1,163 @@
+// fs_internal.h -- shared declarations of libfandomsearch_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <string>
+#include <vector>
+
+#include "../../include/fandom_search.h"
+#include "fs_hash.h"
+
+#define FS_MAX_WINDOW 16          // n <= 16: at most 4 neighbour vectors of halo
+#define FS_NONE 0xFFFFFFFFu
+#define FS_LEV_MAX 256            // code points per side handled by lev_device
+
+void fs_set_error(const char* fmt, ...);
+
+#define FS_HIP(call)                                                        \
+  do {                                                                      \
+    hipError_t e_ = (call);                                                 \
+    if (e_ != hipSuccess) {                                                 \
+      fs_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call,             \
+                   hipGetErrorString(e_));                                  \
+      return FS_E_DEVICE;                                                   \
+    }                                                                       \
+  } while (0)
+
+#define FS_TRY(call)                \
+  do {                              \
+    int rc_ = (call);               \
+    if (rc_ != FS_OK) return rc_;   \
+  } while (0)
+
+// device buffer that only ever grows
+template <class T>
+struct DBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int reserve(size_t count) {
+    if (count <= n && p) return FS_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      fs_set_error("hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+      p = nullptr;
+      return FS_E_NOMEM;
+    }
+    n = count;
+    return FS_OK;
+  }
+  int upload(const T* host, size_t count, hipStream_t s) {
+    FS_TRY(reserve(count));
+    if (count) FS_HIP(hipMemcpyAsync(p, host, count * sizeof(T), hipMemcpyHostToDevice, s));
+    return FS_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DBuf() { release(); }
+  DBuf() = default;
+  DBuf(const DBuf&) = delete;
+  DBuf& operator=(const DBuf&) = delete;
+};
+
+// Device-side totals and overflow flags of one search; read back in one copy.
+struct fs_status {
+  uint32_t n_quads;      // candidate 4-window groups flagged by the scan
+  uint32_t n_hits;       // verified (window, n-gram) hits inside a work
+  uint32_t n_matches;    // (window, script window) pairs
+  uint32_t n_rows;       // output records
+  uint32_t n_cand_windows;  // filter-positive windows (statistics)
+  uint32_t lev_overflow; // a Levenshtein operand exceeded FS_LEV_MAX
+  uint32_t bad_string;   // string id outside the string table
+  uint32_t pad;
+};
+
+// Script-side exact n-gram index (device pointers + geometry), passed by value
+// to kernels.
+struct GramIndexDev {
+  const uint32_t* stok;      // [n_script] script vector ids
+  const uint32_t* filter;    // [1 << log2_words] blocked Bloom filter
+  const uint32_t* table;     // [1 << log2_slots] gram id + 1, 0 = empty
+  const uint32_t* gpos;      // [n_grams][nn] first <= nn script positions, ascending
+  const uint32_t* gcnt;      // [n_grams] min(occurrences, nn)
+  const double*   selfdist;  // [n_windows] canonical distance of a window to itself
+  const uint32_t* schars;    // script word text
+  const uint64_t* soff;      // [n_script + 1]
+  int log2_words;
+  int log2_slots;
+  int n;                     // window size
+  int nn;                    // NearestFilter N
+  uint32_t n_grams;
+};
+
+struct CorpusDev {
+  const uint32_t* tok;       // [n_tok + pad] vector ids
+  const uint32_t* str;       // [n_tok] string ids or nullptr (== vector ids)
+  const uint64_t* work_off;  // [n_works + 1]
+  const uint32_t* chars;     // fan-side string table
+  const uint64_t* coff;      // [n_str + 1]
+  uint32_t n_tok;
+  uint32_t n_works;
+  uint32_t n_str;
+};
+
+struct fs_index {
+  fs_config cfg;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_end = nullptr;
+  fs_index_info info{};
+  uint64_t n_script = 0, n_windows = 0, n_vec = 0;
+  uint32_t n_grams = 0;
+  int log2_words = 0, log2_slots = 0;
+  int num_cu = 256;
+
+  DBuf<uint32_t> d_stok, d_filter, d_table, d_gpos, d_gcnt, d_schars;
+  DBuf<uint64_t> d_soff;
+  DBuf<double> d_q, d_selfdist;
+  DBuf<float> d_emb;
+  DBuf<double> d_normals;
+
+  // workspaces (grow on demand)
+  DBuf<uint64_t> w_qbm;
+  DBuf<uint32_t> w_off1, w_qpos, w_hg, w_hw, w_hoff, w_hit_p, w_hit_g, w_hit_w;
+  DBuf<uint32_t> w_moff, w_mlev, w_roff, w_bsum;
+  DBuf<fs_row> w_rows;
+  DBuf<fs_status> d_status;
+  fs_status* h_status = nullptr;   // pinned
+
+  GramIndexDev gram_dev() const;
+  ~fs_index();
+};
+
+struct fs_corpus {
+  fs_index* ix = nullptr;
+  uint64_t n_tok = 0, n_works = 0, n_str = 0;
+  uint64_t windows = 0;      // sum over works of max(0, len - n + 1)
+  bool has_oov = false;
+  bool has_str = false;
+  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab;
+  DBuf<uint64_t> d_work_off, d_coff;
+  bool levtab_ready = false;
+  CorpusDev dev() const;
+};
+
+// ---- kernel launchers (fs_scan.hip / fs_post.hip / fs_build.hip) ----------
+int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm,
+                   uint32_t n_bm_words, hipStream_t s);
+uint32_t fs_scan_pad_tokens();
+
+int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_bm_words,
+                   uint32_t qcap, uint32_t hcap, uint32_t mcap, uint32_t rcap,
+                   fs_row* d_rows, hipStream_t s);
+
+int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
+
+int fs_launch_rownorms(const float* emb, uint64_t n_vec, int D, double* q, hipStream_t s);
+int fs_launch_selfdist(const uint32_t* stok, uint64_t n_windows, int n, int D,
+                       uint64_t n_vec, const double* q, double* selfdist, hipStream_t s);
+int fs_launch_cmax(const float* emb, uint64_t n_vec, int D, const uint32_t* rows_u,
+                   uint32_t n_u, const double* q, float* embT_scratch, int* d_out_bits,
+                   hipStream_t s);

@@ -1,0 +1,226 @@
+// fs_scan.hip -- the n-gram scan kernel (the HBM-bound hot loop).
+//
+// Replaces, for corpora whose vector table admits the exact-n-gram proof
+// (DESIGN.md), the per-window engine.neighbours() call of the reference
+// (/root/reference/search.py:176-178): every fan window's n vector ids are
+// hashed and tested against the script's n-gram set.
+//
+// Data flow per wave (64 lanes), per 256-token sub-tile:
+//   * one coalesced global_load_dwordx4 per lane: tokens [4L, 4L+4)
+//   * the n-1 halo tokens come from lanes L+1.. by ds_bpermute (no second
+//     global read); the wrap into the next sub-tile is folded into the same
+//     permute by letting the low lanes publish the next vector
+//   * per window: rolling fold of premixed ids, finalise, one ds_read_b32 of
+//     the LDS-resident blocked Bloom filter, three-bit test
+//   * OR of the lane's four window flags -> __ballot -> lane 0 stores one
+//     64-bit word: bit L of word i says "some window starting in tokens
+//     [256 i + 4L, 256 i + 4L + 4) may be a script n-gram"
+// No atomics, no inter-workgroup traffic, output order is position order, so
+// the result is deterministic; exact verification happens downstream on the
+// (rare) flagged quads.  Algorithmic HBM traffic: 4 B read per token +
+// 1/32 B written per token.
+#include "fs_internal.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kTokPerLane = 4;
+constexpr int kSubTile = kWave * kTokPerLane;   // 256 tokens per bitmap word
+
+template <int N>
+__device__ __forceinline__ uint32_t window_flags(const uint32_t* a, const uint32_t* s_filter,
+                                                 int log2_words) {
+  // a[0 .. 4+N-1): premixed ids of this lane's tokens and its halo
+  uint32_t flags = 0;
+#pragma unroll
+  for (int j = 0; j < kTokPerLane; ++j) {
+    uint32_t h = a[j];
+#pragma unroll
+    for (int k = 1; k < N; ++k) h = fs_fold(h, a[j + k]);
+    h = fs_finish(h);
+    const uint32_t word = s_filter[fs_bloom_word(h, log2_words)];
+    const uint32_t mask = fs_bloom_mask(h);
+    flags |= ((word & mask) == mask) ? (1u << j) : 0u;
+  }
+  return flags;
+}
+
+// U sub-tiles (U x 256 tokens) per wave iteration: U independent 16-byte loads
+// in flight per lane before the first use.
+template <int N, int U>
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok, uint32_t n_tok,
+                                               const uint32_t* __restrict__ filter,
+                                               int log2_words, uint64_t* __restrict__ qbm,
+                                               uint32_t n_bm_words, uint32_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
+  {
+    const uint32_t vecs = (1u << log2_words) / 4;
+    const uint4* src = reinterpret_cast<const uint4*>(filter);
+    uint4* dst = reinterpret_cast<uint4*>(s_filter);
+    for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+
+  constexpr int HALO = N - 1;
+  constexpr int NV = (HALO + 3) / 4;            // neighbour vectors needed
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+
+  for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const uint32_t base = tile * (uint32_t)(kSubTile * U);
+    uint4 v[U + 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      v[u] = *reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
+    // first vectors of the next tile, in lanes 0..3 (the buffer is padded)
+    v[U] = *reinterpret_cast<const uint4*>(tok + base + U * kSubTile + 4 * (lane & 3));
+
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      uint32_t a[4 + 4 * NV];
+      a[0] = v[u].x; a[1] = v[u].y; a[2] = v[u].z; a[3] = v[u].w;
+#pragma unroll
+      for (int d = 1; d <= NV; ++d) {
+        // lane L needs the vector of lane L+d; past lane 63 that is a vector of
+        // the next sub-tile, which lanes 0..d-1 publish instead of their own
+        const bool wrap = lane < d;
+        const int src = (lane + d) & 63;
+        const int need = (HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4;
+        a[4 * d + 0] = __shfl(wrap ? v[u + 1].x : v[u].x, src);
+        if (need > 1) a[4 * d + 1] = __shfl(wrap ? v[u + 1].y : v[u].y, src);
+        if (need > 2) a[4 * d + 2] = __shfl(wrap ? v[u + 1].z : v[u].z, src);
+        if (need > 3) a[4 * d + 3] = __shfl(wrap ? v[u + 1].w : v[u].w, src);
+      }
+#pragma unroll
+      for (int i = 0; i < 4 + HALO; ++i) a[i] = fs_premix(a[i]);
+
+      uint32_t flags = window_flags<N>(a, s_filter, log2_words);
+
+      const uint32_t p0 = base + u * kSubTile + 4 * lane;
+      if (base + (uint32_t)(kSubTile * U) + HALO > n_tok) {   // wave-uniform: last tile(s)
+        // window at p is real only if p + N <= n_tok
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
+      }
+      const uint64_t bal = __ballot(flags != 0);
+      const uint32_t word = tile * U + u;
+      if (lane == 0 && word < n_bm_words) qbm[word] = bal;
+    }
+  }
+}
+
+// Simple variant for any n <= FS_MAX_WINDOW: every lane reads its ids straight
+// from global memory (L1-served).  Slower; kept as the cross-check of k_scan and
+// as the fallback for window sizes without a specialisation.
+__global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict__ tok,
+                                                      uint32_t n_tok,
+                                                      const uint32_t* __restrict__ filter,
+                                                      int log2_words, int n,
+                                                      uint64_t* __restrict__ qbm,
+                                                      uint32_t n_bm_words) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
+  for (uint32_t i = threadIdx.x; i < (1u << log2_words); i += blockDim.x) s_filter[i] = filter[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t word = wave; word < n_bm_words; word += n_waves) {
+    const uint32_t p0 = word * kSubTile + 4 * lane;
+    uint32_t flags = 0;
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t p = (uint64_t)p0 + j;
+      if (p + n > n_tok) continue;
+      uint32_t h = fs_premix(tok[p]);
+      for (int k = 1; k < n; ++k) h = fs_fold(h, fs_premix(tok[p + k]));
+      h = fs_finish(h);
+      const uint32_t w = s_filter[fs_bloom_word(h, log2_words)];
+      const uint32_t m = fs_bloom_mask(h);
+      if ((w & m) == m) flags |= 1u << j;
+    }
+    const uint64_t bal = __ballot(flags != 0);
+    if (lane == 0) qbm[word] = bal;
+  }
+}
+
+template <int N, int U>
+int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t n_bm_words,
+                hipStream_t s) {
+  const uint32_t tile_tok = kSubTile * U;
+  const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
+  if (n_tiles == 0) return FS_OK;
+  const size_t lds = (size_t)4 << ix->log2_words;
+  int threads = 1024;
+  const uint32_t waves_per_block = threads / 64;
+  uint32_t blocks_per_cu = lds <= 64 * 1024 ? 2 : 1;
+  uint32_t max_blocks = ix->num_cu * blocks_per_cu;
+  uint32_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
+  if (blocks > max_blocks) blocks = max_blocks;
+  auto kern = k_scan<N, U>;
+  FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, c.tok, c.n_tok,
+                     ix->d_filter.p, ix->log2_words, qbm, n_bm_words, n_tiles);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+template <int N>
+int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t n_bm_words,
+                  hipStream_t s, int unroll) {
+  switch (unroll) {
+    case 1: return launch_fast<N, 1>(ix, c, qbm, n_bm_words, s);
+    case 2: return launch_fast<N, 2>(ix, c, qbm, n_bm_words, s);
+    case 8: return launch_fast<N, 8>(ix, c, qbm, n_bm_words, s);
+    default: return launch_fast<N, 4>(ix, c, qbm, n_bm_words, s);
+  }
+}
+
+}  // namespace
+
+// tokens of zero padding the corpus buffer carries behind n_tok so that the
+// tile loads of the last wave never leave the allocation
+uint32_t fs_scan_pad_tokens() { return kSubTile * 8 + 64; }
+
+int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t n_bm_words,
+                   hipStream_t s) {
+  const int n = ix->cfg.window_size;
+  const char* var = getenv("FS_SCAN_VARIANT");
+  const bool simple = var && var[0] == 's';
+  int unroll = 4;
+  if (const char* u = getenv("FS_SCAN_UNROLL")) unroll = atoi(u);
+  // small inputs: shorter tiles so that every CU gets work
+  if (!getenv("FS_SCAN_UNROLL")) {
+    const uint64_t waves = (uint64_t)ix->num_cu * 16;
+    if ((uint64_t)c.n_tok < waves * kSubTile * 4 * 4) unroll = 2;
+    if ((uint64_t)c.n_tok < waves * kSubTile * 2 * 4) unroll = 1;
+  }
+  if (!simple) {
+    switch (n) {
+      case 2: return launch_fast_u<2>(ix, c, qbm, n_bm_words, s, unroll);
+      case 3: return launch_fast_u<3>(ix, c, qbm, n_bm_words, s, unroll);
+      case 4: return launch_fast_u<4>(ix, c, qbm, n_bm_words, s, unroll);
+      case 5: return launch_fast_u<5>(ix, c, qbm, n_bm_words, s, unroll);
+      case 6: return launch_fast_u<6>(ix, c, qbm, n_bm_words, s, unroll);
+      case 7: return launch_fast_u<7>(ix, c, qbm, n_bm_words, s, unroll);
+      case 8: return launch_fast_u<8>(ix, c, qbm, n_bm_words, s, unroll);
+      case 10: return launch_fast_u<10>(ix, c, qbm, n_bm_words, s, unroll);
+      case 12: return launch_fast_u<12>(ix, c, qbm, n_bm_words, s, unroll);
+      default: break;
+    }
+  }
+  if (n_bm_words == 0) return FS_OK;
+  const size_t lds = (size_t)4 << ix->log2_words;
+  FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_scan_simple),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  uint32_t blocks = (n_bm_words + 15) / 16;
+  const uint32_t max_blocks = ix->num_cu * (lds <= 64 * 1024 ? 2 : 1);
+  if (blocks > max_blocks) blocks = max_blocks;
+  hipLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(1024), lds, s, c.tok, c.n_tok,
+                     ix->d_filter.p, ix->log2_words, n, qbm, n_bm_words);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}

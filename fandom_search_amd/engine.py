@@ -1,0 +1,126 @@
+"""Python face of the C ABI: script index, device-resident corpus, search.
+
+`ScriptIndex` stands where AnnIndexSearch.__init__ / build_lsh_engine stand in
+the reference (/root/reference/search.py:131-154, 86-124); `Corpus` is a batch
+of tokenised works already in HBM; `ScriptIndex.search` is
+AnnIndexSearch.search (search.py:163-226) over the whole batch and returns the
+numeric half of the records (abi.ROW_DTYPE), sorted by (work, fan word index).
+"""
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, abi
+from .vocab import pack_strings
+
+
+class Corpus(object):
+    def __init__(self, index, tok_vec, work_off, str_chars, str_off,
+                 tok_str=None):
+        self.index = index
+        self.tok_vec = abi.as_u32(tok_vec)
+        self.tok_str = abi.as_u32(tok_str) if tok_str is not None else None
+        self.work_off = abi.as_u64(work_off)
+        chars = abi.as_u32(str_chars)
+        off = abi.as_u64(str_off)
+        self.n_works = len(self.work_off) - 1
+        self.n_tok = int(self.work_off[-1])
+        if self.tok_vec.size < self.n_tok:
+            raise ValueError("token buffer shorter than work_off[-1]")
+        self._h = C.c_void_p()
+        L = _lib.load()
+        _lib.check(L.fs_corpus_create(
+            index._h, abi.ptr(self.tok_vec, C.c_uint32),
+            abi.ptr(self.tok_str, C.c_uint32),
+            abi.ptr(self.work_off, C.c_uint64), self.n_works,
+            abi.ptr(chars, C.c_uint32), abi.ptr(off, C.c_uint64),
+            len(off) - 1, C.byref(self._h)), "fs_corpus_create")
+
+    def close(self):
+        if self._h:
+            _lib.load().fs_corpus_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ScriptIndex(object):
+    def __init__(self, script_vec, script_words, emb, normals, cfg=None,
+                 **cfg_kw):
+        L = _lib.load()
+        self.cfg = cfg or abi.make_config(**cfg_kw)
+        sv = abi.as_u32(script_vec)
+        chars, off = pack_strings(list(script_words))
+        if len(off) - 1 != len(sv):
+            raise ValueError("one word per script token expected")
+        emb = np.ascontiguousarray(emb, dtype=np.float32)
+        if emb.ndim != 2 or emb.shape[1] != self.cfg.emb_dim:
+            raise ValueError("embedding must be (V, %d)" % self.cfg.emb_dim)
+        normals = np.ascontiguousarray(normals, dtype=np.float64)
+        want = (self.cfg.number_of_hashes * self.cfg.hash_dimensions
+                * self.cfg.emb_dim * self.cfg.window_size)
+        if normals.size != want:
+            raise ValueError("normals must hold H*B*D*n = %d values" % want)
+        self._h = C.c_void_p()
+        _lib.check(L.fs_index_create(
+            C.byref(self.cfg), abi.ptr(sv, C.c_uint32),
+            abi.ptr(chars, C.c_uint32), abi.ptr(off, C.c_uint64), len(sv),
+            abi.ptr(emb, C.c_float), emb.shape[0],
+            abi.ptr(normals, C.c_double), C.byref(self._h)),
+            "fs_index_create")
+        info = abi.FsIndexInfo()
+        _lib.check(L.fs_index_info_get(self._h, C.byref(info)),
+                   "fs_index_info_get")
+        self.info = info.as_dict()
+
+    def corpus(self, tok_vec, work_off, str_chars, str_off, tok_str=None):
+        return Corpus(self, tok_vec, work_off, str_chars, str_off, tok_str)
+
+    def search(self, corpus, cap=None):
+        """Rows (numpy structured array, host) and stats of one batch."""
+        L = _lib.load()
+        st = abi.FsStats()
+        n = C.c_uint64(0)
+        cap = int(cap) if cap else max(1024, corpus.n_tok // 16)
+        while True:
+            rows = np.empty(cap, dtype=abi.ROW_DTYPE)
+            rc = L.fs_search_corpus(self._h, corpus._h,
+                                    rows.ctypes.data_as(C.c_void_p), cap, 0,
+                                    C.byref(n), C.byref(st))
+            if rc == abi.FS_E_CAPACITY:
+                cap = int(n.value)
+                continue
+            _lib.check(rc, "fs_search_corpus")
+            return rows[:n.value], st
+
+    def search_device(self, corpus, rows_ptr, cap):
+        """Rows written to a caller-owned device buffer (`rows_ptr`: address on
+        this index's device, `cap` records).  Returns (n_rows, stats); raises
+        FsError(FS_E_CAPACITY) with .required when the buffer is too small."""
+        L = _lib.load()
+        st = abi.FsStats()
+        n = C.c_uint64(0)
+        rc = L.fs_search_corpus(self._h, corpus._h, C.c_void_p(rows_ptr),
+                                int(cap), 1, C.byref(n), C.byref(st))
+        if rc == abi.FS_E_CAPACITY:
+            err = _lib.FsError(rc, "fs_search_corpus", "row buffer too small")
+            err.required = int(n.value)
+            raise err
+        _lib.check(rc, "fs_search_corpus")
+        return int(n.value), st
+
+    def close(self):
+        if self._h:
+            _lib.load().fs_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

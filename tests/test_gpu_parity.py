@@ -1,0 +1,83 @@
+"""GPU parity: rows of the HIP library (through the C ABI) against the plain-C
+oracle (reference algorithm, canonical arithmetic) on the same seeded inputs.
+Integer fields and both float64 fields must be bit-identical."""
+
+import os
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import abi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(synth_base, lengths, script_tokens, n=6, first_work=0, **env):
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    normals = synth.lsh_normals(n)
+    script = synth.script_tokens(script_tokens)
+    tok, off = util.ragged_corpus(lengths, script, first_work)
+    cfg = abi.make_config(window_size=n)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        ix = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=cfg)
+        corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        got, st = ix.search(corpus)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    oi = util.oracle_index(cfg, script, words, emb, normals)
+    want, ost = oi.search(tok, off, synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(got, want)
+    assert st.windows_processed == ost.windows_processed
+    assert st.matches == ost.matches
+    assert st.rows == len(want)
+    assert ix.info["proof_ok"] == 1 and ix.info["path"] == abi.FS_MODE_EXACT
+    return got, st
+
+
+def test_c1_shape(synth_base):
+    """BASELINE.json configs[0]: 50 works x 1000 tokens vs a 500-line script."""
+    got, st = _case(synth_base, [1000] * 50, 5000)
+    assert len(got) > 0
+
+
+def test_ragged_and_empty_works(synth_base):
+    lengths = [0, 3, 5, 6, 7, 0, 0, 255, 256, 257, 1023, 1024, 1025, 1, 2000, 0]
+    _case(synth_base, lengths, 3000)
+
+
+def test_single_short_and_no_works(synth_base):
+    _case(synth_base, [4], 1000)
+    _case(synth_base, [], 1000)
+    _case(synth_base, [0, 0], 1000)
+
+
+@pytest.mark.parametrize("unroll", [1, 2, 4, 8])
+def test_scan_unroll_variants(synth_base, unroll):
+    _case(synth_base, [1500] * 40 + [77, 5000], 4000, FS_SCAN_UNROLL=unroll)
+
+
+def test_scan_simple_variant(synth_base):
+    _case(synth_base, [1500] * 40, 4000, FS_SCAN_VARIANT="simple")
+
+
+@pytest.mark.parametrize("lw", [10, 12, 15])
+def test_filter_sizes(synth_base, lw):
+    _case(synth_base, [2000] * 30, 8000, FS_FILTER_LOG2_WORDS=lw)
+
+
+def test_window_size_4(synth_base):
+    _case(synth_base, [800] * 30, 3000, n=4)
+
+
+def test_c2_slice(synth_base):
+    """600 works of BASELINE.json configs[1] (2000 tokens, 20k-token script)."""
+    got, st = _case(synth_base, [2000] * 600, 20000)
+    assert st.scan_ms > 0
