@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""fanworks/sec of the 6-gram search hot path on MI355X.
+
+A step = one pass of the search over one batch of synthetic fan works that is
+already resident in HBM (fs_search_corpus of include/fandom_search.h: scan
+kernel + verify + Levenshtein + per-word records, rows left in HBM).  At N=1
+the batch is BASELINE.json configs[1] ("c2": 10k works x 2k tokens vs a
+2k-line script, 6-gram); with N ranks every rank searches its own c2-sized
+shard of distinct works (weak scaling) and the match rows of all ranks are
+gathered to rank 0 over RCCL inside the step (double-buffered, so the gather
+of step i overlaps the scan of step i+1).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  roofline     scan kernel: algorithmic bytes (4 B per fan token)
+               / HIP-event duration of the kernel, against 8 TB/s HBM
+  cpu_baseline the plain-C oracle (the reference's LSH algorithm) on a bounded
+               sample of the same workload on the host cores (N=1 only)
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2",
+                    help="per-rank shard: c2 (default), c3shard, c3, c1")
+    ap.add_argument("--works", type=int, default=0, help="override works per rank")
+    ap.add_argument("--window", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, script, swords, words, emb, normals, tokens_per_work,
+                 chars, coff, budget_s):
+    """Plain-C oracle (reference algorithm: LSH keys, bucket candidates, cosine,
+    top-10, Levenshtein, per-word dedupe) on the first works of the workload."""
+    from fandom_search_amd import synth, vocab
+    from oracle import c_oracle
+    cores = len(os.sched_getaffinity(0))
+    sch, so = vocab.pack_strings(swords)
+    oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=cores)
+    pilot = 4 * cores
+    tok, off = synth.corpus_tokens(pilot, tokens_per_work, script)
+    oi.search(tok, off, chars, coff)             # also fills the per-token tables
+    t0 = time.perf_counter()
+    oi.search(tok, off, chars, coff)
+    per_work = (time.perf_counter() - t0) / pilot
+    n = int(max(pilot, min(4000, budget_s / max(per_work, 1e-9))))
+    tok, off = synth.corpus_tokens(n, tokens_per_work, script)
+    t0 = time.perf_counter()
+    rows, st = oi.search(tok, off, chars, coff)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "fanworks/s", "cores": cores, "kind": "port",
+            "sample": "first %d works (%d tokens each) of the workload, %.1f s, "
+                      "oracle/fs_oracle.c with OpenMP over works"
+                      % (n, tokens_per_work, dt)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+
+    import torch
+    import torch.distributed as dist
+    from fandom_search_amd import _lib, abi, synth, vocab
+    from fandom_search_amd.engine import ScriptIndex
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    conf = dict(synth.CONFIGS[args.workload])
+    if args.works:
+        conf["n_works"] = args.works
+    n_works, tpw = conf["n_works"], conf["tokens_per_work"]
+    words = synth.vocab_words()
+    emb = synth.embedding()
+    normals = synth.lsh_normals(args.window)
+    script = synth.script_tokens(conf["script_tokens"])
+    swords = [words[int(t)] for t in script]
+    chars, coff = vocab.pack_strings(words)
+    tok, off = synth.corpus_tokens(n_works, tpw, script, first_work=rank * n_works)
+
+    cfg = abi.make_config(window_size=args.window, device=local_rank)
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    corpus = ix.corpus(tok, off, chars, coff)
+
+    # row buffers in HBM (two, so a gather may still read one while the next
+    # step writes the other)
+    cap = max(4096, corpus.n_tok // 16)
+    while True:
+        bufs = [torch.empty(cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        try:
+            n_rows, st = ix.search_device(corpus, bufs[0].data_ptr(), cap)
+            break
+        except _lib.FsError as e:
+            if e.code != abi.FS_E_CAPACITY:
+                raise
+            cap = int(e.required * 1.05) + 64
+    pad = cap
+    if world > 1:
+        t = torch.tensor([cap], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        pad = int(t.item())
+        if pad != cap:
+            cap = pad
+            bufs = [torch.empty(cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        counts = [torch.zeros(world, dtype=torch.int64, device="cuda") for _ in range(2)]
+        mine = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+        gathered = None
+        if rank == 0:
+            gathered = [[torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+                         for _ in range(world)] for _ in range(2)]
+
+    pending = [None, None]
+    scan_ms = []
+    total_rows = 0
+
+    def step(i):
+        nonlocal total_rows
+        b = i & 1
+        if pending[b] is not None:
+            for h in pending[b]:
+                h.wait()
+            pending[b] = None
+        n, st = ix.search_device(corpus, bufs[b].data_ptr(), cap)
+        scan_ms.append(st.scan_ms)
+        total_rows = n
+        if world > 1:
+            mine[b].fill_(n)
+            h1 = dist.all_gather_into_tensor(counts[b], mine[b], async_op=True)
+            h2 = dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0,
+                             async_op=True)
+            pending[b] = (h1, h2)
+        return st
+
+    def drain():
+        for b in (0, 1):
+            if pending[b] is not None:
+                for h in pending[b]:
+                    h.wait()
+                pending[b] = None
+
+    for i in range(args.warmup):
+        step(i)
+    drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    scan_ms.clear()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        st = step(i)
+    drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * n_works * args.steps / dt
+        scan_avg_ms = float(np.mean(scan_ms))
+        algo_bytes = 4.0 * corpus.n_tok           # 4 B per fan token
+        achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath))
+                if rec.get("workload") == args.workload and rec.get("window") == args.window \
+                        and rec.get("n_tok") == corpus.n_tok:
+                    traffic = rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "fanworks/sec (6-gram search)",
+            "value": value,
+            "unit": "fanworks/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d works x %d tokens per GPU vs %d-token script, "
+                                   "%d-gram" % (args.workload, n_works, tpw,
+                                                conf["script_tokens"], args.window),
+                       "works_per_gpu": n_works, "tokens_per_work": tpw,
+                       "script_tokens": conf["script_tokens"], "window": args.window,
+                       "rows_per_gpu_step": int(total_rows),
+                       "gather": "rccl gather to rank 0, overlapped" if world > 1 else "none",
+                       "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh"},
+            "roofline": {"bound": "hbm", "kernel": "k_scan<%d,U>" % args.window,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "avg_launch_ms": scan_avg_ms},
+            "device_total_ms": st.total_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, script, swords, words, emb, normals, tpw,
+                                               chars, coff, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,6 +49,7 @@ GramIndexDev fs_index::gram_dev() const {
 CorpusDev fs_corpus::dev() const {
   CorpusDev c;
   c.tok = d_tok.p; c.str = has_str ? d_str.p : nullptr; c.work_off = d_work_off.p;
+  c.blk_work = d_blk_work.p;
   c.chars = d_chars.p; c.coff = d_coff.p;
   c.n_tok = (uint32_t)n_tok; c.n_works = (uint32_t)n_works; c.n_str = (uint32_t)n_str;
   return c;
@@ -230,7 +231,8 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   FS_HIP(hipEventCreate(&ix->ev_end));
   FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
   FS_TRY(ix->d_status.reserve(1));
-  FS_TRY(ix->w_bsum.reserve(256));
+  FS_TRY(ix->w_bsum.reserve(2048));
+  FS_TRY(ix->w_bsum64.reserve(1024));
 
   // script ids padded by n so that device code may read a full window anywhere
   std::vector<uint32_t> stok(n_script + cfg->window_size + 1, 0u);
@@ -351,6 +353,11 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
     if (T) FS_HIP(hipMemcpyAsync(c->d_str.p, tok_str, T * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
   }
   FS_TRY(c->d_work_off.upload(work_off, n_works + 1, ix->stream));
+  {
+    const uint32_t n_blocks = (uint32_t)((T + 255) / 256);
+    FS_TRY(c->d_blk_work.reserve(n_blocks));
+    FS_TRY(fs_launch_blk_work(c->d_work_off.p, (uint32_t)n_works, n_blocks, c->d_blk_work.p, ix->stream));
+  }
   FS_TRY(c->d_chars.upload(str_chars, n_str ? str_off[n_str] : 0, ix->stream));
   {
     std::vector<uint64_t> coff(n_str + 1, 0);
@@ -395,40 +402,30 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
   const uint32_t n_bm = (uint32_t)((T + 255) / 256);
   const uint32_t nn = ix->cfg.nearest_n;
   // capacities: grown from the device totals when a stage overflows
-  uint64_t qcap = std::max<uint64_t>(4096, T / 8);
-  uint64_t hcap = std::max<uint64_t>(4096, T / 8);
-  uint64_t mcap = c->has_str ? std::max<uint64_t>(4096, T / 4) : 1;
-  uint64_t rcap = rows_on_device ? cap : std::max<uint64_t>(4096, T / 8);
-  qcap = std::max<uint64_t>(qcap, ix->w_qpos.n);
-  hcap = std::max<uint64_t>(hcap, ix->w_hit_p.n);
-  if (c->has_str) mcap = std::max<uint64_t>(mcap, ix->w_mlev.n);
-  if (!rows_on_device) rcap = std::max<uint64_t>(rcap, ix->w_rows.n);
+  uint64_t ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_cpos.n);
+  uint64_t rcap = rows_on_device ? cap
+                                 : std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_rows.n);
 
   float scan_ms = 0, total_ms = 0;
   uint32_t launches = 0;
   for (int attempt = 0; attempt < 8; ++attempt) {
-    FS_TRY(ix->w_qbm.reserve(n_bm));
-    FS_TRY(ix->w_off1.reserve(n_bm));
-    FS_TRY(ix->w_qpos.reserve(qcap));
-    FS_TRY(ix->w_hg.reserve(qcap * 4));
-    FS_TRY(ix->w_hw.reserve(qcap * 4));
-    FS_TRY(ix->w_hoff.reserve(qcap * 4));
-    FS_TRY(ix->w_hit_p.reserve(hcap));
-    FS_TRY(ix->w_hit_g.reserve(hcap));
-    FS_TRY(ix->w_hit_w.reserve(hcap));
-    FS_TRY(ix->w_roff.reserve(hcap));
-    FS_TRY(ix->w_moff.reserve(c->has_str ? hcap : 1));
-    FS_TRY(ix->w_mlev.reserve(mcap));
+    FS_TRY(ix->w_qbm.reserve((size_t)n_bm * 4));
+    FS_TRY(ix->w_qcnt.reserve(n_bm));
+    FS_TRY(ix->w_cpos.reserve(ccap));
+    FS_TRY(ix->w_cg.reserve(ccap));
+    FS_TRY(ix->w_cw.reserve(ccap));
+    FS_TRY(ix->w_mlev.reserve(c->has_str ? ccap * nn : 1));
+    FS_TRY(ix->w_cbest.reserve(c->has_str ? ccap : 1));
     fs_row* d_rows = rows;
     if (!rows_on_device) { FS_TRY(ix->w_rows.reserve(rcap)); d_rows = ix->w_rows.p; }
 
     FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
     FS_HIP(hipEventRecord(ix->ev_begin, s));
     FS_HIP(hipEventRecord(ix->ev_scan0, s));
-    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, n_bm, s));
+    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
     FS_HIP(hipEventRecord(ix->ev_scan1, s));
     ++launches;
-    FS_TRY(fs_launch_post(ix, c, n_bm, (uint32_t)qcap, (uint32_t)hcap, (uint32_t)mcap,
+    FS_TRY(fs_launch_post(ix, c, n_bm, (uint32_t)std::min<uint64_t>(ccap, 0xFFFFFFFFull),
                           (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFull), d_rows, s));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
     FS_HIP(hipEventRecord(ix->ev_end, s));
@@ -442,9 +439,7 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
       return FS_E_UNSUPPORTED;
     }
     bool again = false;
-    if (hs.n_quads > qcap) { qcap = (uint64_t)hs.n_quads + hs.n_quads / 8; again = true; }
-    else if (hs.n_hits > hcap) { hcap = (uint64_t)hs.n_hits + hs.n_hits / 8; again = true; }
-    else if (c->has_str && hs.n_matches > mcap) { mcap = hs.n_matches; again = true; }
+    if (hs.n_cands > ccap) { ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
     else if (!rows_on_device && hs.n_rows > rcap && hs.n_rows <= cap) { rcap = hs.n_rows; again = true; }
     if (!again) break;
     if (attempt == 7) { fs_set_error("workspace growth did not converge"); return FS_E_DEVICE; }
@@ -454,7 +449,7 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
   if (st) {
     memset(st, 0, sizeof *st);
     st->windows_processed = c->windows;
-    st->candidates = hs.n_cand_windows;
+    st->candidates = hs.n_cands;
     st->matches = hs.n_matches;
     st->rows = hs.n_rows;
     st->scan_ms = scan_ms;

@@ -64,14 +64,23 @@ struct DBuf {
 
 // Device-side totals and overflow flags of one search; read back in one copy.
 struct fs_status {
-  uint32_t n_quads;      // candidate 4-window groups flagged by the scan
+  uint32_t n_cands;      // filter-positive windows flagged by the scan
   uint32_t n_hits;       // verified (window, n-gram) hits inside a work
   uint32_t n_matches;    // (window, script window) pairs
   uint32_t n_rows;       // output records
-  uint32_t n_cand_windows;  // filter-positive windows (statistics)
+  uint32_t reserved0;
   uint32_t lev_overflow; // a Levenshtein operand exceeded FS_LEV_MAX
   uint32_t bad_string;   // string id outside the string table
   uint32_t pad;
+};
+
+// what one hit offers to the fan words of its window (first-minimum rank)
+struct fs_best {
+  uint32_t s;      // script position of the chosen rank
+  uint32_t lev;
+  double dist;
+  double comb;
+  double pad;
 };
 
 // Script-side exact n-gram index (device pointers + geometry), passed by value
@@ -96,6 +105,7 @@ struct CorpusDev {
   const uint32_t* tok;       // [n_tok + pad] vector ids
   const uint32_t* str;       // [n_tok] string ids or nullptr (== vector ids)
   const uint64_t* work_off;  // [n_works + 1]
+  const uint32_t* blk_work;  // [ceil(n_tok / 256)] work of token 256*i
   const uint32_t* chars;     // fan-side string table
   const uint64_t* coff;      // [n_str + 1]
   uint32_t n_tok;
@@ -121,9 +131,9 @@ struct fs_index {
   DBuf<double> d_normals;
 
   // workspaces (grow on demand)
-  DBuf<uint64_t> w_qbm;
-  DBuf<uint32_t> w_off1, w_qpos, w_hg, w_hw, w_hoff, w_hit_p, w_hit_g, w_hit_w;
-  DBuf<uint32_t> w_moff, w_mlev, w_roff, w_bsum;
+  DBuf<uint64_t> w_qbm, w_bsum64;
+  DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
+  DBuf<fs_best> w_cbest;
   DBuf<fs_row> w_rows;
   DBuf<fs_status> d_status;
   fs_status* h_status = nullptr;   // pinned
@@ -138,20 +148,22 @@ struct fs_corpus {
   uint64_t windows = 0;      // sum over works of max(0, len - n + 1)
   bool has_oov = false;
   bool has_str = false;
-  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab;
+  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab, d_blk_work;
   DBuf<uint64_t> d_work_off, d_coff;
+  DBuf<fs_best> d_gbest;
   bool levtab_ready = false;
   CorpusDev dev() const;
 };
 
 // ---- kernel launchers (fs_scan.hip / fs_post.hip / fs_build.hip) ----------
-int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm,
+int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                    uint32_t n_bm_words, hipStream_t s);
 uint32_t fs_scan_pad_tokens();
 
-int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_bm_words,
-                   uint32_t qcap, uint32_t hcap, uint32_t mcap, uint32_t rcap,
+int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
                    fs_row* d_rows, hipStream_t s);
+int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
+                       uint32_t* blk_work, hipStream_t s);
 
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 

@@ -1,7 +1,18 @@
-// fs_post.hip -- everything between the scan bitmap and the output records.
+// fs_post.hip -- everything between the scan's window bitmap and the output
+// records: five launches behind the scan, no host round trip.
 //
-//   quad bitmap --popcount/scan--> quad list --verify--> hits (window p, gram g,
-//   work w) --scan--> compact hit list --new-word counts/scan--> records
+//   k_reduce<SubTileCount>   per-block partial sums of the scan's sub-tile counts
+//   k_expand                 bitmap -> candidate window positions, in position
+//                            order (block prefix from the partial sums + an
+//                            in-block scan; one wave expands one sub-tile)
+//   k_verify                 candidate -> (n-gram id, work id) or FS_NONE: exact
+//                            id-for-id comparison with the script n-gram found
+//                            through the open-addressing table; windows that
+//                            cross a work boundary are dropped
+//   k_reduce<HitRows>        per-block (hits, records) partial sums
+//   k_rows                   per hit, the fan words it is first to cover; each
+//                            word's record is the first minimum of dist*lev
+//                            over all (hit, rank) pairs covering it
 //
 // Reference semantics reproduced here (file:line in /root/reference):
 //   search.py:182-184  keep candidates with distance < threshold: in the exact
@@ -14,18 +25,17 @@
 //   search.py:224-226  per fan word the FIRST record of minimal combined
 //                      distance, output sorted by word index
 // A window that crosses a work boundary is not a window of the reference
-// (windows are built per file, search.py:170-173); verify drops those.
+// (windows are built per file, search.py:170-173).
 //
-// No kernel here needs a host round trip: element counts live in the device
-// status block, every kernel is a grid-stride loop over a device-side count,
-// producers clamp to their buffer capacity and the host re-runs with larger
-// buffers if a total exceeded it.
+// Element counts live in the device status block; every kernel sizes its loops
+// from there, producers clamp to their buffer capacity and the host re-runs
+// with larger buffers if a total exceeded it.
 #include "fs_internal.h"
 
 namespace {
 
-constexpr int kScanBlocks = 256;
-constexpr int kScanThreads = 256;
+constexpr int kNB = 1024;        // blocks of every chunked kernel (and partial sums)
+constexpr int kThreads = 256;
 
 struct NSrc {               // element count, known on the host or on the device
   const uint32_t* ptr;      // device count (clamped to cap, times mult) ...
@@ -41,26 +51,28 @@ struct NSrc {               // element count, known on the host or on the device
 
 // ---- block-wide helpers ----------------------------------------------------
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+template <class V>
+__device__ __forceinline__ V wave_incl_scan(V v, int lane) {
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d);
+    V t = __shfl_up(v, d);
     if (lane >= d) v += t;
   }
   return v;
 }
 
 // exclusive scan of one value per thread over a 256-thread block; returns the
-// thread's exclusive prefix, *total = block sum.  s_w: 4 words of LDS.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, uint32_t* total) {
+// thread's exclusive prefix, *total = block sum.  s_w: 4 values of LDS.
+template <class V>
+__device__ __forceinline__ V block_excl_scan(V v, V* s_w, V* total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t inc = wave_incl_scan(v, lane);
+  const V inc = wave_incl_scan(v, lane);
   if (lane == 63) s_w[w] = inc;
   __syncthreads();
-  uint32_t base = 0, tot = 0;
+  V base = 0, tot = 0;
 #pragma unroll
-  for (int i = 0; i < kScanThreads / 64; ++i) {
-    const uint32_t x = s_w[i];
+  for (int i = 0; i < kThreads / 64; ++i) {
+    const V x = s_w[i];
     if (i < w) base += x;
     tot += x;
   }
@@ -69,176 +81,158 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* s_w, u
   return base + inc - v;
 }
 
-// ---- three-kernel exclusive scan over f(0..n) -------------------------------
+// sum of the partial sums of all blocks before this one, and of all blocks
+template <class V>
+__device__ __forceinline__ V block_prefix(const V* __restrict__ bsum, V* s_w, V* total) {
+  V pre = 0, all = 0;
+  for (int i = threadIdx.x; i < kNB; i += kThreads) {
+    const V x = bsum[i];
+    all += x;
+    if (i < (int)blockIdx.x) pre += x;
+  }
+  V t_all, t_pre;
+  block_excl_scan(all, s_w, &t_all);
+  block_excl_scan(pre, s_w, &t_pre);
+  *total = t_all;
+  return t_pre;
+}
 
-template <class F>
-__global__ __launch_bounds__(kScanThreads) void k_scan_reduce(F f, NSrc ns, uint32_t* bsum) {
-  __shared__ uint32_t s_w[4];
-  const uint32_t n = ns.get();
-  const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
-  const uint32_t lo = blockIdx.x * chunk;
-  uint32_t hi = lo + chunk;
-  if (hi > n) hi = n;
-  uint32_t acc = 0;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += kScanThreads) acc += f(i);
-  uint32_t tot;
+__device__ __forceinline__ void chunk_of_block(uint32_t n, uint32_t* lo, uint32_t* hi) {
+  const uint32_t chunk = (n + kNB - 1) / kNB;
+  const uint64_t l = (uint64_t)blockIdx.x * chunk;
+  *lo = l < n ? (uint32_t)l : n;
+  const uint64_t h = l + chunk;
+  *hi = h < n ? (uint32_t)h : n;
+}
+
+template <class F, class V>
+__global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict__ bsum) {
+  __shared__ V s_w[4];
+  uint32_t lo, hi;
+  chunk_of_block(ns.get(), &lo, &hi);
+  V acc = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += f(i);
+  V tot;
   block_excl_scan(acc, s_w, &tot);
   if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(kScanBlocks) void k_scan_mid(uint32_t* bsum, uint32_t* total) {
-  __shared__ uint32_t s_w[4];
-  uint32_t tot;
-  const uint32_t v = bsum[threadIdx.x];
-  const uint32_t ex = block_excl_scan(v, s_w, &tot);
-  bsum[threadIdx.x] = ex;
-  if (threadIdx.x == 0) *total = tot;
-}
-
-template <class F>
-__global__ __launch_bounds__(kScanThreads) void k_scan_down(F f, NSrc ns, const uint32_t* bsum,
-                                                            uint32_t* out) {
-  __shared__ uint32_t s_w[4];
-  const uint32_t n = ns.get();
-  const uint32_t chunk = (n + kScanBlocks - 1) / kScanBlocks;
-  const uint32_t lo = blockIdx.x * chunk;
-  uint32_t hi = lo + chunk;
-  if (hi > n) hi = n;
-  uint32_t carry = bsum[blockIdx.x];
-  for (uint32_t t = lo; t < hi; t += kScanThreads) {
-    const uint32_t i = t + threadIdx.x;
-    const uint32_t v = i < hi ? f(i) : 0;
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(v, s_w, &tot);
-    if (i < hi) out[i] = carry + ex;
-    carry += tot;
-  }
-}
-
-template <class F>
-int device_scan(F f, NSrc ns, uint32_t* out, uint32_t* bsum, uint32_t* total, hipStream_t s) {
-  hipLaunchKernelGGL(k_scan_reduce<F>, dim3(kScanBlocks), dim3(kScanThreads), 0, s, f, ns, bsum);
-  hipLaunchKernelGGL(k_scan_mid, dim3(1), dim3(kScanBlocks), 0, s, bsum, total);
-  hipLaunchKernelGGL(k_scan_down<F>, dim3(kScanBlocks), dim3(kScanThreads), 0, s, f, ns, bsum, out);
-  FS_HIP(hipGetLastError());
-  return FS_OK;
-}
-
 // ---- count functors -----------------------------------------------------------
 
-struct PopcountF {
-  const uint64_t* qbm;
-  __device__ uint32_t operator()(uint32_t i) const { return __popcll(qbm[i]); }
+struct SubTileCountF {
+  const uint32_t* qcnt;
+  __device__ uint32_t operator()(uint32_t i) const { return qcnt[i]; }
 };
-struct IsHitF {
-  const uint32_t* hg;
-  __device__ uint32_t operator()(uint32_t i) const { return hg[i] != FS_NONE; }
-};
-struct MatchCountF {
-  const uint32_t* hit_g;
-  const uint32_t* gcnt;
-  __device__ uint32_t operator()(uint32_t h) const { return gcnt[hit_g[h]]; }
-};
-// fan words first covered by hit h: the last min(n, p_h - p_{h-1}) words of its
-// window (hits are in ascending position; windows of different works are at
-// least n apart because a window never crosses a work boundary)
-struct NewWordsF {
-  const uint32_t* hit_p;
+
+// per candidate: low word 1 if it is a hit, high word = number of fan words the
+// hit is the first to cover: the last min(n, p - p_prev_hit) words of its window
+// (hits are in ascending position; a hit of another work is at least n away
+// because no window crosses a work boundary)
+struct HitRowsF {
+  const uint32_t* cpos;
+  const uint32_t* cg;
   uint32_t n;
-  __device__ uint32_t operator()(uint32_t h) const {
-    if (h == 0) return n;
-    const uint32_t d = hit_p[h] - hit_p[h - 1];
-    return d < n ? d : n;
+  __device__ uint64_t operator()(uint32_t c) const {
+    if (cg[c] == FS_NONE) return 0;
+    const uint32_t p = cpos[c];
+    uint32_t cnt = n;
+    for (uint32_t j = c; j-- > 0;) {
+      const uint32_t d = p - cpos[j];
+      if (d >= n) break;
+      if (cg[j] != FS_NONE) { cnt = d; break; }
+    }
+    return 1ull | ((uint64_t)cnt << 32);
   }
 };
 
 // ---- kernels --------------------------------------------------------------------
 
-__global__ void k_expand(const uint64_t* __restrict__ qbm, uint32_t n_words,
-                         const uint32_t* __restrict__ off1, uint32_t* __restrict__ qpos,
-                         uint32_t qcap) {
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_words;
-       i += gridDim.x * blockDim.x) {
-    uint64_t bits = qbm[i];
-    uint32_t idx = off1[i];
-    while (bits) {
-      const int b = __ffsll((unsigned long long)bits) - 1;
-      bits &= bits - 1;
-      if (idx < qcap) qpos[idx] = i * 256u + 4u * (uint32_t)b;
-      ++idx;
+__global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict__ qbm,
+                                                     const uint32_t* __restrict__ qcnt,
+                                                     uint32_t n_sub,
+                                                     const uint32_t* __restrict__ bsum,
+                                                     uint32_t* __restrict__ cpos, uint32_t ccap,
+                                                     fs_status* st) {
+  __shared__ uint32_t s_w[4];
+  uint32_t total;
+  uint32_t carry = block_prefix(bsum, s_w, &total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->n_cands = total;
+  uint32_t lo, hi;
+  chunk_of_block(n_sub, &lo, &hi);
+  for (uint32_t t0 = lo; t0 < hi; t0 += kThreads) {
+    const uint32_t sub = t0 + threadIdx.x;
+    const uint32_t cnt = sub < hi ? qcnt[sub] : 0;
+    uint32_t tile_total;
+    uint32_t idx = carry + block_excl_scan(cnt, s_w, &tile_total);
+    if (cnt) {
+      // windows in position order: lane L (tokens 4L..4L+3), then j
+      const uint64_t* w = qbm + (size_t)sub * 4;
+      const uint64_t b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3];
+      uint64_t any = b0 | b1 | b2 | b3;
+      while (any) {
+        const int L = __ffsll((unsigned long long)any) - 1;
+        any &= any - 1;
+        const uint32_t base = sub * 256u + 4u * (uint32_t)L;
+        if ((b0 >> L) & 1) { if (idx < ccap) cpos[idx] = base; ++idx; }
+        if ((b1 >> L) & 1) { if (idx < ccap) cpos[idx] = base + 1; ++idx; }
+        if ((b2 >> L) & 1) { if (idx < ccap) cpos[idx] = base + 2; ++idx; }
+        if ((b3 >> L) & 1) { if (idx < ccap) cpos[idx] = base + 3; ++idx; }
+      }
     }
+    carry += tile_total;
   }
 }
 
-// first index with work_off[idx] > p, minus one
-__device__ __forceinline__ uint32_t work_of(const uint64_t* work_off, uint32_t n_works, uint64_t p) {
-  uint32_t lo = 0, hi = n_works;   // invariant: work_off[lo] <= p < work_off[hi] (p < n_tok)
-  while (hi - lo > 1) {
-    const uint32_t mid = lo + ((hi - lo) >> 1);
-    if (work_off[mid] <= p) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
-__global__ void k_verify(CorpusDev c, GramIndexDev g, const uint32_t* __restrict__ qpos,
-                         NSrc nq4, uint32_t* __restrict__ hg, uint32_t* __restrict__ hw,
-                         fs_status* st) {
-  const uint32_t total = nq4.get();
+__global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g,
+                                                     const uint32_t* __restrict__ cpos,
+                                                     NSrc nc, uint32_t* __restrict__ cg,
+                                                     uint32_t* __restrict__ cw,
+                                                     uint32_t* __restrict__ bmatch) {
+  __shared__ uint32_t s_w[4];
+  const uint32_t total = nc.get();
   const uint32_t slot_mask = (1u << g.log2_slots) - 1;
-  uint32_t positives = 0;
+  uint32_t matches = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += gridDim.x * blockDim.x) {
-    const uint64_t p = (uint64_t)qpos[i >> 2] + (i & 3);
+    const uint64_t p = cpos[i];
     uint32_t gram = FS_NONE;
     if (p + g.n <= c.n_tok) {
       const uint32_t* t = c.tok + p;
-      uint32_t h = fs_premix(t[0]);
-      for (int k = 1; k < g.n; ++k) h = fs_fold(h, fs_premix(t[k]));
+      uint32_t ids[FS_MAX_WINDOW];
+#pragma unroll
+      for (int k = 0; k < FS_MAX_WINDOW; ++k) ids[k] = k < g.n ? t[k] : 0u;
+      uint32_t h = fs_premix(ids[0]);
+#pragma unroll
+      for (int k = 1; k < FS_MAX_WINDOW; ++k)
+        if (k < g.n) h = fs_fold(h, fs_premix(ids[k]));
       h = fs_finish(h);
-      const uint32_t word = g.filter[fs_bloom_word(h, g.log2_words)];
-      const uint32_t mask = fs_bloom_mask(h);
-      if ((word & mask) == mask) {
-        ++positives;
-        uint32_t slot = fs_table_slot(h, g.log2_slots);
-        for (;;) {
-          const uint32_t e = g.table[slot];
-          if (e == 0) break;
-          const uint32_t* s = g.stok + g.gpos[(size_t)(e - 1) * g.nn];
-          bool same = true;
-          for (int k = 0; k < g.n; ++k) same = same && (s[k] == t[k]);
-          if (same) { gram = e - 1; break; }
-          slot = (slot + 1) & slot_mask;
-        }
+      uint32_t slot = fs_table_slot(h, g.log2_slots);
+      for (;;) {
+        const uint32_t e = g.table[slot];
+        if (e == 0) break;
+        const uint32_t* s = g.stok + g.gpos[(size_t)(e - 1) * g.nn];
+        bool same = true;
+#pragma unroll
+        for (int k = 0; k < FS_MAX_WINDOW; ++k)
+          if (k < g.n) same = same && (s[k] == ids[k]);
+        if (same) { gram = e - 1; break; }
+        slot = (slot + 1) & slot_mask;
       }
       if (gram != FS_NONE) {
-        const uint32_t w = work_of(c.work_off, c.n_works, p);
+        // work of token p: start from the work of its 256-token block
+        uint32_t w = c.blk_work[p >> 8];
+        while (c.work_off[w + 1] <= p) ++w;
         if (p + g.n > c.work_off[w + 1]) gram = FS_NONE;   // crosses into the next work
-        else hw[i] = w;
+        else { cw[i] = w; matches += g.gcnt[gram]; }
       }
     }
-    hg[i] = gram;
+    cg[i] = gram;
   }
-  // statistics: filter-positive windows
-  for (int d = 32; d > 0; d >>= 1) positives += __shfl_xor(positives, d);
-  if ((threadIdx.x & 63) == 0 && positives) atomicAdd(&st->n_cand_windows, positives);
-}
-
-__global__ void k_compact(const uint32_t* __restrict__ qpos, NSrc nq4,
-                          const uint32_t* __restrict__ hg, const uint32_t* __restrict__ hw,
-                          const uint32_t* __restrict__ hoff, uint32_t hcap,
-                          uint32_t* __restrict__ hit_p, uint32_t* __restrict__ hit_g,
-                          uint32_t* __restrict__ hit_w) {
-  const uint32_t total = nq4.get();
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += gridDim.x * blockDim.x) {
-    const uint32_t gram = hg[i];
-    if (gram == FS_NONE) continue;
-    const uint32_t idx = hoff[i];
-    if (idx >= hcap) continue;
-    hit_p[idx] = qpos[i >> 2] + (i & 3);
-    hit_g[idx] = gram;
-    hit_w[idx] = hw[i];
-  }
+  // (window, script window) pairs of this block; summed by k_rows (a single
+  // counter would serialise thousands of same-address atomics)
+  uint32_t tot;
+  block_excl_scan(matches, s_w, &tot);
+  if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
 }
 
 // Levenshtein.distance(match_str, fan_context), search.py:189-190:
@@ -251,8 +245,7 @@ __device__ uint32_t lev_device(const GramIndexDev& g, uint32_t s, const uint32_t
   uint32_t a[FS_LEV_MAX], b[FS_LEV_MAX];
   uint16_t row[FS_LEV_MAX + 1];
   uint32_t la = 0, lb = 0;
-  bool ok = true;
-  for (int k = 0; k < g.n && ok; ++k) {
+  for (int k = 0; k < g.n; ++k) {
     if (k) { if (la < FS_LEV_MAX) a[la] = ' '; ++la; }
     for (uint64_t c = g.soff[s + k]; c < g.soff[s + k + 1]; ++c) {
       if (la < FS_LEV_MAX) a[la] = g.schars[c];
@@ -267,7 +260,7 @@ __device__ uint32_t lev_device(const GramIndexDev& g, uint32_t s, const uint32_t
       if (lb < FS_LEV_MAX) b[lb] = ' '; ++lb;
     }
     const uint32_t sid = fan_sid[k];
-    if (sid >= n_str) { st->bad_string = 1; ok = false; break; }
+    if (sid >= n_str) { st->bad_string = 1; return 0; }
     for (uint64_t c = coff[sid]; c < coff[sid + 1]; ++c) {
       if (lb < FS_LEV_MAX) b[lb] = chars[c];
       ++lb;
@@ -275,7 +268,6 @@ __device__ uint32_t lev_device(const GramIndexDev& g, uint32_t s, const uint32_t
   }
   if (lb < FS_LEV_MAX) b[lb] = ']';
   ++lb;
-  if (!ok) return 0;
   if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { st->lev_overflow = 1; return 0; }
   for (uint32_t j = 0; j <= lb; ++j) row[j] = (uint16_t)j;
   for (uint32_t x = 1; x <= la; ++x) {
@@ -313,144 +305,217 @@ __global__ void k_levtab(GramIndexDev g, CorpusDev c, uint32_t* __restrict__ lev
   }
 }
 
-// Per match Levenshtein when fan tokens carry their own string ids.
-__global__ void k_matchlev(GramIndexDev g, CorpusDev c, const uint32_t* __restrict__ hit_p,
-                           const uint32_t* __restrict__ hit_g, const uint32_t* __restrict__ moff,
-                           NSrc nh_nn, uint32_t mcap, uint32_t* __restrict__ mlev,
-                           fs_status* st) {
-  const uint32_t total = nh_nn.get();
+// Per (candidate, rank) Levenshtein when fan tokens carry their own string ids.
+__global__ void k_matchlev(GramIndexDev g, CorpusDev c, const uint32_t* __restrict__ cpos,
+                           const uint32_t* __restrict__ cg, NSrc nc_nn,
+                           uint32_t* __restrict__ mlev, fs_status* st) {
+  const uint32_t total = nc_nn.get();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += gridDim.x * blockDim.x) {
-    const uint32_t h = i / g.nn, r = i % g.nn;
-    const uint32_t gram = hit_g[h];
-    if (r >= g.gcnt[gram]) continue;
-    const uint32_t idx = moff[h] + r;
-    if (idx >= mcap) continue;
+    const uint32_t cand = i / g.nn, r = i % g.nn;
+    const uint32_t gram = cg[cand];
+    if (gram == FS_NONE || r >= g.gcnt[gram]) continue;
     const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
-    mlev[idx] = lev_device(g, s, c.str + hit_p[h], c.chars, c.coff, c.n_str, st);
+    mlev[i] = lev_device(g, s, c.str + cpos[cand], c.chars, c.coff, c.n_str, st);
   }
 }
 
-// One thread per (hit, k): the k-th fan word first covered by hit h.  Its record
-// is the first minimum of dist*lev over every (hit, rank) whose window covers
-// the word, in the reference's insertion order: ascending window position, then
-// NearestFilter rank (search.py:176-218, 224-225).
-__global__ void k_rows(GramIndexDev g, CorpusDev c, const uint32_t* __restrict__ hit_p,
-                       const uint32_t* __restrict__ hit_g, const uint32_t* __restrict__ hit_w,
-                       const uint32_t* __restrict__ roff, const uint32_t* __restrict__ levtab,
-                       const uint32_t* __restrict__ moff, const uint32_t* __restrict__ mlev,
-                       const uint32_t* n_hits_ptr, uint32_t hcap, uint32_t rcap,
-                       fs_row* __restrict__ rows) {
-  uint32_t nh = *n_hits_ptr;
-  if (nh > hcap) nh = hcap;
-  const uint32_t n = g.n;
-  const uint32_t total = nh * n;
+// The record a hit offers to every fan word of its window: the first minimum of
+// dist*lev over its NearestFilter ranks (all ranks of one hit precede all ranks
+// of the next in the reference's insertion order, so the per-word first minimum
+// over (hit, rank) pairs equals the first minimum over hits of this record).
+//   levs: lev[rank] of the gram (levtab mode) or of the candidate (mlev mode)
+__device__ __forceinline__ fs_best best_of_ranks(const GramIndexDev& g, uint32_t gram,
+                                                 const uint32_t* levs) {
+  fs_best b;
+  const uint32_t m = g.gcnt[gram];
+  b.s = 0; b.lev = 0; b.dist = 0.0; b.comb = 0.0;
+  for (uint32_t r = 0; r < m; ++r) {
+    const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
+    const double dist = g.selfdist[s];
+    const double comb = __dmul_rn(dist, (double)levs[r]);
+    if (r == 0 || comb < b.comb) { b.s = s; b.lev = levs[r]; b.dist = dist; b.comb = comb; }
+  }
+  return b;
+}
+
+__global__ void k_gbest(GramIndexDev g, const uint32_t* __restrict__ levtab,
+                        fs_best* __restrict__ gbest) {
+  for (uint32_t gram = blockIdx.x * blockDim.x + threadIdx.x; gram < g.n_grams;
+       gram += gridDim.x * blockDim.x)
+    gbest[gram] = best_of_ranks(g, gram, levtab + (size_t)gram * g.nn);
+}
+
+__global__ void k_cbest(GramIndexDev g, const uint32_t* __restrict__ cg,
+                        const uint32_t* __restrict__ mlev, NSrc nc, fs_best* __restrict__ cbest) {
+  const uint32_t total = nc.get();
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += gridDim.x * blockDim.x) {
-    const uint32_t h = i / n, k = i % n;
-    const uint32_t p = hit_p[h];
-    uint32_t cnt = n;
-    if (h) { const uint32_t d = p - hit_p[h - 1]; if (d < n) cnt = d; }
-    if (k >= cnt) continue;
-    const uint32_t ridx = roff[h] + k;
-    if (ridx >= rcap) continue;
-    const uint32_t x = p + n - cnt + k;           // global token position of the word
-    bool have = false;
-    fs_row best;
-    for (uint32_t h2 = h; h2 < nh; ++h2) {
-      const uint32_t p2 = hit_p[h2];
-      if (p2 > x) break;
-      const uint32_t gram = hit_g[h2];
-      const uint32_t m = g.gcnt[gram];
-      for (uint32_t r = 0; r < m; ++r) {
-        const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
-        const uint32_t lv = levtab ? levtab[(size_t)gram * g.nn + r] : mlev[moff[h2] + r];
-        const double dist = g.selfdist[s];
-        const double comb = __dmul_rn(dist, (double)lv);
-        if (!have || comb < best.comb) {
+    const uint32_t gram = cg[i];
+    if (gram != FS_NONE) cbest[i] = best_of_ranks(g, gram, mlev + (size_t)i * g.nn);
+  }
+}
+
+// Records.  Per 256-candidate tile a block scan gives every hit the offset of
+// the fan words it is the first to cover; the tile's records are then computed
+// one per thread.  A word's record is the first minimum of dist*lev over every
+// hit whose window covers the word, in the reference's insertion order
+// (ascending window position; search.py:176-218, 224-225), each hit offering
+// its best rank (best_of_ranks).
+__global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
+                                                   const uint32_t* __restrict__ cpos,
+                                                   const uint32_t* __restrict__ cg,
+                                                   const uint32_t* __restrict__ cw,
+                                                   const uint64_t* __restrict__ bsum,
+                                                   const uint32_t* __restrict__ bmatch,
+                                                   const fs_best* __restrict__ best_tab,
+                                                   int best_per_cand, NSrc nc, uint32_t rcap,
+                                                   fs_row* __restrict__ rows, fs_status* st) {
+  __shared__ uint64_t s_w[4];
+  __shared__ uint32_t s_w32[4];
+  __shared__ uint32_t s_roff[kThreads];
+  uint64_t total;
+  uint64_t carry = block_prefix(bsum, s_w, &total);
+  if (blockIdx.x == 0) {
+    uint32_t m = 0, mt;
+    for (int i = threadIdx.x; i < kNB; i += kThreads) m += bmatch[i];
+    block_excl_scan(m, s_w32, &mt);
+    if (threadIdx.x == 0) {
+      st->n_hits = (uint32_t)total;
+      st->n_rows = (uint32_t)(total >> 32);
+      st->n_matches = mt;
+    }
+  }
+  const uint32_t NC = nc.get();
+  const uint32_t n = g.n;
+  const HitRowsF f{cpos, cg, n};
+  uint32_t lo, hi;
+  chunk_of_block(NC, &lo, &hi);
+  for (uint32_t t0 = lo; t0 < hi; t0 += kThreads) {
+    const uint32_t i = t0 + threadIdx.x;
+    const uint64_t v = i < hi ? f(i) : 0;
+    uint64_t tile_total;
+    const uint64_t ex = block_excl_scan(v, s_w, &tile_total);
+    s_roff[threadIdx.x] = (uint32_t)(ex >> 32);
+    __syncthreads();
+    const uint32_t tile_rows = (uint32_t)(tile_total >> 32);
+    const uint32_t rbase = (uint32_t)(carry >> 32);
+    for (uint32_t r = threadIdx.x; r < tile_rows; r += kThreads) {
+      // owner: last tile entry whose exclusive offset is <= r (a hit: entries
+      // that are not hits share the offset of the hit that follows them)
+      uint32_t a = 0, b = kThreads;
+      while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (s_roff[mid] <= r) a = mid; else b = mid;
+      }
+      const uint32_t own = t0 + a;
+      const uint32_t k = r - s_roff[a];
+      const uint32_t ridx = rbase + r;
+      if (ridx >= rcap) continue;
+      const uint32_t p = cpos[own];
+      // words first covered by `own`: the last cnt of its window; cnt from the
+      // next entry's offset
+      const uint32_t next_off = a + 1 < kThreads ? s_roff[a + 1] : tile_rows;
+      const uint32_t cnt = next_off - s_roff[a];
+      const uint32_t x = p + n - cnt + k;          // global token position of the word
+      bool have = false;
+      fs_row out;
+      for (uint32_t j = own; j < NC; ++j) {
+        const uint32_t p2 = cpos[j];
+        if (p2 > x) break;
+        const uint32_t gram = cg[j];
+        if (gram == FS_NONE) continue;
+        const fs_best bb = best_tab[best_per_cand ? j : gram];
+        if (!have || bb.comb < out.comb) {
           have = true;
-          best.orig_ix = s + (x - p2);
-          best.lev = lv;
-          best.dist = dist;
-          best.comb = comb;
+          out.orig_ix = bb.s + (x - p2);
+          out.lev = bb.lev;
+          out.dist = bb.dist;
+          out.comb = bb.comb;
         }
       }
+      const uint32_t w = cw[own];
+      out.work = w;
+      out.fan_ix = (uint32_t)((uint64_t)x - c.work_off[w]);
+      rows[ridx] = out;
     }
-    const uint32_t w = hit_w[h];
-    best.work = w;
-    best.fan_ix = (uint32_t)((uint64_t)x - c.work_off[w]);
-    rows[ridx] = best;
+    __syncthreads();
+    carry += tile_total;
   }
 }
 
-__global__ void k_count_matches(const uint32_t* __restrict__ hit_g,
-                                const uint32_t* __restrict__ gcnt, const uint32_t* n_hits_ptr,
-                                uint32_t hcap, fs_status* st) {
-  uint32_t nh = *n_hits_ptr;
-  if (nh > hcap) nh = hcap;
-  uint32_t acc = 0;
-  for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < nh; h += gridDim.x * blockDim.x)
-    acc += gcnt[hit_g[h]];
-  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
-  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&st->n_matches, acc);
+// work id of the first token of every 256-token block (corpus build time)
+__global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_works,
+                           uint32_t n_blocks, uint32_t* __restrict__ blk_work) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_blocks) return;
+  const uint64_t p = (uint64_t)b * 256;
+  uint32_t lo = 0, hi = n_works;   // work_off[lo] <= p < work_off[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + ((hi - lo) >> 1);
+    if (work_off[mid] <= p) lo = mid; else hi = mid;
+  }
+  blk_work[b] = lo;
 }
 
 }  // namespace
 
+int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
+                       uint32_t* blk_work, hipStream_t s) {
+  if (!n_blocks || !n_works) return FS_OK;
+  hipLaunchKernelGGL(k_blk_work, dim3((n_blocks + 255) / 256), dim3(256), 0, s, work_off, n_works,
+                     n_blocks, blk_work);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   const size_t total = (size_t)ix->n_grams * ix->cfg.nearest_n;
   FS_TRY(c->d_levtab.reserve(total));
+  FS_TRY(c->d_gbest.reserve(ix->n_grams));
   if (total) {
     const uint32_t blocks = (uint32_t)((total + 255) / 256);
     hipLaunchKernelGGL(k_levtab, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s,
                        ix->gram_dev(), c->dev(), c->d_levtab.p, ix->d_status.p);
+    const uint32_t gb = (ix->n_grams + 255) / 256;
+    hipLaunchKernelGGL(k_gbest, dim3(gb > 1024 ? 1024 : gb), dim3(256), 0, s, ix->gram_dev(),
+                       c->d_levtab.p, c->d_gbest.p);
     FS_HIP(hipGetLastError());
   }
   return FS_OK;
 }
 
-int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_bm_words, uint32_t qcap,
-                   uint32_t hcap, uint32_t mcap, uint32_t rcap, fs_row* d_rows, hipStream_t s) {
+int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
+                   fs_row* d_rows, hipStream_t s) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->d_status.p;
-  uint32_t* bsum = ix->w_bsum.p;
+  uint32_t* bsum32 = ix->w_bsum.p;
+  uint32_t* bmatch = ix->w_bsum.p + kNB;
+  uint64_t* bsum64 = ix->w_bsum64.p;
   const uint32_t nn = ix->cfg.nearest_n;
   const uint32_t n = ix->cfg.window_size;
-  const bool use_levtab = !c->has_str;
-  const int grid = ix->num_cu * 4;
+  const bool per_cand = c->has_str;
 
-  // 1. quads
-  FS_TRY(device_scan(PopcountF{ix->w_qbm.p}, NSrc{nullptr, 0, 0, n_bm_words}, ix->w_off1.p, bsum,
-                     &st->n_quads, s));
-  if (n_bm_words) {
-    hipLaunchKernelGGL(k_expand, dim3(grid), dim3(256), 0, s, ix->w_qbm.p, n_bm_words,
-                       ix->w_off1.p, ix->w_qpos.p, qcap);
+  hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
+                     SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32);
+  hipLaunchKernelGGL(k_expand, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p, n_sub,
+                     bsum32, ix->w_cpos.p, ccap, st);
+  const NSrc nc{&st->n_cands, 1, ccap, 0};
+  hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->w_cpos.p, nc,
+                     ix->w_cg.p, ix->w_cw.p, bmatch);
+  if (per_cand) {
+    const NSrc nc_nn{&st->n_cands, nn, ccap, 0};
+    hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->w_cpos.p,
+                       ix->w_cg.p, nc_nn, ix->w_mlev.p, st);
+    hipLaunchKernelGGL(k_cbest, dim3(kNB), dim3(kThreads), 0, s, g, ix->w_cg.p, ix->w_mlev.p, nc,
+                       ix->w_cbest.p);
   }
-  // 2. verify the four windows of every quad
-  const NSrc nq4{&st->n_quads, 4, qcap, 0};
-  hipLaunchKernelGGL(k_verify, dim3(grid), dim3(256), 0, s, cd, g, ix->w_qpos.p, nq4, ix->w_hg.p,
-                     ix->w_hw.p, st);
-  FS_TRY(device_scan(IsHitF{ix->w_hg.p}, nq4, ix->w_hoff.p, bsum, &st->n_hits, s));
-  hipLaunchKernelGGL(k_compact, dim3(grid), dim3(256), 0, s, ix->w_qpos.p, nq4, ix->w_hg.p,
-                     ix->w_hw.p, ix->w_hoff.p, hcap, ix->w_hit_p.p, ix->w_hit_g.p, ix->w_hit_w.p);
-  // 3. matches
-  const NSrc nh{&st->n_hits, 1, hcap, 0};
-  if (use_levtab) {
-    hipLaunchKernelGGL(k_count_matches, dim3(grid), dim3(256), 0, s, ix->w_hit_g.p, ix->d_gcnt.p,
-                       &st->n_hits, hcap, st);
-  } else {
-    FS_TRY(device_scan(MatchCountF{ix->w_hit_g.p, ix->d_gcnt.p}, nh, ix->w_moff.p, bsum,
-                       &st->n_matches, s));
-    const NSrc nh_nn{&st->n_hits, nn, hcap, 0};
-    hipLaunchKernelGGL(k_matchlev, dim3(grid), dim3(256), 0, s, g, cd, ix->w_hit_p.p,
-                       ix->w_hit_g.p, ix->w_moff.p, nh_nn, mcap, ix->w_mlev.p, st);
-  }
-  // 4. records
-  FS_TRY(device_scan(NewWordsF{ix->w_hit_p.p, n}, nh, ix->w_roff.p, bsum, &st->n_rows, s));
-  hipLaunchKernelGGL(k_rows, dim3(grid), dim3(256), 0, s, g, cd, ix->w_hit_p.p, ix->w_hit_g.p,
-                     ix->w_hit_w.p, ix->w_roff.p, use_levtab ? c->d_levtab.p : nullptr,
-                     ix->w_moff.p, ix->w_mlev.p, &st->n_hits, hcap, rcap, d_rows);
+  hipLaunchKernelGGL((k_reduce<HitRowsF, uint64_t>), dim3(kNB), dim3(kThreads), 0, s,
+                     HitRowsF{ix->w_cpos.p, ix->w_cg.p, n}, nc, bsum64);
+  hipLaunchKernelGGL(k_rows, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->w_cpos.p, ix->w_cg.p,
+                     ix->w_cw.p, bsum64, bmatch, per_cand ? ix->w_cbest.p : c->d_gbest.p,
+                     per_cand ? 1 : 0, nc, rcap, d_rows, st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -12,13 +12,13 @@
 //     permute by letting the low lanes publish the next vector
 //   * per window: rolling fold of premixed ids, finalise, one ds_read_b32 of
 //     the LDS-resident blocked Bloom filter, three-bit test
-//   * OR of the lane's four window flags -> __ballot -> lane 0 stores one
-//     64-bit word: bit L of word i says "some window starting in tokens
-//     [256 i + 4L, 256 i + 4L + 4) may be a script n-gram"
-// No atomics, no inter-workgroup traffic, output order is position order, so
-// the result is deterministic; exact verification happens downstream on the
-// (rare) flagged quads.  Algorithmic HBM traffic: 4 B read per token +
-// 1/32 B written per token.
+//   * four __ballot words per sub-tile: bit L of word 4 i + j says "the window
+//     starting at token 256 i + 4 L + j may be a script n-gram"; lanes 0..3
+//     store them, lane 0 also stores the sub-tile's popcount
+// No atomics, no inter-workgroup traffic, the output position is a function of
+// the token position, so the result is deterministic; exact verification
+// happens downstream on the (rare) flagged windows.  Algorithmic HBM traffic:
+// 4 B read per token + 36 B written per 256 tokens.
 #include "fs_internal.h"
 
 #include <stdlib.h>
@@ -28,6 +28,19 @@ namespace {
 constexpr int kWave = 64;
 constexpr int kTokPerLane = 4;
 constexpr int kSubTile = kWave * kTokPerLane;   // 256 tokens per bitmap word
+
+// flags: bit j = window 4*lane + j of sub-tile `word` is filter-positive
+__device__ __forceinline__ void store_flags(uint32_t flags, int lane, uint32_t word,
+                                            uint32_t n_bm_words, uint64_t* __restrict__ qbm,
+                                            uint32_t* __restrict__ qcnt) {
+  const uint64_t b0 = __ballot(flags & 1u), b1 = __ballot(flags & 2u);
+  const uint64_t b2 = __ballot(flags & 4u), b3 = __ballot(flags & 8u);
+  if (word < n_bm_words && lane < 4) {
+    const uint64_t mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    qbm[(size_t)word * 4 + lane] = mine;
+    if (lane == 0) qcnt[word] = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+  }
+}
 
 template <int N>
 __device__ __forceinline__ uint32_t window_flags(const uint32_t* a, const uint32_t* s_filter,
@@ -53,6 +66,7 @@ template <int N, int U>
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok, uint32_t n_tok,
                                                const uint32_t* __restrict__ filter,
                                                int log2_words, uint64_t* __restrict__ qbm,
+                                               uint32_t* __restrict__ qcnt,
                                                uint32_t n_bm_words, uint32_t n_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   {
@@ -106,9 +120,7 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
         for (int j = 0; j < 4; ++j)
           if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
       }
-      const uint64_t bal = __ballot(flags != 0);
-      const uint32_t word = tile * U + u;
-      if (lane == 0 && word < n_bm_words) qbm[word] = bal;
+      store_flags(flags, lane, tile * U + u, n_bm_words, qbm, qcnt);
     }
   }
 }
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
                                                       const uint32_t* __restrict__ filter,
                                                       int log2_words, int n,
                                                       uint64_t* __restrict__ qbm,
+                                                      uint32_t* __restrict__ qcnt,
                                                       uint32_t n_bm_words) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   for (uint32_t i = threadIdx.x; i < (1u << log2_words); i += blockDim.x) s_filter[i] = filter[i];
@@ -141,14 +154,13 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
       const uint32_t m = fs_bloom_mask(h);
       if ((w & m) == m) flags |= 1u << j;
     }
-    const uint64_t bal = __ballot(flags != 0);
-    if (lane == 0) qbm[word] = bal;
+    store_flags(flags, lane, word, n_bm_words, qbm, qcnt);
   }
 }
 
 template <int N, int U>
-int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t n_bm_words,
-                hipStream_t s) {
+int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                uint32_t n_bm_words, hipStream_t s) {
   const uint32_t tile_tok = kSubTile * U;
   const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
   if (n_tiles == 0) return FS_OK;
@@ -163,19 +175,19 @@ int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t 
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, c.tok, c.n_tok,
-                     ix->d_filter.p, ix->log2_words, qbm, n_bm_words, n_tiles);
+                     ix->d_filter.p, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 template <int N>
-int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t n_bm_words,
-                  hipStream_t s, int unroll) {
+int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                  uint32_t n_bm_words, hipStream_t s, int unroll) {
   switch (unroll) {
-    case 1: return launch_fast<N, 1>(ix, c, qbm, n_bm_words, s);
-    case 2: return launch_fast<N, 2>(ix, c, qbm, n_bm_words, s);
-    case 8: return launch_fast<N, 8>(ix, c, qbm, n_bm_words, s);
-    default: return launch_fast<N, 4>(ix, c, qbm, n_bm_words, s);
+    case 1: return launch_fast<N, 1>(ix, c, qbm, qcnt, n_bm_words, s);
+    case 2: return launch_fast<N, 2>(ix, c, qbm, qcnt, n_bm_words, s);
+    case 8: return launch_fast<N, 8>(ix, c, qbm, qcnt, n_bm_words, s);
+    default: return launch_fast<N, 4>(ix, c, qbm, qcnt, n_bm_words, s);
   }
 }
 
@@ -185,8 +197,8 @@ int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
 // tile loads of the last wave never leave the allocation
 uint32_t fs_scan_pad_tokens() { return kSubTile * 8 + 64; }
 
-int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t n_bm_words,
-                   hipStream_t s) {
+int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                   uint32_t n_bm_words, hipStream_t s) {
   const int n = ix->cfg.window_size;
   const char* var = getenv("FS_SCAN_VARIANT");
   const bool simple = var && var[0] == 's';
@@ -200,15 +212,15 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   }
   if (!simple) {
     switch (n) {
-      case 2: return launch_fast_u<2>(ix, c, qbm, n_bm_words, s, unroll);
-      case 3: return launch_fast_u<3>(ix, c, qbm, n_bm_words, s, unroll);
-      case 4: return launch_fast_u<4>(ix, c, qbm, n_bm_words, s, unroll);
-      case 5: return launch_fast_u<5>(ix, c, qbm, n_bm_words, s, unroll);
-      case 6: return launch_fast_u<6>(ix, c, qbm, n_bm_words, s, unroll);
-      case 7: return launch_fast_u<7>(ix, c, qbm, n_bm_words, s, unroll);
-      case 8: return launch_fast_u<8>(ix, c, qbm, n_bm_words, s, unroll);
-      case 10: return launch_fast_u<10>(ix, c, qbm, n_bm_words, s, unroll);
-      case 12: return launch_fast_u<12>(ix, c, qbm, n_bm_words, s, unroll);
+      case 2: return launch_fast_u<2>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 3: return launch_fast_u<3>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 4: return launch_fast_u<4>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 5: return launch_fast_u<5>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 6: return launch_fast_u<6>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 7: return launch_fast_u<7>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 8: return launch_fast_u<8>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 10: return launch_fast_u<10>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 12: return launch_fast_u<12>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
       default: break;
     }
   }
@@ -220,7 +232,7 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   const uint32_t max_blocks = ix->num_cu * (lds <= 64 * 1024 ? 2 : 1);
   if (blocks > max_blocks) blocks = max_blocks;
   hipLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(1024), lds, s, c.tok, c.n_tok,
-                     ix->d_filter.p, ix->log2_words, n, qbm, n_bm_words);
+                     ix->d_filter.p, ix->log2_words, n, qbm, qcnt, n_bm_words);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

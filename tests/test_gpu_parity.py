@@ -81,3 +81,31 @@ def test_c2_slice(synth_base):
     """600 works of BASELINE.json configs[1] (2000 tokens, 20k-token script)."""
     got, st = _case(synth_base, [2000] * 600, 20000)
     assert st.scan_ms > 0
+
+
+def test_separate_string_ids(synth_base):
+    """Fan tokens whose text differs from the text of their vector row (the
+    reference's fan side is case-sensitive, the script side lower-cased:
+    search.py:151 vs :166): string ids travel next to vector ids and the
+    Levenshtein distance is computed per match."""
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+    words, emb = synth_base["words"], synth_base["emb"]
+    n = 6
+    normals = synth.lsh_normals(n)
+    script = synth.script_tokens(3000)
+    tok, off = util.ragged_corpus([700] * 25 + [0, 9, 1300], script)
+    rng = np.random.default_rng(5)
+    # string table: lower-case words, then Capitalised, then UPPER + '!!'
+    strings = list(words) + [w.capitalize() for w in words] + [w.upper() + "!!" for w in words]
+    variant = rng.integers(0, 3, size=len(tok)).astype(np.uint32)
+    tok_str = (tok + variant * len(words)).astype(np.uint32)
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config(window_size=n)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=cfg)
+    got, st = ix.search(ix.corpus(tok, off, chars, coff, tok_str=tok_str))
+    oi = util.oracle_index(cfg, script, words, emb, normals)
+    want, ost = oi.search(tok, off, chars, coff, tok_str=tok_str)
+    util.assert_rows_equal(got, want)
+    assert len(set(got["lev"].tolist())) > 3      # text variants change the distance
+    assert st.matches == ost.matches
