@@ -1,0 +1,76 @@
+"""Command line of the search path: the `search`, `matrix` and `validate`
+sub-commands of the reference's ao3.py (/root/reference/ao3.py:509-519 and
+_deprecated.py:83-89), same positionals, flags and output files.  The
+reference's scrape / clean / getmeta / format / vis sub-commands are outside
+this package (out of scope)."""
+
+import argparse
+import sys
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(
+        description='n-gram text-reuse search of fan works against a script '
+                    '(MI355X build of the `ao3.py search` path).')
+    subparsers = parser.add_subparsers(help='search, matrix or validate')
+
+    validate_parser = subparsers.add_parser('validate', help='validate script markup')
+    validate_parser.add_argument('script', action='store',
+                                 help='filename for markup version of script')
+    validate_parser.set_defaults(func=_validate)
+
+    search_parser = subparsers.add_parser(
+        'search', help='compare fanworks with the original script')
+    search_parser.add_argument('fan_works', action='store',
+                               help='directory of fanwork text files')
+    search_parser.add_argument('script', action='store',
+                               help='filename for markup version of script')
+    search_parser.add_argument('-n', '--num-works', default=-1, type=int,
+                               help="number of works to search (for subsampling)")
+    search_parser.add_argument('-s', '--skip-works', default=0, type=int,
+                               help="number of works to skip (for subsampling)")
+    # additions; defaults reproduce the reference's behaviour
+    search_parser.add_argument('--window-size', default=None, type=int,
+                               help='n-gram size (reference: fixed at 6)')
+    search_parser.add_argument('--device', default=0, type=int,
+                               help='HIP device ordinal')
+    search_parser.set_defaults(func=_search)
+
+    matrix_parser = subparsers.add_parser(
+        'matrix', help='deduplicates and builds matrix for best n-gram matches')
+    matrix_parser.add_argument('i', action='store', help='input csv file')
+    matrix_parser.add_argument('m', action='store',
+                               help='fandom/movie name for output file prefix')
+    matrix_parser.add_argument('-n', action='store', default=6, type=int,
+                               help='n-gram size, default is 6-grams')
+    matrix_parser.set_defaults(func=_matrix)
+    return parser
+
+
+def _validate(args):
+    from . import search
+    return search.validate_cmd(args)
+
+
+def _search(args):
+    from . import search
+    return search.analyze(args)
+
+
+def _matrix(args):
+    from . import matrix
+    return matrix.process(args)
+
+
+def main(argv=None):
+    parser = build_parser()
+    args = parser.parse_args(argv)
+    if hasattr(args, 'func'):
+        args.func(args)
+    else:
+        parser.print_help()
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,367 @@
+"""Host side of the n-gram text-reuse search: the reference's `search.py`
+interface on top of libfandomsearch_hip.so.
+
+Same names and argument meaning as /root/reference/search.py so that the CLI
+(`ao3.py search`) and callers of `AnnIndexSearch` can switch over:
+
+  new_record_structure   search.py:20-37    12-column output schema
+  load_markup_script     search.py:290-329  script markup -> word rows
+  validate_markup_script search.py:228-288  markup linter
+  AnnIndexSearch         search.py:130-226  .search(filename) -> sorted records
+  write_records          search.py:331-334  csv.writer rows
+  analyze                search.py:336-399  batch driver, batch + dated CSVs
+
+What differs, and why:
+  * the per-window engine.neighbours / Levenshtein / dedupe work runs on the
+    GPU for a whole batch of works at once (AnnIndexSearch.search_batch); there
+    is no multiprocessing.Pool and no CPU fallback
+  * the inputs the reference leaves to chance are explicit: LSH hyperplanes
+    (NearPy draws them unseeded, search.py:114-115) come from a seeded
+    generator, the out-of-vocabulary hash (salted hash(), search.py:81-83) is
+    seeded, and the directory listing (search.py:349) is sorted before the
+    reference's seeded shuffle
+  * spaCy / en_core_web_md are replaced by fandom_search_amd.vocab (tokenizer,
+    string hashes, vector table)
+"""
+
+import csv
+import datetime
+import os
+import random
+import re
+
+import numpy as np
+
+from . import abi, synth, vocab as vocab_mod
+
+new_record_structure = {
+    'fields': ['FAN_WORK_FILENAME',
+               'FAN_WORK_WORD_INDEX',
+               'FAN_WORK_WORD',
+               'FAN_WORK_ORTH_ID',
+               'ORIGINAL_SCRIPT_WORD_INDEX',
+               'ORIGINAL_SCRIPT_WORD',
+               'ORIGINAL_SCRIPT_ORTH_ID',
+               'ORIGINAL_SCRIPT_CHARACTER',
+               'ORIGINAL_SCRIPT_SCENE',
+               'BEST_MATCH_DISTANCE',
+               'BEST_LEVENSHTEIN_DISTANCE',
+               'BEST_COMBINED_DISTANCE',
+               ],
+    'types': [str, int, str, int, int, str,
+              int, str, int, float, int, float
+              ]
+}
+
+_VOCAB = None
+SHUFFLE_SEED = 4815162342        # search.py:354
+
+
+def get_vocab():
+    """The process-wide vocabulary (stands where get_spacy_model stands,
+    search.py:40-45).  FANDOM_SEARCH_VECTORS=<file.npz with 'words' and
+    'vectors'> selects a real table; the default is the synthetic vocabulary of
+    SURVEY.md 8(d)."""
+    global _VOCAB
+    if _VOCAB is None:
+        path = os.environ.get("FANDOM_SEARCH_VECTORS")
+        if path:
+            data = np.load(path, allow_pickle=False)
+            _VOCAB = vocab_mod.Vocab([str(w) for w in data["words"]],
+                                     data["vectors"])
+        else:
+            _VOCAB = vocab_mod.Vocab(synth.vocab_words(), synth.embedding())
+    return _VOCAB
+
+
+def set_vocab(v):
+    global _VOCAB
+    _VOCAB = v
+
+
+def default_normals(window_size, number_of_hashes, hash_dimensions, dim):
+    return synth.lsh_normals(window_size, number_of_hashes, hash_dimensions,
+                             dim)
+
+
+# ---------------------------------------------------------------------------
+# script markup
+# ---------------------------------------------------------------------------
+
+_LINE_REX = re.compile('LINE<<(?P<line>[^>]*)>>')
+_SCENE_REX = re.compile('SCENE_NUMBER<<(?P<scene>[^>]*)>>')
+_CHAR_REX = re.compile('CHARACTER_NAME<<(?P<character>[^>]*)>>')
+_EXPECTED_TAGS = frozenset(('LINE', 'DIRECTION', 'SCENE_NUMBER',
+                            'SCENE_DESCRIPTION', 'CHARACTER_NAME'))
+
+
+def load_markup_script(filename):
+    """Rows [LOWERCASE, SPACY_ORTH_ID, SCENE, CHARACTER] under a header row.
+
+    Per text line, first match wins in the order scene / character / line
+    (search.py:304-321).  A scene label keeps only its digits; the first label
+    without digits switches, for the rest of the file, to the running count of
+    scene tags (search.py:309-317)."""
+    rows = [['LOWERCASE', 'SPACY_ORTH_ID', 'SCENE', 'CHARACTER']]
+    scene = None
+    scene_tags = 0
+    count_scenes = False
+    character = None
+    with open(filename, encoding='utf-8') as ip:
+        for text in ip:
+            m = _SCENE_REX.search(text)
+            if m:
+                scene_tags += 1
+                digits = ''.join(ch for ch in m.group('scene') if ch.isdigit())
+                if digits:
+                    scene = int(digits)
+                else:
+                    count_scenes = True
+                    print("Error in Scene markup: {}".format(text))
+                if count_scenes:
+                    scene = scene_tags
+                continue
+            m = _CHAR_REX.search(text)
+            if m:
+                character = m.group('character')
+                continue
+            m = _LINE_REX.search(text)
+            if m:
+                for tok in vocab_mod.tokenize(m.group('line')):
+                    low = tok.lower()
+                    rows.append([low, vocab_mod.hash_string(low), scene,
+                                 character])
+    return rows
+
+
+def validate_markup_script(filename, interactive=False):
+    """Markup linter (search.py:228-285): unbalanced << or >> delimiters and
+    unknown tag labels, each reported with its line number."""
+    with open(filename, encoding='utf-8') as ip:
+        script = ip.read()
+
+    def line_of(pos):
+        return script[:pos + 1].count('\n') + 1
+
+    print('Checking script for markup errors.')
+    print()
+    errs = False
+    checks = (('Unbalanced left tag delimiters:', re.compile('<<[^>]*<<')),
+              ('Unbalanced right tag delimiters:', re.compile('>>[^<]*>>')))
+    for title, rex in checks:
+        found = list(rex.finditer(script))
+        if found:
+            print(title)
+            for m in found:
+                print('  On line {}'.format(line_of(m.start())))
+                print('    {}'.format(m.group().strip()))
+            errs = True
+            print()
+
+    tag_rex = re.compile(r'>>\s*([^<]*)\s*<<')
+    bad = [m for m in tag_rex.finditer(script)
+           if m.group(1).strip() not in _EXPECTED_TAGS]
+    if bad:
+        print('Unexpected tag labels:')
+        for m in bad:
+            print('  On line {}'.format(line_of(m.start(1))))
+            print('    {}'.format(m.group(1).strip()))
+        errs = True
+        print()
+
+    if not errs:
+        print('No markup errors found.')
+        return True
+    if interactive:
+        print('Errors were found in the script markup. Do you want to '
+              'continue? (Default is no.)')
+        print()
+        r = ''
+        while r.lower() not in ('y', 'yes', 'n', 'no'):
+            r = input('Enter y for yes or n for no: ')
+            if not r.strip():
+                r = 'n'
+        return r.lower() in ('y', 'yes')
+    return False
+
+
+def validate_cmd(args):
+    return validate_markup_script(args.script)
+
+
+# ---------------------------------------------------------------------------
+# search
+# ---------------------------------------------------------------------------
+
+def read_work_tokens(filename):
+    """Token texts of a fan work (search.py:164-166: read, chunked parse,
+    whitespace tokens dropped)."""
+    with open(filename, encoding='utf8') as fan_file:
+        fan = fan_file.read()
+    return [t for ch in vocab_mod.chunk_text(fan)
+            for t in vocab_mod.tokenize(ch)]
+
+
+class AnnIndexSearch(object):
+    def __init__(self, original_script_filename, window_size,
+                 number_of_hashes, hash_dimensions, distance_threshold,
+                 vocab=None, normals=None, device=0, mode=abi.FS_MODE_AUTO,
+                 unique_filter=True):
+        from .engine import ScriptIndex   # needs the HIP library: fail loudly
+
+        orig_csv = load_markup_script(original_script_filename)[1:]
+        self.word_index = tuple(range(len(orig_csv)))
+        self.word_lowercase = tuple(r[0] for r in orig_csv)
+        self.orth_id = tuple(r[1] for r in orig_csv)
+        self.scene = tuple(r[2] for r in orig_csv)
+        self.character = tuple(r[3] for r in orig_csv)
+
+        self.window_size = window_size
+        self.distance_threshold = distance_threshold
+        self.vocab = vocab or get_vocab()
+        if normals is None:
+            normals = default_normals(window_size, number_of_hashes,
+                                      hash_dimensions, self.vocab.dim)
+        _sids, script_vec = self.vocab.encode(list(self.word_lowercase))
+        cfg = abi.make_config(window_size=window_size,
+                              number_of_hashes=number_of_hashes,
+                              hash_dimensions=hash_dimensions,
+                              distance_threshold=distance_threshold,
+                              emb_dim=self.vocab.dim, device=device, mode=mode,
+                              unique_filter=unique_filter)
+        self.engine = ScriptIndex(script_vec, self.word_lowercase,
+                                  self.vocab.vectors, normals, cfg=cfg)
+        self.last_stats = None
+        self.reset_stats()
+
+    def reset_stats(self):
+        self._windows_processed = 0
+
+    @property
+    def windows_processed(self):
+        return self._windows_processed
+
+    def search(self, filename):
+        """Sorted 12-field records of one fan work (search.py:163-226)."""
+        return self.search_batch([filename])
+
+    def search_batch(self, filenames):
+        """Records of many works from one pass over the batch, in the order
+        `[r for r_set in pool.map(...) for r in r_set]` produces
+        (search.py:382-386): works in list order, words ascending."""
+        texts = [read_work_tokens(f) for f in filenames]
+        return self.search_tokens(filenames, texts)
+
+    def search_tokens(self, filenames, texts):
+        v = self.vocab
+        sid_parts, vid_parts = [], []
+        off = np.zeros(len(texts) + 1, dtype=np.uint64)
+        for i, toks in enumerate(texts):
+            sids, vids = v.encode(toks)
+            sid_parts.append(sids)
+            vid_parts.append(vids)
+            off[i + 1] = off[i] + np.uint64(len(toks))
+        tok_str = np.concatenate(sid_parts) if sid_parts else \
+            np.zeros(0, np.uint32)
+        tok_vec = np.concatenate(vid_parts) if vid_parts else \
+            np.zeros(0, np.uint32)
+        chars, coff = v.string_table()
+        same = bool(np.array_equal(tok_str, tok_vec))
+        corpus = self.engine.corpus(tok_vec, off, chars, coff,
+                                    tok_str=None if same else tok_str)
+        try:
+            rows, st = self.engine.search(corpus)
+        finally:
+            corpus.close()
+        self.last_stats = st
+        self._windows_processed += int(st.windows_processed)
+        return self._records(filenames, tok_str, off, rows)
+
+    def _records(self, filenames, tok_str, off, rows):
+        v = self.vocab
+        work = rows['work'].tolist()
+        fan_ix = rows['fan_ix'].tolist()
+        orig_ix = rows['orig_ix'].tolist()
+        lev = rows['lev'].tolist()
+        dist = rows['dist'].tolist()
+        comb = rows['comb'].tolist()
+        base = off.tolist()
+        sid = tok_str
+        out = []
+        for w, f, o, l, d, c in zip(work, fan_ix, orig_ix, lev, dist, comb):
+            s = int(sid[base[w] + f])
+            out.append([filenames[w], f, v.strings[s], v.orth(s),
+                        o, self.word_lowercase[o], self.orth_id[o],
+                        self.character[o], self.scene[o], d, l, c])
+        return out
+
+
+def write_records(records, filename):
+    with open(filename, 'w', encoding='utf-8') as out:
+        wr = csv.writer(out)
+        wr.writerows(records)
+
+
+def list_fan_works(fan_work_directory, skip_works=0, num_works=-1):
+    """Work list of analyze (search.py:345-358): directory listing (sorted
+    here; filesystem order in the reference), the reference's seeded shuffle,
+    then the -s / -n window."""
+    subsample_start = 0 if skip_works < 0 else skip_works
+    subsample_end = (None if num_works < 0 else num_works + subsample_start)
+    fan_works = sorted(os.listdir(fan_work_directory))
+    fan_works = [os.path.join(fan_work_directory, f) for f in fan_works]
+    random.seed(SHUFFLE_SEED)
+    random.shuffle(fan_works)
+    return fan_works[subsample_start:subsample_end]
+
+
+def unused_result_name(filename_base):
+    """match-<n>gram-YYYYMMDD.csv, then -YYYYMMDD-1.csv, ... (search.py:390-396)."""
+    i = 0
+    today_str = '-{:%Y%m%d}.csv'.format(datetime.date.today())
+    name_check = filename_base.format(today_str)
+    while os.path.exists(name_check):
+        i += 1
+        today_str = '-{:%Y%m%d}-{}.csv'.format(datetime.date.today(), i)
+        name_check = filename_base.format(today_str)
+    return name_check
+
+
+def analyze(args,
+            window_size=6,
+            number_of_hashes=15,
+            hash_dimensions=14,
+            distance_threshold=0.1,
+            chunk_size=500):
+    """`ao3.py search` (search.py:336-399): per cluster of `chunk_size` works a
+    header-less batch CSV, at the end a dated CSV with header, both in the
+    current directory."""
+    fan_works = list_fan_works(args.fan_works, args.skip_works, args.num_works)
+    window_size = getattr(args, 'window_size', None) or window_size
+    device = getattr(args, 'device', 0) or 0
+
+    fan_clusters = [fan_works[i:i + chunk_size]
+                    for i in range(0, len(fan_works), chunk_size)]
+
+    filename_base = 'match-{}gram{{}}'.format(window_size)
+    batch_filename = filename_base.format('-batch-{}.csv')
+
+    accumulated_records = [new_record_structure['fields']]
+    ann_index = AnnIndexSearch(args.script,
+                               window_size,
+                               number_of_hashes,
+                               hash_dimensions,
+                               distance_threshold,
+                               device=device)
+
+    for i, fan_cluster in enumerate(fan_clusters):
+        print('Processing cluster {} ({}-{})'.format(i,
+                                                     chunk_size * i,
+                                                     chunk_size * (i + 1)))
+        records = ann_index.search_batch(fan_cluster)
+        write_records(records, batch_filename.format(i))
+        accumulated_records.extend(records)
+
+    name = unused_result_name(filename_base)
+    write_records(accumulated_records, name)
+    return name

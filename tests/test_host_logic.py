@@ -1,0 +1,150 @@
+"""Host-side logic that needs no GPU: work listing, CSV bytes, result naming,
+script markup parsing and linting, vocabulary ids, the matrix command."""
+
+import csv
+import datetime
+import os
+import types
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import abi, matrix, search, synth, vocab
+from fandom_search_amd.cli import build_parser
+
+
+def test_list_fan_works_is_sorted_then_seeded_shuffle(tmp_path):
+    for i in range(10):
+        (tmp_path / ("w%d.txt" % i)).write_text("x")
+    got = [os.path.basename(p) for p in search.list_fan_works(str(tmp_path))]
+    # random.seed(4815162342); shuffle(range(10)) == [5,4,2,3,1,8,7,0,6,9]
+    assert got == ["w%d.txt" % i for i in [5, 4, 2, 3, 1, 8, 7, 0, 6, 9]]
+    assert [os.path.basename(p) for p in search.list_fan_works(str(tmp_path), 2, 3)] == \
+        ["w2.txt", "w3.txt", "w1.txt"]
+    assert len(search.list_fan_works(str(tmp_path), -5, -1)) == 10
+
+
+def test_write_records_bytes(tmp_path):
+    """csv.writer defaults: \\r\\n terminators, minimal quoting, None -> empty,
+    floats by repr (search.py:331-334)."""
+    p = tmp_path / "r.csv"
+    search.write_records([["a.txt", 3, 'say "hi", ok', 12345678901234567890, 7, "w", 1, None, 2,
+                           1.1102230246251565e-16, 7, 7.771561172376096e-16]], str(p))
+    assert p.read_bytes() == (b'a.txt,3,"say ""hi"", ok",12345678901234567890,7,w,1,,2,'
+                              b'1.1102230246251565e-16,7,7.771561172376096e-16\r\n')
+
+
+def test_unused_result_name(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    today = '{:%Y%m%d}'.format(datetime.date.today())
+    base = 'match-6gram{}'
+    assert search.unused_result_name(base) == 'match-6gram-%s.csv' % today
+    open('match-6gram-%s.csv' % today, 'w').close()
+    assert search.unused_result_name(base) == 'match-6gram-%s-1.csv' % today
+    open('match-6gram-%s-1.csv' % today, 'w').close()
+    assert search.unused_result_name(base) == 'match-6gram-%s-2.csv' % today
+
+
+def test_load_markup_script_rows(tmp_path):
+    p = tmp_path / "s.txt"
+    p.write_text("SCENE_NUMBER<<12A>>\nCHARACTER_NAME<<REY>>\nLINE<<Hello there, General>>\n"
+                 "DIRECTION<<She leaves>>\nSCENE_NUMBER<<INT>>\nLINE<<Run>>\n"
+                 "SCENE_NUMBER<<40>>\nCHARACTER_NAME<<FINN>>\nLINE<<go  now>>\n")
+    rows = search.load_markup_script(str(p))
+    assert rows[0] == ['LOWERCASE', 'SPACY_ORTH_ID', 'SCENE', 'CHARACTER']
+    body = rows[1:]
+    assert [r[0] for r in body] == ["hello", "there", ",", "general", "run", "go", "now"]
+    assert body[0][1] == vocab.hash_string("hello")
+    # '12A' -> 12; 'INT' has no digits -> from then on the running tag count
+    assert [r[2] for r in body] == [12, 12, 12, 12, 2, 3, 3]
+    assert [r[3] for r in body] == ["REY"] * 5 + ["FINN"] * 2
+
+
+def test_synthetic_script_round_trip(tmp_path):
+    words = synth.vocab_words()
+    script = synth.script_tokens(1234)
+    p = tmp_path / "script.txt"
+    p.write_text(synth.script_markup(script, words))
+    rows = search.load_markup_script(str(p))[1:]
+    scene, char = synth.script_columns(len(script))
+    assert [r[0] for r in rows] == [words[t] for t in script]
+    assert [r[2] for r in rows] == scene.tolist() and [r[3] for r in rows] == char
+    assert search.validate_markup_script(str(p)) is True
+
+
+def test_validate_reports_errors(tmp_path, capsys):
+    p = tmp_path / "bad.txt"
+    p.write_text("LINE<<ok>>\nLINE<<unbalanced << left>>\nLYNE<<typo>>\nLINE<<x>> >>\n")
+    assert search.validate_markup_script(str(p)) is False
+    out = capsys.readouterr().out
+    assert "Unbalanced left tag delimiters:" in out and "On line 2" in out
+    assert "Unbalanced right tag delimiters:" in out
+    assert "Unexpected tag labels:" in out and "LYNE" in out
+
+
+def test_vocab_ids_and_oov_encoding():
+    words = ["alpha", "beta"]
+    emb = np.eye(2, 8, dtype=np.float32)
+    v = vocab.Vocab(words, emb, oov_hash=lambda s: {"zz": 3, "zzzz": 1, "zzzzzz": 3}.get(s, 0))
+    sids, vids = v.encode(["beta", "zz", "alpha", "zz"])
+    assert vids[0] == 1 and vids[2] == 0 and sids[1] == sids[3] == 2
+    assert vids[1] & abi.FS_OOV_FLAG
+    code = int(vids[1]) & 0x7FFFFFFF
+    assert (code // 64, (code // 8) % 8, code % 8) == (1, 3, 3)      # sorted hot positions
+    assert v.vector(2).tolist() == [0, 1, 0, 1, 0, 0, 0, 0]
+    chars, off = v.string_table()
+    assert off.tolist() == [0, 5, 9, 11] and chars.dtype == np.uint32
+
+
+def test_chunk_text_cuts_at_spaces():
+    txt = ("ab " * 40000).strip()                      # 119999 chars
+    parts = list(vocab.chunk_text(txt))
+    assert len(parts) == 2 and all(len(p) <= 100000 for p in parts)
+    assert " ".join(parts) == txt
+    assert list(vocab.chunk_text("short text")) == ["short text"]
+
+
+def test_cli_shape():
+    ap = build_parser()
+    a = ap.parse_args(["search", "fandir", "script.txt", "-n", "5", "-s", "2"])
+    assert (a.fan_works, a.script, a.num_works, a.skip_works) == ("fandir", "script.txt", 5, 2)
+    a = ap.parse_args(["search", "d", "s"])
+    assert (a.num_works, a.skip_works) == (-1, 0)
+    a = ap.parse_args(["matrix", "in.csv", "sw", "-n", "4"])
+    assert (a.i, a.m, a.n) == ("in.csv", "sw", 4)
+    assert ap.parse_args(["matrix", "in.csv", "sw"]).n == 6
+
+
+def _match_csv(path, spans):
+    """spans: (work, fan_start, script_start, length)."""
+    script_words = ["W%d" % i for i in range(200)]
+    with open(path, "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(search.new_record_structure['fields'])
+        for work, f0, s0, ln in spans:
+            for k in range(ln):
+                wr.writerow([work, f0 + k, "x", 1, s0 + k, script_words[s0 + k], 1, "C", 1,
+                             0.0, 7, 0.0])
+
+
+def test_matrix_intent(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    # three works quote script words 10..17 (three 6-gram starts 10,11,12);
+    # start 11 is the most common start overall, so every span is represented
+    # by the n-gram starting at 11; a 5-word span is too short to count
+    _match_csv("m.csv", [("a.txt", 0, 10, 8), ("b.txt", 5, 11, 6), ("c.txt", 9, 11, 7),
+                         ("c.txt", 40, 50, 5), ("d.txt", 0, 100, 6)])
+    out = matrix.process(types.SimpleNamespace(i="m.csv", m="sw", n=6))
+    assert out == "sw-most-common-perfect-matches-no-overlap-6-gram-match-matrix.csv"
+    rows = list(csv.reader(open(out)))
+    assert rows[0] == ["FILENAME", "w11 w12 w13 w14 w15 w16", "w100 w101 w102 w103 w104 w105"]
+    assert rows[1] == ["(total)", "3", "1"]
+    assert rows[2:] == [["a.txt", "1", "0"], ["b.txt", "1", "0"], ["c.txt", "1", "0"],
+                        ["d.txt", "0", "1"]]
+
+
+def test_matrix_empty(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    _match_csv("m.csv", [("a.txt", 0, 10, 3)])
+    out = matrix.process(types.SimpleNamespace(i="m.csv", m="x", n=6))
+    assert list(csv.reader(open(out))) == [["FILENAME"], ["(total)"]]
