@@ -249,10 +249,16 @@ class AnnIndexSearch(object):
         """Records of many works from one pass over the batch, in the order
         `[r for r_set in pool.map(...) for r in r_set]` produces
         (search.py:382-386): works in list order, words ascending."""
-        texts = [read_work_tokens(f) for f in filenames]
-        return self.search_tokens(filenames, texts)
+        rows, words = self.search_rows(filenames)
+        return self.records(filenames, rows, words)
 
-    def search_tokens(self, filenames, texts):
+    def search_rows(self, filenames):
+        """(fs_row array with work indices into `filenames`, fan word text per
+        row) -- the form that travels between ranks (fandom_search_amd.dist)."""
+        texts = [read_work_tokens(f) for f in filenames]
+        return self.search_tokens(texts)
+
+    def search_tokens(self, texts):
         v = self.vocab
         sid_parts, vid_parts = [], []
         off = np.zeros(len(texts) + 1, dtype=np.uint64)
@@ -275,25 +281,28 @@ class AnnIndexSearch(object):
             corpus.close()
         self.last_stats = st
         self._windows_processed += int(st.windows_processed)
-        return self._records(filenames, tok_str, off, rows)
+        pos = off[rows['work']].astype(np.int64) + rows['fan_ix'].astype(np.int64)
+        words = [v.strings[s] for s in tok_str[pos].tolist()]
+        return rows, words
 
-    def _records(self, filenames, tok_str, off, rows):
-        v = self.vocab
-        work = rows['work'].tolist()
-        fan_ix = rows['fan_ix'].tolist()
-        orig_ix = rows['orig_ix'].tolist()
-        lev = rows['lev'].tolist()
-        dist = rows['dist'].tolist()
-        comb = rows['comb'].tolist()
-        base = off.tolist()
-        sid = tok_str
-        out = []
-        for w, f, o, l, d, c in zip(work, fan_ix, orig_ix, lev, dist, comb):
-            s = int(sid[base[w] + f])
-            out.append([filenames[w], f, v.strings[s], v.orth(s),
-                        o, self.word_lowercase[o], self.orth_id[o],
-                        self.character[o], self.scene[o], d, l, c])
-        return out
+    def records(self, filenames, rows, words):
+        """Join the numeric rows with file name, fan word / orth id and the
+        script columns into the 12-field records of search.py:203-217."""
+        return join_records(filenames, rows, words, self.word_lowercase,
+                            self.orth_id, self.character, self.scene)
+
+
+def join_records(filenames, rows, words, word_lowercase, orth_id, character,
+                 scene):
+    out = []
+    for w, f, o, l, d, c, fw in zip(rows['work'].tolist(), rows['fan_ix'].tolist(),
+                                    rows['orig_ix'].tolist(), rows['lev'].tolist(),
+                                    rows['dist'].tolist(), rows['comb'].tolist(),
+                                    words):
+        out.append([filenames[w], f, fw, vocab_mod.hash_string(fw),
+                    o, word_lowercase[o], orth_id[o], character[o], scene[o],
+                    d, l, c])
+    return out
 
 
 def write_records(records, filename):
@@ -332,13 +341,23 @@ def analyze(args,
             number_of_hashes=15,
             hash_dimensions=14,
             distance_threshold=0.1,
-            chunk_size=500):
+            chunk_size=500,
+            searcher=None):
     """`ao3.py search` (search.py:336-399): per cluster of `chunk_size` works a
     header-less batch CSV, at the end a dated CSV with header, both in the
-    current directory."""
+    current directory.
+
+    Launched under torch.distributed.run (WORLD_SIZE > 1) every cluster is
+    split over the ranks, one GPU each, and rank 0 writes the files: the bytes
+    are the same for any number of GPUs.  `searcher` (tests) replaces the
+    AnnIndexSearch instance; it needs search_rows() and the script columns."""
+    from . import dist
+    rank, local_rank, world = dist.init_from_env()
     fan_works = list_fan_works(args.fan_works, args.skip_works, args.num_works)
     window_size = getattr(args, 'window_size', None) or window_size
     device = getattr(args, 'device', 0) or 0
+    if world > 1:
+        device = local_rank
 
     fan_clusters = [fan_works[i:i + chunk_size]
                     for i in range(0, len(fan_works), chunk_size)]
@@ -347,21 +366,34 @@ def analyze(args,
     batch_filename = filename_base.format('-batch-{}.csv')
 
     accumulated_records = [new_record_structure['fields']]
-    ann_index = AnnIndexSearch(args.script,
-                               window_size,
-                               number_of_hashes,
-                               hash_dimensions,
-                               distance_threshold,
-                               device=device)
+    ann_index = searcher or AnnIndexSearch(args.script,
+                                           window_size,
+                                           number_of_hashes,
+                                           hash_dimensions,
+                                           distance_threshold,
+                                           device=device)
 
     for i, fan_cluster in enumerate(fan_clusters):
-        print('Processing cluster {} ({}-{})'.format(i,
-                                                     chunk_size * i,
-                                                     chunk_size * (i + 1)))
-        records = ann_index.search_batch(fan_cluster)
+        if rank == 0:
+            print('Processing cluster {} ({}-{})'.format(i,
+                                                         chunk_size * i,
+                                                         chunk_size * (i + 1)))
+        if world > 1:
+            weights = [os.path.getsize(f) for f in fan_cluster]
+            rows, words = dist.search_sharded(fan_cluster, weights,
+                                              ann_index.search_rows)
+        else:
+            rows, words = ann_index.search_rows(fan_cluster)
+        if rank != 0:
+            continue
+        records = join_records(fan_cluster, rows, words,
+                               ann_index.word_lowercase, ann_index.orth_id,
+                               ann_index.character, ann_index.scene)
         write_records(records, batch_filename.format(i))
         accumulated_records.extend(records)
 
+    if rank != 0:
+        return None
     name = unused_result_name(filename_base)
     write_records(accumulated_records, name)
     return name

@@ -1,0 +1,114 @@
+"""The N>1 path on CPU: world_size-2 gloo processes run analyze() with an
+oracle-backed searcher; the CSVs must be byte-identical to a single-process
+run.  Also the range splitter and the variable-length row gather."""
+
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import abi, dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_split_contiguous():
+    assert dist.split_contiguous([1] * 10, 2) == [0, 5, 10]
+    assert dist.split_contiguous([1] * 10, 4) == [0, 3, 5, 8, 10]
+    b = dist.split_contiguous([100, 1, 1, 1, 1, 100], 3)
+    assert b[0] == 0 and b[-1] == 6 and b == sorted(b)
+    assert dist.split_contiguous([], 3) == [0, 0, 0, 0]
+    assert dist.split_contiguous([5], 4) == [0, 0, 0, 0, 1] or dist.split_contiguous([5], 4)[-1] == 1
+    for parts in (1, 2, 3, 8):
+        w = np.random.default_rng(parts).integers(1, 50, size=37)
+        b = dist.split_contiguous(w, parts)
+        assert len(b) == parts + 1 and b[0] == 0 and b[-1] == 37 and b == sorted(b)
+
+
+def test_gather_rows_single_process_is_identity():
+    rows = np.zeros(3, dtype=abi.ROW_DTYPE)
+    rows["work"] = [0, 1, 2]
+    out = dist.gather_rows(rows)
+    assert out.tobytes() == rows.tobytes()
+
+
+WORKER = textwrap.dedent('''
+    import os, sys, types
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    from fandom_search_amd import abi, search, synth, vocab
+    from tests import util
+
+    class OracleSearcher(object):
+        """Stands in for AnnIndexSearch on a machine without a GPU: same
+        search_rows contract, rows from the plain-C oracle."""
+        def __init__(self, script_path):
+            rows = search.load_markup_script(script_path)[1:]
+            self.word_lowercase = tuple(r[0] for r in rows)
+            self.orth_id = tuple(r[1] for r in rows)
+            self.scene = tuple(r[2] for r in rows)
+            self.character = tuple(r[3] for r in rows)
+            self.words = synth.vocab_words()
+            self.ids = {w: i for i, w in enumerate(self.words)}
+            self.emb = synth.embedding()
+            script = np.array([self.ids[w] for w in self.word_lowercase], np.uint32)
+            self.cfg = abi.make_config()
+            self.oi = util.oracle_index(self.cfg, script, self.words, self.emb,
+                                        synth.lsh_normals(6), threads=2)
+            self.chars, self.coff = vocab.pack_strings(self.words)
+        def search_rows(self, filenames):
+            texts = [search.read_work_tokens(f) for f in filenames]
+            off = np.zeros(len(texts) + 1, np.uint64)
+            off[1:] = np.cumsum([len(t) for t in texts])
+            tok = np.array([self.ids[t] for ts in texts for t in ts], np.uint32)
+            rows, _ = self.oi.search(tok, off, self.chars, self.coff)
+            pos = off[rows["work"]].astype(np.int64) + rows["fan_ix"].astype(np.int64)
+            return rows, [self.words[t] for t in tok[pos].tolist()]
+
+    os.chdir(sys.argv[1])
+    args = types.SimpleNamespace(fan_works=sys.argv[2], script=sys.argv[3],
+                                 skip_works=0, num_works=-1)
+    search.analyze(args, chunk_size=7, searcher=OracleSearcher(sys.argv[3]))
+''')
+
+
+def _run(tmp_path, outdir, fandir, script, world):
+    worker = tmp_path / "worker.py"
+    worker.write_text(WORKER % dict(root=ROOT))
+    os.makedirs(outdir, exist_ok=True)
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    if world == 1:
+        cmd = [sys.executable, str(worker), outdir, fandir, script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+               "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", "29533", str(worker), outdir, fandir, script]
+    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+    return {f: open(os.path.join(outdir, f), "rb").read() for f in sorted(os.listdir(outdir))}
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_run_writes_identical_csvs(tmp_path):
+    from fandom_search_amd import synth
+    words = synth.vocab_words()
+    script = synth.script_tokens(1500)
+    fandir = str(tmp_path / "fan")
+    # ragged works, including an empty file and one shorter than a window
+    lens = [300, 0, 120, 4, 260, 310, 90, 200, 150, 333, 70, 128, 256, 64, 180, 222, 199]
+    os.makedirs(fandir)
+    for i, n in enumerate(lens):
+        tok = synth.fanwork_tokens(i, n, script) if n else []
+        with open(os.path.join(fandir, synth.work_name(i)), "w") as fh:
+            fh.write(" ".join(words[int(t)] for t in tok))
+    spath = str(tmp_path / "script.txt")
+    with open(spath, "w") as fh:
+        fh.write(synth.script_markup(script, words))
+    one = _run(tmp_path, str(tmp_path / "out1"), fandir, spath, 1)
+    two = _run(tmp_path, str(tmp_path / "out2"), fandir, spath, 2)
+    assert list(one) == list(two) and len(one) == 4          # 3 batch files + dated file
+    for name in one:
+        assert one[name] == two[name], name
+    assert sum(len(v) for v in one.values()) > 1000
