@@ -16,7 +16,8 @@ _LIB = None
 
 SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_index_info_get", "fs_index_destroy", "fs_corpus_create",
-           "fs_corpus_destroy", "fs_search_corpus", "fs_search")
+           "fs_corpus_destroy", "fs_search_corpus", "fs_search",
+           "fs_scan_benchmark")
 
 
 class FsError(RuntimeError):
@@ -81,6 +82,9 @@ def load():
     L.fs_search.argtypes = [
         C.c_void_p, u32p, u32p, u64p, C.c_uint64, u32p, u64p, C.c_uint64,
         C.c_void_p, C.c_uint64, u64p, C.POINTER(abi.FsStats)]
+    L.fs_scan_benchmark.restype = C.c_int
+    L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
+                                    C.POINTER(C.c_double)]
     if L.fs_version() != 1:
         raise RuntimeError("ABI version mismatch in %s" % path)
     _LIB = L

@@ -476,3 +476,22 @@ extern "C" int fs_search(fs_index* ix, const uint32_t* tok_vec, const uint32_t* 
   fs_corpus_destroy(c);
   return rc;
 }
+
+extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms) {
+  if (!ix || !c || c->ix != ix || !avg_ms || reps == 0) return FS_E_INVALID;
+  FS_HIP(hipSetDevice(ix->device));
+  hipStream_t s = ix->stream;
+  const uint32_t n_bm = (uint32_t)((c->n_tok + 255) / 256);
+  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * 4));
+  FS_TRY(ix->w_qcnt.reserve(n_bm));
+  FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));   // warm
+  FS_HIP(hipEventRecord(ix->ev_scan0, s));
+  for (uint32_t r = 0; r < reps; ++r)
+    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
+  FS_HIP(hipEventRecord(ix->ev_scan1, s));
+  FS_HIP(hipStreamSynchronize(s));
+  float ms = 0;
+  FS_HIP(hipEventElapsedTime(&ms, ix->ev_scan0, ix->ev_scan1));
+  *avg_ms = (double)ms / reps;
+  return FS_OK;
+}

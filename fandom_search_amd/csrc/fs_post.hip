@@ -201,11 +201,10 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
       uint32_t ids[FS_MAX_WINDOW];
 #pragma unroll
       for (int k = 0; k < FS_MAX_WINDOW; ++k) ids[k] = k < g.n ? t[k] : 0u;
-      uint32_t h = fs_premix(ids[0]);
+      uint32_t h = 0;
 #pragma unroll
-      for (int k = 1; k < FS_MAX_WINDOW; ++k)
-        if (k < g.n) h = fs_fold(h, fs_premix(ids[k]));
-      h = fs_finish(h);
+      for (int k = 0; k < FS_MAX_WINDOW; ++k)
+        if (k < g.n) h ^= fs_rotl(fs_premix(ids[k]), fs_rot_of(g.n - 1 - k));
       uint32_t slot = fs_table_slot(h, g.log2_slots);
       for (;;) {
         const uint32_t e = g.table[slot];

@@ -42,27 +42,30 @@ __device__ __forceinline__ void store_flags(uint32_t flags, int lane, uint32_t w
   }
 }
 
+// m[0 .. 4+N-1): premixed ids of this lane's four tokens and their halo.
+// Window 0 pays the full XOR-rotate fold, windows 1..3 slide (fs_hash.h).
 template <int N>
-__device__ __forceinline__ uint32_t window_flags(const uint32_t* a, const uint32_t* s_filter,
-                                                 int log2_words) {
-  // a[0 .. 4+N-1): premixed ids of this lane's tokens and its halo
+__device__ __forceinline__ uint32_t window_flags(const uint32_t* m, const uint32_t* s_filter,
+                                                 int word_shift) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) x ^= fs_rotl(m[k], fs_rot_of(N - 1 - k));
   uint32_t flags = 0;
 #pragma unroll
   for (int j = 0; j < kTokPerLane; ++j) {
-    uint32_t h = a[j];
-#pragma unroll
-    for (int k = 1; k < N; ++k) h = fs_fold(h, a[j + k]);
-    h = fs_finish(h);
-    const uint32_t word = s_filter[fs_bloom_word(h, log2_words)];
-    const uint32_t mask = fs_bloom_mask(h);
-    flags |= ((word & mask) == mask) ? (1u << j) : 0u;
+    if (j) x = fs_rotl(x ^ fs_rotl(m[j - 1], fs_rot_of(N - 1)), 7) ^ m[j - 1 + N];
+    const uint32_t word = s_filter[x >> word_shift];
+    flags |= fs_bloom_test(word, x) << j;
   }
   return flags;
 }
 
-// U sub-tiles (U x 256 tokens) per wave iteration: U independent 16-byte loads
-// in flight per lane before the first use.
-template <int N, int U>
+// U sub-tiles (U x 256 tokens) per wave iteration, all loads issued before the
+// first use.  HALO_LOADS: the n-1 tokens behind a lane's own four come from
+// further global loads at immediate offsets (+16 B, +32 B ...: the same cache
+// lines the neighbouring lanes fetch, no VALU); otherwise from the neighbouring
+// lanes by ds_bpermute.
+template <int N, int U, bool HALO_LOADS>
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok, uint32_t n_tok,
                                                const uint32_t* __restrict__ filter,
                                                int log2_words, uint64_t* __restrict__ qbm,
@@ -79,39 +82,63 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
 
   constexpr int HALO = N - 1;
   constexpr int NV = (HALO + 3) / 4;            // neighbour vectors needed
+  const int word_shift = 32 - log2_words;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
 
   for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
     const uint32_t base = tile * (uint32_t)(kSubTile * U);
-    uint4 v[U + 1];
+    uint32_t a[U][4 + 4 * NV];
+    if constexpr (HALO_LOADS) {
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      v[u] = *reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
-    // first vectors of the next tile, in lanes 0..3 (the buffer is padded)
-    v[U] = *reinterpret_cast<const uint4*>(tok + base + U * kSubTile + 4 * (lane & 3));
+      for (int u = 0; u < U; ++u) {
+        const uint32_t* p = tok + base + u * kSubTile + 4 * lane;
+#pragma unroll
+        for (int d = 0; d <= NV; ++d) {
+          const int need = d == 0 ? 4 : ((HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4);
+          if (need == 1) {
+            a[u][4 * d] = p[4 * d];
+          } else if (need == 2) {
+            const uint2 t = *reinterpret_cast<const uint2*>(p + 4 * d);
+            a[u][4 * d] = t.x; a[u][4 * d + 1] = t.y;
+          } else {
+            const uint4 t = *reinterpret_cast<const uint4*>(p + 4 * d);
+            a[u][4 * d] = t.x; a[u][4 * d + 1] = t.y; a[u][4 * d + 2] = t.z;
+            if (need > 3) a[u][4 * d + 3] = t.w;
+          }
+        }
+      }
+    } else {
+      uint4 v[U + 1];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = *reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
+      // first vectors of the next tile, in lanes 0..3 (the buffer is padded)
+      v[U] = *reinterpret_cast<const uint4*>(tok + base + U * kSubTile + 4 * (lane & 3));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u][0] = v[u].x; a[u][1] = v[u].y; a[u][2] = v[u].z; a[u][3] = v[u].w;
+#pragma unroll
+        for (int d = 1; d <= NV; ++d) {
+          // lane L needs the vector of lane L+d; past lane 63 that is a vector of
+          // the next sub-tile, which lanes 0..d-1 publish instead of their own
+          const bool wrap = lane < d;
+          const int src = (lane + d) & 63;
+          const int need = (HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4;
+          a[u][4 * d + 0] = __shfl(wrap ? v[u + 1].x : v[u].x, src);
+          if (need > 1) a[u][4 * d + 1] = __shfl(wrap ? v[u + 1].y : v[u].y, src);
+          if (need > 2) a[u][4 * d + 2] = __shfl(wrap ? v[u + 1].z : v[u].z, src);
+          if (need > 3) a[u][4 * d + 3] = __shfl(wrap ? v[u + 1].w : v[u].w, src);
+        }
+      }
+    }
 
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      uint32_t a[4 + 4 * NV];
-      a[0] = v[u].x; a[1] = v[u].y; a[2] = v[u].z; a[3] = v[u].w;
 #pragma unroll
-      for (int d = 1; d <= NV; ++d) {
-        // lane L needs the vector of lane L+d; past lane 63 that is a vector of
-        // the next sub-tile, which lanes 0..d-1 publish instead of their own
-        const bool wrap = lane < d;
-        const int src = (lane + d) & 63;
-        const int need = (HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4;
-        a[4 * d + 0] = __shfl(wrap ? v[u + 1].x : v[u].x, src);
-        if (need > 1) a[4 * d + 1] = __shfl(wrap ? v[u + 1].y : v[u].y, src);
-        if (need > 2) a[4 * d + 2] = __shfl(wrap ? v[u + 1].z : v[u].z, src);
-        if (need > 3) a[4 * d + 3] = __shfl(wrap ? v[u + 1].w : v[u].w, src);
-      }
-#pragma unroll
-      for (int i = 0; i < 4 + HALO; ++i) a[i] = fs_premix(a[i]);
-
-      uint32_t flags = window_flags<N>(a, s_filter, log2_words);
+      for (int i = 0; i < 4 + HALO; ++i) a[u][i] = fs_premix(a[u][i]);
+      uint32_t flags = window_flags<N>(a[u], s_filter, word_shift);
 
       const uint32_t p0 = base + u * kSubTile + 4 * lane;
       if (base + (uint32_t)(kSubTile * U) + HALO > n_tok) {   // wave-uniform: last tile(s)
@@ -147,9 +174,7 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
     for (int j = 0; j < 4; ++j) {
       const uint64_t p = (uint64_t)p0 + j;
       if (p + n > n_tok) continue;
-      uint32_t h = fs_premix(tok[p]);
-      for (int k = 1; k < n; ++k) h = fs_fold(h, fs_premix(tok[p + k]));
-      h = fs_finish(h);
+      const uint32_t h = fs_gram_hash(tok + p, n);
       const uint32_t w = s_filter[fs_bloom_word(h, log2_words)];
       const uint32_t m = fs_bloom_mask(h);
       if ((w & m) == m) flags |= 1u << j;
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
   }
 }
 
-template <int N, int U>
+template <int N, int U, bool HL>
 int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                 uint32_t n_bm_words, hipStream_t s) {
   const uint32_t tile_tok = kSubTile * U;
@@ -168,10 +193,14 @@ int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
   int threads = 1024;
   const uint32_t waves_per_block = threads / 64;
   uint32_t blocks_per_cu = lds <= 64 * 1024 ? 2 : 1;
+  if (const char* e = getenv("FS_SCAN_BLOCKS_PER_CU")) {
+    const int v = atoi(e);
+    if (v > 0) blocks_per_cu = v;
+  }
   uint32_t max_blocks = ix->num_cu * blocks_per_cu;
   uint32_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > max_blocks) blocks = max_blocks;
-  auto kern = k_scan<N, U>;
+  auto kern = k_scan<N, U, HL>;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, c.tok, c.n_tok,
@@ -182,12 +211,20 @@ int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
 
 template <int N>
 int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s, int unroll) {
+                  uint32_t n_bm_words, hipStream_t s, int unroll, bool halo_loads) {
+  if (halo_loads) {
+    switch (unroll) {
+      case 1: return launch_fast<N, 1, true>(ix, c, qbm, qcnt, n_bm_words, s);
+      case 2: return launch_fast<N, 2, true>(ix, c, qbm, qcnt, n_bm_words, s);
+      case 8: return launch_fast<N, 8, true>(ix, c, qbm, qcnt, n_bm_words, s);
+      default: return launch_fast<N, 4, true>(ix, c, qbm, qcnt, n_bm_words, s);
+    }
+  }
   switch (unroll) {
-    case 1: return launch_fast<N, 1>(ix, c, qbm, qcnt, n_bm_words, s);
-    case 2: return launch_fast<N, 2>(ix, c, qbm, qcnt, n_bm_words, s);
-    case 8: return launch_fast<N, 8>(ix, c, qbm, qcnt, n_bm_words, s);
-    default: return launch_fast<N, 4>(ix, c, qbm, qcnt, n_bm_words, s);
+    case 1: return launch_fast<N, 1, false>(ix, c, qbm, qcnt, n_bm_words, s);
+    case 2: return launch_fast<N, 2, false>(ix, c, qbm, qcnt, n_bm_words, s);
+    case 8: return launch_fast<N, 8, false>(ix, c, qbm, qcnt, n_bm_words, s);
+    default: return launch_fast<N, 4, false>(ix, c, qbm, qcnt, n_bm_words, s);
   }
 }
 
@@ -202,25 +239,23 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   const int n = ix->cfg.window_size;
   const char* var = getenv("FS_SCAN_VARIANT");
   const bool simple = var && var[0] == 's';
-  int unroll = 4;
+  // measured on MI355X (tools/scan_sweep.py, profiles/): two sub-tiles per wave
+  // iteration and the shuffle halo are fastest up to the Infinity Cache size, four beyond (2 GB of ids)
+  int unroll = (uint64_t)c.n_tok * 4 > (256ull << 20) ? 4 : 2;
   if (const char* u = getenv("FS_SCAN_UNROLL")) unroll = atoi(u);
-  // small inputs: shorter tiles so that every CU gets work
-  if (!getenv("FS_SCAN_UNROLL")) {
-    const uint64_t waves = (uint64_t)ix->num_cu * 16;
-    if ((uint64_t)c.n_tok < waves * kSubTile * 4 * 4) unroll = 2;
-    if ((uint64_t)c.n_tok < waves * kSubTile * 2 * 4) unroll = 1;
-  }
+  bool halo_loads = false;
+  if (const char* h = getenv("FS_SCAN_HALO")) halo_loads = h[0] == 'l';   // "loads"
   if (!simple) {
     switch (n) {
-      case 2: return launch_fast_u<2>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 3: return launch_fast_u<3>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 4: return launch_fast_u<4>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 5: return launch_fast_u<5>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 6: return launch_fast_u<6>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 7: return launch_fast_u<7>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 8: return launch_fast_u<8>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 10: return launch_fast_u<10>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
-      case 12: return launch_fast_u<12>(ix, c, qbm, qcnt, n_bm_words, s, unroll);
+      case 2: return launch_fast_u<2>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 3: return launch_fast_u<3>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 4: return launch_fast_u<4>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 5: return launch_fast_u<5>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 6: return launch_fast_u<6>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 7: return launch_fast_u<7>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 8: return launch_fast_u<8>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 10: return launch_fast_u<10>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 12: return launch_fast_u<12>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
       default: break;
     }
   }

@@ -114,6 +114,13 @@ class ScriptIndex(object):
         _lib.check(rc, "fs_search_corpus")
         return int(n.value), st
 
+    def scan_benchmark(self, corpus, reps=20):
+        """Average milliseconds of one scan-kernel launch over `corpus`."""
+        ms = C.c_double(0)
+        _lib.check(_lib.load().fs_scan_benchmark(self._h, corpus._h, reps, C.byref(ms)),
+                   "fs_scan_benchmark")
+        return ms.value
+
     def close(self):
         if self._h:
             _lib.load().fs_index_destroy(self._h)

@@ -167,6 +167,12 @@ int fs_search(fs_index* ix,
               uint64_t n_str,
               fs_row* rows, uint64_t cap, uint64_t* n_rows, fs_stats* st);
 
+/* Diagnostics: `reps` back-to-back launches of the scan kernel alone over `c`,
+ * timed with one pair of HIP events; *avg_ms = time per launch.  Used by
+ * tools/scan_sweep.py to compare kernel variants without per-launch event
+ * overhead.  Not part of the search path. */
+int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms);
+
 #ifdef __cplusplus
 }
 #endif
