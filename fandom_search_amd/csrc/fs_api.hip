@@ -137,11 +137,12 @@ static int prove_exact(fs_index* ix, const uint32_t* stok) {
     return FS_OK;
   }
   std::vector<uint32_t> rows_u;
+  bool script_oov = false;
   {
     std::vector<uint8_t> seen(V, 0);
     for (uint64_t i = 0; i < ix->n_script; ++i) {
       const uint32_t id = stok[i];
-      if (id & FS_OOV_FLAG) return FS_OK;   // 3-hot vectors: norms differ, no proof
+      if (id & FS_OOV_FLAG) { script_oov = true; continue; }   // 3-hot vectors: no proof
       if (!seen[id]) { seen[id] = 1; rows_u.push_back(id); }
     }
   }
@@ -165,11 +166,13 @@ static int prove_exact(fs_index* ix, const uint32_t* stok) {
   for (uint64_t v = 1; v < V; ++v) { qmin = std::min(qmin, q[v]); qmax = std::max(qmax, q[v]); }
   inf.norm_min = sqrt(qmin); inf.norm_max = sqrt(qmax);
   inf.c_max = cmaxf;
-  if (!(qmin > 0.0)) return FS_OK;
+  ix->lsh_cmax = std::min(1.0, (double)cmaxf + 1e-4);
+  if (!(qmin > 0.0) || script_oov) return FS_OK;
   const double c = std::min(1.0, (double)cmaxf + 1e-4);     // float32 accumulation slack
   const double n1 = (double)ix->cfg.window_size - 1.0;
   inf.cos_bound = (n1 * qmax + c * qmin) / (n1 * qmax + qmin);
   inf.proof_ok = inf.cos_bound < 1.0 - ix->cfg.distance_threshold - 1e-6 ? 1u : 0u;
+  if (V > FS_MAX_EXACT_ID) inf.proof_ok = 0;   // the scan's 24-bit premix needs ids < 2^24
   return FS_OK;
 }
 
@@ -270,12 +273,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     return FS_E_UNPROVEN;
   }
   ix->info.path = exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
-  if (!exact) {
-    fs_set_error("the general LSH pipeline is not built yet: this vector table does not admit "
-                 "the exact n-gram prefilter (cos bound %.6f, c_max %.6f) or FS_MODE_GENERAL "
-                 "was requested", ix->info.cos_bound, ix->info.c_max);
-    return FS_E_UNSUPPORTED;
-  }
+  if (!exact) FS_TRY(fs_lsh_build(ix));
   guard.p = nullptr;
   *out = ix;
   return FS_OK;
@@ -332,12 +330,10 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
     for (uint64_t i = 0; i < T; ++i) mx = std::max(mx, tok_vec[i]);
     if (mx >= n_str) { fs_set_error("string table smaller than the largest token id"); return FS_E_INVALID; }
   }
-  if (oov && ix->info.path == FS_MODE_EXACT) {
-    fs_set_error("corpus holds out-of-vocabulary vector ids; the exact n-gram path is not proven "
-                 "for them and the general LSH pipeline is not built yet");
-    return FS_E_UNSUPPORTED;
-  }
   FS_HIP(hipSetDevice(ix->device));
+  // out-of-vocabulary vectors are outside the exact n-gram proof: such a corpus
+  // goes through the LSH pipeline (built now if the index did not need it before)
+  if (oov && ix->info.path == FS_MODE_EXACT) FS_TRY(fs_lsh_build(ix));
   fs_corpus* c = new (std::nothrow) fs_corpus();
   if (!c) return FS_E_NOMEM;
   struct Guard { fs_corpus* p; ~Guard() { delete p; } } guard{c};
@@ -365,7 +361,7 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
     FS_TRY(c->d_coff.upload(coff.data(), coff.size(), ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
-  if (!c->has_str) {
+  if (!c->has_str && !oov && ix->info.path == FS_MODE_EXACT) {
     // string id == vector id: Levenshtein per (n-gram, rank) once per corpus
     FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
@@ -401,6 +397,7 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
   const uint64_t T = c->n_tok;
   const uint32_t n_bm = (uint32_t)((T + 255) / 256);
   const uint32_t nn = ix->cfg.nearest_n;
+  const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   // capacities: grown from the device totals when a stage overflows
   uint64_t ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_cpos.n);
   uint64_t rcap = rows_on_device ? cap
@@ -414,19 +411,28 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
     FS_TRY(ix->w_cpos.reserve(ccap));
     FS_TRY(ix->w_cg.reserve(ccap));
     FS_TRY(ix->w_cw.reserve(ccap));
-    FS_TRY(ix->w_mlev.reserve(c->has_str ? ccap * nn : 1));
-    FS_TRY(ix->w_cbest.reserve(c->has_str ? ccap : 1));
+    FS_TRY(ix->w_mlev.reserve(exact && c->has_str ? ccap * nn : 1));
+    FS_TRY(ix->w_cbest.reserve(!exact || c->has_str ? ccap : 1));
     fs_row* d_rows = rows;
     if (!rows_on_device) { FS_TRY(ix->w_rows.reserve(rcap)); d_rows = ix->w_rows.p; }
 
     FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
     FS_HIP(hipEventRecord(ix->ev_begin, s));
     FS_HIP(hipEventRecord(ix->ev_scan0, s));
-    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
-    FS_HIP(hipEventRecord(ix->ev_scan1, s));
+    const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(ccap, 0xFFFFFFFFull);
+    const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFull);
+    if (exact) {
+      FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
+      FS_HIP(hipEventRecord(ix->ev_scan1, s));
+      FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, s));
+    } else {
+      FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
+      FS_HIP(hipEventRecord(ix->ev_scan1, s));
+      FS_TRY(fs_launch_expand(ix, n_bm, ccap32, s));
+      FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
+      FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, s));
+    }
     ++launches;
-    FS_TRY(fs_launch_post(ix, c, n_bm, (uint32_t)std::min<uint64_t>(ccap, 0xFFFFFFFFull),
-                          (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFull), d_rows, s));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
     FS_HIP(hipEventRecord(ix->ev_end, s));
     FS_HIP(hipStreamSynchronize(s));
@@ -454,7 +460,7 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
     st->rows = hs.n_rows;
     st->scan_ms = scan_ms;
     st->total_ms = total_ms;
-    st->path = FS_MODE_EXACT;
+    st->path = exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
     st->scan_launches = launches;
   }
   if (hs.n_rows > cap) return FS_E_CAPACITY;

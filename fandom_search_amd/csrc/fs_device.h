@@ -1,0 +1,151 @@
+// fs_device.h -- device helpers shared by fs_post.hip and fs_lsh.hip.
+#pragma once
+#include "fs_internal.h"
+
+namespace fsdev {
+
+constexpr int kNB = 1024;        // blocks of every chunked kernel (and partial sums)
+constexpr int kThreads = 256;
+
+struct NSrc {               // element count, known on the host or on the device
+  const uint32_t* ptr;      // device count (clamped to cap, times mult) ...
+  uint32_t mult, cap;
+  uint32_t fixed;           // ... or a host constant when ptr == nullptr
+  __device__ uint32_t get() const {
+    if (!ptr) return fixed;
+    uint32_t v = *ptr;
+    if (v > cap) v = cap;
+    return v * mult;
+  }
+};
+
+// ---- block-wide helpers ----------------------------------------------------
+
+template <class V>
+__device__ __forceinline__ V wave_incl_scan(V v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    V t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block; returns the
+// thread's exclusive prefix, *total = block sum.  s_w: 4 values of LDS.
+template <class V>
+__device__ __forceinline__ V block_excl_scan(V v, V* s_w, V* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const V inc = wave_incl_scan(v, lane);
+  if (lane == 63) s_w[w] = inc;
+  __syncthreads();
+  V base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kThreads / 64; ++i) {
+    const V x = s_w[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// sum of the partial sums of all blocks before this one, and of all blocks
+template <class V>
+__device__ __forceinline__ V block_prefix(const V* __restrict__ bsum, V* s_w, V* total) {
+  V pre = 0, all = 0;
+  for (int i = threadIdx.x; i < kNB; i += kThreads) {
+    const V x = bsum[i];
+    all += x;
+    if (i < (int)blockIdx.x) pre += x;
+  }
+  V t_all, t_pre;
+  block_excl_scan(all, s_w, &t_all);
+  block_excl_scan(pre, s_w, &t_pre);
+  *total = t_all;
+  return t_pre;
+}
+
+__device__ __forceinline__ void chunk_of_block(uint32_t n, uint32_t* lo, uint32_t* hi) {
+  const uint32_t chunk = (n + kNB - 1) / kNB;
+  const uint64_t l = (uint64_t)blockIdx.x * chunk;
+  *lo = l < n ? (uint32_t)l : n;
+  const uint64_t h = l + chunk;
+  *hi = h < n ? (uint32_t)h : n;
+}
+
+template <class F, class V>
+__global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict__ bsum) {
+  __shared__ V s_w[4];
+  uint32_t lo, hi;
+  chunk_of_block(ns.get(), &lo, &hi);
+  V acc = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += f(i);
+  V tot;
+  block_excl_scan(acc, s_w, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+
+// work of token p: start from the work of its 256-token block
+__device__ __forceinline__ uint32_t work_of_token(const CorpusDev& c, uint64_t p) {
+  uint32_t w = c.blk_work[p >> 8];
+  while (c.work_off[w + 1] <= p) ++w;
+  return w;
+}
+
+// Levenshtein.distance(match_str, fan_context), search.py:189-190:
+//   match_str   = script words s .. s+n-1 joined by single spaces
+//   fan_context = '[' + ', '.join(fan token texts) + ']'
+// unit costs over code points.  One thread, operands in scratch.
+__device__ inline uint32_t lev_device(const GramIndexDev& g, uint32_t s, const uint32_t* fan_sid,
+                               const uint32_t* chars, const uint64_t* coff, uint32_t n_str,
+                               fs_status* st) {
+  uint32_t a[FS_LEV_MAX], b[FS_LEV_MAX];
+  uint16_t row[FS_LEV_MAX + 1];
+  uint32_t la = 0, lb = 0;
+  for (int k = 0; k < g.n; ++k) {
+    if (k) { if (la < FS_LEV_MAX) a[la] = ' '; ++la; }
+    for (uint64_t c = g.soff[s + k]; c < g.soff[s + k + 1]; ++c) {
+      if (la < FS_LEV_MAX) a[la] = g.schars[c];
+      ++la;
+    }
+  }
+  if (lb < FS_LEV_MAX) b[lb] = '[';
+  ++lb;
+  for (int k = 0; k < g.n; ++k) {
+    if (k) {
+      if (lb < FS_LEV_MAX) b[lb] = ','; ++lb;
+      if (lb < FS_LEV_MAX) b[lb] = ' '; ++lb;
+    }
+    const uint32_t sid = fan_sid[k];
+    if (sid >= n_str) { st->bad_string = 1; return 0; }
+    for (uint64_t c = coff[sid]; c < coff[sid + 1]; ++c) {
+      if (lb < FS_LEV_MAX) b[lb] = chars[c];
+      ++lb;
+    }
+  }
+  if (lb < FS_LEV_MAX) b[lb] = ']';
+  ++lb;
+  if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { st->lev_overflow = 1; return 0; }
+  for (uint32_t j = 0; j <= lb; ++j) row[j] = (uint16_t)j;
+  for (uint32_t x = 1; x <= la; ++x) {
+    uint32_t diag = row[0];
+    row[0] = (uint16_t)x;
+    const uint32_t ca = a[x - 1];
+    for (uint32_t j = 1; j <= lb; ++j) {
+      const uint32_t up = row[j];
+      uint32_t best = diag + (ca != b[j - 1] ? 1u : 0u);
+      if (up + 1 < best) best = up + 1;
+      const uint32_t left = row[j - 1];
+      if (left + 1 < best) best = left + 1;
+      diag = up;
+      row[j] = (uint16_t)best;
+    }
+  }
+  return row[lb];
+}
+
+
+}  // namespace fsdev

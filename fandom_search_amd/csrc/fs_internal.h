@@ -130,6 +130,12 @@ struct fs_index {
   DBuf<float> d_emb;
   DBuf<double> d_normals;
 
+  // general (LSH) pipeline, built on demand (fs_lsh_build)
+  DBuf<double> d_nt, d_atab, d_ss;
+  DBuf<uint32_t> d_boff, d_bids;
+  bool lsh_ready = false;
+  double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors
+
   // workspaces (grow on demand)
   DBuf<uint64_t> w_qbm, w_bsum64;
   DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
@@ -162,6 +168,13 @@ uint32_t fs_scan_pad_tokens();
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
                    fs_row* d_rows, hipStream_t s);
+int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, hipStream_t s);
+int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, hipStream_t s);
+int fs_lsh_build(fs_index* ix);
+int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                       uint32_t n_sub, hipStream_t s);
+int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
                        uint32_t* blk_work, hipStream_t s);
 

@@ -1,0 +1,479 @@
+// fs_lsh.hip -- the general pipeline: the reference's algorithm as written.
+//
+// Every fan window is hashed with all H random-binary-projection tables, every
+// bucket candidate is scored with the cosine distance, NearestFilter keeps the N
+// nearest, the threshold keeps those below `distance_threshold`
+// (/root/reference/search.py:112-123, 176-184 and NearPy's Engine).
+// Used whenever the exact n-gram proof does not hold: window sizes for which one
+// substituted token can stay within the threshold (n = 8, 10 on the synthetic
+// table), out-of-vocabulary tokens, vector tables with near-duplicate rows.
+//
+//   RandomBinaryProjections.hash_vector   window_keys: per-token projection
+//        tables A[k][v][c] (k_atab), window projection = sum over k in order,
+//        key bit = (p > 0.0); canonical arithmetic of DESIGN.md section 3
+//   Engine.store_vector                   fs_lsh_build: script window keys on
+//        the device, CSR buckets per table (ascending window index) on the host
+//   Engine.neighbours                     lsh_neighbours: bucket entries of
+//        table 0, 1, ... in order, UniqueFilter by script window, cosine
+//        distance (canonical), stable NearestFilter(N), threshold
+//
+// Two kernels use them:
+//   k_lsh_scan     one block per 256-window sub-tile: keys for all 256 windows
+//                  (threads = projection columns, coalesced 8-byte reads of A
+//                  rows), then one thread per window asks "is any candidate
+//                  within the threshold?" and the answers go out in the scan's
+//                  bitmap format, so k_expand / k_rows of fs_post.hip are shared
+//   k_lsh_verify   one wave per flagged window: keys again, the full
+//                  neighbours list, Levenshtein per kept match (one lane each),
+//                  best rank -> per-candidate record for k_rows
+//
+// A candidate's exact distance is skipped only when a sound upper bound on its
+// cosine is already below 1 - threshold (matching slots contribute q, other
+// slots at most c_max * (q_f + q_s) / 2); skipped candidates can never be in the
+// output, so the result equals the oracle's, which computes every distance.
+#include "fs_device.h"
+
+#include <algorithm>
+#include <vector>
+
+using namespace fsdev;
+
+namespace {
+
+struct LshDev {
+  const double* atab;      // [n][V][C]
+  const double* nt;        // [n][D][C] normals transposed
+  const uint32_t* boff;    // [H][2^B + 1]
+  const uint32_t* bids;    // [H][W]
+  const double* ss;        // [W] sum of q over script window
+  const double* q;         // [V]
+  const float* emb;        // [V][D]
+  const uint32_t* stok;    // script vector ids
+  uint32_t V, W;
+  int n, H, B, D, C, nn, unique;
+  double thr, cmax;
+};
+
+// ---- canonical per-token quantities ------------------------------------------
+
+__device__ __forceinline__ void oov_hot(uint32_t id, int D, uint32_t* a, uint32_t* b, uint32_t* c) {
+  const uint32_t code = id & ~FS_OOV_FLAG;
+  *c = code % D; *b = (code / D) % D; *a = code / ((uint32_t)D * D);
+}
+
+// A[k][id][c]
+__device__ __forceinline__ double a_value(const LshDev& L, int k, uint32_t id, int c) {
+  if (!(id & FS_OOV_FLAG)) return L.atab[((size_t)k * L.V + id) * L.C + c];
+  uint32_t a, b, cc;
+  oov_hot(id, L.D, &a, &b, &cc);
+  const double* nt = L.nt + (size_t)k * L.D * L.C + c;
+  double acc = __dadd_rn(0.0, nt[(size_t)a * L.C]);
+  if (b != a) acc = __dadd_rn(acc, nt[(size_t)b * L.C]);
+  if (cc != b) acc = __dadd_rn(acc, nt[(size_t)cc * L.C]);
+  return acc;
+}
+
+__device__ __forceinline__ double q_of(const LshDev& L, uint32_t id) {
+  if (!(id & FS_OOV_FLAG)) return L.q[id];
+  uint32_t a, b, c;
+  oov_hot(id, L.D, &a, &b, &c);
+  return 1.0 + (b != a ? 1.0 : 0.0) + (c != b ? 1.0 : 0.0);
+}
+
+// g(u, v) = seqsum_d e_u[d] * e_v[d], u != v
+__device__ double g_of(const LshDev& L, uint32_t u, uint32_t v) {
+  const bool uo = u & FS_OOV_FLAG, vo = v & FS_OOV_FLAG;
+  if (!uo && !vo) {
+    const float* eu = L.emb + (size_t)u * L.D;
+    const float* ev = L.emb + (size_t)v * L.D;
+    double acc = 0.0;
+    for (int d = 0; d < L.D; ++d) acc = __dadd_rn(acc, __dmul_rn((double)eu[d], (double)ev[d]));
+    return acc;
+  }
+  if (uo && vo) {
+    uint32_t ua[3], va[3];
+    oov_hot(u, L.D, &ua[0], &ua[1], &ua[2]);
+    oov_hot(v, L.D, &va[0], &va[1], &va[2]);
+    double acc = 0.0;
+    for (int i = 0; i < 3; ++i) {
+      if (i && ua[i] == ua[i - 1]) continue;
+      bool hit = false;
+      for (int j = 0; j < 3; ++j) hit = hit || va[j] == ua[i];
+      if (hit) acc = __dadd_rn(acc, 1.0);
+    }
+    return acc;
+  }
+  const uint32_t row = uo ? v : u, oov = uo ? u : v;
+  uint32_t h[3];
+  oov_hot(oov, L.D, &h[0], &h[1], &h[2]);
+  const float* e = L.emb + (size_t)row * L.D;
+  double acc = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    if (i && h[i] == h[i - 1]) continue;
+    acc = __dadd_rn(acc, (double)e[h[i]]);
+  }
+  return acc;
+}
+
+// key h from the per-64-column ballots bal[]: bit j of the key string is column
+// h*B + j, first column = most significant bit
+__device__ __forceinline__ uint32_t assemble_key(const uint64_t* bal, int h, int B) {
+  const int start = h * B, word = start >> 6, off = start & 63;
+  uint64_t field = bal[word] >> off;
+  if (off + B > 64) field |= bal[word + 1] << (64 - off);
+  const uint32_t f = (uint32_t)field & ((1u << B) - 1);
+  return __brev(f) >> (32 - B);
+}
+
+// CosineDistance of fan window f[] to script window s (canonical), with the
+// sound skip described in the file header.  Returns false when skipped or NaN.
+__device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, double ff,
+                                double* out) {
+  const double ss = L.ss[s];
+  // upper bound on SF
+  double ub = 0.0;
+  for (int k = 0; k < L.n; ++k) {
+    const uint32_t u = L.stok[s + k], v = f[k];
+    const double qu = q_of(L, u);
+    if (u == v) { ub += qu; continue; }
+    const double c = ((u | v) & FS_OOV_FLAG) ? 1.0 : L.cmax;
+    ub += c * 0.5 * (qu + q_of(L, v));
+  }
+  const double lim = (1.0 - L.thr - 1e-6);
+  if (ub <= 0.0 || ub * ub < lim * lim * ss * ff * (1.0 - 1e-9)) return false;
+  double sf = 0.0;
+  for (int k = 0; k < L.n; ++k) {
+    const uint32_t u = L.stok[s + k], v = f[k];
+    sf = __dadd_rn(sf, u == v ? q_of(L, u) : g_of(L, u, v));
+  }
+  const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(__dsqrt_rn(ss), __dsqrt_rn(ff))));
+  if (d != d) return false;
+  *out = d;
+  return true;
+}
+
+// Engine.neighbours + threshold.  ANY: stop at the first candidate within the
+// threshold (return 1).  Otherwise fill top_s/top_d (capacity nn) with the kept
+// matches in NearestFilter order and return their number.
+template <bool ANY>
+__device__ int lsh_neighbours(const LshDev& L, const uint32_t* keys, const uint32_t* f,
+                              uint32_t* top_s, double* top_d) {
+  double ff = 0.0;
+  for (int k = 0; k < L.n; ++k) ff = __dadd_rn(ff, q_of(L, f[k]));
+  const uint32_t nb1 = (1u << L.B) + 1;
+  int cnt = 0;
+  for (int h = 0; h < L.H; ++h) {
+    const uint32_t* o = L.boff + (size_t)h * nb1 + keys[h];
+    const uint32_t e0 = o[0], e1 = o[1];
+    for (uint32_t e = e0; e < e1; ++e) {
+      const uint32_t s = L.bids[(size_t)h * L.W + e];
+      if (!ANY && L.unique) {
+        bool seen = false;
+        for (int t = 0; t < cnt; ++t) seen = seen || top_s[t] == s;
+        if (seen) continue;
+      }
+      double d;
+      if (!window_distance(L, s, f, ff, &d)) continue;
+      if (!(d < L.thr)) continue;
+      if (ANY) return 1;
+      // stable insertion: behind every entry with distance <= d
+      int pos = cnt;
+      while (pos > 0 && d < top_d[pos - 1]) --pos;
+      if (pos >= L.nn) continue;
+      const int last = cnt < L.nn ? cnt : L.nn - 1;
+      for (int m = last; m > pos; --m) { top_d[m] = top_d[m - 1]; top_s[m] = top_s[m - 1]; }
+      top_d[pos] = d; top_s[pos] = s;
+      if (cnt < L.nn) ++cnt;
+    }
+  }
+  return cnt;
+}
+
+// ---- build kernels -----------------------------------------------------------
+
+__global__ void k_nt(const double* __restrict__ normals, int n, int D, int C,
+                     double* __restrict__ nt) {
+  // nt[k][d][c] = normals[c][k*D + d]
+  const size_t total = (size_t)n * D * C;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const size_t kd = i / C;
+    nt[i] = normals[(size_t)c * n * D + kd];
+  }
+}
+
+// A[k][v][c] = seqsum_d nt[k][d][c] * (double)E[v][d]; block = one (k, v)
+__global__ void k_atab(const double* __restrict__ nt, const float* __restrict__ emb, uint32_t V,
+                       int D, int C, double* __restrict__ atab) {
+  const uint32_t v = blockIdx.x;
+  const int k = blockIdx.y;
+  const float* e = emb + (size_t)v * D;
+  const double* ntk = nt + (size_t)k * D * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double acc = 0.0;
+    for (int d = 0; d < D; ++d)
+      acc = __dadd_rn(acc, __dmul_rn(ntk[(size_t)d * C + c], (double)e[d]));
+    atab[((size_t)k * V + v) * C + c] = acc;
+  }
+}
+
+__global__ void k_ss(const uint32_t* __restrict__ stok, uint32_t W, LshDev L,
+                     double* __restrict__ ss) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= W) return;
+  double acc = 0.0;
+  for (int k = 0; k < L.n; ++k) acc = __dadd_rn(acc, q_of(L, stok[w + k]));
+  ss[w] = acc;
+}
+
+// keys of the windows of a token stream; one wave per window
+__global__ __launch_bounds__(256) void k_keys(LshDev L, const uint32_t* __restrict__ tok,
+                                              uint32_t n_windows, uint32_t* __restrict__ keys) {
+  __shared__ uint64_t s_bal[4][32];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int NW = (L.C + 63) >> 6;
+  for (uint32_t w = blockIdx.x * 4 + wave; w < n_windows; w += gridDim.x * 4) {
+    for (int ch = 0; ch < NW; ++ch) {
+      const int c = ch * 64 + lane;
+      bool bit = false;
+      if (c < L.C) {
+        double acc = a_value(L, 0, tok[w], c);
+        for (int k = 1; k < L.n; ++k) acc = __dadd_rn(acc, a_value(L, k, tok[w + k], c));
+        bit = acc > 0.0;
+      }
+      const uint64_t b = __ballot(bit);
+      if (lane == 0) s_bal[wave][ch] = b;
+    }
+    if (lane == 0) s_bal[wave][NW] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < L.H) keys[(size_t)w * L.H + lane] = assemble_key(s_bal[wave], lane, L.B);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// ---- search kernels ------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
+                                                  uint64_t* __restrict__ qbm,
+                                                  uint32_t* __restrict__ qcnt, uint32_t n_sub) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const int NW = (L.C + 63) >> 6;                    // ballot words per window
+  uint64_t* s_bal = reinterpret_cast<uint64_t*>(s_raw);                 // [256][NW + 1]
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(s_bal + 256 * (NW + 1));   // [256][H]
+  uint32_t* s_tok = s_key + 256 * L.H;                                  // [256 + 16]
+  __shared__ uint32_t s_cnt[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = L.n;
+  for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
+    const uint64_t p0 = (uint64_t)sub * 256;
+    for (int i = threadIdx.x; i < 256 + n - 1; i += 256) s_tok[i] = c.tok[p0 + i];
+    for (int i = threadIdx.x; i < 256; i += 256) s_bal[i * (NW + 1) + NW] = 0;
+    __syncthreads();
+    // phase 1: threads are projection columns
+    for (int ch0 = 0; ch0 < L.C; ch0 += 256) {
+      const int col = ch0 + threadIdx.x;
+      const bool active = col < L.C;
+      const int cc = active ? col : 0;
+#pragma unroll 4
+      for (int w = 0; w < 256; ++w) {
+        double acc = a_value(L, 0, s_tok[w], cc);
+        for (int k = 1; k < n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_tok[w + k], cc));
+        const uint64_t b = __ballot(active && acc > 0.0);
+        if (lane == 0 && ch0 + wave * 64 < L.C) s_bal[w * (NW + 1) + (ch0 >> 6) + wave] = b;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 256 * L.H; i += 256) {
+      const int w = i / L.H, h = i - w * L.H;
+      s_key[i] = assemble_key(s_bal + w * (NW + 1), h, L.B);
+    }
+    __syncthreads();
+    // phase 2: thread (wave j, lane l) owns window 4 l + j, so that wave j's ballot
+    // is bitmap word j of the sub-tile
+    const int w = 4 * lane + wave;
+    bool flag = false;
+    if (p0 + w + n <= c.n_tok)
+      flag = lsh_neighbours<true>(L, s_key + w * L.H, s_tok + w, nullptr, nullptr) != 0;
+    const uint64_t b = __ballot(flag);
+    if (lane == 0) {
+      qbm[(size_t)sub * 4 + wave] = b;
+      s_cnt[wave] = __popcll(b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) qcnt[sub] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+}
+
+// one wave per flagged window
+__global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
+                                                    const uint32_t* __restrict__ cpos, NSrc nc,
+                                                    uint32_t* __restrict__ cg,
+                                                    uint32_t* __restrict__ cw,
+                                                    fs_best* __restrict__ cbest,
+                                                    uint32_t* __restrict__ bmatch, fs_status* st) {
+  __shared__ uint64_t s_bal[4][32];
+  __shared__ uint32_t s_key[4][64];
+  __shared__ uint32_t s_top_s[4][64];
+  __shared__ double s_top_d[4][64];
+  __shared__ uint32_t s_lev[4][64];
+  __shared__ uint32_t s_f[4][FS_MAX_WINDOW];
+  __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];
+  __shared__ int s_n[4];
+  __shared__ uint32_t s_w32[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t total = nc.get();
+  const int NW = (L.C + 63) >> 6;
+  uint32_t matches = 0;
+  for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
+    const uint64_t p = cpos[i];
+    bool ok = p + L.n <= c.n_tok;
+    uint32_t w = 0;
+    if (ok) {
+      w = work_of_token(c, p);
+      ok = p + L.n <= c.work_off[w + 1];        // a window never crosses a work boundary
+    }
+    if (!ok) {                                  // wave-uniform
+      if (lane == 0) cg[i] = FS_NONE;
+      continue;
+    }
+    if (lane < L.n) {
+      s_f[wave][lane] = c.tok[p + lane];
+      s_fs[wave][lane] = c.str ? c.str[p + lane] : c.tok[p + lane];
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int ch = 0; ch < NW; ++ch) {
+      const int col = ch * 64 + lane;
+      bool bit = false;
+      if (col < L.C) {
+        double acc = a_value(L, 0, s_f[wave][0], col);
+        for (int k = 1; k < L.n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_f[wave][k], col));
+        bit = acc > 0.0;
+      }
+      const uint64_t b = __ballot(bit);
+      if (lane == 0) s_bal[wave][ch] = b;
+    }
+    if (lane == 0) s_bal[wave][NW] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < L.H) s_key[wave][lane] = assemble_key(s_bal[wave], lane, L.B);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0)
+      s_n[wave] = lsh_neighbours<false>(L, s_key[wave], s_f[wave], s_top_s[wave], s_top_d[wave]);
+    __builtin_amdgcn_wave_barrier();
+    const int cnt = s_n[wave];
+    if (cnt == 0) {
+      if (lane == 0) cg[i] = FS_NONE;
+      continue;
+    }
+    // Levenshtein of every kept match, one lane each (search.py:189-190)
+    if (lane < cnt)
+      s_lev[wave][lane] = lev_device(g, s_top_s[wave][lane], s_fs[wave], c.chars, c.coff, c.n_str, st);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      fs_best b;
+      b.pad = 0.0;
+      for (int r = 0; r < cnt; ++r) {           // first minimum of dist * lev in rank order
+        const double comb = __dmul_rn(s_top_d[wave][r], (double)s_lev[wave][r]);
+        if (r == 0 || comb < b.comb) {
+          b.s = s_top_s[wave][r]; b.lev = s_lev[wave][r]; b.dist = s_top_d[wave][r]; b.comb = comb;
+        }
+      }
+      cbest[i] = b;
+      cg[i] = 0;
+      cw[i] = w;
+      matches += (uint32_t)cnt;
+    }
+  }
+  uint32_t tot;
+  block_excl_scan(matches, s_w32, &tot);
+  if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+}
+
+}  // namespace
+
+// ---- host side -----------------------------------------------------------------
+
+static LshDev lsh_dev(const fs_index* ix) {
+  LshDev L;
+  L.atab = ix->d_atab.p; L.nt = ix->d_nt.p; L.boff = ix->d_boff.p; L.bids = ix->d_bids.p;
+  L.ss = ix->d_ss.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
+  L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
+  L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
+  L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
+  L.nn = (int)ix->cfg.nearest_n; L.unique = ix->cfg.unique_filter ? 1 : 0;
+  L.thr = ix->cfg.distance_threshold;
+  L.cmax = ix->lsh_cmax;
+  return L;
+}
+
+// Engine.store_vector for every script window (search.py:122-123)
+int fs_lsh_build(fs_index* ix) {
+  if (ix->lsh_ready) return FS_OK;
+  if (!ix->d_normals.p) { fs_set_error("normals are required for the LSH pipeline"); return FS_E_INVALID; }
+  hipStream_t s = ix->stream;
+  const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
+  const int H = (int)ix->cfg.number_of_hashes, B = (int)ix->cfg.hash_dimensions, C = H * B;
+  const uint64_t V = ix->n_vec, W = ix->n_windows;
+  FS_TRY(ix->d_nt.reserve((size_t)n * D * C));
+  FS_TRY(ix->d_atab.reserve((size_t)n * V * C));
+  FS_TRY(ix->d_ss.reserve(W));
+  hipLaunchKernelGGL(k_nt, dim3(1024), dim3(256), 0, s, ix->d_normals.p, n, D, C, ix->d_nt.p);
+  if (V)
+    hipLaunchKernelGGL(k_atab, dim3((uint32_t)V, n), dim3(256), 0, s, ix->d_nt.p, ix->d_emb.p,
+                       (uint32_t)V, D, C, ix->d_atab.p);
+  FS_HIP(hipGetLastError());
+  const uint32_t nb = 1u << B;
+  std::vector<uint32_t> boff((size_t)H * (nb + 1), 0u), bids((size_t)H * std::max<uint64_t>(W, 1), 0u);
+  if (W) {
+    LshDev L = lsh_dev(ix);
+    hipLaunchKernelGGL(k_ss, dim3((uint32_t)((W + 255) / 256)), dim3(256), 0, s, ix->d_stok.p,
+                       (uint32_t)W, L, ix->d_ss.p);
+    DBuf<uint32_t> d_keys;
+    FS_TRY(d_keys.reserve(W * H));
+    hipLaunchKernelGGL(k_keys, dim3((uint32_t)std::min<uint64_t>((W + 3) / 4, 4096)), dim3(256), 0,
+                       s, L, ix->d_stok.p, (uint32_t)W, d_keys.p);
+    FS_HIP(hipGetLastError());
+    std::vector<uint32_t> keys(W * H);
+    FS_HIP(hipMemcpyAsync(keys.data(), d_keys.p, keys.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    for (int h = 0; h < H; ++h) {            // counting sort: ascending window index per bucket
+      uint32_t* off = boff.data() + (size_t)h * (nb + 1);
+      for (uint64_t w = 0; w < W; ++w) off[keys[w * H + h] + 1]++;
+      for (uint32_t b = 0; b < nb; ++b) off[b + 1] += off[b];
+      std::vector<uint32_t> cur(off, off + nb);
+      for (uint64_t w = 0; w < W; ++w) bids[(size_t)h * W + cur[keys[w * H + h]]++] = (uint32_t)w;
+    }
+  }
+  FS_TRY(ix->d_boff.upload(boff.data(), boff.size(), s));
+  FS_TRY(ix->d_bids.upload(bids.data(), bids.size(), s));
+  FS_HIP(hipStreamSynchronize(s));
+  ix->lsh_ready = true;
+  return FS_OK;
+}
+
+int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                       uint32_t n_sub, hipStream_t s) {
+  if (!n_sub) return FS_OK;
+  const LshDev L = lsh_dev(ix);
+  const int NW = (L.C + 63) >> 6;
+  const size_t lds = (size_t)256 * (NW + 1) * 8 + (size_t)256 * L.H * 4 + (256 + 16) * 4;
+  FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsh_scan),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+  const uint32_t blocks = std::min<uint32_t>(n_sub, ix->num_cu * per_cu);
+  hipLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), lds, s, c, L, qbm, qcnt, n_sub);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s) {
+  const LshDev L = lsh_dev(ix);
+  fs_status* st = ix->d_status.p;
+  const NSrc nc{&st->n_cands, 1, ccap, 0};
+  hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+                     ix->w_cpos.p, nc, ix->w_cg.p, ix->w_cw.p, ix->w_cbest.p,
+                     ix->w_bsum.p + kNB, st);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}

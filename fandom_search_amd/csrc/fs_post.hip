@@ -30,92 +30,11 @@
 // Element counts live in the device status block; every kernel sizes its loops
 // from there, producers clamp to their buffer capacity and the host re-runs
 // with larger buffers if a total exceeded it.
-#include "fs_internal.h"
+#include "fs_device.h"
 
 namespace {
 
-constexpr int kNB = 1024;        // blocks of every chunked kernel (and partial sums)
-constexpr int kThreads = 256;
-
-struct NSrc {               // element count, known on the host or on the device
-  const uint32_t* ptr;      // device count (clamped to cap, times mult) ...
-  uint32_t mult, cap;
-  uint32_t fixed;           // ... or a host constant when ptr == nullptr
-  __device__ uint32_t get() const {
-    if (!ptr) return fixed;
-    uint32_t v = *ptr;
-    if (v > cap) v = cap;
-    return v * mult;
-  }
-};
-
-// ---- block-wide helpers ----------------------------------------------------
-
-template <class V>
-__device__ __forceinline__ V wave_incl_scan(V v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    V t = __shfl_up(v, d);
-    if (lane >= d) v += t;
-  }
-  return v;
-}
-
-// exclusive scan of one value per thread over a 256-thread block; returns the
-// thread's exclusive prefix, *total = block sum.  s_w: 4 values of LDS.
-template <class V>
-__device__ __forceinline__ V block_excl_scan(V v, V* s_w, V* total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const V inc = wave_incl_scan(v, lane);
-  if (lane == 63) s_w[w] = inc;
-  __syncthreads();
-  V base = 0, tot = 0;
-#pragma unroll
-  for (int i = 0; i < kThreads / 64; ++i) {
-    const V x = s_w[i];
-    if (i < w) base += x;
-    tot += x;
-  }
-  __syncthreads();
-  *total = tot;
-  return base + inc - v;
-}
-
-// sum of the partial sums of all blocks before this one, and of all blocks
-template <class V>
-__device__ __forceinline__ V block_prefix(const V* __restrict__ bsum, V* s_w, V* total) {
-  V pre = 0, all = 0;
-  for (int i = threadIdx.x; i < kNB; i += kThreads) {
-    const V x = bsum[i];
-    all += x;
-    if (i < (int)blockIdx.x) pre += x;
-  }
-  V t_all, t_pre;
-  block_excl_scan(all, s_w, &t_all);
-  block_excl_scan(pre, s_w, &t_pre);
-  *total = t_all;
-  return t_pre;
-}
-
-__device__ __forceinline__ void chunk_of_block(uint32_t n, uint32_t* lo, uint32_t* hi) {
-  const uint32_t chunk = (n + kNB - 1) / kNB;
-  const uint64_t l = (uint64_t)blockIdx.x * chunk;
-  *lo = l < n ? (uint32_t)l : n;
-  const uint64_t h = l + chunk;
-  *hi = h < n ? (uint32_t)h : n;
-}
-
-template <class F, class V>
-__global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict__ bsum) {
-  __shared__ V s_w[4];
-  uint32_t lo, hi;
-  chunk_of_block(ns.get(), &lo, &hi);
-  V acc = 0;
-  for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) acc += f(i);
-  V tot;
-  block_excl_scan(acc, s_w, &tot);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
-}
+using namespace fsdev;
 
 // ---- count functors -----------------------------------------------------------
 
@@ -219,8 +138,7 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
       }
       if (gram != FS_NONE) {
         // work of token p: start from the work of its 256-token block
-        uint32_t w = c.blk_work[p >> 8];
-        while (c.work_off[w + 1] <= p) ++w;
+        const uint32_t w = work_of_token(c, p);
         if (p + g.n > c.work_off[w + 1]) gram = FS_NONE;   // crosses into the next work
         else { cw[i] = w; matches += g.gcnt[gram]; }
       }
@@ -232,58 +150,6 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
   uint32_t tot;
   block_excl_scan(matches, s_w, &tot);
   if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
-}
-
-// Levenshtein.distance(match_str, fan_context), search.py:189-190:
-//   match_str   = script words s .. s+n-1 joined by single spaces
-//   fan_context = '[' + ', '.join(fan token texts) + ']'
-// unit costs over code points.  One thread, operands in scratch.
-__device__ uint32_t lev_device(const GramIndexDev& g, uint32_t s, const uint32_t* fan_sid,
-                               const uint32_t* chars, const uint64_t* coff, uint32_t n_str,
-                               fs_status* st) {
-  uint32_t a[FS_LEV_MAX], b[FS_LEV_MAX];
-  uint16_t row[FS_LEV_MAX + 1];
-  uint32_t la = 0, lb = 0;
-  for (int k = 0; k < g.n; ++k) {
-    if (k) { if (la < FS_LEV_MAX) a[la] = ' '; ++la; }
-    for (uint64_t c = g.soff[s + k]; c < g.soff[s + k + 1]; ++c) {
-      if (la < FS_LEV_MAX) a[la] = g.schars[c];
-      ++la;
-    }
-  }
-  if (lb < FS_LEV_MAX) b[lb] = '[';
-  ++lb;
-  for (int k = 0; k < g.n; ++k) {
-    if (k) {
-      if (lb < FS_LEV_MAX) b[lb] = ','; ++lb;
-      if (lb < FS_LEV_MAX) b[lb] = ' '; ++lb;
-    }
-    const uint32_t sid = fan_sid[k];
-    if (sid >= n_str) { st->bad_string = 1; return 0; }
-    for (uint64_t c = coff[sid]; c < coff[sid + 1]; ++c) {
-      if (lb < FS_LEV_MAX) b[lb] = chars[c];
-      ++lb;
-    }
-  }
-  if (lb < FS_LEV_MAX) b[lb] = ']';
-  ++lb;
-  if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { st->lev_overflow = 1; return 0; }
-  for (uint32_t j = 0; j <= lb; ++j) row[j] = (uint16_t)j;
-  for (uint32_t x = 1; x <= la; ++x) {
-    uint32_t diag = row[0];
-    row[0] = (uint16_t)x;
-    const uint32_t ca = a[x - 1];
-    for (uint32_t j = 1; j <= lb; ++j) {
-      const uint32_t up = row[j];
-      uint32_t best = diag + (ca != b[j - 1] ? 1u : 0u);
-      if (up + 1 < best) best = up + 1;
-      const uint32_t left = row[j - 1];
-      if (left + 1 < best) best = left + 1;
-      diag = up;
-      row[j] = (uint16_t)best;
-    }
-  }
-  return row[lb];
 }
 
 // Per (gram, rank) Levenshtein table for corpora whose string id == vector id:
@@ -484,22 +350,43 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   return FS_OK;
 }
 
+// bitmap + counts -> candidate positions (w_cpos), n_cands in the status block
+int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, hipStream_t s) {
+  uint32_t* bsum32 = ix->w_bsum.p;
+  hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
+                     SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32);
+  hipLaunchKernelGGL(k_expand, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p, n_sub,
+                     bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+// verified candidates (w_cpos, w_cg, w_cw) + best records -> output rows
+int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, hipStream_t s) {
+  fs_status* st = ix->d_status.p;
+  const NSrc nc{&st->n_cands, 1, ccap, 0};
+  uint32_t* bmatch = ix->w_bsum.p + kNB;
+  uint64_t* bsum64 = ix->w_bsum64.p;
+  hipLaunchKernelGGL((k_reduce<HitRowsF, uint64_t>), dim3(kNB), dim3(kThreads), 0, s,
+                     HitRowsF{ix->w_cpos.p, ix->w_cg.p, ix->cfg.window_size}, nc, bsum64);
+  hipLaunchKernelGGL(k_rows, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
+                     ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, bsum64, bmatch, best_tab, best_per_cand,
+                     nc, rcap, d_rows, st);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
                    fs_row* d_rows, hipStream_t s) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->d_status.p;
-  uint32_t* bsum32 = ix->w_bsum.p;
   uint32_t* bmatch = ix->w_bsum.p + kNB;
-  uint64_t* bsum64 = ix->w_bsum64.p;
   const uint32_t nn = ix->cfg.nearest_n;
-  const uint32_t n = ix->cfg.window_size;
   const bool per_cand = c->has_str;
 
-  hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
-                     SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32);
-  hipLaunchKernelGGL(k_expand, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p, n_sub,
-                     bsum32, ix->w_cpos.p, ccap, st);
+  FS_TRY(fs_launch_expand(ix, n_sub, ccap, s));
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->w_cpos.p, nc,
                      ix->w_cg.p, ix->w_cw.p, bmatch);
@@ -510,11 +397,7 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, ui
     hipLaunchKernelGGL(k_cbest, dim3(kNB), dim3(kThreads), 0, s, g, ix->w_cg.p, ix->w_mlev.p, nc,
                        ix->w_cbest.p);
   }
-  hipLaunchKernelGGL((k_reduce<HitRowsF, uint64_t>), dim3(kNB), dim3(kThreads), 0, s,
-                     HitRowsF{ix->w_cpos.p, ix->w_cg.p, n}, nc, bsum64);
-  hipLaunchKernelGGL(k_rows, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->w_cpos.p, ix->w_cg.p,
-                     ix->w_cw.p, bsum64, bmatch, per_cand ? ix->w_cbest.p : c->d_gbest.p,
-                     per_cand ? 1 : 0, nc, rcap, d_rows, st);
   FS_HIP(hipGetLastError());
-  return FS_OK;
+  return fs_launch_rows(ix, c, per_cand ? ix->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
+                        rcap, d_rows, s);
 }

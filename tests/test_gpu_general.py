@@ -1,0 +1,178 @@
+"""GPU parity of the general (LSH) pipeline: window sizes, vector tables and
+tokens for which the exact n-gram proof does not hold.  Rows must be
+bit-identical to the plain-C oracle, which runs the reference's algorithm with
+no shortcut."""
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import abi, synth
+from fandom_search_amd.vocab import pack_strings
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cfg, script, swords, emb, normals, tok, off, chars, coff, tok_str=None, words=None):
+    from fandom_search_amd.engine import ScriptIndex
+    from oracle import c_oracle
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    got, st = ix.search(ix.corpus(tok, off, chars, coff, tok_str=tok_str))
+    sch, so = pack_strings(swords)
+    oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
+    want, ost = oi.search(tok, off, chars, coff, tok_str=tok_str)
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and st.windows_processed == ost.windows_processed
+    return ix, got, st
+
+
+@pytest.mark.parametrize("n", [8, 10])
+def test_window_sizes_without_proof(synth_base, n):
+    """BASELINE.json configs[3] (n-gram sweep): for n = 8 and 10 one substituted
+    token can stay within the threshold ((n-1+c_max)/n > 0.9), so the index must
+    take the LSH pipeline."""
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(3000)
+    tok, off = util.ragged_corpus([700] * 12 + [0, n - 1, n, 1500], script)
+    cfg = abi.make_config(window_size=n)
+    ix, got, st = _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(n),
+                       tok, off, synth_base["chars"], synth_base["off"])
+    assert ix.info["proof_ok"] == 0 and st.path == abi.FS_MODE_GENERAL
+    assert len(got) > 0
+
+
+def test_general_mode_equals_exact_mode(synth_base):
+    """Forcing the LSH pipeline where the proof holds must not change a byte."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(4000)
+    tok, off = util.ragged_corpus([900] * 20 + [3, 0, 2100], script)
+    normals = synth.lsh_normals(6)
+    swords = [words[int(t)] for t in script]
+    cfg = abi.make_config(mode=abi.FS_MODE_GENERAL)
+    ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
+                       synth_base["chars"], synth_base["off"])
+    assert st.path == abi.FS_MODE_GENERAL and ix.info["proof_ok"] == 1
+    ex = ScriptIndex(script, swords, emb, normals, cfg=abi.make_config(mode=abi.FS_MODE_EXACT))
+    got2, st2 = ex.search(ex.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    assert st2.path == abi.FS_MODE_EXACT
+    assert got.tobytes() == got2.tobytes()
+
+
+@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+def test_general_mode_reproduces_golden(name, synth_base):
+    from fandom_search_amd.engine import ScriptIndex
+    case = util.load_case(name)
+    cfg = util.case_config(case, mode=abi.FS_MODE_GENERAL)
+    normals = synth.lsh_normals(cfg.window_size, cfg.number_of_hashes, cfg.hash_dimensions)
+    words = synth_base["words"]
+    script = np.asarray(case["script"], dtype=np.uint32)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], synth_base["emb"], normals, cfg=cfg)
+    tok, off = util.case_arrays(case)
+    rows, st = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    assert st.path == abi.FS_MODE_GENERAL
+    assert util.rows_to_csv(rows, case, words) == util.golden_text(name, "canonical")
+
+
+def test_near_duplicate_vectors_give_approximate_matches(synth_base):
+    """A table with near-synonyms (cos 0.99): a 6-gram with a synonym swapped in
+    is a genuine approximate match (distance ~0.002), found through LSH bucket
+    collisions, scored with real dot products."""
+    words = synth_base["words"][:2000]
+    rng = np.random.default_rng(11)
+    emb = synth_base["emb"][:2000].copy()
+    for i in range(0, 400, 2):                     # rows i+1 ~ rows i
+        v = emb[i] + 0.12 * rng.standard_normal(300).astype(np.float32) / np.sqrt(300)
+        emb[i + 1] = v / np.linalg.norm(v)
+    script = rng.integers(0, 400, size=1500).astype(np.uint32)
+    works = []
+    for w in range(10):
+        t = rng.integers(400, 2000, size=600).astype(np.uint32)
+        for _ in range(4):
+            ln = int(rng.integers(6, 20))
+            src = int(rng.integers(0, len(script) - ln))
+            dst = int(rng.integers(0, 600 - ln))
+            span = script[src:src + ln].copy()
+            swap = rng.random(ln) < 0.3
+            span[swap] ^= 1                         # synonym of each swapped token
+            t[dst:dst + ln] = span
+        works.append(t)
+    tok = np.concatenate(works)
+    off = np.arange(11, dtype=np.uint64) * np.uint64(600)
+    chars, coff = pack_strings(words)
+    cfg = abi.make_config()
+    ix, got, st = _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                       tok, off, chars, coff)
+    assert ix.info["proof_ok"] == 0 and ix.info["c_max"] > 0.9
+    inexact = got[got["dist"] > 1e-6]
+    assert len(inexact) > 10 and float(inexact["dist"].max()) < 0.1
+
+
+def test_out_of_vocabulary_tokens(synth_base):
+    """3-hot vectors (search.py:79-83) in the script and in the fan works."""
+    words = list(synth_base["words"][:3000])
+    emb = synth_base["emb"][:3000]
+    D = 300
+    rng = np.random.default_rng(23)
+
+    def oov_id():
+        a, b, c = sorted(int(x) for x in rng.integers(0, D, size=3))
+        return abi.FS_OOV_FLAG | ((a * D + b) * D + c)
+
+    oov = np.array([oov_id() for _ in range(40)] + [abi.FS_OOV_FLAG | ((7 * D + 7) * D + 9)],
+                   dtype=np.uint32)                 # one with a repeated hot position
+    strings = words + ["Oov%d" % i for i in range(len(oov))]
+    script = rng.integers(0, 3000, size=1200).astype(np.uint32)
+    script_str = script.copy()
+    for pos in rng.integers(0, 1200, size=60):
+        k = int(rng.integers(0, len(oov)))
+        script[pos] = oov[k]
+        script_str[pos] = 3000 + k
+    works, works_str = [], []
+    for w in range(8):
+        t = rng.integers(0, 3000, size=500).astype(np.uint32)
+        ts = t.copy()
+        for pos in rng.integers(0, 500, size=15):
+            k = int(rng.integers(0, len(oov)))
+            t[pos] = oov[k]
+            ts[pos] = 3000 + k
+        for _ in range(3):
+            ln = int(rng.integers(6, 30))
+            src = int(rng.integers(0, 1200 - ln))
+            dst = int(rng.integers(0, 500 - ln))
+            t[dst:dst + ln] = script[src:src + ln]
+            ts[dst:dst + ln] = script_str[src:src + ln]
+        works.append(t)
+        works_str.append(ts)
+    tok = np.concatenate(works)
+    tok_str = np.concatenate(works_str)
+    off = np.arange(9, dtype=np.uint64) * np.uint64(500)
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config()
+    swords = [strings[int(s)].lower() for s in script_str]
+    ix, got, st = _run(cfg, script, swords, emb, synth.lsh_normals(6), tok, off, chars, coff,
+                       tok_str=tok_str)
+    assert st.path == abi.FS_MODE_GENERAL and len(got) > 0
+    hit_oov = [r for r in got if script[r["orig_ix"]] & abi.FS_OOV_FLAG]
+    assert hit_oov, "no record landed on an out-of-vocabulary script word"
+
+
+def test_oov_corpus_on_an_exact_index(synth_base):
+    """The index proves the exact scan, the corpus carries OOV ids: that corpus
+    alone takes the LSH pipeline."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(2000)
+    tok, off = util.ragged_corpus([800] * 6, script)
+    tok = tok.copy()
+    tok[5::97] = abi.FS_OOV_FLAG | ((1 * 300 + 2) * 300 + 3)
+    strings = list(words) + ["Zzz"]
+    tok_str = np.where(tok & abi.FS_OOV_FLAG, len(words), tok).astype(np.uint32)
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config()
+    ix, got, st = _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                       tok, off, chars, coff, tok_str=tok_str)
+    assert ix.info["path"] == abi.FS_MODE_EXACT and st.path == abi.FS_MODE_GENERAL
+    clean, off2 = util.ragged_corpus([800] * 6, script)
+    got2, st2 = ix.search(ix.corpus(clean, off2, synth_base["chars"], synth_base["off"]))
+    assert st2.path == abi.FS_MODE_EXACT and len(got2) >= len(got)
