@@ -42,8 +42,25 @@ def parse():
     ap.add_argument("--works", type=int, default=0, help="override works per rank")
     ap.add_argument("--window", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: every rank "
+                         "computes on GPU 0, rows gathered through host memory)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
+
+
+def host_cores():
+    """CPU cores this process may actually use: the affinity mask capped by the
+    cgroup CPU quota (a GPU box exposes all host CPUs but grants a share)."""
+    cores = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    env = os.environ.get("FS_BENCH_CORES")
+    return int(env) if env else cores
 
 
 def cpu_baseline(cfg, script, swords, words, emb, normals, tokens_per_work,
@@ -52,7 +69,7 @@ def cpu_baseline(cfg, script, swords, words, emb, normals, tokens_per_work,
     top-10, Levenshtein, per-word dedupe) on the first works of the workload."""
     from fandom_search_amd import synth, vocab
     from oracle import c_oracle
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     sch, so = vocab.pack_strings(swords)
     oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=cores)
     pilot = 4 * cores
@@ -85,9 +102,15 @@ def main():
     from fandom_search_amd import _lib, abi, synth, vocab
     from fandom_search_amd.engine import ScriptIndex
 
-    torch.cuda.set_device(local_rank)
+    rehearsal = args.backend == "gloo"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if rehearsal else "cuda"        # where collectives run
 
     conf = dict(synth.CONFIGS[args.workload])
     if args.works:
@@ -101,7 +124,7 @@ def main():
     chars, coff = vocab.pack_strings(words)
     tok, off = synth.corpus_tokens(n_works, tpw, script, first_work=rank * n_works)
 
-    cfg = abi.make_config(window_size=args.window, device=local_rank)
+    cfg = abi.make_config(window_size=args.window, device=dev_index)
     ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
     corpus = ix.corpus(tok, off, chars, coff)
 
@@ -119,17 +142,17 @@ def main():
             cap = int(e.required * 1.05) + 64
     pad = cap
     if world > 1:
-        t = torch.tensor([cap], dtype=torch.int64, device="cuda")
+        t = torch.tensor([cap], dtype=torch.int64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         pad = int(t.item())
         if pad != cap:
             cap = pad
             bufs = [torch.empty(cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        counts = [torch.zeros(world, dtype=torch.int64, device="cuda") for _ in range(2)]
-        mine = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+        counts = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(2)]
+        mine = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(2)]
         gathered = None
         if rank == 0:
-            gathered = [[torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+            gathered = [[torch.empty(cap * 32, dtype=torch.uint8, device=cdev)
                          for _ in range(world)] for _ in range(2)]
 
     pending = [None, None]
@@ -149,7 +172,8 @@ def main():
         if world > 1:
             mine[b].fill_(n)
             h1 = dist.all_gather_into_tensor(counts[b], mine[b], async_op=True)
-            h2 = dist.gather(bufs[b], gathered[b] if rank == 0 else None, dst=0,
+            send = bufs[b].cpu() if rehearsal else bufs[b]
+            h2 = dist.gather(send, gathered[b] if rank == 0 else None, dst=0,
                              async_op=True)
             pending[b] = (h1, h2)
         return st
@@ -177,7 +201,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -185,7 +209,17 @@ def main():
         ms_per_step = dt / args.steps * 1e3
         value = world * n_works * args.steps / dt
         scan_avg_ms = float(np.mean(scan_ms))
-        algo_bytes = 4.0 * corpus.n_tok           # 4 B per fan token
+        exact = st.path == abi.FS_MODE_EXACT
+        if exact:
+            kernel = "k_scan<%d,U,shuffle>" % args.window
+            algo_bytes = 4.0 * corpus.n_tok       # 4 B per fan token
+            note = "4 B per fan token"
+        else:
+            # LSH pipeline: per window n rows of H*B float64 projections are gathered
+            # (L2 / Infinity Cache resident table, so 'hbm' is nominal here)
+            kernel = "k_lsh_scan"
+            algo_bytes = float(st.windows_processed) * args.window * 15 * 14 * 8
+            note = "n*H*B*8 B of projection-table rows per window (cache-served gather)"
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
@@ -216,9 +250,10 @@ def main():
                        "works_per_gpu": n_works, "tokens_per_work": tpw,
                        "script_tokens": conf["script_tokens"], "window": args.window,
                        "rows_per_gpu_step": int(total_rows),
-                       "gather": "rccl gather to rank 0, overlapped" if world > 1 else "none",
+                       "gather": ("%s gather to rank 0, overlapped" % ("gloo (rehearsal)" if rehearsal
+                                                                        else "rccl")) if world > 1 else "none",
                        "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh"},
-            "roofline": {"bound": "hbm", "kernel": "k_scan<%d,U>" % args.window,
+            "roofline": {"bound": "hbm", "kernel": kernel, "bytes_model": note,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
