@@ -1,0 +1,136 @@
+"""Parity at BASELINE.json's full sizes, where the oracle would take hours:
+size-independent properties of the records, an independent numpy n-gram join
+for completeness, idempotence, and byte equality of the two device pipelines
+(exact scan vs LSH) on the whole C2 corpus."""
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import abi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+U64 = np.uint64
+
+
+def _covered_words(tok, off, script, n):
+    """Independent numpy implementation of "which fan words lie inside a window
+    whose n ids equal a script window's" (64-bit polynomial hash join, every hit
+    verified id for id)."""
+    def hashes(a):
+        a = a.astype(U64)
+        w = len(a) - n + 1
+        h = np.zeros(max(w, 0), dtype=U64)
+        for k in range(n):
+            h = h * U64(1000003) + a[k:k + w]
+        return h
+    hs = hashes(script)
+    hf = hashes(tok)
+    cand = np.nonzero(np.isin(hf, np.unique(hs)))[0]
+    swin = {bytes(script[i:i + n].tobytes()) for i in range(len(script) - n + 1)}
+    work = np.searchsorted(off, cand, side="right") - 1
+    inside = cand + n <= off[work + 1]
+    cand = cand[inside]
+    ok = np.fromiter((tok[p:p + n].tobytes() in swin for p in cand), dtype=bool, count=len(cand))
+    starts = cand[ok]
+    cover = np.zeros(len(tok) + 1, dtype=np.int32)
+    np.add.at(cover, starts, 1)
+    np.add.at(cover, starts + n, -1)
+    return np.nonzero(np.cumsum(cover[:-1]) > 0)[0], len(starts)
+
+
+def _check_rows(rows, tok, off, script, n):
+    pos = off[rows["work"]].astype(np.int64) + rows["fan_ix"].astype(np.int64)
+    # sorted by (work, fan word), one record per word
+    assert np.all(np.diff(pos) > 0)
+    assert np.all(rows["fan_ix"].astype(np.int64) < (off[rows["work"] + 1] - off[rows["work"]]).astype(np.int64))
+    # the matched script word carries the same vector id as the fan word
+    assert np.array_equal(tok[pos], script[rows["orig_ix"]])
+    # some window over the word matches the script at the same alignment
+    good = np.zeros(len(rows), dtype=bool)
+    o = rows["orig_ix"].astype(np.int64)
+    wlo = off[rows["work"]].astype(np.int64)
+    whi = off[rows["work"] + 1].astype(np.int64)
+    for k in range(n):
+        p0, o0 = pos - k, o - k
+        valid = (p0 >= wlo) & (p0 + n <= whi) & (o0 >= 0) & (o0 + n <= len(script))
+        eq = valid.copy()
+        for j in range(n):
+            idx = np.where(valid, p0 + j, 0)
+            jdx = np.where(valid, o0 + j, 0)
+            eq &= tok[idx] == script[jdx]
+        good |= eq
+    assert good.all()
+    # synthetic text is lower-case on both sides: Levenshtein n+1, distance ~ 0
+    assert np.all(rows["lev"] == n + 1)
+    assert np.all(np.abs(rows["dist"]) < 1e-15)
+    assert np.array_equal(rows["comb"], rows["dist"] * rows["lev"])
+    return pos
+
+
+@pytest.fixture(scope="module")
+def c2(synth_base):
+    conf = synth.CONFIGS["c2"]
+    script = synth.script_tokens(conf["script_tokens"])
+    tok, off = synth.corpus_tokens(conf["n_works"], conf["tokens_per_work"], script)
+    return script, tok, off
+
+
+def test_c2_full_properties_and_pipeline_equality(c2, synth_base):
+    """BASELINE.json configs[1]: 10k works x 2k tokens vs a 20k-token script."""
+    from fandom_search_amd.engine import ScriptIndex
+    script, tok, off = c2
+    words, emb = synth_base["words"], synth_base["emb"]
+    n = 6
+    normals = synth.lsh_normals(n)
+    swords = [words[int(t)] for t in script]
+    ix = ScriptIndex(script, swords, emb, normals, cfg=abi.make_config())
+    corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    rows, st = ix.search(corpus)
+    assert st.path == abi.FS_MODE_EXACT and st.windows_processed == 10000 * 1995
+    pos = _check_rows(rows, tok, off, script, n)
+    want_pos, n_windows = _covered_words(tok, off, script, n)
+    assert np.array_equal(pos, want_pos)            # completeness and no extras
+    # idempotence
+    rows2, _ = ix.search(corpus)
+    assert rows.tobytes() == rows2.tobytes()
+    # the LSH pipeline over the same 20M windows gives the same bytes
+    gx = ScriptIndex(script, swords, emb, normals, cfg=abi.make_config(mode=abi.FS_MODE_GENERAL))
+    grows, gst = gx.search(gx.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    assert gst.path == abi.FS_MODE_GENERAL
+    assert grows.tobytes() == rows.tobytes()
+    assert gst.matches == st.matches
+    # a 300-work slice against the oracle, embedded in the full run
+    cut = int(off[300])
+    oi = util.oracle_index(abi.make_config(), script, words, emb, normals)
+    want, _ = oi.search(tok[:cut], off[:301], synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(rows[rows["work"] < 300], want)
+
+
+def test_c3_shard_properties(synth_base):
+    """One GPU's share of BASELINE.json configs[2]: 12.5k works x 5k tokens."""
+    from fandom_search_amd.engine import ScriptIndex
+    conf = synth.CONFIGS["c3shard"]
+    script = synth.script_tokens(conf["script_tokens"])
+    rng = np.random.default_rng(99)
+    # ragged: work lengths 5000 +- 2000, a few empty
+    lens = rng.integers(3000, 7001, size=conf["n_works"])
+    lens[rng.integers(0, len(lens), size=20)] = 0
+    lens[-1] += conf["n_works"] * 5000 - int(lens.sum())
+    off = np.zeros(len(lens) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lens)
+    tok = synth._draw(rng, int(off[-1]), len(synth_base["words"]))
+    for _ in range(30000):                          # planted verbatim spans
+        ln = int(rng.integers(6, 25))
+        src = int(rng.integers(0, len(script) - ln))
+        dst = int(rng.integers(0, len(tok) - ln))
+        tok[dst:dst + ln] = script[src:src + ln]
+    words = synth_base["words"]
+    ix = ScriptIndex(script, [words[int(t)] for t in script], synth_base["emb"],
+                     synth.lsh_normals(6), cfg=abi.make_config())
+    rows, st = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    pos = _check_rows(rows, tok, off, script, 6)
+    want_pos, _ = _covered_words(tok, off, script, 6)
+    assert np.array_equal(pos, want_pos)
+    assert st.rows == len(rows) and st.windows_processed == int(np.maximum(lens - 5, 0).sum())
