@@ -102,14 +102,16 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
   ix->log2_words = lw;
   ix->log2_slots = std::max(4, ceil_log2((uint64_t)G * 2 + 1));
   if (ix->log2_slots > 31) { fs_set_error("script too large"); return FS_E_UNSUPPORTED; }
-  std::vector<uint32_t> filter(1u << lw, 0u), table(1u << ix->log2_slots, 0u);
+  std::vector<uint32_t> filter(1u << lw, 0u), table((size_t)4 << ix->log2_slots, 0u);
   const uint32_t slot_mask = (1u << ix->log2_slots) - 1;
   for (uint32_t g = 0; g < G; ++g) {
     const uint32_t h = fs_gram_hash(stok + gpos[(size_t)g * nn], (int)n);
     filter[fs_bloom_word(h, lw)] |= fs_bloom_mask(h);
     uint32_t slot = fs_table_slot(h, ix->log2_slots);
-    while (table[slot]) slot = (slot + 1) & slot_mask;
-    table[slot] = g + 1;
+    while (table[4 * (size_t)slot]) slot = (slot + 1) & slot_mask;
+    table[4 * (size_t)slot] = g + 1;            // {gram + 1, first position, kept occurrences, 0}
+    table[4 * (size_t)slot + 1] = gpos[(size_t)g * nn];
+    table[4 * (size_t)slot + 2] = gcnt[g];
   }
   FS_TRY(ix->d_filter.upload(filter.data(), filter.size(), ix->stream));
   FS_TRY(ix->d_table.upload(table.data(), table.size(), ix->stream));
@@ -234,11 +236,11 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   FS_HIP(hipEventCreate(&ix->ev_end));
   FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
   FS_TRY(ix->d_status.reserve(1));
-  FS_TRY(ix->w_bsum.reserve(2048));
-  FS_TRY(ix->w_bsum64.reserve(1024));
+  FS_TRY(ix->w_bsum.reserve(4096));
+  FS_TRY(ix->w_bsum64.reserve(2048));
 
   // script ids padded by n so that device code may read a full window anywhere
-  std::vector<uint32_t> stok(n_script + cfg->window_size + 1, 0u);
+  std::vector<uint32_t> stok(n_script + FS_MAX_WINDOW + 1, 0u);
   if (n_script) memcpy(stok.data(), script_vec, n_script * sizeof(uint32_t));
   FS_TRY(ix->d_stok.upload(stok.data(), stok.size(), ix->stream));
   const uint64_t n_chars = n_script ? script_off[n_script] : 0;
@@ -411,6 +413,7 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
     FS_TRY(ix->w_cpos.reserve(ccap));
     FS_TRY(ix->w_cg.reserve(ccap));
     FS_TRY(ix->w_cw.reserve(ccap));
+    FS_TRY(ix->w_hv.reserve(ccap));
     FS_TRY(ix->w_mlev.reserve(exact && c->has_str ? ccap * nn : 1));
     FS_TRY(ix->w_cbest.reserve(!exact || c->has_str ? ccap : 1));
     fs_row* d_rows = rows;

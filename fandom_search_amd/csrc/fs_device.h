@@ -4,7 +4,7 @@
 
 namespace fsdev {
 
-constexpr int kNB = 1024;        // blocks of every chunked kernel (and partial sums)
+constexpr int kNB = 2048;        // blocks of every chunked kernel (and partial sums)
 constexpr int kThreads = 256;
 
 struct NSrc {               // element count, known on the host or on the device

@@ -75,7 +75,7 @@ struct fs_status {
 };
 
 // what one hit offers to the fan words of its window (first-minimum rank)
-struct fs_best {
+struct alignas(16) fs_best {
   uint32_t s;      // script position of the chosen rank
   uint32_t lev;
   double dist;
@@ -88,7 +88,7 @@ struct fs_best {
 struct GramIndexDev {
   const uint32_t* stok;      // [n_script] script vector ids
   const uint32_t* filter;    // [1 << log2_words] blocked Bloom filter
-  const uint32_t* table;     // [1 << log2_slots] gram id + 1, 0 = empty
+  const uint32_t* table;     // [1 << log2_slots][4] {gram id + 1 (0 = empty), first position, kept occurrences, 0}
   const uint32_t* gpos;      // [n_grams][nn] first <= nn script positions, ascending
   const uint32_t* gcnt;      // [n_grams] min(occurrences, nn)
   const double*   selfdist;  // [n_windows] canonical distance of a window to itself
@@ -137,7 +137,7 @@ struct fs_index {
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors
 
   // workspaces (grow on demand)
-  DBuf<uint64_t> w_qbm, w_bsum64;
+  DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
   DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
   DBuf<fs_best> w_cbest;
   DBuf<fs_row> w_rows;

@@ -64,6 +64,25 @@ struct HitRowsF {
   }
 };
 
+// (hits, records) partial sums; the per-candidate value is kept for k_rows so that
+// the backward walk is done once
+__global__ __launch_bounds__(kThreads) void k_hitrows(HitRowsF f, NSrc ns,
+                                                      uint64_t* __restrict__ hv,
+                                                      uint64_t* __restrict__ bsum) {
+  __shared__ uint64_t s_w[4];
+  uint32_t lo, hi;
+  chunk_of_block(ns.get(), &lo, &hi);
+  uint64_t acc = 0;
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    const uint64_t v = f(i);
+    hv[i] = v;
+    acc += v;
+  }
+  uint64_t tot;
+  block_excl_scan(acc, s_w, &tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
 // ---- kernels --------------------------------------------------------------------
 
 __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict__ qbm,
@@ -85,8 +104,10 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
     uint32_t idx = carry + block_excl_scan(cnt, s_w, &tile_total);
     if (cnt) {
       // windows in position order: lane L (tokens 4L..4L+3), then j
-      const uint64_t* w = qbm + (size_t)sub * 4;
-      const uint64_t b0 = w[0], b1 = w[1], b2 = w[2], b3 = w[3];
+      const uint4* w = reinterpret_cast<const uint4*>(qbm + (size_t)sub * 4);   // 32 B aligned
+      const uint4 lo4 = w[0], hi4 = w[1];
+      const uint64_t b0 = lo4.x | ((uint64_t)lo4.y << 32), b1 = lo4.z | ((uint64_t)lo4.w << 32);
+      const uint64_t b2 = hi4.x | ((uint64_t)hi4.y << 32), b3 = hi4.z | ((uint64_t)hi4.w << 32);
       uint64_t any = b0 | b1 | b2 | b3;
       while (any) {
         const int L = __ffsll((unsigned long long)any) - 1;
@@ -102,6 +123,15 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
   }
 }
 
+// ids of a window: two (n <= 8) or four 16-byte loads.  The window start is only
+// 4-byte aligned; gfx950 global loads accept that (unaligned access mode), and
+// the token buffers are padded, so reading up to 16 ids is always in bounds.
+struct Ids16 { uint32_t v[16]; };
+__device__ __forceinline__ void load_ids(const uint32_t* p, int n, Ids16* out) {
+  __builtin_memcpy(out->v, p, 32);
+  if (n > 8) __builtin_memcpy(out->v + 8, p + 8, 32);
+}
+
 __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g,
                                                      const uint32_t* __restrict__ cpos,
                                                      NSrc nc, uint32_t* __restrict__ cg,
@@ -110,37 +140,38 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
   __shared__ uint32_t s_w[4];
   const uint32_t total = nc.get();
   const uint32_t slot_mask = (1u << g.log2_slots) - 1;
+  // {gram + 1 (0 = empty), first position, occurrences kept, 0}
+  const uint4* table = reinterpret_cast<const uint4*>(g.table);
   uint32_t matches = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += gridDim.x * blockDim.x) {
     const uint64_t p = cpos[i];
     uint32_t gram = FS_NONE;
     if (p + g.n <= c.n_tok) {
-      const uint32_t* t = c.tok + p;
-      uint32_t ids[FS_MAX_WINDOW];
-#pragma unroll
-      for (int k = 0; k < FS_MAX_WINDOW; ++k) ids[k] = k < g.n ? t[k] : 0u;
+      // two independent chains: ids -> table -> script ids, and block -> work
+      Ids16 f;
+      load_ids(c.tok + p, g.n, &f);
+      const uint32_t w = work_of_token(c, p);
+      const bool inside = p + g.n <= c.work_off[w + 1];   // a window never crosses works
       uint32_t h = 0;
 #pragma unroll
       for (int k = 0; k < FS_MAX_WINDOW; ++k)
-        if (k < g.n) h ^= fs_rotl(fs_premix(ids[k]), fs_rot_of(g.n - 1 - k));
+        if (k < g.n) h ^= fs_rotl(fs_premix(f.v[k]), fs_rot_of(g.n - 1 - k));
       uint32_t slot = fs_table_slot(h, g.log2_slots);
       for (;;) {
-        const uint32_t e = g.table[slot];
-        if (e == 0) break;
-        const uint32_t* s = g.stok + g.gpos[(size_t)(e - 1) * g.nn];
+        const uint4 e = table[slot];
+        if (e.x == 0) break;
+        Ids16 sc;
+        load_ids(g.stok + e.y, g.n, &sc);
         bool same = true;
 #pragma unroll
         for (int k = 0; k < FS_MAX_WINDOW; ++k)
-          if (k < g.n) same = same && (s[k] == ids[k]);
-        if (same) { gram = e - 1; break; }
+          if (k < g.n) same = same && (sc.v[k] == f.v[k]);
+        if (same) {
+          if (inside) { gram = e.x - 1; cw[i] = w; matches += e.z; }
+          break;
+        }
         slot = (slot + 1) & slot_mask;
-      }
-      if (gram != FS_NONE) {
-        // work of token p: start from the work of its 256-token block
-        const uint32_t w = work_of_token(c, p);
-        if (p + g.n > c.work_off[w + 1]) gram = FS_NONE;   // crosses into the next work
-        else { cw[i] = w; matches += g.gcnt[gram]; }
       }
     }
     cg[i] = gram;
@@ -231,6 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
                                                    const uint32_t* __restrict__ cpos,
                                                    const uint32_t* __restrict__ cg,
                                                    const uint32_t* __restrict__ cw,
+                                                   const uint64_t* __restrict__ hv,
                                                    const uint64_t* __restrict__ bsum,
                                                    const uint32_t* __restrict__ bmatch,
                                                    const fs_best* __restrict__ best_tab,
@@ -253,12 +285,11 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
   }
   const uint32_t NC = nc.get();
   const uint32_t n = g.n;
-  const HitRowsF f{cpos, cg, n};
   uint32_t lo, hi;
   chunk_of_block(NC, &lo, &hi);
   for (uint32_t t0 = lo; t0 < hi; t0 += kThreads) {
     const uint32_t i = t0 + threadIdx.x;
-    const uint64_t v = i < hi ? f(i) : 0;
+    const uint64_t v = i < hi ? hv[i] : 0;
     uint64_t tile_total;
     const uint64_t ex = block_excl_scan(v, s_w, &tile_total);
     s_roff[threadIdx.x] = (uint32_t)(ex >> 32);
@@ -278,6 +309,8 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
       const uint32_t ridx = rbase + r;
       if (ridx >= rcap) continue;
       const uint32_t p = cpos[own];
+      const uint32_t w = cw[own];
+      const uint64_t wbase = c.work_off[w];
       // words first covered by `own`: the last cnt of its window; cnt from the
       // next entry's offset
       const uint32_t next_off = a + 1 < kThreads ? s_roff[a + 1] : tile_rows;
@@ -299,10 +332,16 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
           out.comb = bb.comb;
         }
       }
-      const uint32_t w = cw[own];
       out.work = w;
-      out.fan_ix = (uint32_t)((uint64_t)x - c.work_off[w]);
-      rows[ridx] = out;
+      out.fan_ix = (uint32_t)((uint64_t)x - wbase);
+      // one 32-byte record = two 16-byte stores (row buffers are 16-byte aligned)
+      uint4 q0, q1;
+      q0.x = out.work; q0.y = out.fan_ix; q0.z = out.orig_ix; q0.w = out.lev;
+      const uint64_t db = (uint64_t)__double_as_longlong(out.dist);
+      const uint64_t cb = (uint64_t)__double_as_longlong(out.comb);
+      q1.x = (uint32_t)db; q1.y = (uint32_t)(db >> 32); q1.z = (uint32_t)cb; q1.w = (uint32_t)(cb >> 32);
+      uint4* dst = reinterpret_cast<uint4*>(rows + ridx);
+      dst[0] = q0; dst[1] = q1;
     }
     __syncthreads();
     carry += tile_total;
@@ -368,11 +407,11 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   uint32_t* bmatch = ix->w_bsum.p + kNB;
   uint64_t* bsum64 = ix->w_bsum64.p;
-  hipLaunchKernelGGL((k_reduce<HitRowsF, uint64_t>), dim3(kNB), dim3(kThreads), 0, s,
-                     HitRowsF{ix->w_cpos.p, ix->w_cg.p, ix->cfg.window_size}, nc, bsum64);
+  hipLaunchKernelGGL(k_hitrows, dim3(kNB), dim3(kThreads), 0, s,
+                     HitRowsF{ix->w_cpos.p, ix->w_cg.p, ix->cfg.window_size}, nc, ix->w_hv.p, bsum64);
   hipLaunchKernelGGL(k_rows, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
-                     ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, bsum64, bmatch, best_tab, best_per_cand,
-                     nc, rcap, d_rows, st);
+                     ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
+                     best_per_cand, nc, rcap, d_rows, st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -152,8 +152,8 @@ int fs_corpus_create(fs_index* ix,
 void fs_corpus_destroy(fs_corpus* c);
 
 /* Search every work of `c`.  `rows` is a host buffer of `cap` records, or,
- * when rows_on_device != 0, a device pointer on the index's device (for a
- * collective gather without a host round trip).  On FS_E_CAPACITY *n_rows is
+ * when rows_on_device != 0, a 16-byte aligned device pointer on the index's
+ * device (for a collective gather without a host round trip).  On FS_E_CAPACITY *n_rows is
  * the number required.  `st` may be NULL. */
 int fs_search_corpus(fs_index* ix, fs_corpus* c,
                      fs_row* rows, uint64_t cap, int rows_on_device,
