@@ -29,24 +29,28 @@ constexpr int kWave = 64;
 constexpr int kTokPerLane = 4;
 constexpr int kSubTile = kWave * kTokPerLane;   // 256 tokens per bitmap word
 
-// flags: bit j = window 4*lane + j of sub-tile `word` is filter-positive
-__device__ __forceinline__ void store_flags(uint32_t flags, int lane, uint32_t word,
-                                            uint32_t n_bm_words, uint64_t* __restrict__ qbm,
-                                            uint32_t* __restrict__ qcnt) {
-  const uint64_t b0 = __ballot(flags & 1u), b1 = __ballot(flags & 2u);
-  const uint64_t b2 = __ballot(flags & 4u), b3 = __ballot(flags & 8u);
+// b[j]: wave mask of "window 4*lane + j of sub-tile `word` is filter-positive"
+__device__ __forceinline__ void store_ballots(const uint64_t* b, int lane, uint32_t word,
+                                              uint32_t n_bm_words, uint64_t* __restrict__ qbm,
+                                              uint32_t* __restrict__ qcnt) {
   if (word < n_bm_words && lane < 4) {
-    const uint64_t mine = lane == 0 ? b0 : lane == 1 ? b1 : lane == 2 ? b2 : b3;
+    const uint64_t mine = lane == 0 ? b[0] : lane == 1 ? b[1] : lane == 2 ? b[2] : b[3];
     qbm[(size_t)word * 4 + lane] = mine;
-    if (lane == 0) qcnt[word] = __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+    if (lane == 0)
+      qcnt[word] = __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
   }
 }
 
 // m[0 .. 4+N-1): premixed ids of this lane's four tokens and their halo.
-// Window 0 pays the full XOR-rotate fold, windows 1..3 slide (fs_hash.h).
-template <int N>
-__device__ __forceinline__ uint32_t window_flags(const uint32_t* m, const uint32_t* s_filter,
-                                                 int word_shift) {
+// Window 0 pays the full XOR-rotate fold, windows 1..3 slide (fs_hash.h).  The
+// Bloom test is a compare whose result is the wave mask itself (no per-lane flag
+// word).  TAIL: the tile touches the end of the buffer; a window at p is real
+// only if p + N <= n_tok.
+// Alternative: collect the four tests in a per-lane flag word first, ballot after.
+template <int N, bool TAIL>
+__device__ __forceinline__ void window_ballots_word(const uint32_t* m, const uint32_t* s_filter,
+                                                    int word_shift, uint32_t p0, uint32_t n_tok,
+                                                    uint64_t* b) {
   uint32_t x = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) x ^= fs_rotl(m[k], fs_rot_of(N - 1 - k));
@@ -57,7 +61,31 @@ __device__ __forceinline__ uint32_t window_flags(const uint32_t* m, const uint32
     const uint32_t word = s_filter[x >> word_shift];
     flags |= fs_bloom_test(word, x) << j;
   }
-  return flags;
+  if (TAIL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
+  }
+  b[0] = __ballot(flags & 1u); b[1] = __ballot(flags & 2u);
+  b[2] = __ballot(flags & 4u); b[3] = __ballot(flags & 8u);
+}
+
+template <int N, bool TAIL>
+__device__ __forceinline__ void window_ballots(const uint32_t* m, const uint32_t* s_filter,
+                                               int word_shift, uint32_t p0, uint32_t n_tok,
+                                               uint64_t* b) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) x ^= fs_rotl(m[k], fs_rot_of(N - 1 - k));
+#pragma unroll
+  for (int j = 0; j < kTokPerLane; ++j) {
+    if (j) x = fs_rotl(x ^ fs_rotl(m[j - 1], fs_rot_of(N - 1)), 7) ^ m[j - 1 + N];
+    const uint32_t word = s_filter[x >> word_shift];
+    const uint32_t mask = fs_bloom_mask(x);
+    bool hit = (word & mask) == mask;
+    if (TAIL) hit = hit && ((uint64_t)p0 + j + N <= n_tok);
+    b[j] = __ballot(hit);
+  }
 }
 
 // U sub-tiles (U x 256 tokens) per wave iteration, all loads issued before the
@@ -65,7 +93,7 @@ __device__ __forceinline__ uint32_t window_flags(const uint32_t* m, const uint32
 // further global loads at immediate offsets (+16 B, +32 B ...: the same cache
 // lines the neighbouring lanes fetch, no VALU); otherwise from the neighbouring
 // lanes by ds_bpermute.
-template <int N, int U, bool HALO_LOADS>
+template <int N, int U, bool HALO_LOADS, bool DIRECT, bool NT>
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok, uint32_t n_tok,
                                                const uint32_t* __restrict__ filter,
                                                int log2_words, uint64_t* __restrict__ qbm,
@@ -112,8 +140,16 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
     } else {
       uint4 v[U + 1];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        v[u] = *reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
+      for (int u = 0; u < U; ++u) {
+        const uint4* src = reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
+        if constexpr (NT) {
+          // the id stream is read once: keep it out of the caches' way
+          v[u].x = __builtin_nontemporal_load(&src->x); v[u].y = __builtin_nontemporal_load(&src->y);
+          v[u].z = __builtin_nontemporal_load(&src->z); v[u].w = __builtin_nontemporal_load(&src->w);
+        } else {
+          v[u] = *src;
+        }
+      }
       // first vectors of the next tile, in lanes 0..3 (the buffer is padded)
       v[U] = *reinterpret_cast<const uint4*>(tok + base + U * kSubTile + 4 * (lane & 3));
 #pragma unroll
@@ -138,16 +174,17 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
     for (int u = 0; u < U; ++u) {
 #pragma unroll
       for (int i = 0; i < 4 + HALO; ++i) a[u][i] = fs_premix(a[u][i]);
-      uint32_t flags = window_flags<N>(a[u], s_filter, word_shift);
-
       const uint32_t p0 = base + u * kSubTile + 4 * lane;
-      if (base + (uint32_t)(kSubTile * U) + HALO > n_tok) {   // wave-uniform: last tile(s)
-        // window at p is real only if p + N <= n_tok
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
+      uint64_t b[4];
+      const bool tail = base + (uint32_t)(kSubTile * U) + HALO > n_tok;   // wave-uniform
+      if constexpr (DIRECT) {
+        if (tail) window_ballots<N, true>(a[u], s_filter, word_shift, p0, n_tok, b);
+        else window_ballots<N, false>(a[u], s_filter, word_shift, p0, n_tok, b);
+      } else {
+        if (tail) window_ballots_word<N, true>(a[u], s_filter, word_shift, p0, n_tok, b);
+        else window_ballots_word<N, false>(a[u], s_filter, word_shift, p0, n_tok, b);
       }
-      store_flags(flags, lane, tile * U + u, n_bm_words, qbm, qcnt);
+      store_ballots(b, lane, tile * U + u, n_bm_words, qbm, qcnt);
     }
   }
 }
@@ -170,22 +207,25 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   for (uint32_t word = wave; word < n_bm_words; word += n_waves) {
     const uint32_t p0 = word * kSubTile + 4 * lane;
-    uint32_t flags = 0;
+    uint64_t b[4];
     for (int j = 0; j < 4; ++j) {
       const uint64_t p = (uint64_t)p0 + j;
-      if (p + n > n_tok) continue;
-      const uint32_t h = fs_gram_hash(tok + p, n);
-      const uint32_t w = s_filter[fs_bloom_word(h, log2_words)];
-      const uint32_t m = fs_bloom_mask(h);
-      if ((w & m) == m) flags |= 1u << j;
+      bool hit = false;
+      if (p + n <= n_tok) {
+        const uint32_t h = fs_gram_hash(tok + p, n);
+        const uint32_t w = s_filter[fs_bloom_word(h, log2_words)];
+        const uint32_t m = fs_bloom_mask(h);
+        hit = (w & m) == m;
+      }
+      b[j] = __ballot(hit);
     }
-    store_flags(flags, lane, word, n_bm_words, qbm, qcnt);
+    store_ballots(b, lane, word, n_bm_words, qbm, qcnt);
   }
 }
 
-template <int N, int U, bool HL>
-int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                uint32_t n_bm_words, hipStream_t s) {
+template <int N, int U, bool HL, bool DIRECT, bool NT>
+int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                  uint32_t n_bm_words, hipStream_t s) {
   const uint32_t tile_tok = kSubTile * U;
   const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
   if (n_tiles == 0) return FS_OK;
@@ -200,13 +240,29 @@ int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
   uint32_t max_blocks = ix->num_cu * blocks_per_cu;
   uint32_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > max_blocks) blocks = max_blocks;
-  auto kern = k_scan<N, U, HL>;
+  auto kern = k_scan<N, U, HL, DIRECT, NT>;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, c.tok, c.n_tok,
                      ix->d_filter.p, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
   FS_HIP(hipGetLastError());
   return FS_OK;
+}
+
+template <int N, int U, bool HL>
+int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                uint32_t n_bm_words, hipStream_t s) {
+  // Variants measured in one process (tools/scan_sweep.py, profiles/r01_scan_ab_*.log):
+  //   word   per-lane flag word, then four ballots: 3-4 % faster than comparing
+  //          straight into the ballot ("direct")
+  //   nt     non-temporal id loads: +6 % once the ids cannot stay in the 256 MiB
+  //          Infinity Cache (2 GB), -7 % when a resident corpus is scanned again
+  const char* e = getenv("FS_SCAN_FLAGS");
+  const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
+  if (e && e[0] == 'd') return launch_fast_k<N, U, HL, true, false>(ix, c, qbm, qcnt, n_bm_words, s);
+  if ((e && e[0] == 'n') || (!e && big))
+    return launch_fast_k<N, U, HL, false, true>(ix, c, qbm, qcnt, n_bm_words, s);
+  return launch_fast_k<N, U, HL, false, false>(ix, c, qbm, qcnt, n_bm_words, s);
 }
 
 template <int N>

@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--unrolls", default="1,2,4,8")
     ap.add_argument("--halos", default="loads,shuffle")
     ap.add_argument("--blocks", default="0")
+    ap.add_argument("--flags", default="word,direct")
+    ap.add_argument("--rounds", type=int, default=3)
     a = ap.parse_args()
     conf = dict(synth.CONFIGS[a.workload])
     if a.works:
@@ -58,16 +60,28 @@ def main():
         os.environ["FS_FILTER_LOG2_WORDS"] = str(lw)
         ix = ScriptIndex(script, swords, emb, normals, cfg=abi.make_config(window_size=a.window))
         corpus = ix.corpus(tok, off, chars, coff)
-        for halo, un, blk in itertools.product(a.halos.split(","),
-                                               [int(x) for x in a.unrolls.split(",")],
-                                               [int(x) for x in a.blocks.split(",")]):
-            os.environ["FS_SCAN_HALO"] = halo
-            os.environ["FS_SCAN_UNROLL"] = str(un)
-            os.environ["FS_SCAN_BLOCKS_PER_CU"] = str(blk)
-            ms = min(ix.scan_benchmark(corpus, a.reps) for _ in range(3))
+        variants = list(itertools.product(a.halos.split(","),
+                                          [int(x) for x in a.unrolls.split(",")],
+                                          [int(x) for x in a.blocks.split(",")],
+                                          a.flags.split(",")))
+        best = {}
+        for _round in range(a.rounds):           # interleaved rounds in one process
+            for v in variants:
+                halo, un, blk, fl = v
+                os.environ["FS_SCAN_HALO"] = halo
+                os.environ["FS_SCAN_UNROLL"] = str(un)
+                os.environ["FS_SCAN_BLOCKS_PER_CU"] = str(blk)
+                os.environ["FS_SCAN_FLAGS"] = fl
+                ms = ix.scan_benchmark(corpus, a.reps)
+                best.setdefault(v, []).append(ms)
+        for v in variants:
+            halo, un, blk, fl = v
+            ms = min(best[v])
+            med = sorted(best[v])[len(best[v]) // 2]
             gbs = 4.0 * len(tok) / (ms * 1e-3) / 1e9
             rec = dict(filter_kb=(4 << lw) // 1024, halo=halo, unroll=un, blocks_per_cu=blk,
-                       ms=round(ms, 5), GBps=round(gbs, 1), frac=round(gbs / 8000, 4))
+                       flags=fl, ms=round(ms, 5), ms_median=round(med, 5), GBps=round(gbs, 1),
+                       frac=round(gbs / 8000, 4))
             out.append(rec)
             print(json.dumps(rec), flush=True)
         corpus.close()
