@@ -17,7 +17,8 @@ _LIB = None
 SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_index_info_get", "fs_index_destroy", "fs_corpus_create",
            "fs_corpus_destroy", "fs_search_corpus", "fs_search",
-           "fs_scan_benchmark")
+           "fs_scan_benchmark", "fs_corpus_update_begin", "fs_corpus_update_end",
+           "fs_host_alloc", "fs_host_free")
 
 
 class FsError(RuntimeError):
@@ -82,6 +83,14 @@ def load():
     L.fs_search.argtypes = [
         C.c_void_p, u32p, u32p, u64p, C.c_uint64, u32p, u64p, C.c_uint64,
         C.c_void_p, C.c_uint64, u64p, C.POINTER(abi.FsStats)]
+    L.fs_corpus_update_begin.restype = C.c_int
+    L.fs_corpus_update_begin.argtypes = [C.c_void_p, u32p, u32p, u64p, C.c_uint64]
+    L.fs_corpus_update_end.restype = C.c_int
+    L.fs_corpus_update_end.argtypes = [C.c_void_p]
+    L.fs_host_alloc.restype = C.c_int
+    L.fs_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
+    L.fs_host_free.restype = None
+    L.fs_host_free.argtypes = [C.c_void_p]
     L.fs_scan_benchmark.restype = C.c_int
     L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.POINTER(C.c_double)]

@@ -294,19 +294,25 @@ extern "C" void fs_index_destroy(fs_index* ix) {
   delete ix;
 }
 
-extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uint32_t* tok_str,
-                                const uint64_t* work_off, uint64_t n_works,
-                                const uint32_t* str_chars, const uint64_t* str_off, uint64_t n_str,
-                                fs_corpus** out) {
-  if (!ix || !out || !work_off || (n_str && (!str_chars || !str_off))) {
-    fs_set_error("null argument");
-    return FS_E_INVALID;
-  }
-  *out = nullptr;
+fs_corpus::~fs_corpus() {
+  if (ev_ready) (void)hipEventDestroy(ev_ready);
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  if (h_check) (void)hipHostFree(h_check);
+}
+
+// Enqueue the upload of a batch of works on the corpus's copy stream: ids,
+// optional string ids, work offsets, the block -> work table and a device-side
+// validation pass.  Returns as soon as everything is queued; the host buffers
+// must stay untouched until fs_corpus_update_end.
+extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
+                                      const uint32_t* tok_str, const uint64_t* work_off,
+                                      uint64_t n_works) {
+  if (!c || !work_off) { fs_set_error("null argument"); return FS_E_INVALID; }
+  fs_index* ix = c->ix;
   if (work_off[0] != 0) { fs_set_error("work_off[0] must be 0"); return FS_E_INVALID; }
   const uint64_t T = work_off[n_works];
   if (T && !tok_vec) { fs_set_error("null token buffer"); return FS_E_INVALID; }
-  if (T >= (1ull << 32) - 65536 || n_works >= (1ull << 32) - 1 || n_str >= (1ull << 32)) {
+  if (T >= (1ull << 32) - 65536 || n_works >= (1ull << 32) - 1) {
     fs_set_error("one corpus batch holds fewer than 2^32 tokens; split the batch");
     return FS_E_UNSUPPORTED;
   }
@@ -317,54 +323,64 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
     const uint64_t len = work_off[w + 1] - work_off[w];
     if (len >= n) windows += len - n + 1;
   }
-  bool oov = false;
-  for (uint64_t i = 0; i < T; ++i) {
-    const uint32_t id = tok_vec[i];
-    if (id & FS_OOV_FLAG) oov = true;
-    else if (id >= ix->n_vec) {
-      fs_set_error("tok_vec[%llu] = %u is outside the vector table", (unsigned long long)i, id);
-      return FS_E_INVALID;
-    }
-  }
-  if (!tok_str && n_str < ix->n_vec && T) {
-    // string id == vector id: every id must have a string
-    uint32_t mx = 0;
-    for (uint64_t i = 0; i < T; ++i) mx = std::max(mx, tok_vec[i]);
-    if (mx >= n_str) { fs_set_error("string table smaller than the largest token id"); return FS_E_INVALID; }
-  }
   FS_HIP(hipSetDevice(ix->device));
-  // out-of-vocabulary vectors are outside the exact n-gram proof: such a corpus
-  // goes through the LSH pipeline (built now if the index did not need it before)
-  if (oov && ix->info.path == FS_MODE_EXACT) FS_TRY(fs_lsh_build(ix));
-  fs_corpus* c = new (std::nothrow) fs_corpus();
-  if (!c) return FS_E_NOMEM;
-  struct Guard { fs_corpus* p; ~Guard() { delete p; } } guard{c};
-  c->ix = ix; c->n_tok = T; c->n_works = n_works; c->n_str = n_str; c->windows = windows;
-  c->has_oov = oov; c->has_str = tok_str != nullptr;
+  if (c->pending) FS_HIP(hipEventSynchronize(c->ev_ready));
+  hipStream_t cs = c->copy_stream;
+  c->n_tok = T; c->n_works = n_works; c->windows = windows;
+  c->has_str = tok_str != nullptr;
   const size_t pad = fs_scan_pad_tokens();
   FS_TRY(c->d_tok.reserve(T + pad));
-  FS_HIP(hipMemsetAsync(c->d_tok.p + T, 0, pad * sizeof(uint32_t), ix->stream));
-  if (T) FS_HIP(hipMemcpyAsync(c->d_tok.p, tok_vec, T * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+  FS_HIP(hipMemsetAsync(c->d_tok.p + T, 0, pad * sizeof(uint32_t), cs));
+  if (T) FS_HIP(hipMemcpyAsync(c->d_tok.p, tok_vec, T * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
   if (tok_str) {
-    FS_TRY(c->d_str.reserve(T + n + 1));
-    FS_HIP(hipMemsetAsync(c->d_str.p, 0, (T + n + 1) * sizeof(uint32_t), ix->stream));
-    if (T) FS_HIP(hipMemcpyAsync(c->d_str.p, tok_str, T * sizeof(uint32_t), hipMemcpyHostToDevice, ix->stream));
+    FS_TRY(c->d_str.reserve(T + FS_MAX_WINDOW + 1));
+    FS_HIP(hipMemsetAsync(c->d_str.p + T, 0, (FS_MAX_WINDOW + 1) * sizeof(uint32_t), cs));
+    if (T) FS_HIP(hipMemcpyAsync(c->d_str.p, tok_str, T * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
   }
-  FS_TRY(c->d_work_off.upload(work_off, n_works + 1, ix->stream));
-  {
-    const uint32_t n_blocks = (uint32_t)((T + 255) / 256);
-    FS_TRY(c->d_blk_work.reserve(n_blocks));
-    FS_TRY(fs_launch_blk_work(c->d_work_off.p, (uint32_t)n_works, n_blocks, c->d_blk_work.p, ix->stream));
+  FS_TRY(c->d_work_off.upload(work_off, n_works + 1, cs));
+  const uint32_t n_blocks = (uint32_t)((T + 255) / 256);
+  FS_TRY(c->d_blk_work.reserve(n_blocks));
+  FS_TRY(fs_launch_blk_work(c->d_work_off.p, (uint32_t)n_works, n_blocks, c->d_blk_work.p, cs));
+  FS_TRY(c->d_check.reserve(4));
+  FS_HIP(hipMemsetAsync(c->d_check.p, 0, 4 * sizeof(uint32_t), cs));
+  FS_TRY(fs_launch_corpus_check(c->d_tok.p, tok_str ? c->d_str.p : nullptr, (uint32_t)T,
+                                c->d_check.p, cs));
+  FS_HIP(hipMemcpyAsync(c->h_check, c->d_check.p, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+  FS_HIP(hipEventRecord(c->ev_ready, cs));
+  c->pending = true;
+  return FS_OK;
+}
+
+// Wait for the upload, read the validation result, prepare what the search of
+// this batch needs (LSH structures for OOV ids, the per-n-gram Levenshtein table).
+extern "C" int fs_corpus_update_end(fs_corpus* c) {
+  if (!c) return FS_E_INVALID;
+  if (!c->pending) return FS_OK;
+  fs_index* ix = c->ix;
+  FS_HIP(hipSetDevice(ix->device));
+  FS_HIP(hipEventSynchronize(c->ev_ready));
+  c->pending = false;
+  const uint32_t max_row_plus1 = c->h_check[0], any_oov = c->h_check[1], max_str_plus1 = c->h_check[2];
+  if (max_row_plus1 > ix->n_vec) {
+    fs_set_error("a vector id (%u) is outside the vector table (%llu rows)", max_row_plus1 - 1,
+                 (unsigned long long)ix->n_vec);
+    return FS_E_INVALID;
   }
-  FS_TRY(c->d_chars.upload(str_chars, n_str ? str_off[n_str] : 0, ix->stream));
-  {
-    std::vector<uint64_t> coff(n_str + 1, 0);
-    if (n_str) memcpy(coff.data(), str_off, (n_str + 1) * sizeof(uint64_t));
-    FS_TRY(c->d_coff.upload(coff.data(), coff.size(), ix->stream));
-    FS_HIP(hipStreamSynchronize(ix->stream));
+  if (max_str_plus1 > c->n_str) {
+    fs_set_error("a string id (%u) is outside the string table (%llu strings)", max_str_plus1 - 1,
+                 (unsigned long long)c->n_str);
+    return FS_E_INVALID;
   }
-  if (!c->has_str && !oov && ix->info.path == FS_MODE_EXACT) {
-    // string id == vector id: Levenshtein per (n-gram, rank) once per corpus
+  if (any_oov && !c->has_str) {
+    fs_set_error("out-of-vocabulary vector ids need string ids (tok_str)");
+    return FS_E_INVALID;
+  }
+  c->has_oov = any_oov != 0;
+  // out-of-vocabulary vectors are outside the exact n-gram proof: such a batch
+  // goes through the LSH pipeline (built now if the index did not need it before)
+  if (c->has_oov && ix->info.path == FS_MODE_EXACT) FS_TRY(fs_lsh_build(ix));
+  if (!c->has_str && !c->has_oov && ix->info.path == FS_MODE_EXACT && !c->levtab_ready) {
+    // string id == vector id: Levenshtein per (n-gram, rank), once per string table
     FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
@@ -376,15 +392,61 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
     }
     c->levtab_ready = true;
   }
-  FS_HIP(hipStreamSynchronize(ix->stream));
+  return FS_OK;
+}
+
+extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uint32_t* tok_str,
+                                const uint64_t* work_off, uint64_t n_works,
+                                const uint32_t* str_chars, const uint64_t* str_off, uint64_t n_str,
+                                fs_corpus** out) {
+  if (!ix || !out || !work_off || (n_str && (!str_chars || !str_off))) {
+    fs_set_error("null argument");
+    return FS_E_INVALID;
+  }
+  *out = nullptr;
+  if (n_str >= (1ull << 32)) { fs_set_error("string table too large"); return FS_E_UNSUPPORTED; }
+  FS_HIP(hipSetDevice(ix->device));
+  fs_corpus* c = new (std::nothrow) fs_corpus();
+  if (!c) return FS_E_NOMEM;
+  struct Guard { fs_corpus* p; ~Guard() { delete p; } } guard{c};
+  c->ix = ix; c->n_str = n_str;
+  FS_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+  FS_HIP(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  FS_HIP(hipHostMalloc((void**)&c->h_check, 4 * sizeof(uint32_t), hipHostMallocDefault));
+  FS_TRY(c->d_chars.upload(str_chars, n_str ? str_off[n_str] : 0, c->copy_stream));
+  {
+    std::vector<uint64_t> coff(n_str + 1, 0);
+    if (n_str) memcpy(coff.data(), str_off, (n_str + 1) * sizeof(uint64_t));
+    FS_TRY(c->d_coff.upload(coff.data(), coff.size(), c->copy_stream));
+    FS_HIP(hipStreamSynchronize(c->copy_stream));
+  }
+  FS_TRY(fs_corpus_update_begin(c, tok_vec, tok_str, work_off, n_works));
+  FS_TRY(fs_corpus_update_end(c));
   guard.p = nullptr;
   *out = c;
   return FS_OK;
 }
 
+// pinned host memory for staging streamed batches
+extern "C" int fs_host_alloc(uint64_t bytes, void** out) {
+  if (!out) return FS_E_INVALID;
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) { fs_set_error("hipHostMalloc(%llu) -> %s", (unsigned long long)bytes, hipGetErrorString(e)); return FS_E_NOMEM; }
+  return FS_OK;
+}
+
+extern "C" void fs_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" void fs_corpus_destroy(fs_corpus* c) {
   if (!c) return;
-  if (c->ix) { (void)hipSetDevice(c->ix->device); (void)hipStreamSynchronize(c->ix->stream); }
+  if (c->ix) {
+    (void)hipSetDevice(c->ix->device);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamSynchronize(c->ix->stream);
+  }
   delete c;
 }
 
@@ -395,6 +457,7 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
     return FS_E_INVALID;
   }
   FS_HIP(hipSetDevice(ix->device));
+  FS_TRY(fs_corpus_update_end(c));          // no-op unless an upload is in flight
   hipStream_t s = ix->stream;
   const uint64_t T = c->n_tok;
   const uint32_t n_bm = (uint32_t)((T + 255) / 256);

@@ -154,11 +154,16 @@ struct fs_corpus {
   uint64_t windows = 0;      // sum over works of max(0, len - n + 1)
   bool has_oov = false;
   bool has_str = false;
-  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab, d_blk_work;
+  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab, d_blk_work, d_check;
+  hipStream_t copy_stream = nullptr;   // uploads run here, beside the search stream
+  hipEvent_t ev_ready = nullptr;
+  uint32_t* h_check = nullptr;         // pinned: {max table id + 1, any OOV, max string id + 1}
+  bool pending = false;                // an upload is queued and not yet waited for
   DBuf<uint64_t> d_work_off, d_coff;
   DBuf<fs_best> d_gbest;
   bool levtab_ready = false;
   CorpusDev dev() const;
+  ~fs_corpus();
 };
 
 // ---- kernel launchers (fs_scan.hip / fs_post.hip / fs_build.hip) ----------
@@ -175,6 +180,8 @@ int fs_lsh_build(fs_index* ix);
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                        uint32_t n_sub, hipStream_t s);
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
+int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
+                           uint32_t* check, hipStream_t s);
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
                        uint32_t* blk_work, hipStream_t s);
 

@@ -362,7 +362,47 @@ __global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_wor
   blk_work[b] = lo;
 }
 
+// validation of an uploaded batch: largest embedding row id + 1, "any OOV id",
+// largest string id + 1 (string id == vector id when str is null)
+__global__ __launch_bounds__(256) void k_corpus_check(const uint32_t* __restrict__ tok,
+                                                      const uint32_t* __restrict__ str,
+                                                      uint32_t n_tok, uint32_t* __restrict__ check) {
+  uint32_t max_row = 0, oov = 0, max_str = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tok; i += gridDim.x * blockDim.x) {
+    const uint32_t id = tok[i];
+    if (id & FS_OOV_FLAG) oov = 1; else max_row = max(max_row, id + 1);
+    const uint32_t sid = str ? str[i] : id;
+    if (str || !(id & FS_OOV_FLAG)) max_str = max(max_str, sid + 1);
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    max_row = max(max_row, (uint32_t)__shfl_xor(max_row, d));
+    max_str = max(max_str, (uint32_t)__shfl_xor(max_str, d));
+    oov |= __shfl_xor(oov, d);
+  }
+  __shared__ uint32_t s_m[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { s_m[0][wave] = max_row; s_m[1][wave] = oov; s_m[2][wave] = max_str; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t a = 0, b = 0, c = 0;
+    for (int w = 0; w < 4; ++w) { a = max(a, s_m[0][w]); b |= s_m[1][w]; c = max(c, s_m[2][w]); }
+    if (a) atomicMax(&check[0], a);
+    if (b) atomicOr(&check[1], b);
+    if (c) atomicMax(&check[2], c);
+  }
+}
+
 }  // namespace
+
+int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
+                           uint32_t* check, hipStream_t s) {
+  if (!n_tok) return FS_OK;
+  uint32_t blocks = (n_tok + 256 * 16 - 1) / (256 * 16);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(k_corpus_check, dim3(blocks), dim3(256), 0, s, tok, str, n_tok, check);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
 
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
                        uint32_t* blk_work, hipStream_t s) {

@@ -37,6 +37,23 @@ class Corpus(object):
             abi.ptr(chars, C.c_uint32), abi.ptr(off, C.c_uint64),
             len(off) - 1, C.byref(self._h)), "fs_corpus_create")
 
+    def update_begin(self, tok_vec, work_off, tok_str=None):
+        """Queue the upload of a new batch of works into this corpus (copy
+        stream; returns at once).  The arrays must stay alive and untouched until
+        update_end() or the next search on this corpus; pass pinned arrays
+        (`pinned_array`) for the copy to overlap a running search."""
+        self.tok_vec = abi.as_u32(tok_vec)
+        self.tok_str = abi.as_u32(tok_str) if tok_str is not None else None
+        self.work_off = abi.as_u64(work_off)
+        self.n_works = len(self.work_off) - 1
+        self.n_tok = int(self.work_off[-1])
+        _lib.check(_lib.load().fs_corpus_update_begin(
+            self._h, abi.ptr(self.tok_vec, C.c_uint32), abi.ptr(self.tok_str, C.c_uint32),
+            abi.ptr(self.work_off, C.c_uint64), self.n_works), "fs_corpus_update_begin")
+
+    def update_end(self):
+        _lib.check(_lib.load().fs_corpus_update_end(self._h), "fs_corpus_update_end")
+
     def close(self):
         if self._h:
             _lib.load().fs_corpus_destroy(self._h)
@@ -47,6 +64,67 @@ class Corpus(object):
             self.close()
         except Exception:
             pass
+
+
+class PinnedBuffer(object):
+    """Page-locked host memory (hipHostMalloc) viewed as a numpy array."""
+
+    def __init__(self, count, dtype):
+        self.dtype = np.dtype(dtype)
+        self._p = C.c_void_p()
+        nbytes = max(1, int(count)) * self.dtype.itemsize
+        _lib.check(_lib.load().fs_host_alloc(nbytes, C.byref(self._p)), "fs_host_alloc")
+        buf = (C.c_char * nbytes).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(count))
+
+    def close(self):
+        if self._p:
+            self.array = None
+            _lib.load().fs_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def search_stream(index, batches, str_chars, str_off):
+    """Search a corpus that arrives batch by batch (BASELINE configs[4]).
+
+    `batches` yields (tok_vec, work_off) pairs, or (tok_vec, work_off, tok_str).
+    Two device corpora alternate: while batch i is searched, batch i+1 is copied
+    to the GPU on the other corpus's copy stream.  Yields (rows, stats) per batch,
+    work indices local to the batch."""
+    it = iter(batches)
+    slots = [None, None]
+    cur = None
+
+    def stage(slot, batch):
+        tok_str = batch[2] if len(batch) > 2 else None
+        if slots[slot] is None:
+            slots[slot] = index.corpus(batch[0], batch[1], str_chars, str_off, tok_str=tok_str)
+        else:
+            slots[slot].update_begin(batch[0], batch[1], tok_str=tok_str)
+
+    try:
+        first = next(it)
+    except StopIteration:
+        return
+    stage(0, first)
+    cur = 0
+    while cur is not None:
+        nxt_batch = next(it, None)
+        nxt = None
+        if nxt_batch is not None:
+            nxt = cur ^ 1
+            stage(nxt, nxt_batch)            # queued; overlaps the search below
+        yield index.search(slots[cur])
+        cur = nxt
+    for c in slots:
+        if c is not None:
+            c.close()
 
 
 class ScriptIndex(object):

@@ -151,6 +151,21 @@ int fs_corpus_create(fs_index* ix,
                      fs_corpus** out);
 void fs_corpus_destroy(fs_corpus* c);
 
+/* Streaming (BASELINE configs[4]: corpora larger than one batch, streamed from
+ * pinned host memory).  fs_corpus_update_begin replaces the works of `c` with a
+ * new batch: the copies, the block->work table and a device-side validation of
+ * the ids are queued on the corpus's own copy stream and the call returns at
+ * once, so the upload overlaps a search that is running on another corpus of
+ * the same index.  The host buffers must stay untouched until
+ * fs_corpus_update_end (or the next fs_search_corpus on `c`) has returned.
+ * The string table given at fs_corpus_create is kept.  Use fs_host_alloc for
+ * the staging buffers: copies from pageable memory do not overlap. */
+int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec, const uint32_t* tok_str,
+                           const uint64_t* work_off, uint64_t n_works);
+int fs_corpus_update_end(fs_corpus* c);
+int fs_host_alloc(uint64_t bytes, void** out);
+void fs_host_free(void* p);
+
 /* Search every work of `c`.  `rows` is a host buffer of `cap` records, or,
  * when rows_on_device != 0, a 16-byte aligned device pointer on the index's
  * device (for a collective gather without a host round trip).  On FS_E_CAPACITY *n_rows is

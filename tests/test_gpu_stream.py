@@ -1,0 +1,82 @@
+"""Streamed corpora (BASELINE configs[4]): batches uploaded on a copy stream
+while the previous batch is searched give the same rows as one monolithic
+search; device-side validation of uploaded ids."""
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import _lib, abi, synth
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def test_streamed_batches_equal_monolithic(synth_base):
+    from fandom_search_amd.engine import PinnedBuffer, ScriptIndex, search_stream
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(5000)
+    n_works, tpw, per_batch = 2400, 1000, 400
+    tok, off = synth.corpus_tokens(n_works, tpw, script)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    whole, st = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    # batches of different sizes, staged in pinned memory (two staging buffers)
+    sizes = [per_batch, per_batch // 2, per_batch * 2, per_batch, per_batch + 37,
+             n_works - (5 * per_batch + per_batch // 2 + 37)]
+    assert sum(sizes) == n_works
+    stage_tok = [PinnedBuffer(max(sizes) * tpw, np.uint32) for _ in range(2)]
+    stage_off = [PinnedBuffer(max(sizes) + 1, np.uint64) for _ in range(2)]
+
+    def batches():
+        w0 = 0
+        for i, nb in enumerate(sizes):
+            t = stage_tok[i & 1].array[:nb * tpw]
+            o = stage_off[i & 1].array[:nb + 1]
+            t[:] = tok[w0 * tpw:(w0 + nb) * tpw]
+            o[:] = off[w0:w0 + nb + 1] - off[w0]
+            yield t, o
+            w0 += nb
+
+    parts, w0, windows = [], 0, 0
+    for (rows, bst), nb in zip(search_stream(ix, batches(), synth_base["chars"],
+                                             synth_base["off"]), sizes):
+        rows = rows.copy()
+        rows["work"] += np.uint32(w0)
+        parts.append(rows)
+        windows += bst.windows_processed
+        w0 += nb
+    got = np.concatenate(parts)
+    assert got.tobytes() == whole.tobytes()
+    assert windows == st.windows_processed
+    # and against the oracle on the first batch
+    oi = util.oracle_index(abi.make_config(), script, words, emb, synth.lsh_normals(6))
+    want, _ = oi.search(tok[:sizes[0] * tpw], off[:sizes[0] + 1], synth_base["chars"],
+                        synth_base["off"])
+    util.assert_rows_equal(parts[0], want)
+
+
+def test_device_side_validation(synth_base):
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(500)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    tok = np.arange(100, dtype=np.uint32)
+    off = np.array([0, 100], dtype=np.uint64)
+    bad = tok.copy()
+    bad[57] = 8192                                   # one past the vector table
+    with pytest.raises(_lib.FsError, match="outside the vector table"):
+        ix.corpus(bad, off, synth_base["chars"], synth_base["off"])
+    short_chars, short_off = synth_base["chars"][:40], synth_base["off"][:11]   # 10 strings
+    with pytest.raises(_lib.FsError, match="outside the string table"):
+        ix.corpus(tok, off, short_chars, short_off)
+    oov = tok.copy()
+    oov[3] = abi.FS_OOV_FLAG | 5
+    with pytest.raises(_lib.FsError, match="need string ids"):
+        ix.corpus(oov, off, synth_base["chars"], synth_base["off"])
+    with pytest.raises(_lib.FsError, match="work_off"):
+        ix.corpus(tok, np.array([0, 60, 50], dtype=np.uint64), synth_base["chars"],
+                  synth_base["off"])
+    # a good corpus still works afterwards
+    rows, _ = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    assert len(rows) == 0
