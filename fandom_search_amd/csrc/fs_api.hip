@@ -83,12 +83,17 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
     const int c = memcmp(stok + a, stok + b, n * sizeof(uint32_t));
     return c != 0 ? c < 0 : a < b;
   });
-  std::vector<uint32_t> gpos, gcnt;
+  // gkept: entries of the reference's NearestFilter list for a window equal to
+  // this n-gram (statistics only): every occurrence once, or once per table when
+  // the UniqueFilter is off, capped at N
+  std::vector<uint32_t> gpos, gcnt, gkept;
+  const uint64_t per_occ = ix->cfg.unique_filter ? 1 : ix->cfg.number_of_hashes;
   for (uint64_t i = 0; i < W;) {
     uint64_t j = i;
     while (j < W && memcmp(stok + order[i], stok + order[j], n * sizeof(uint32_t)) == 0) ++j;
     const uint32_t cnt = (uint32_t)std::min<uint64_t>(j - i, nn);
     gcnt.push_back(cnt);
+    gkept.push_back((uint32_t)std::min<uint64_t>((j - i) * per_occ, nn));
     for (uint32_t r = 0; r < nn; ++r) gpos.push_back(r < cnt ? order[i + r] : 0u);
     i = j;
   }
@@ -111,7 +116,7 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
     while (table[4 * (size_t)slot]) slot = (slot + 1) & slot_mask;
     table[4 * (size_t)slot] = g + 1;            // {gram + 1, first position, kept occurrences, 0}
     table[4 * (size_t)slot + 1] = gpos[(size_t)g * nn];
-    table[4 * (size_t)slot + 2] = gcnt[g];
+    table[4 * (size_t)slot + 2] = gkept[g];
   }
   FS_TRY(ix->d_filter.upload(filter.data(), filter.size(), ix->stream));
   FS_TRY(ix->d_table.upload(table.data(), table.size(), ix->stream));
