@@ -129,12 +129,15 @@ def main():
     corpus = ix.corpus(tok, off, chars, coff)
 
     # row buffers in HBM (two, so a gather may still read one while the next
-    # step writes the other)
+    # step writes the other).  With more than one rank the exact pipeline emits
+    # 16-byte wire records (half the gather bytes); rank 0 expands them again.
+    packed = world > 1 and ix.info["path"] == abi.FS_MODE_EXACT
+    rec_bytes = 16 if packed else 32
     cap = max(4096, corpus.n_tok // 16)
     while True:
-        bufs = [torch.empty(cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        bufs = [torch.zeros(cap * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
         try:
-            n_rows, st = ix.search_device(corpus, bufs[0].data_ptr(), cap)
+            n_rows, st = ix.search_device(corpus, bufs[0].data_ptr(), cap, packed=packed)
             break
         except _lib.FsError as e:
             if e.code != abi.FS_E_CAPACITY:
@@ -147,43 +150,53 @@ def main():
         pad = int(t.item())
         if pad != cap:
             cap = pad
-            bufs = [torch.empty(cap * 32, dtype=torch.uint8, device="cuda") for _ in range(2)]
+            bufs = [torch.zeros(cap * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
         counts = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(2)]
         mine = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(2)]
-        gathered = None
+        gathered = full_rows = None
         if rank == 0:
-            gathered = [[torch.empty(cap * 32, dtype=torch.uint8, device=cdev)
-                         for _ in range(world)] for _ in range(2)]
+            # one contiguous landing buffer per slot; rank r's records at [r*cap, ...)
+            gathered = [torch.zeros(world * cap * rec_bytes, dtype=torch.uint8, device=cdev)
+                        for _ in range(2)]
+            if packed:
+                full_rows = torch.empty(world * cap * 32, dtype=torch.uint8, device="cuda")
 
     pending = [None, None]
     scan_ms = []
     total_rows = 0
 
+    def finish(b):
+        """Wait for slot b's gather; rank 0 expands wire records to full rows."""
+        if pending[b] is None:
+            return
+        for h in pending[b]:
+            h.wait()
+        pending[b] = None
+        if rank == 0 and packed:
+            src = gathered[b].cuda() if rehearsal else gathered[b]
+            if not rehearsal:
+                torch.cuda.current_stream().synchronize()
+            ix.unpack_device(src.data_ptr(), world * cap, full_rows.data_ptr())
+
     def step(i):
         nonlocal total_rows
         b = i & 1
-        if pending[b] is not None:
-            for h in pending[b]:
-                h.wait()
-            pending[b] = None
-        n, st = ix.search_device(corpus, bufs[b].data_ptr(), cap)
+        finish(b)
+        n, st = ix.search_device(corpus, bufs[b].data_ptr(), cap, packed=packed)
         scan_ms.append(st.scan_ms)
         total_rows = n
         if world > 1:
             mine[b].fill_(n)
             h1 = dist.all_gather_into_tensor(counts[b], mine[b], async_op=True)
             send = bufs[b].cpu() if rehearsal else bufs[b]
-            h2 = dist.gather(send, gathered[b] if rank == 0 else None, dst=0,
+            h2 = dist.gather(send, list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
                              async_op=True)
             pending[b] = (h1, h2)
         return st
 
     def drain():
         for b in (0, 1):
-            if pending[b] is not None:
-                for h in pending[b]:
-                    h.wait()
-                pending[b] = None
+            finish(b)
 
     for i in range(args.warmup):
         step(i)
@@ -204,6 +217,29 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # outside the timed region: what rank 0 holds after the last gather must be
+    # every rank's own records (CRC of the 32-byte rows)
+    gather_verified = None
+    if world > 1:
+        import zlib
+        own, _ = ix.search(corpus)
+        crc = torch.tensor([zlib.crc32(own.tobytes()), len(own)], dtype=torch.int64, device=cdev)
+        crcs = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(crcs, crc)
+        if rank == 0:
+            last = (args.steps - 1) & 1
+            crcs = crcs.cpu().tolist()
+            cnts = counts[last].cpu().tolist()
+            if packed:
+                landed = full_rows.cpu().numpy()
+            else:
+                landed = gathered[last].cpu().numpy()
+            gather_verified = True
+            for r in range(world):
+                chunk = landed[r * cap * 32:(r * cap + cnts[r]) * 32]
+                if cnts[r] != crcs[2 * r + 1] or zlib.crc32(chunk.tobytes()) != crcs[2 * r]:
+                    gather_verified = False
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -250,6 +286,8 @@ def main():
                        "works_per_gpu": n_works, "tokens_per_work": tpw,
                        "script_tokens": conf["script_tokens"], "window": args.window,
                        "rows_per_gpu_step": int(total_rows),
+                       "wire_record_bytes": rec_bytes if world > 1 else None,
+                       "gather_verified": gather_verified,
                        "gather": ("%s gather to rank 0, overlapped" % ("gloo (rehearsal)" if rehearsal
                                                                         else "rccl")) if world > 1 else "none",
                        "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh"},

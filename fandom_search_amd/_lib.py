@@ -18,7 +18,7 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_index_info_get", "fs_index_destroy", "fs_corpus_create",
            "fs_corpus_destroy", "fs_search_corpus", "fs_search",
            "fs_scan_benchmark", "fs_corpus_update_begin", "fs_corpus_update_end",
-           "fs_host_alloc", "fs_host_free")
+           "fs_host_alloc", "fs_host_free", "fs_rows_unpack")
 
 
 class FsError(RuntimeError):
@@ -54,6 +54,15 @@ def load():
             "%s is not built; run `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C fandom_search_amd/csrc`. There is no CPU "
             "fallback for the search path." % path)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so
+    # (SONAME libamdhip64.so.7).  Loaded first, it satisfies this library's
+    # DT_NEEDED libamdhip64.so.7 as well; loaded second, it would come in as a second
+    # runtime next to /opt/rocm's (two sets of queues and contexts, and torch can then
+    # fail with "No HIP GPUs are available" late in a long process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.fs_version.restype = C.c_int
@@ -91,6 +100,8 @@ def load():
     L.fs_host_alloc.argtypes = [C.c_uint64, C.POINTER(C.c_void_p)]
     L.fs_host_free.restype = None
     L.fs_host_free.argtypes = [C.c_void_p]
+    L.fs_rows_unpack.restype = C.c_int
+    L.fs_rows_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.fs_scan_benchmark.restype = C.c_int
     L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.POINTER(C.c_double)]

@@ -18,6 +18,11 @@ FS_MODE_EXACT = 2
 
 FS_OOV_FLAG = 0x80000000
 
+FS_ROWS_HOST = 0
+FS_ROWS_DEVICE = 1
+FS_ROWS_DEVICE_PACKED = 2
+PACKED_ROW_BYTES = 16
+
 
 class FsConfig(C.Structure):
     _fields_ = [("struct_size", C.c_uint32),

@@ -468,6 +468,12 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
   const uint32_t n_bm = (uint32_t)((T + 255) / 256);
   const uint32_t nn = ix->cfg.nearest_n;
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
+  const bool packed = rows_on_device == FS_ROWS_DEVICE_PACKED;
+  if (packed && !exact) {
+    fs_set_error("packed rows exist for the exact n-gram pipeline only (there the distance is a "
+                 "function of the matched script window)");
+    return FS_E_UNSUPPORTED;
+  }
   // capacities: grown from the device totals when a stage overflows
   uint64_t ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_cpos.n);
   uint64_t rcap = rows_on_device ? cap
@@ -495,13 +501,13 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
     if (exact) {
       FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
       FS_HIP(hipEventRecord(ix->ev_scan1, s));
-      FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, s));
+      FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, packed, s));
     } else {
       FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
       FS_HIP(hipEventRecord(ix->ev_scan1, s));
       FS_TRY(fs_launch_expand(ix, n_bm, ccap32, s));
       FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
-      FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, s));
+      FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, s));
     }
     ++launches;
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
@@ -570,5 +576,13 @@ extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, doub
   float ms = 0;
   FS_HIP(hipEventElapsedTime(&ms, ix->ev_scan0, ix->ev_scan1));
   *avg_ms = (double)ms / reps;
+  return FS_OK;
+}
+
+extern "C" int fs_rows_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows) {
+  if (!ix || (n && (!packed || !rows))) return FS_E_INVALID;
+  FS_HIP(hipSetDevice(ix->device));
+  FS_TRY(fs_launch_unpack(ix, packed, n, rows, ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
   return FS_OK;
 }

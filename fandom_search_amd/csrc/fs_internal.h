@@ -172,10 +172,11 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
 uint32_t fs_scan_pad_tokens();
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
-                   fs_row* d_rows, hipStream_t s);
+                   fs_row* d_rows, bool packed, hipStream_t s);
+int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, hipStream_t s);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
-                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, hipStream_t s);
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s);
 int fs_lsh_build(fs_index* ix);
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                        uint32_t n_sub, hipStream_t s);

@@ -32,6 +32,8 @@
 // with larger buffers if a total exceeded it.
 #include "fs_device.h"
 
+#include <algorithm>
+
 namespace {
 
 using namespace fsdev;
@@ -258,6 +260,7 @@ __global__ void k_cbest(GramIndexDev g, const uint32_t* __restrict__ cg,
 // hit whose window covers the word, in the reference's insertion order
 // (ascending window position; search.py:176-218, 224-225), each hit offering
 // its best rank (best_of_ranks).
+template <bool PACKED>
 __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
                                                    const uint32_t* __restrict__ cpos,
                                                    const uint32_t* __restrict__ cg,
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
       const uint32_t x = p + n - cnt + k;          // global token position of the word
       bool have = false;
       fs_row out;
+      uint32_t koff = 0;
       for (uint32_t j = own; j < NC; ++j) {
         const uint32_t p2 = cpos[j];
         if (p2 > x) break;
@@ -330,10 +334,19 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
           out.lev = bb.lev;
           out.dist = bb.dist;
           out.comb = bb.comb;
+          koff = x - p2;
         }
       }
       out.work = w;
       out.fan_ix = (uint32_t)((uint64_t)x - wbase);
+      if (PACKED) {
+        // 16-byte wire record {work, fan_ix, orig_ix, lev | k << 16}: k = offset of the
+        // word inside the matched window, so that dist = selfdist[orig_ix - k]
+        uint4 q;
+        q.x = out.work; q.y = out.fan_ix; q.z = out.orig_ix; q.w = out.lev | (koff << 16);
+        reinterpret_cast<uint4*>(rows)[ridx] = q;
+        continue;
+      }
       // one 32-byte record = two 16-byte stores (row buffers are 16-byte aligned)
       uint4 q0, q1;
       q0.x = out.work; q0.y = out.fan_ix; q0.z = out.orig_ix; q0.w = out.lev;
@@ -345,6 +358,25 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
     }
     __syncthreads();
     carry += tile_total;
+  }
+}
+
+// 16-byte wire records -> full records (on the rank that gathers them)
+__global__ void k_unpack(const uint4* __restrict__ packed, uint64_t n,
+                         const double* __restrict__ selfdist, fs_row* __restrict__ rows) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 q = packed[i];
+    const uint32_t lev = q.w & 0xFFFFu, k = q.w >> 16;
+    const double dist = selfdist[q.z - k];
+    const double comb = __dmul_rn(dist, (double)lev);
+    uint4 q0, q1;
+    q0.x = q.x; q0.y = q.y; q0.z = q.z; q0.w = lev;
+    const uint64_t db = (uint64_t)__double_as_longlong(dist);
+    const uint64_t cb = (uint64_t)__double_as_longlong(comb);
+    q1.x = (uint32_t)db; q1.y = (uint32_t)(db >> 32); q1.z = (uint32_t)cb; q1.w = (uint32_t)(cb >> 32);
+    uint4* dst = reinterpret_cast<uint4*>(rows + i);
+    dst[0] = q0; dst[1] = q1;
   }
 }
 
@@ -441,23 +473,37 @@ int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, hipStream_t s)
 }
 
 // verified candidates (w_cpos, w_cg, w_cw) + best records -> output rows
+int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s) {
+  if (!n) return FS_OK;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_unpack, dim3(blocks), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(packed), n, ix->d_selfdist.p, rows);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
-                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, hipStream_t s) {
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s) {
   fs_status* st = ix->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   uint32_t* bmatch = ix->w_bsum.p + kNB;
   uint64_t* bsum64 = ix->w_bsum64.p;
   hipLaunchKernelGGL(k_hitrows, dim3(kNB), dim3(kThreads), 0, s,
                      HitRowsF{ix->w_cpos.p, ix->w_cg.p, ix->cfg.window_size}, nc, ix->w_hv.p, bsum64);
-  hipLaunchKernelGGL(k_rows, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
-                     ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
-                     best_per_cand, nc, rcap, d_rows, st);
+  if (packed)
+    hipLaunchKernelGGL(k_rows<true>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
+                       ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
+                       best_per_cand, nc, rcap, d_rows, st);
+  else
+    hipLaunchKernelGGL(k_rows<false>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
+                       ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
+                       best_per_cand, nc, rcap, d_rows, st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
-                   fs_row* d_rows, hipStream_t s) {
+                   fs_row* d_rows, bool packed, hipStream_t s) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->d_status.p;
@@ -478,5 +524,5 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, ui
   }
   FS_HIP(hipGetLastError());
   return fs_launch_rows(ix, c, per_cand ? ix->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
-                        rcap, d_rows, s);
+                        rcap, d_rows, packed, s);
 }

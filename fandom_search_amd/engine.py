@@ -176,21 +176,30 @@ class ScriptIndex(object):
             _lib.check(rc, "fs_search_corpus")
             return rows[:n.value], st
 
-    def search_device(self, corpus, rows_ptr, cap):
-        """Rows written to a caller-owned device buffer (`rows_ptr`: address on
-        this index's device, `cap` records).  Returns (n_rows, stats); raises
-        FsError(FS_E_CAPACITY) with .required when the buffer is too small."""
+    def search_device(self, corpus, rows_ptr, cap, packed=False):
+        """Rows written to a caller-owned device buffer (`rows_ptr`: 16-byte
+        aligned address on this index's device, `cap` records of 32 bytes, or of
+        16 bytes when `packed`: the wire format of the exact pipeline, see
+        unpack_device).  Returns (n_rows, stats); raises FsError(FS_E_CAPACITY)
+        with .required when the buffer is too small."""
         L = _lib.load()
         st = abi.FsStats()
         n = C.c_uint64(0)
+        mode = abi.FS_ROWS_DEVICE_PACKED if packed else abi.FS_ROWS_DEVICE
         rc = L.fs_search_corpus(self._h, corpus._h, C.c_void_p(rows_ptr),
-                                int(cap), 1, C.byref(n), C.byref(st))
+                                int(cap), mode, C.byref(n), C.byref(st))
         if rc == abi.FS_E_CAPACITY:
             err = _lib.FsError(rc, "fs_search_corpus", "row buffer too small")
             err.required = int(n.value)
             raise err
         _lib.check(rc, "fs_search_corpus")
         return int(n.value), st
+
+    def unpack_device(self, packed_ptr, n, rows_ptr):
+        """Expand `n` 16-byte wire records at device address `packed_ptr` into
+        fs_row records at `rows_ptr` (both on this index's device)."""
+        _lib.check(_lib.load().fs_rows_unpack(self._h, C.c_void_p(packed_ptr), int(n),
+                                              C.c_void_p(rows_ptr)), "fs_rows_unpack")
 
     def scan_benchmark(self, corpus, reps=20):
         """Average milliseconds of one scan-kernel launch over `corpus`."""

@@ -166,6 +166,16 @@ int fs_corpus_update_end(fs_corpus* c);
 int fs_host_alloc(uint64_t bytes, void** out);
 void fs_host_free(void* p);
 
+/* where fs_search_corpus leaves the records */
+enum {
+  FS_ROWS_HOST = 0,           /* `rows` is a host buffer of fs_row                        */
+  FS_ROWS_DEVICE = 1,         /* `rows` is a device buffer of fs_row                      */
+  FS_ROWS_DEVICE_PACKED = 2   /* `rows` is a device buffer of 16-byte wire records
+                                 {work, fan_ix, orig_ix, lev | k << 16} (exact n-gram
+                                 pipeline only, else FS_E_UNSUPPORTED): half the bytes
+                                 for the gather; fs_rows_unpack restores fs_row          */
+};
+
 /* Search every work of `c`.  `rows` is a host buffer of `cap` records, or,
  * when rows_on_device != 0, a 16-byte aligned device pointer on the index's
  * device (for a collective gather without a host round trip).  On FS_E_CAPACITY *n_rows is
@@ -173,6 +183,11 @@ void fs_host_free(void* p);
 int fs_search_corpus(fs_index* ix, fs_corpus* c,
                      fs_row* rows, uint64_t cap, int rows_on_device,
                      uint64_t* n_rows, fs_stats* st);
+
+/* Expand n packed wire records (device) into fs_row records (device) on an index
+ * built from the same script, vectors and config: dist = the matched script
+ * window's self distance, comb = dist * lev. */
+int fs_rows_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows);
 
 /* fs_corpus_create + fs_search_corpus + fs_corpus_destroy. */
 int fs_search(fs_index* ix,

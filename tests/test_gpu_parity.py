@@ -39,6 +39,9 @@ def _case(synth_base, lengths, script_tokens, n=6, first_work=0, **env):
     assert st.matches == ost.matches
     assert st.rows == len(want)
     assert ix.info["proof_ok"] == 1 and ix.info["path"] == abi.FS_MODE_EXACT
+    corpus.close()
+    ix.close()
+    oi.close()
     return got, st
 
 
@@ -109,3 +112,35 @@ def test_separate_string_ids(synth_base):
     util.assert_rows_equal(got, want)
     assert len(set(got["lev"].tolist())) > 3      # text variants change the distance
     assert st.matches == ost.matches
+
+
+def test_packed_wire_rows_round_trip(synth_base):
+    """16-byte wire records of the exact pipeline expand to the same fs_row bytes."""
+    import torch
+    from fandom_search_amd import _lib
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(6000)
+    tok, off = util.ragged_corpus([1200] * 40 + [0, 5, 3000], script)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    want, _ = ix.search(corpus)
+    cap = len(want) + 10
+    packed = torch.zeros(cap * 16, dtype=torch.uint8, device="cuda")
+    n, st = ix.search_device(corpus, packed.data_ptr(), cap, packed=True)
+    assert n == len(want)
+    full = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    ix.unpack_device(packed.data_ptr(), n, full.data_ptr())
+    got = full.cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
+    assert got.tobytes() == want.tobytes()
+    with pytest.raises(_lib.FsError) as e:
+        ix.search_device(corpus, packed.data_ptr(), 10, packed=True)
+    assert e.value.code == abi.FS_E_CAPACITY and e.value.required == len(want)
+    # the LSH pipeline has no packed form
+    gx = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config(mode=abi.FS_MODE_GENERAL))
+    gc = gx.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    with pytest.raises(_lib.FsError) as e:
+        gx.search_device(gc, packed.data_ptr(), cap, packed=True)
+    assert e.value.code == abi.FS_E_UNSUPPORTED
