@@ -98,20 +98,14 @@ __device__ __forceinline__ uint32_t work_of_token(const CorpusDev& c, uint64_t p
 // Levenshtein.distance(match_str, fan_context), search.py:189-190:
 //   match_str   = script words s .. s+n-1 joined by single spaces
 //   fan_context = '[' + ', '.join(fan token texts) + ']'
-// unit costs over code points.  One thread, operands in scratch.
+// unit costs over code points.  One thread; the fan operand and one DP row live in
+// scratch (FS_LEV_MAX code points), the script operand is walked word by word.
 __device__ inline uint32_t lev_device(const GramIndexDev& g, uint32_t s, const uint32_t* fan_sid,
-                               const uint32_t* chars, const uint64_t* coff, uint32_t n_str,
-                               fs_status* st) {
-  uint32_t a[FS_LEV_MAX], b[FS_LEV_MAX];
+                                      const uint32_t* chars, const uint64_t* coff, uint32_t n_str,
+                                      fs_status* st) {
+  uint32_t b[FS_LEV_MAX];
   uint16_t row[FS_LEV_MAX + 1];
-  uint32_t la = 0, lb = 0;
-  for (int k = 0; k < g.n; ++k) {
-    if (k) { if (la < FS_LEV_MAX) a[la] = ' '; ++la; }
-    for (uint64_t c = g.soff[s + k]; c < g.soff[s + k + 1]; ++c) {
-      if (la < FS_LEV_MAX) a[la] = g.schars[c];
-      ++la;
-    }
-  }
+  uint32_t lb = 0;
   if (lb < FS_LEV_MAX) b[lb] = '[';
   ++lb;
   for (int k = 0; k < g.n; ++k) {
@@ -128,24 +122,30 @@ __device__ inline uint32_t lev_device(const GramIndexDev& g, uint32_t s, const u
   }
   if (lb < FS_LEV_MAX) b[lb] = ']';
   ++lb;
+  const uint64_t la = g.soff[s + g.n] - g.soff[s] + (uint64_t)(g.n - 1);
   if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { st->lev_overflow = 1; return 0; }
   for (uint32_t j = 0; j <= lb; ++j) row[j] = (uint16_t)j;
-  for (uint32_t x = 1; x <= la; ++x) {
-    uint32_t diag = row[0];
-    row[0] = (uint16_t)x;
-    const uint32_t ca = a[x - 1];
-    for (uint32_t j = 1; j <= lb; ++j) {
-      const uint32_t up = row[j];
-      uint32_t best = diag + (ca != b[j - 1] ? 1u : 0u);
-      if (up + 1 < best) best = up + 1;
-      const uint32_t left = row[j - 1];
-      if (left + 1 < best) best = left + 1;
-      diag = up;
-      row[j] = (uint16_t)best;
+  uint32_t x = 0;
+  for (int k = 0; k < g.n; ++k) {
+    // characters of script word k, preceded by the joining space
+    const uint64_t c0 = g.soff[s + k], c1 = g.soff[s + k + 1];
+    for (uint64_t c = k ? c0 - 1 : c0; c < c1; ++c) {
+      const uint32_t ca = (k && c == c0 - 1) ? (uint32_t)' ' : g.schars[c];
+      ++x;
+      uint32_t diag = row[0];
+      row[0] = (uint16_t)x;
+      for (uint32_t j = 1; j <= lb; ++j) {
+        const uint32_t up = row[j];
+        uint32_t best = diag + (ca != b[j - 1] ? 1u : 0u);
+        if (up + 1 < best) best = up + 1;
+        const uint32_t left = row[j - 1];
+        if (left + 1 < best) best = left + 1;
+        diag = up;
+        row[j] = (uint16_t)best;
+      }
     }
   }
   return row[lb];
 }
-
 
 }  // namespace fsdev

@@ -11,7 +11,7 @@
 
 #define FS_MAX_WINDOW 16          // n <= 16: at most 4 neighbour vectors of halo
 #define FS_NONE 0xFFFFFFFFu
-#define FS_LEV_MAX 256            // code points per side handled by lev_device
+#define FS_LEV_MAX 512            // code points per side handled by lev_device
 
 void fs_set_error(const char* fmt, ...);
 

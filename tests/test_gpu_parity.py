@@ -144,3 +144,32 @@ def test_packed_wire_rows_round_trip(synth_base):
     with pytest.raises(_lib.FsError) as e:
         gx.search_device(gc, packed.data_ptr(), cap, packed=True)
     assert e.value.code == abi.FS_E_UNSUPPORTED
+
+
+def test_long_tokens_and_levenshtein_limit(synth_base):
+    """Levenshtein operands up to 512 code points per side are computed on the
+    device (bit-equal to the oracle); longer n-gram texts are refused loudly."""
+    from fandom_search_amd import _lib
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+    words, emb = synth_base["words"], synth_base["emb"]
+    n = 6
+    script = synth.script_tokens(800)
+    tok, off = util.ragged_corpus([400] * 6, script)
+    # fan strings: every third word id gets a 70-character spelling (6 of them: 6*70+12 = 432)
+    strings = [w if i % 3 else (w * 18)[:70].upper() for i, w in enumerate(words)]
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config(window_size=n)
+    normals = synth.lsh_normals(n)
+    swords = [words[int(t)] for t in script]
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    got, st = ix.search(ix.corpus(tok, off, chars, coff, tok_str=tok))
+    oi = util.oracle_index(cfg, script, words, emb, normals)
+    want, _ = oi.search(tok, off, chars, coff, tok_str=tok)
+    util.assert_rows_equal(got, want)
+    assert int(got["lev"].max()) > 200
+    too_long = [w * 30 for w in words]                # 120 code points per word: 6*120+12 > 512
+    chars2, coff2 = pack_strings(too_long)
+    with pytest.raises(_lib.FsError) as e:
+        ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
+    assert e.value.code == abi.FS_E_UNSUPPORTED and "512" in str(e.value)
