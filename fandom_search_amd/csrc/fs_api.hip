@@ -495,16 +495,15 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
 
     FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
     FS_HIP(hipEventRecord(ix->ev_begin, s));
-    FS_HIP(hipEventRecord(ix->ev_scan0, s));
     const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(ccap, 0xFFFFFFFFull);
     const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFull);
     if (exact) {
-      FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
-      FS_HIP(hipEventRecord(ix->ev_scan1, s));
+      FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, ix->ev_scan0,
+                            ix->ev_scan1));
       FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, packed, s));
     } else {
-      FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
-      FS_HIP(hipEventRecord(ix->ev_scan1, s));
+      FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, ix->ev_scan0,
+                                ix->ev_scan1));
       FS_TRY(fs_launch_expand(ix, n_bm, ccap32, s));
       FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
       FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, s));
@@ -513,7 +512,8 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
     FS_HIP(hipEventRecord(ix->ev_end, s));
     FS_HIP(hipStreamSynchronize(s));
-    FS_HIP(hipEventElapsedTime(&scan_ms, ix->ev_scan0, ix->ev_scan1));
+    scan_ms = 0;
+    if (n_bm) FS_HIP(hipEventElapsedTime(&scan_ms, ix->ev_scan0, ix->ev_scan1));
     FS_HIP(hipEventElapsedTime(&total_ms, ix->ev_begin, ix->ev_end));
     const fs_status& hs = *ix->h_status;
     if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }

@@ -168,7 +168,8 @@ struct fs_corpus {
 
 // ---- kernel launchers (fs_scan.hip / fs_post.hip / fs_build.hip) ----------
 int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                   uint32_t n_bm_words, hipStream_t s);
+                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0 = nullptr,
+                   hipEvent_t e1 = nullptr);
 uint32_t fs_scan_pad_tokens();
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
@@ -179,7 +180,8 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s);
 int fs_lsh_build(fs_index* ix);
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                       uint32_t n_sub, hipStream_t s);
+                       uint32_t n_sub, hipStream_t s, hipEvent_t e0 = nullptr,
+                       hipEvent_t e1 = nullptr);
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
                            uint32_t* check, hipStream_t s);

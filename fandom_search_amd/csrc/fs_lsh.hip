@@ -33,6 +33,8 @@
 // output, so the result equals the oracle's, which computes every distance.
 #include "fs_device.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -453,7 +455,7 @@ int fs_lsh_build(fs_index* ix) {
 }
 
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                       uint32_t n_sub, hipStream_t s) {
+                       uint32_t n_sub, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   if (!n_sub) return FS_OK;
   const LshDev L = lsh_dev(ix);
   const int NW = (L.C + 63) >> 6;
@@ -462,7 +464,8 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
   const uint32_t blocks = std::min<uint32_t>(n_sub, ix->num_cu * per_cu);
-  hipLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), lds, s, c, L, qbm, qcnt, n_sub);
+  hipExtLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), (uint32_t)lds, s, e0, e1, 0u, c, L, qbm,
+                        qcnt, n_sub);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -21,6 +21,7 @@
 // 4 B read per token + 36 B written per 256 tokens.
 #include "fs_internal.h"
 
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 
 namespace {
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
 
 template <int N, int U, bool HL, bool DIRECT, bool NT>
 int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s) {
+                  uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const uint32_t tile_tok = kSubTile * U;
   const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
   if (n_tiles == 0) return FS_OK;
@@ -243,15 +244,18 @@ int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   auto kern = k_scan<N, U, HL, DIRECT, NT>;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, c.tok, c.n_tok,
-                     ix->d_filter.p, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
+  // start/stop events attached to the dispatch itself: their difference is the
+  // kernel's execution time (what rocprofv3 reports), not kernel + marker gaps
+  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), (uint32_t)lds, s, e0, e1, 0u, c.tok,
+                        c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
+                        n_bm_words, n_tiles);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 template <int N, int U, bool HL>
 int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                uint32_t n_bm_words, hipStream_t s) {
+                uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   // Variants measured in one process (tools/scan_sweep.py, profiles/r01_scan_ab_*.log):
   //   word   per-lane flag word, then four ballots: 3-4 % faster than comparing
   //          straight into the ballot ("direct")
@@ -259,28 +263,29 @@ int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
   //          Infinity Cache (2 GB), -7 % when a resident corpus is scanned again
   const char* e = getenv("FS_SCAN_FLAGS");
   const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
-  if (e && e[0] == 'd') return launch_fast_k<N, U, HL, true, false>(ix, c, qbm, qcnt, n_bm_words, s);
+  if (e && e[0] == 'd') return launch_fast_k<N, U, HL, true, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
   if ((e && e[0] == 'n') || (!e && big))
-    return launch_fast_k<N, U, HL, false, true>(ix, c, qbm, qcnt, n_bm_words, s);
-  return launch_fast_k<N, U, HL, false, false>(ix, c, qbm, qcnt, n_bm_words, s);
+    return launch_fast_k<N, U, HL, false, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+  return launch_fast_k<N, U, HL, false, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
 }
 
 template <int N>
 int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s, int unroll, bool halo_loads) {
+                  uint32_t n_bm_words, hipStream_t s, int unroll, bool halo_loads, hipEvent_t e0,
+                  hipEvent_t e1) {
   if (halo_loads) {
     switch (unroll) {
-      case 1: return launch_fast<N, 1, true>(ix, c, qbm, qcnt, n_bm_words, s);
-      case 2: return launch_fast<N, 2, true>(ix, c, qbm, qcnt, n_bm_words, s);
-      case 8: return launch_fast<N, 8, true>(ix, c, qbm, qcnt, n_bm_words, s);
-      default: return launch_fast<N, 4, true>(ix, c, qbm, qcnt, n_bm_words, s);
+      case 1: return launch_fast<N, 1, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+      case 2: return launch_fast<N, 2, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+      case 8: return launch_fast<N, 8, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+      default: return launch_fast<N, 4, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
     }
   }
   switch (unroll) {
-    case 1: return launch_fast<N, 1, false>(ix, c, qbm, qcnt, n_bm_words, s);
-    case 2: return launch_fast<N, 2, false>(ix, c, qbm, qcnt, n_bm_words, s);
-    case 8: return launch_fast<N, 8, false>(ix, c, qbm, qcnt, n_bm_words, s);
-    default: return launch_fast<N, 4, false>(ix, c, qbm, qcnt, n_bm_words, s);
+    case 1: return launch_fast<N, 1, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 2: return launch_fast<N, 2, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 8: return launch_fast<N, 8, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    default: return launch_fast<N, 4, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
   }
 }
 
@@ -291,7 +296,7 @@ int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
 uint32_t fs_scan_pad_tokens() { return kSubTile * 8 + 64; }
 
 int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                   uint32_t n_bm_words, hipStream_t s) {
+                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const int n = ix->cfg.window_size;
   const char* var = getenv("FS_SCAN_VARIANT");
   const bool simple = var && var[0] == 's';
@@ -303,15 +308,15 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   if (const char* h = getenv("FS_SCAN_HALO")) halo_loads = h[0] == 'l';   // "loads"
   if (!simple) {
     switch (n) {
-      case 2: return launch_fast_u<2>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 3: return launch_fast_u<3>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 4: return launch_fast_u<4>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 5: return launch_fast_u<5>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 6: return launch_fast_u<6>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 7: return launch_fast_u<7>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 8: return launch_fast_u<8>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 10: return launch_fast_u<10>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
-      case 12: return launch_fast_u<12>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads);
+      case 2: return launch_fast_u<2>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 3: return launch_fast_u<3>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 4: return launch_fast_u<4>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 5: return launch_fast_u<5>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 6: return launch_fast_u<6>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 7: return launch_fast_u<7>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 8: return launch_fast_u<8>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 10: return launch_fast_u<10>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
+      case 12: return launch_fast_u<12>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
       default: break;
     }
   }
@@ -322,8 +327,9 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   uint32_t blocks = (n_bm_words + 15) / 16;
   const uint32_t max_blocks = ix->num_cu * (lds <= 64 * 1024 ? 2 : 1);
   if (blocks > max_blocks) blocks = max_blocks;
-  hipLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(1024), lds, s, c.tok, c.n_tok,
-                     ix->d_filter.p, ix->log2_words, n, qbm, qcnt, n_bm_words);
+  hipExtLaunchKernelGGL(k_scan_simple, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u,
+                        c.tok, c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, n, qbm,
+                        qcnt, n_bm_words);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
