@@ -1,8 +1,8 @@
-"""Command line of the search path: the `search`, `matrix` and `validate`
-sub-commands of the reference's ao3.py (/root/reference/ao3.py:509-519 and
-_deprecated.py:83-89), same positionals, flags and output files.  The
-reference's scrape / clean / getmeta / format / vis sub-commands are outside
-this package (out of scope)."""
+"""Command line of the search path: the `search`, `format`, `matrix` and
+`validate` sub-commands of the reference's ao3.py (/root/reference/ao3.py:509-526
+and _deprecated.py:83-89), same positionals, flags and output files.  The
+reference's scrape / clean / getmeta / vis sub-commands are outside this package
+(out of scope)."""
 
 import argparse
 import sys
@@ -12,7 +12,7 @@ def build_parser():
     parser = argparse.ArgumentParser(
         description='n-gram text-reuse search of fan works against a script '
                     '(MI355X build of the `ao3.py search` path).')
-    subparsers = parser.add_subparsers(help='search, matrix or validate')
+    subparsers = parser.add_subparsers(help='search, format, matrix or validate')
 
     validate_parser = subparsers.add_parser('validate', help='validate script markup')
     validate_parser.add_argument('script', action='store',
@@ -36,6 +36,20 @@ def build_parser():
                                help='HIP device ordinal')
     search_parser.set_defaults(func=_search)
 
+    data_parser = subparsers.add_parser(
+        'format', help='takes a script and outputs a csv with reuse counts for each word '
+                       'formatted for javascript visualization')
+    data_parser.add_argument('matches', action='store', help='filename for search output')
+    data_parser.add_argument('script', action='store',
+                             help='filename for markup version of script')
+    data_parser.add_argument('-o', '--output', action='store', default='js-data.csv',
+                             help='filename for csv output file of data formatted for visualization')
+    data_parser.add_argument('--lexicon', default=None,
+                             help='emotion lexicon, lines "word<TAB>TAG[<TAB>0|1]" '
+                                  '(the reference uses lextrie emolex_en)')
+    data_parser.add_argument('--device', default=0, type=int, help='HIP device ordinal')
+    data_parser.set_defaults(func=_format)
+
     matrix_parser = subparsers.add_parser(
         'matrix', help='deduplicates and builds matrix for best n-gram matches')
     matrix_parser.add_argument('i', action='store', help='input csv file')
@@ -55,6 +69,11 @@ def _validate(args):
 def _search(args):
     from . import search
     return search.analyze(args)
+
+
+def _format(args):
+    from . import format as format_mod
+    return format_mod.format_data(args)
 
 
 def _matrix(args):

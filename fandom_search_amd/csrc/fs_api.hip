@@ -586,3 +586,42 @@ extern "C" int fs_rows_unpack(fs_index* ix, const void* packed, uint64_t n, fs_r
   FS_HIP(hipStreamSynchronize(ix->stream));
   return FS_OK;
 }
+
+extern "C" int fs_reuse_histogram(int device, const uint32_t* orig_ix, const double* comb,
+                                  uint64_t n_rows, uint64_t n_script, const double* thresholds,
+                                  uint32_t n_thr, uint32_t* counts) {
+  if ((n_rows && (!orig_ix || !comb)) || !thresholds || !n_thr || n_thr > 64 ||
+      (n_script && !counts)) {
+    fs_set_error("null argument or n_thr outside 1..64");
+    return FS_E_INVALID;
+  }
+  for (uint32_t t = 1; t < n_thr; ++t)
+    if (!(thresholds[t - 1] <= thresholds[t])) { fs_set_error("thresholds must ascend"); return FS_E_INVALID; }
+  FS_HIP(hipSetDevice(device));
+  DBuf<uint32_t> d_orig, d_counts;
+  DBuf<double> d_comb, d_thr;
+  FS_TRY(d_orig.upload(orig_ix, n_rows, nullptr));
+  FS_TRY(d_comb.upload(comb, n_rows, nullptr));
+  FS_TRY(d_thr.upload(thresholds, n_thr, nullptr));
+  FS_TRY(d_counts.reserve(n_script * (n_thr + 1)));
+  FS_TRY(fs_launch_histogram(d_orig.p, d_comb.p, nullptr, n_rows, n_script, d_thr.p, n_thr,
+                             d_counts.p, nullptr));
+  if (n_script)
+    FS_HIP(hipMemcpy(counts, d_counts.p, n_script * (n_thr + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  FS_HIP(hipDeviceSynchronize());
+  return FS_OK;
+}
+
+extern "C" int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint64_t n_rows,
+                                       const double* thresholds, uint32_t n_thr, uint32_t* d_counts) {
+  if (!ix || (n_rows && !d_rows) || !thresholds || !n_thr || n_thr > 64 || !d_counts) return FS_E_INVALID;
+  for (uint32_t t = 1; t < n_thr; ++t)
+    if (!(thresholds[t - 1] <= thresholds[t])) { fs_set_error("thresholds must ascend"); return FS_E_INVALID; }
+  FS_HIP(hipSetDevice(ix->device));
+  DBuf<double> d_thr;
+  FS_TRY(d_thr.upload(thresholds, n_thr, ix->stream));
+  FS_TRY(fs_launch_histogram(nullptr, nullptr, d_rows, n_rows, ix->n_script, d_thr.p, n_thr, d_counts,
+                             ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  return FS_OK;
+}

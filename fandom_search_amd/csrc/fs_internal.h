@@ -185,6 +185,9 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
                            uint32_t* check, hipStream_t s);
+int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_row* d_rows,
+                        uint64_t n_rows, uint64_t n_script, const double* d_thr, uint32_t n_thr,
+                        uint32_t* d_counts, hipStream_t s);
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
                        uint32_t* blk_work, hipStream_t s);
 

@@ -380,6 +380,48 @@ __global__ void k_unpack(const uint4* __restrict__ packed, uint64_t n,
   }
 }
 
+// ---- `format` aggregation -----------------------------------------------------
+// first[word][b] += 1 where b is the first threshold with comb <= t_b (n_thr if none)
+template <class GetIx, class GetComb>
+__device__ __forceinline__ void hist_body(GetIx ix_of, GetComb comb_of, uint64_t n_rows,
+                                          uint64_t n_script, const double* thr, uint32_t n_thr,
+                                          uint32_t* first) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t o = ix_of(i);
+    if (o >= n_script) continue;
+    const double c = comb_of(i);
+    uint32_t b = n_thr;
+    for (uint32_t t = 0; t < n_thr; ++t)
+      if (c <= thr[t]) { b = t; break; }
+    atomicAdd(&first[(size_t)o * (n_thr + 1) + b], 1u);
+  }
+}
+
+__global__ void k_hist_cols(const uint32_t* __restrict__ orig_ix, const double* __restrict__ comb,
+                            uint64_t n_rows, uint64_t n_script, const double* __restrict__ thr,
+                            uint32_t n_thr, uint32_t* __restrict__ first) {
+  hist_body([&](uint64_t i) { return orig_ix[i]; }, [&](uint64_t i) { return comb[i]; }, n_rows,
+            n_script, thr, n_thr, first);
+}
+
+__global__ void k_hist_rows(const fs_row* __restrict__ rows, uint64_t n_rows, uint64_t n_script,
+                            const double* __restrict__ thr, uint32_t n_thr,
+                            uint32_t* __restrict__ first) {
+  hist_body([&](uint64_t i) { return rows[i].orig_ix; }, [&](uint64_t i) { return rows[i].comb; },
+            n_rows, n_script, thr, n_thr, first);
+}
+
+// counts[word][b] = records with comb <= t_b = sum of first[word][0..b]; column
+// n_thr = all records of the word
+__global__ void k_hist_cumulate(uint32_t* __restrict__ counts, uint64_t n_script, uint32_t n_thr) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_script) return;
+  uint32_t* c = counts + w * (n_thr + 1);
+  uint32_t acc = 0;
+  for (uint32_t b = 0; b <= n_thr; ++b) { acc += c[b]; c[b] = acc; }
+}
+
 // work id of the first token of every 256-token block (corpus build time)
 __global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_works,
                            uint32_t n_blocks, uint32_t* __restrict__ blk_work) {
@@ -432,6 +474,26 @@ int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_
   uint32_t blocks = (n_tok + 256 * 16 - 1) / (256 * 16);
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(k_corpus_check, dim3(blocks), dim3(256), 0, s, tok, str, n_tok, check);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_row* d_rows,
+                        uint64_t n_rows, uint64_t n_script, const double* d_thr, uint32_t n_thr,
+                        uint32_t* d_counts, hipStream_t s) {
+  FS_HIP(hipMemsetAsync(d_counts, 0, n_script * (n_thr + 1) * sizeof(uint32_t), s));
+  if (n_rows) {
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>((n_rows + 255) / 256, 4096);
+    if (d_rows)
+      hipLaunchKernelGGL(k_hist_rows, dim3(blocks), dim3(256), 0, s, d_rows, n_rows, n_script, d_thr,
+                         n_thr, d_counts);
+    else
+      hipLaunchKernelGGL(k_hist_cols, dim3(blocks), dim3(256), 0, s, d_orig, d_comb, n_rows,
+                         n_script, d_thr, n_thr, d_counts);
+  }
+  if (n_script)
+    hipLaunchKernelGGL(k_hist_cumulate, dim3((uint32_t)((n_script + 255) / 256)), dim3(256), 0, s,
+                       d_counts, n_script, n_thr);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -201,6 +201,19 @@ class ScriptIndex(object):
         _lib.check(_lib.load().fs_rows_unpack(self._h, C.c_void_p(packed_ptr), int(n),
                                               C.c_void_p(rows_ptr)), "fs_rows_unpack")
 
+    def reuse_histogram_device(self, rows_ptr, n_rows, thresholds):
+        """`format` aggregation over device-resident fs_row records (after a
+        search or a gather): counts[n_script][len(thresholds) + 1] on the host."""
+        import torch
+        thr = np.ascontiguousarray(thresholds, dtype=np.float64)
+        n_script = int(self.info["n_script"])
+        out = torch.zeros(max(1, n_script) * (len(thr) + 1), dtype=torch.int32, device="cuda")
+        _lib.check(_lib.load().fs_reuse_histogram_rows(
+            self._h, C.c_void_p(rows_ptr), int(n_rows), abi.ptr(thr, C.c_double), len(thr),
+            C.c_void_p(out.data_ptr())), "fs_reuse_histogram_rows")
+        return out.cpu().numpy().view(np.uint32)[:n_script * (len(thr) + 1)] \
+            .reshape(n_script, len(thr) + 1)
+
     def scan_benchmark(self, corpus, reps=20):
         """Average milliseconds of one scan-kernel launch over `corpus`."""
         ms = C.c_double(0)

@@ -197,6 +197,21 @@ int fs_search(fs_index* ix,
               uint64_t n_str,
               fs_row* rows, uint64_t cap, uint64_t* n_rows, fs_stats* st);
 
+/* `ao3.py format` aggregation (ao3.py:351-363, 407-416): for every script word the
+ * number of match records whose BEST_COMBINED_DISTANCE is <= each of `n_thr`
+ * ascending thresholds (the reference uses 0, 0.05, ... 0.5), plus, in column
+ * n_thr, the number of records of that word at all.
+ *   orig_ix[n_rows], comb[n_rows]   host arrays (two columns of the match CSV)
+ *   counts[n_script][n_thr + 1]     host, uint32
+ * NaN never satisfies <=, as in pandas.  Runs on HIP device `device`. */
+int fs_reuse_histogram(int device, const uint32_t* orig_ix, const double* comb, uint64_t n_rows,
+                       uint64_t n_script, const double* thresholds, uint32_t n_thr,
+                       uint32_t* counts);
+/* The same over device-resident fs_row records (e.g. straight after a search or a
+ * gather); d_counts is a device buffer of n_script * (n_thr + 1) uint32. */
+int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint64_t n_rows,
+                            const double* thresholds, uint32_t n_thr, uint32_t* d_counts);
+
 /* Diagnostics: `reps` back-to-back launches of the scan kernel alone over `c`,
  * timed with one pair of HIP events; *avg_ms = time per launch.  Used by
  * tools/scan_sweep.py to compare kernel variants without per-launch event

@@ -1,0 +1,103 @@
+"""`format` aggregation: known answers for the pandas restatement of
+ao3.py:346-428 (CPU) and byte equality of the GPU-backed command with it."""
+
+import csv
+import io
+import types
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import search
+from tests import util
+
+
+def _script(tmp_path):
+    p = tmp_path / "script.txt"
+    p.write_text("SCENE_NUMBER<<1>>\nCHARACTER_NAME<<REY>>\nLINE<<we are the spark>>\n"
+                 "CHARACTER_NAME<<Finn>>\nLINE<<that will light the fire>>\n"
+                 "CHARACTER_NAME<<REY>>\nLINE<<hope>>\n")
+    return str(p)
+
+
+def _matches(tmp_path, rows):
+    p = tmp_path / "m.csv"
+    with open(p, "w", newline="") as fh:
+        wr = csv.writer(fh)
+        wr.writerow(search.new_record_structure['fields'])
+        for o, word, comb in rows:
+            wr.writerow(["f.txt", 1, "x", 1, o, word, 1, "C", 1, 0.0, 7, comb])
+    return str(p)
+
+
+ROWS = [(0, "we", 0.0), (0, "we", -1e-16), (0, "we", 0.07), (2, "the", 0.5), (2, "the", 0.50001),
+        (4, "that", 0.049999), (9, "hope", float("nan")), (9, "hope", 0.3), (50, "zzz", 0.0)]
+LEX = {"spark": {"JOY", "POSITIVE"}, "fire": {"FEAR", "ANGER"}, "hope": {"TRUST"}}
+
+
+def test_oracle_known_answers(tmp_path):
+    from oracle import format_restated as fr
+    frame = fr.format_frame(_matches(tmp_path, ROWS), search.load_markup_script(_script(tmp_path)),
+                            lambda w: LEX.get(w, set()))
+    assert len(frame) == 10 and frame.index.name == 'ORIGINAL_SCRIPT_WORD_INDEX'
+    exact = frame['Frequency of Reuse (Exact Matches)'].tolist()
+    assert exact == [2, 0, 0, 0, 0, 0, 0, 0, 0, 0]          # 0.0 and -1e-16 are <= 0
+    assert frame['Frequency of Reuse (0-0.05)'].tolist()[:5] == [2, 0, 0, 0, 1]
+    assert frame['Frequency of Reuse (0-0.1)'].tolist()[0] == 3
+    assert frame['Frequency of Reuse (0-0.5)'].tolist() == [3, 0, 1, 0, 1, 0, 0, 0, 0, 1]   # NaN never counts
+    assert frame['ORIGINAL_SCRIPT_WORD'].tolist()[0] == "we" and frame['ORIGINAL_SCRIPT_WORD'].isna()[1]
+    assert frame['JOY'].tolist()[3] == 1 and frame['FEAR'].tolist()[8] == 1
+    assert frame['CHARACTER_REY'].tolist() == [1, 1, 1, 1, 0, 0, 0, 0, 0, 1]
+    assert frame['CHARACTER_FINN'].sum() == 5
+
+
+@pytest.mark.gpu
+def test_format_command_equals_restatement(tmp_path, monkeypatch):
+    from fandom_search_amd.cli import main
+    from oracle import format_restated as fr
+    monkeypatch.chdir(tmp_path)
+    script, matches = _script(tmp_path), _matches(tmp_path, ROWS)
+    lex = tmp_path / "lex.tsv"
+    lex.write_text("".join("%s\t%s\t1\n" % (w, t) for w, ts in LEX.items() for t in sorted(ts))
+                   + "spark\tSADNESS\t0\n")
+    assert main(["format", matches, script, "-o", "out.csv", "--lexicon", str(lex)]) == 0
+    fr.format_data(matches, search.load_markup_script(script), lambda w: LEX.get(w, set()),
+                   "want.csv")
+    assert open("out.csv", "rb").read() == open("want.csv", "rb").read()
+    # default output name, no lexicon
+    assert main(["format", matches, script]) == 0
+    fr.format_data(matches, search.load_markup_script(script), lambda w: set(), "want2.csv")
+    assert open("js-data.csv", "rb").read() == open("want2.csv", "rb").read()
+
+
+@pytest.mark.gpu
+def test_format_on_search_output(tmp_path, monkeypatch, synth_base):
+    """format over the golden match CSV of the synthetic case, and the fused
+    device-row histogram straight after a search."""
+    import torch
+    from fandom_search_amd import abi, format as fmt, synth
+    from fandom_search_amd.engine import ScriptIndex
+    from oracle import format_restated as fr
+    monkeypatch.chdir(tmp_path)
+    case = util.load_case("synthetic_small")
+    words = synth_base["words"]
+    script = np.asarray(case["script"], dtype=np.uint32)
+    (tmp_path / "script.txt").write_text(synth.script_markup(script, words))
+    with open("m.csv", "w", newline="") as fh:
+        fh.write(",".join(search.new_record_structure['fields']) + "\r\n")
+        fh.write(util.golden_text("synthetic_small", "canonical"))
+    fmt.format_data(types.SimpleNamespace(matches="m.csv", script="script.txt", output="o.csv"))
+    fr.format_data("m.csv", search.load_markup_script("script.txt"), lambda w: set(), "w.csv")
+    assert open("o.csv", "rb").read() == open("w.csv", "rb").read()
+    # fused: histogram of device rows right after the search
+    cfg = util.case_config(case)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], synth_base["emb"],
+                     synth.lsh_normals(cfg.window_size), cfg=cfg)
+    tok, off = util.case_arrays(case)
+    corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    rows, _ = ix.search(corpus)
+    buf = torch.zeros(len(rows) * 32 + 32, dtype=torch.uint8, device="cuda")
+    n, _ = ix.search_device(corpus, buf.data_ptr(), len(rows) + 1)
+    counts = ix.reuse_histogram_device(buf.data_ptr(), n, fmt.THRESHOLDS)
+    want = fmt.reuse_histogram(rows["orig_ix"], rows["comb"], len(script))
+    assert np.array_equal(counts, want) and counts[:, -1].sum() == len(rows)
