@@ -166,16 +166,19 @@ def main():
     total_rows = 0
 
     def finish(b):
-        """Wait for slot b's gather; rank 0 expands wire records to full rows."""
+        """Slot b is about to be reused: its gather must be complete.  Work.wait()
+        on RCCL only orders torch's current stream, so the host also waits for that
+        stream (the library writes the buffers from its own stream).  Rank 0 then
+        expands wire records to full rows."""
         if pending[b] is None:
             return
         for h in pending[b]:
             h.wait()
         pending[b] = None
+        if not rehearsal:
+            torch.cuda.current_stream().synchronize()
         if rank == 0 and packed:
             src = gathered[b].cuda() if rehearsal else gathered[b]
-            if not rehearsal:
-                torch.cuda.current_stream().synchronize()
             ix.unpack_device(src.data_ptr(), world * cap, full_rows.data_ptr())
 
     def step(i):
