@@ -161,12 +161,28 @@ def main():
             if packed:
                 full_rows = torch.empty(world * cap * 32, dtype=torch.uint8, device="cuda")
 
-    pending = [None, None]
+    # Software pipeline over NB row buffers: the search of step i is queued while
+    # the GPU still finishes step i-1 (fs_search_corpus_begin / _end), and with more
+    # than one rank the gather of step i-1 runs beside the search of step i.
+    NB = 3
+    while len(bufs) < NB:
+        bufs.append(torch.zeros(cap * rec_bytes, dtype=torch.uint8, device="cuda"))
+    if world > 1:
+        while len(counts) < NB:
+            counts.append(torch.zeros(world, dtype=torch.int64, device=cdev))
+            mine.append(torch.zeros(1, dtype=torch.int64, device=cdev))
+            if rank == 0:
+                gathered.append(torch.zeros(world * cap * rec_bytes, dtype=torch.uint8,
+                                            device=cdev))
+    pending = [None] * NB       # gathers in flight, per buffer
+    tickets = {}                # step -> (ticket, buffer)
     scan_ms = []
     total_rows = 0
+    last_st = [None]
+    last_gathered = [0]
 
     def finish(b):
-        """Slot b is about to be reused: its gather must be complete.  Work.wait()
+        """Buffer b is about to be reused: its gather must be complete.  Work.wait()
         on RCCL only orders torch's current stream, so the host also waits for that
         stream (the library writes the buffers from its own stream).  Rank 0 then
         expands wire records to full rows."""
@@ -180,14 +196,16 @@ def main():
         if rank == 0 and packed:
             src = gathered[b].cuda() if rehearsal else gathered[b]
             ix.unpack_device(src.data_ptr(), world * cap, full_rows.data_ptr())
+        last_gathered[0] = b
 
-    def step(i):
+    def complete(i):
+        """Finish the search of step i and hand its rows to the gather."""
         nonlocal total_rows
-        b = i & 1
-        finish(b)
-        n, st = ix.search_device(corpus, bufs[b].data_ptr(), cap, packed=packed)
+        t, b = tickets.pop(i)
+        n, st = ix.search_end(t)
         scan_ms.append(st.scan_ms)
         total_rows = n
+        last_st[0] = st
         if world > 1:
             mine[b].fill_(n)
             h1 = dist.all_gather_into_tensor(counts[b], mine[b], async_op=True)
@@ -195,10 +213,18 @@ def main():
             h2 = dist.gather(send, list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
                              async_op=True)
             pending[b] = (h1, h2)
-        return st
+
+    def step(i):
+        b = i % NB
+        finish(b)
+        tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr(), cap, packed=packed), b)
+        if i - 1 in tickets:
+            complete(i - 1)
 
     def drain():
-        for b in (0, 1):
+        for i in sorted(tickets):
+            complete(i)
+        for b in range(NB):
             finish(b)
 
     for i in range(args.warmup):
@@ -210,8 +236,9 @@ def main():
     scan_ms.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        st = step(i)
+        step(args.warmup + i)
     drain()
+    st = last_st[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -231,7 +258,7 @@ def main():
         crcs = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
         dist.all_gather_into_tensor(crcs, crc)
         if rank == 0:
-            last = (args.steps - 1) & 1
+            last = last_gathered[0]
             crcs = crcs.cpu().tolist()
             cnts = counts[last].cpu().tolist()
             if packed:
@@ -291,6 +318,8 @@ def main():
                        "rows_per_gpu_step": int(total_rows),
                        "wire_record_bytes": rec_bytes if world > 1 else None,
                        "gather_verified": gather_verified,
+                       "pipeline": "search of step i queued while step i-1 completes "
+                                   "(fs_search_corpus_begin/_end, %d row buffers)" % NB,
                        "gather": ("%s gather to rank 0, overlapped" % ("gloo (rehearsal)" if rehearsal
                                                                         else "rccl")) if world > 1 else "none",
                        "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh"},

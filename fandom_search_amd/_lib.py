@@ -19,7 +19,8 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_corpus_destroy", "fs_search_corpus", "fs_search",
            "fs_scan_benchmark", "fs_corpus_update_begin", "fs_corpus_update_end",
            "fs_host_alloc", "fs_host_free", "fs_rows_unpack",
-           "fs_reuse_histogram", "fs_reuse_histogram_rows")
+           "fs_reuse_histogram", "fs_reuse_histogram_rows",
+           "fs_search_corpus_begin", "fs_search_corpus_end")
 
 
 class FsError(RuntimeError):
@@ -109,6 +110,11 @@ def load():
     L.fs_reuse_histogram_rows.restype = C.c_int
     L.fs_reuse_histogram_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64,
                                           C.POINTER(C.c_double), C.c_uint32, C.c_void_p]
+    L.fs_search_corpus_begin.restype = C.c_int
+    L.fs_search_corpus_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                         C.POINTER(C.c_uint32)]
+    L.fs_search_corpus_end.restype = C.c_int
+    L.fs_search_corpus_end.argtypes = [C.c_void_p, C.c_uint32, u64p, C.POINTER(abi.FsStats)]
     L.fs_scan_benchmark.restype = C.c_int
     L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.POINTER(C.c_double)]

@@ -61,6 +61,14 @@ fs_index::~fs_index() {
   if (ev_scan1) (void)hipEventDestroy(ev_scan1);
   if (ev_end) (void)hipEventDestroy(ev_end);
   if (h_status) (void)hipHostFree(h_status);
+  for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
+    Slot& sl = slots[i];
+    if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
+    if (sl.ev_scan0) (void)hipEventDestroy(sl.ev_scan0);
+    if (sl.ev_scan1) (void)hipEventDestroy(sl.ev_scan1);
+    if (sl.ev_end) (void)hipEventDestroy(sl.ev_end);
+    if (sl.h_status) (void)hipHostFree(sl.h_status);
+  }
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -240,6 +248,14 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   FS_HIP(hipEventCreate(&ix->ev_scan1));
   FS_HIP(hipEventCreate(&ix->ev_end));
   FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
+  for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
+    fs_index::Slot& sl = ix->slots[i];
+    FS_HIP(hipEventCreate(&sl.ev_begin));
+    FS_HIP(hipEventCreate(&sl.ev_scan0));
+    FS_HIP(hipEventCreate(&sl.ev_scan1));
+    FS_HIP(hipEventCreate(&sl.ev_end));
+    FS_HIP(hipHostMalloc((void**)&sl.h_status, sizeof(fs_status), hipHostMallocDefault));
+  }
   FS_TRY(ix->d_status.reserve(1));
   FS_TRY(ix->w_bsum.reserve(4096));
   FS_TRY(ix->w_bsum64.reserve(2048));
@@ -455,98 +471,154 @@ extern "C" void fs_corpus_destroy(fs_corpus* c) {
   delete c;
 }
 
-extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap,
-                                int rows_on_device, uint64_t* n_rows, fs_stats* st) {
-  if (!ix || !c || c->ix != ix || !n_rows || (cap && !rows)) {
+// ---- search: enqueue / finish ---------------------------------------------------
+// A search is queued on the index's stream into one of FS_SEARCH_SLOTS slots and
+// finished later; the synchronous entry point is begin + end.  All queued
+// searches share the workspaces and the device status block: they run in stream
+// order, and each one's status is copied to its slot's pinned block before the
+// next one's memset.
+
+static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
+  hipStream_t s = ix->stream;
+  fs_corpus* c = sl.c;
+  const uint32_t nn = ix->cfg.nearest_n;
+  const uint32_t n_bm = sl.n_bm;
+  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * 4));
+  FS_TRY(ix->w_qcnt.reserve(n_bm));
+  FS_TRY(ix->w_cpos.reserve(sl.ccap));
+  FS_TRY(ix->w_cg.reserve(sl.ccap));
+  FS_TRY(ix->w_cw.reserve(sl.ccap));
+  FS_TRY(ix->w_hv.reserve(sl.ccap));
+  FS_TRY(ix->w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
+  FS_TRY(ix->w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
+  fs_row* d_rows = sl.rows;
+  if (sl.mode == FS_ROWS_HOST) { FS_TRY(ix->w_rows.reserve(sl.rcap)); d_rows = ix->w_rows.p; }
+  const bool packed = sl.mode == FS_ROWS_DEVICE_PACKED;
+
+  FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
+  FS_HIP(hipEventRecord(sl.ev_begin, s));
+  const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
+  const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
+  if (sl.exact) {
+    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, sl.ev_scan0, sl.ev_scan1));
+    FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, packed, s));
+  } else {
+    FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, sl.ev_scan0,
+                              sl.ev_scan1));
+    FS_TRY(fs_launch_expand(ix, n_bm, ccap32, s));
+    FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
+    FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, s));
+  }
+  ++sl.launches;
+  FS_HIP(hipMemcpyAsync(sl.h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipEventRecord(sl.ev_end, s));
+  return FS_OK;
+}
+
+extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap,
+                                      int rows_mode, uint32_t* ticket) {
+  if (!ix || !c || c->ix != ix || !ticket || (cap && !rows)) {
     fs_set_error("null or mismatched handle");
+    return FS_E_INVALID;
+  }
+  if (rows_mode != FS_ROWS_HOST && rows_mode != FS_ROWS_DEVICE && rows_mode != FS_ROWS_DEVICE_PACKED) {
+    fs_set_error("rows_mode must be FS_ROWS_HOST, FS_ROWS_DEVICE or FS_ROWS_DEVICE_PACKED");
     return FS_E_INVALID;
   }
   FS_HIP(hipSetDevice(ix->device));
   FS_TRY(fs_corpus_update_end(c));          // no-op unless an upload is in flight
-  hipStream_t s = ix->stream;
+  const uint32_t id = ix->next_slot % FS_SEARCH_SLOTS;
+  fs_index::Slot& sl = ix->slots[id];
+  if (sl.busy) {
+    fs_set_error("%d searches already in flight on this index", FS_SEARCH_SLOTS);
+    return FS_E_INVALID;
+  }
+  if (rows_mode == FS_ROWS_HOST)
+    for (int i = 0; i < FS_SEARCH_SLOTS; ++i)
+      if (ix->slots[i].busy) {
+        fs_set_error("host rows need the index to itself: finish the searches in flight first");
+        return FS_E_INVALID;
+      }
   const uint64_t T = c->n_tok;
-  const uint32_t n_bm = (uint32_t)((T + 255) / 256);
-  const uint32_t nn = ix->cfg.nearest_n;
-  const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
-  const bool packed = rows_on_device == FS_ROWS_DEVICE_PACKED;
-  if (packed && !exact) {
+  sl.c = c; sl.rows = rows; sl.cap = cap; sl.mode = rows_mode; sl.launches = 0;
+  sl.n_bm = (uint32_t)((T + 255) / 256);
+  sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
+  if (rows_mode == FS_ROWS_DEVICE_PACKED && !sl.exact) {
     fs_set_error("packed rows exist for the exact n-gram pipeline only (there the distance is a "
                  "function of the matched script window)");
     return FS_E_UNSUPPORTED;
   }
   // capacities: grown from the device totals when a stage overflows
-  uint64_t ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_cpos.n);
-  uint64_t rcap = rows_on_device ? cap
-                                 : std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_rows.n);
+  sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_cpos.n);
+  sl.rcap = rows_mode != FS_ROWS_HOST
+                ? cap
+                : std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_rows.n);
+  FS_TRY(search_enqueue(ix, sl));
+  sl.busy = true;
+  *ticket = id;
+  ++ix->next_slot;
+  return FS_OK;
+}
 
+extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_rows, fs_stats* st) {
+  if (!ix || ticket >= FS_SEARCH_SLOTS || !n_rows || !ix->slots[ticket].busy) {
+    fs_set_error("no such search in flight");
+    return FS_E_INVALID;
+  }
+  FS_HIP(hipSetDevice(ix->device));
+  fs_index::Slot& sl = ix->slots[ticket];
+  sl.busy = false;
   float scan_ms = 0, total_ms = 0;
-  uint32_t launches = 0;
-  for (int attempt = 0; attempt < 8; ++attempt) {
-    FS_TRY(ix->w_qbm.reserve((size_t)n_bm * 4));
-    FS_TRY(ix->w_qcnt.reserve(n_bm));
-    FS_TRY(ix->w_cpos.reserve(ccap));
-    FS_TRY(ix->w_cg.reserve(ccap));
-    FS_TRY(ix->w_cw.reserve(ccap));
-    FS_TRY(ix->w_hv.reserve(ccap));
-    FS_TRY(ix->w_mlev.reserve(exact && c->has_str ? ccap * nn : 1));
-    FS_TRY(ix->w_cbest.reserve(!exact || c->has_str ? ccap : 1));
-    fs_row* d_rows = rows;
-    if (!rows_on_device) { FS_TRY(ix->w_rows.reserve(rcap)); d_rows = ix->w_rows.p; }
-
-    FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
-    FS_HIP(hipEventRecord(ix->ev_begin, s));
-    const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(ccap, 0xFFFFFFFFull);
-    const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(rcap, 0xFFFFFFFFull);
-    if (exact) {
-      FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, ix->ev_scan0,
-                            ix->ev_scan1));
-      FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, packed, s));
-    } else {
-      FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, ix->ev_scan0,
-                                ix->ev_scan1));
-      FS_TRY(fs_launch_expand(ix, n_bm, ccap32, s));
-      FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
-      FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, s));
-    }
-    ++launches;
-    FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
-    FS_HIP(hipEventRecord(ix->ev_end, s));
-    FS_HIP(hipStreamSynchronize(s));
+  for (int attempt = 0;; ++attempt) {
+    FS_HIP(hipEventSynchronize(sl.ev_end));
     scan_ms = 0;
-    if (n_bm) FS_HIP(hipEventElapsedTime(&scan_ms, ix->ev_scan0, ix->ev_scan1));
-    FS_HIP(hipEventElapsedTime(&total_ms, ix->ev_begin, ix->ev_end));
-    const fs_status& hs = *ix->h_status;
+    if (sl.n_bm) FS_HIP(hipEventElapsedTime(&scan_ms, sl.ev_scan0, sl.ev_scan1));
+    FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
+    const fs_status& hs = *sl.h_status;
     if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }
     if (hs.lev_overflow) {
       fs_set_error("an n-gram text exceeds %d code points", FS_LEV_MAX);
       return FS_E_UNSUPPORTED;
     }
     bool again = false;
-    if (hs.n_cands > ccap) { ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
-    else if (!rows_on_device && hs.n_rows > rcap && hs.n_rows <= cap) { rcap = hs.n_rows; again = true; }
+    if (hs.n_cands > sl.ccap) { sl.ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
+    else if (sl.mode == FS_ROWS_HOST && hs.n_rows > sl.rcap && hs.n_rows <= sl.cap) {
+      sl.rcap = hs.n_rows; again = true;
+    }
     if (!again) break;
     if (attempt == 7) { fs_set_error("workspace growth did not converge"); return FS_E_DEVICE; }
+    // a workspace was too small: grow it (the reallocation waits for everything
+    // queued so far) and run this search again
+    FS_TRY(search_enqueue(ix, sl));
   }
-  const fs_status hs = *ix->h_status;
+  const fs_status hs = *sl.h_status;
   *n_rows = hs.n_rows;
   if (st) {
     memset(st, 0, sizeof *st);
-    st->windows_processed = c->windows;
+    st->windows_processed = sl.c->windows;
     st->candidates = hs.n_cands;
     st->matches = hs.n_matches;
     st->rows = hs.n_rows;
     st->scan_ms = scan_ms;
     st->total_ms = total_ms;
-    st->path = exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
-    st->scan_launches = launches;
+    st->path = sl.exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
+    st->scan_launches = sl.launches;
   }
-  if (hs.n_rows > cap) return FS_E_CAPACITY;
-  if (!rows_on_device && hs.n_rows) {
-    FS_HIP(hipMemcpyAsync(rows, ix->w_rows.p, (size_t)hs.n_rows * sizeof(fs_row), hipMemcpyDeviceToHost, s));
-    FS_HIP(hipStreamSynchronize(s));
+  if (hs.n_rows > sl.cap) return FS_E_CAPACITY;
+  if (sl.mode == FS_ROWS_HOST && hs.n_rows) {
+    FS_HIP(hipMemcpyAsync(sl.rows, ix->w_rows.p, (size_t)hs.n_rows * sizeof(fs_row),
+                          hipMemcpyDeviceToHost, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
   }
-  (void)nn;
   return FS_OK;
+}
+
+extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap,
+                                int rows_on_device, uint64_t* n_rows, fs_stats* st) {
+  if (!n_rows) { fs_set_error("null argument"); return FS_E_INVALID; }
+  uint32_t ticket = 0;
+  FS_TRY(fs_search_corpus_begin(ix, c, rows, cap, rows_on_device, &ticket));
+  return fs_search_corpus_end(ix, ticket, n_rows, st);
 }
 
 extern "C" int fs_search(fs_index* ix, const uint32_t* tok_vec, const uint32_t* tok_str,

@@ -11,6 +11,7 @@
 
 #define FS_MAX_WINDOW 16          // n <= 16: at most 4 neighbour vectors of halo
 #define FS_NONE 0xFFFFFFFFu
+#define FS_SEARCH_SLOTS 4         // searches that may be in flight on one index
 #define FS_LEV_MAX 512            // code points per side handled by lev_device
 
 void fs_set_error(const char* fmt, ...);
@@ -143,6 +144,21 @@ struct fs_index {
   DBuf<fs_row> w_rows;
   DBuf<fs_status> d_status;
   fs_status* h_status = nullptr;   // pinned
+
+  // searches in flight (fs_search_corpus_begin / _end)
+  struct Slot {
+    hipEvent_t ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_end = nullptr;
+    fs_status* h_status = nullptr;    // pinned
+    bool busy = false;
+    fs_corpus* c = nullptr;
+    fs_row* rows = nullptr;
+    uint64_t cap = 0, ccap = 0, rcap = 0;
+    int mode = 0;
+    bool exact = false;
+    uint32_t n_bm = 0, launches = 0;
+  };
+  Slot slots[FS_SEARCH_SLOTS];
+  uint32_t next_slot = 0;
 
   GramIndexDev gram_dev() const;
   ~fs_index();

@@ -195,6 +195,29 @@ class ScriptIndex(object):
         _lib.check(rc, "fs_search_corpus")
         return int(n.value), st
 
+    def search_begin(self, corpus, rows_ptr, cap, packed=False):
+        """Queue a search (rows to the device buffer at `rows_ptr`) and return a
+        ticket for search_end; up to four may be in flight per index."""
+        t = C.c_uint32(0)
+        mode = abi.FS_ROWS_DEVICE_PACKED if packed else abi.FS_ROWS_DEVICE
+        _lib.check(_lib.load().fs_search_corpus_begin(
+            self._h, corpus._h, C.c_void_p(rows_ptr), int(cap), mode, C.byref(t)),
+            "fs_search_corpus_begin")
+        return t.value
+
+    def search_end(self, ticket):
+        """(n_rows, stats) of a queued search; FsError(FS_E_CAPACITY).required when
+        the row buffer was too small."""
+        st = abi.FsStats()
+        n = C.c_uint64(0)
+        rc = _lib.load().fs_search_corpus_end(self._h, int(ticket), C.byref(n), C.byref(st))
+        if rc == abi.FS_E_CAPACITY:
+            err = _lib.FsError(rc, "fs_search_corpus_end", "row buffer too small")
+            err.required = int(n.value)
+            raise err
+        _lib.check(rc, "fs_search_corpus_end")
+        return int(n.value), st
+
     def unpack_device(self, packed_ptr, n, rows_ptr):
         """Expand `n` 16-byte wire records at device address `packed_ptr` into
         fs_row records at `rows_ptr` (both on this index's device)."""

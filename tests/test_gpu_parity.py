@@ -173,3 +173,38 @@ def test_long_tokens_and_levenshtein_limit(synth_base):
     with pytest.raises(_lib.FsError) as e:
         ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
     assert e.value.code == abi.FS_E_UNSUPPORTED and "512" in str(e.value)
+
+
+def test_searches_in_flight(synth_base):
+    """fs_search_corpus_begin/_end: several searches queued before the first is
+    collected give the rows of the synchronous call."""
+    import torch
+    from fandom_search_amd import _lib
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(4000)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    corpora, want = [], []
+    for k in range(4):
+        tok, off = util.ragged_corpus([600 + 100 * k] * (10 + k) + [0, 4], script, first_work=50 * k)
+        c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        corpora.append(c)
+        want.append(ix.search(c)[0])
+    bufs = [torch.zeros((len(w) + 8) * 32, dtype=torch.uint8, device="cuda") for w in want]
+    tickets = [ix.search_begin(c, b.data_ptr(), len(w) + 8) for c, b, w in zip(corpora, bufs, want)]
+    with pytest.raises(_lib.FsError, match="in flight"):
+        ix.search_begin(corpora[0], bufs[0].data_ptr(), 8)
+    for order in (2, 0, 3, 1):                       # collected out of order
+        n, st = ix.search_end(tickets[order])
+        got = bufs[order].cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
+        assert got.tobytes() == want[order].tobytes()
+        assert st.scan_ms > 0
+    with pytest.raises(_lib.FsError, match="no such search"):
+        ix.search_end(tickets[0])
+    # a too small buffer is reported at _end, and the slot is free again afterwards
+    t = ix.search_begin(corpora[1], bufs[1].data_ptr(), 3)
+    with pytest.raises(_lib.FsError) as e:
+        ix.search_end(t)
+    assert e.value.code == abi.FS_E_CAPACITY and e.value.required == len(want[1])
+    assert ix.search(corpora[1])[0].tobytes() == want[1].tobytes()
