@@ -132,7 +132,8 @@ struct fs_index {
   DBuf<double> d_normals;
 
   // general (LSH) pipeline, built on demand (fs_lsh_build)
-  DBuf<double> d_nt, d_atab, d_ss;
+  DBuf<double> d_nt, d_atab, d_ss, d_gtab;
+  DBuf<int32_t> d_sidx;
   DBuf<uint32_t> d_boff, d_bids;
   bool lsh_ready = false;
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors

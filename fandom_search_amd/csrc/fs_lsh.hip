@@ -35,6 +35,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
 #include <vector>
 
@@ -51,6 +53,8 @@ struct LshDev {
   const double* q;         // [V]
   const float* emb;        // [V][D]
   const uint32_t* stok;    // script vector ids
+  const double* gtab;      // [n_srow][V] g(script row, table row), or nullptr
+  const int32_t* sidx;     // [V] row of gtab for a table id, -1 if not a script word
   uint32_t V, W;
   int n, H, B, D, C, nn, unique;
   double thr, cmax;
@@ -82,10 +86,15 @@ __device__ __forceinline__ double q_of(const LshDev& L, uint32_t id) {
   return 1.0 + (b != a ? 1.0 : 0.0) + (c != b ? 1.0 : 0.0);
 }
 
-// g(u, v) = seqsum_d e_u[d] * e_v[d], u != v
+// g(u, v) = seqsum_d e_u[d] * e_v[d], u != v; u is a script token.  For table
+// rows the sum was computed once per index (k_gtab, same order of operations).
 __device__ double g_of(const LshDev& L, uint32_t u, uint32_t v) {
   const bool uo = u & FS_OOV_FLAG, vo = v & FS_OOV_FLAG;
   if (!uo && !vo) {
+    if (L.gtab) {
+      const int32_t r = L.sidx[u];
+      if (r >= 0) return L.gtab[(size_t)r * L.V + v];
+    }
     const float* eu = L.emb + (size_t)u * L.D;
     const float* ev = L.emb + (size_t)v * L.D;
     double acc = 0.0;
@@ -218,6 +227,31 @@ __global__ void k_atab(const double* __restrict__ nt, const float* __restrict__ 
       acc = __dadd_rn(acc, __dmul_rn(ntk[(size_t)d * C + c], (double)e[d]));
     atab[((size_t)k * V + v) * C + c] = acc;
   }
+}
+
+// embT[d][v] = (double) E[v][d]: coalesced reads for k_gtab
+__global__ void k_embT(const float* __restrict__ emb, uint32_t V, int D, float* __restrict__ embT) {
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  for (int d = 0; d < D; ++d) embT[(size_t)d * V + v] = emb[(size_t)v * D + d];
+}
+
+// gtab[r][v] = seqsum_d E[srow[r]][d] * E[v][d]  (canonical: mul then add, d ascending)
+__global__ __launch_bounds__(256) void k_gtab(const float* __restrict__ emb,
+                                              const float* __restrict__ embT, uint32_t V, int D,
+                                              const uint32_t* __restrict__ srow,
+                                              double* __restrict__ gtab) {
+  extern __shared__ float s_u[];     // the script row, D floats
+  const uint32_t r = blockIdx.y;
+  const float* eu = emb + (size_t)srow[r] * D;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) s_u[d] = eu[d];
+  __syncthreads();
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  double acc = 0.0;
+  for (int d = 0; d < D; ++d)
+    acc = __dadd_rn(acc, __dmul_rn((double)s_u[d], (double)embT[(size_t)d * V + v]));
+  gtab[(size_t)r * V + v] = acc;
 }
 
 __global__ void k_ss(const uint32_t* __restrict__ stok, uint32_t W, LshDev L,
@@ -400,6 +434,7 @@ static LshDev lsh_dev(const fs_index* ix) {
   LshDev L;
   L.atab = ix->d_atab.p; L.nt = ix->d_nt.p; L.boff = ix->d_boff.p; L.bids = ix->d_bids.p;
   L.ss = ix->d_ss.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
+  L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
   L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
@@ -425,6 +460,38 @@ int fs_lsh_build(fs_index* ix) {
     hipLaunchKernelGGL(k_atab, dim3((uint32_t)V, n), dim3(256), 0, s, ix->d_nt.p, ix->d_emb.p,
                        (uint32_t)V, D, C, ix->d_atab.p);
   FS_HIP(hipGetLastError());
+  // pair dot products g(script row, table row): one 8-byte lookup per window slot
+  // instead of D multiply-adds when a candidate's exact distance is needed.  Capped
+  // at 64 GiB of the 288 GB HBM; beyond that g is computed on the fly.
+  {
+    std::vector<uint32_t> stok_h(ix->n_script);
+    FS_HIP(hipMemcpyAsync(stok_h.data(), ix->d_stok.p, ix->n_script * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    std::vector<int32_t> sidx(std::max<uint64_t>(V, 1), -1);
+    std::vector<uint32_t> srow;
+    for (uint32_t id : stok_h)
+      if (!(id & FS_OOV_FLAG) && sidx[id] < 0) { sidx[id] = (int32_t)srow.size(); srow.push_back(id); }
+    FS_TRY(ix->d_sidx.upload(sidx.data(), sidx.size(), s));
+    const uint64_t bytes = (uint64_t)srow.size() * V * sizeof(double);
+    if (!srow.empty() && V && bytes <= (64ull << 30) && !getenv("FS_LSH_NO_GTAB")) {
+      DBuf<uint32_t> d_srow;
+      DBuf<float> embT;
+      FS_TRY(d_srow.upload(srow.data(), srow.size(), s));
+      FS_TRY(embT.reserve((size_t)V * D));
+      FS_TRY(ix->d_gtab.reserve((size_t)srow.size() * V));
+      hipLaunchKernelGGL(k_embT, dim3((uint32_t)((V + 255) / 256)), dim3(256), 0, s, ix->d_emb.p,
+                         (uint32_t)V, D, embT.p);
+      for (size_t r0 = 0; r0 < srow.size(); r0 += 32768) {        // grid.y limit
+        const uint32_t rows = (uint32_t)std::min<size_t>(32768, srow.size() - r0);
+        hipLaunchKernelGGL(k_gtab, dim3((uint32_t)((V + 255) / 256), rows), dim3(256),
+                           D * sizeof(float), s, ix->d_emb.p, embT.p, (uint32_t)V, D,
+                           d_srow.p + r0, ix->d_gtab.p + r0 * V);
+      }
+      FS_HIP(hipGetLastError());
+      FS_HIP(hipStreamSynchronize(s));
+    }
+  }
   const uint32_t nb = 1u << B;
   std::vector<uint32_t> boff((size_t)H * (nb + 1), 0u), bids((size_t)H * std::max<uint64_t>(W, 1), 0u);
   if (W) {

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Throughput of the general (LSH) pipeline on vector tables where the exact
+n-gram proof fails (diagnostic).
+
+  python tools/lsh_bench.py [--table clustered|synthetic] [--window 6] [--works 500]
+
+clustered: 8192 unit vectors in 1024 clusters of 8 near-synonyms (cosine
+0.85-0.97 inside a cluster), the shape of a real word-embedding table as far as
+this search is concerned: approximate matches exist and c_max ~ 1."""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+from fandom_search_amd import abi, synth, vocab  # noqa: E402
+from fandom_search_amd.engine import ScriptIndex  # noqa: E402
+
+
+def clustered_table(seed=3, clusters=1024, per=8, dim=300, noise=0.25):
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((clusters, dim))
+    emb = np.repeat(centers, per, axis=0) + noise * rng.standard_normal((clusters * per, dim))
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    perm = rng.permutation(len(emb))            # synonyms are not neighbours in id space
+    return emb[perm].astype(np.float32), perm
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--table", default="clustered")
+    ap.add_argument("--window", type=int, default=6)
+    ap.add_argument("--works", type=int, default=500)
+    ap.add_argument("--tokens", type=int, default=2000)
+    ap.add_argument("--script-tokens", type=int, default=20000)
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--oracle-works", type=int, default=0, help="also check N works against the oracle")
+    a = ap.parse_args()
+    words = synth.vocab_words()
+    if a.table == "clustered":
+        emb, perm = clustered_table()
+        inv = np.argsort(perm)
+    else:
+        emb = synth.embedding()
+    script = synth.script_tokens(a.script_tokens)
+    tok, off = synth.corpus_tokens(a.works, a.tokens, script)
+    if a.table == "clustered":
+        # swap 10 % of the planted/ordinary tokens for a synonym: genuine approximate matches
+        rng = np.random.default_rng(9)
+        sel = np.nonzero(rng.random(len(tok)) < 0.1)[0]
+        orig = inv[tok[sel]]                      # position in the clustered order
+        syn = (orig // 8) * 8 + rng.integers(0, 8, size=len(sel))
+        tok[sel] = perm[syn].astype(np.uint32)
+    chars, coff = vocab.pack_strings(words)
+    cfg = abi.make_config(window_size=a.window, mode=abi.FS_MODE_GENERAL)
+    t0 = time.time()
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(a.window), cfg=cfg)
+    t_index = time.time() - t0
+    corpus = ix.corpus(tok, off, chars, coff)
+    rows, st = ix.search(corpus)
+    best = None
+    for _ in range(a.reps):
+        rows, st = ix.search(corpus)
+        best = st.total_ms if best is None else min(best, st.total_ms)
+    out = {"table": a.table, "window": a.window, "works": a.works, "tokens": a.tokens,
+           "c_max": ix.info["c_max"], "index_s": round(t_index, 2), "total_ms": best,
+           "scan_ms": st.scan_ms, "rows": len(rows), "matches": int(st.matches),
+           "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()),
+           "fanworks_per_s": a.works / (best * 1e-3),
+           "windows_per_s": st.windows_processed / (best * 1e-3)}
+    if a.oracle_works:
+        from oracle import c_oracle
+        sch, so = vocab.pack_strings([words[int(t)] for t in script])
+        oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, synth.lsh_normals(a.window), threads=16)
+        cut = int(off[a.oracle_works])
+        t0 = time.time()
+        want, _ = oi.search(tok[:cut], off[:a.oracle_works + 1], chars, coff)
+        out["oracle_s"] = round(time.time() - t0, 2)
+        got = rows[rows["work"] < a.oracle_works]
+        out["oracle_equal"] = bool(got.tobytes() == want.tobytes())
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
