@@ -148,4 +148,75 @@ __device__ inline uint32_t lev_device(const GramIndexDev& g, uint32_t s, const u
   return row[lb];
 }
 
+// The same distance computed by a whole wave (all 64 lanes must call it with the
+// same arguments).  Both operands are assembled in LDS (`s_a`, `s_b`: FS_LEV_MAX
+// code points each, private to the wave); when the shorter one has at most 64 code
+// points the distance comes from Myers' bit-vector recurrence: lane j holds
+// pattern[j], __ballot(pattern == c) is the match mask of text character c, and
+// the column update is a dozen 64-bit operations.  Longer patterns take the
+// scratch DP of lev_device on lane 0.
+__device__ inline uint32_t lev_wave(const GramIndexDev& g, uint32_t s, const uint32_t* fan_sid,
+                                    const uint32_t* chars, const uint64_t* coff, uint32_t n_str,
+                                    fs_status* st, uint32_t* s_a, uint32_t* s_b) {
+  const int lane = threadIdx.x & 63;
+  // lengths (uniform)
+  uint32_t la = g.n - 1, lb = 2 + 2 * (g.n - 1);
+  bool bad = false;
+  for (int k = 0; k < g.n; ++k) {
+    la += (uint32_t)(g.soff[s + k + 1] - g.soff[s + k]);
+    const uint32_t sid = fan_sid[k];
+    if (sid >= n_str) { bad = true; break; }
+    lb += (uint32_t)(coff[sid + 1] - coff[sid]);
+  }
+  if (bad) { if (lane == 0) st->bad_string = 1; return 0; }
+  if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { if (lane == 0) st->lev_overflow = 1; return 0; }
+  // operands into LDS: a = script words joined by ' ', b = '[' + ', '.join(fan) + ']'
+  uint32_t pa = 0, pb = 0;
+  if (lane == 0) s_b[0] = '[';
+  pb = 1;
+  for (int k = 0; k < g.n; ++k) {
+    if (k) {
+      if (lane == 0) { s_a[pa] = ' '; s_b[pb] = ','; s_b[pb + 1] = ' '; }
+      pa += 1; pb += 2;
+    }
+    const uint64_t a0 = g.soff[s + k], a1 = g.soff[s + k + 1];
+    for (uint64_t c = a0 + lane; c < a1; c += 64) s_a[pa + (uint32_t)(c - a0)] = g.schars[c];
+    pa += (uint32_t)(a1 - a0);
+    const uint32_t sid = fan_sid[k];
+    const uint64_t b0 = coff[sid], b1 = coff[sid + 1];
+    for (uint64_t c = b0 + lane; c < b1; c += 64) s_b[pb + (uint32_t)(c - b0)] = chars[c];
+    pb += (uint32_t)(b1 - b0);
+  }
+  if (lane == 0) s_b[pb] = ']';
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t* pat = la <= lb ? s_a : s_b;
+  const uint32_t* txt = la <= lb ? s_b : s_a;
+  const uint32_t m = la <= lb ? la : lb, t = la <= lb ? lb : la;
+  if (m == 0) return t;
+  if (m > 64) {
+    uint32_t r = 0;
+    if (lane == 0) r = lev_device(g, s, fan_sid, chars, coff, n_str, st);
+    return __shfl(r, 0);
+  }
+  const uint32_t pc = lane < (int)m ? pat[lane] : 0xFFFFFFFFu;    // never equal to a code point
+  const uint64_t last = 1ull << (m - 1);
+  uint64_t pv = ~0ull, mv = 0;
+  uint32_t score = m;
+  for (uint32_t i = 0; i < t; ++i) {
+    const uint32_t c = txt[i];
+    const uint64_t eq = __ballot(pc == c);
+    const uint64_t xv = eq | mv;
+    const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
+    uint64_t ph = mv | ~(xh | pv);
+    uint64_t mh = pv & xh;
+    if (ph & last) ++score;
+    if (mh & last) --score;
+    ph = (ph << 1) | 1ull;
+    mh <<= 1;
+    pv = mh | ~(xv | ph);
+    mv = ph & xv;
+  }
+  return score;
+}
+
 }  // namespace fsdev

@@ -134,6 +134,7 @@ struct fs_index {
   // general (LSH) pipeline, built on demand (fs_lsh_build)
   DBuf<double> d_nt, d_atab, d_ss, d_gtab;
   DBuf<int32_t> d_sidx;
+  DBuf<float> d_atab32, d_amax;
   DBuf<uint32_t> d_boff, d_bids;
   bool lsh_ready = false;
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors

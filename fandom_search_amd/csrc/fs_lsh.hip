@@ -35,6 +35,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <math.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -53,6 +54,11 @@ struct LshDev {
   const double* q;         // [V]
   const float* emb;        // [V][D]
   const uint32_t* stok;    // script vector ids
+  const float* atab32;     // [n][V][C] float32 copy of atab, or nullptr
+  const float* amax;       // [n][V] >= max_c |atab[k][v][c]|
+  float bound_scale;       // n * 2^-22 (times a test factor)
+  int m_min;               // fewer id-identical slots than this cannot reach the threshold
+  int diag;                // diagnostics: 1 = skip candidate walk, 2 = skip key computation
   const double* gtab;      // [n_srow][V] g(script row, table row), or nullptr
   const int32_t* sidx;     // [V] row of gtab for a table id, -1 if not a script word
   uint32_t V, W;
@@ -140,11 +146,26 @@ __device__ __forceinline__ uint32_t assemble_key(const uint64_t* bal, int h, int
 // sound skip described in the file header.  Returns false when skipped or NaN.
 __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, double ff,
                                 double* out) {
+  // stage 0: integer only.  With all table norms in [sqrt(q_min), sqrt(q_max)] and
+  // no OOV vector involved, m identical slots bound the cosine by
+  // (m q_max + (n-m) c_max q_max) / (n q_min); m_min is the smallest m for which that
+  // reaches 1 - threshold (host side, lsh_dev).
+  uint32_t sid[FS_MAX_WINDOW];
+  {
+    int same = 0;
+    uint32_t anyoov = 0;
+    for (int k = 0; k < L.n; ++k) {
+      sid[k] = L.stok[s + k];
+      same += sid[k] == f[k];
+      anyoov |= sid[k] | f[k];
+    }
+    if (same < L.m_min && !(anyoov & FS_OOV_FLAG)) return false;
+  }
   const double ss = L.ss[s];
   // upper bound on SF
   double ub = 0.0;
   for (int k = 0; k < L.n; ++k) {
-    const uint32_t u = L.stok[s + k], v = f[k];
+    const uint32_t u = sid[k], v = f[k];
     const double qu = q_of(L, u);
     if (u == v) { ub += qu; continue; }
     const double c = ((u | v) & FS_OOV_FLAG) ? 1.0 : L.cmax;
@@ -154,7 +175,7 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
   if (ub <= 0.0 || ub * ub < lim * lim * ss * ff * (1.0 - 1e-9)) return false;
   double sf = 0.0;
   for (int k = 0; k < L.n; ++k) {
-    const uint32_t u = L.stok[s + k], v = f[k];
+    const uint32_t u = sid[k], v = f[k];
     sf = __dadd_rn(sf, u == v ? q_of(L, u) : g_of(L, u, v));
   }
   const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(__dsqrt_rn(ss), __dsqrt_rn(ff))));
@@ -215,18 +236,31 @@ __global__ void k_nt(const double* __restrict__ normals, int n, int D, int C,
 }
 
 // A[k][v][c] = seqsum_d nt[k][d][c] * (double)E[v][d]; block = one (k, v)
-__global__ void k_atab(const double* __restrict__ nt, const float* __restrict__ emb, uint32_t V,
-                       int D, int C, double* __restrict__ atab) {
+__global__ __launch_bounds__(256) void k_atab(const double* __restrict__ nt,
+                                              const float* __restrict__ emb, uint32_t V, int D,
+                                              int C, double* __restrict__ atab,
+                                              float* __restrict__ atab32,
+                                              float* __restrict__ amax) {
+  __shared__ float s_m[4];
   const uint32_t v = blockIdx.x;
   const int k = blockIdx.y;
   const float* e = emb + (size_t)v * D;
   const double* ntk = nt + (size_t)k * D * C;
+  float mx = 0.0f;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double acc = 0.0;
     for (int d = 0; d < D; ++d)
       acc = __dadd_rn(acc, __dmul_rn(ntk[(size_t)d * C + c], (double)e[d]));
-    atab[((size_t)k * V + v) * C + c] = acc;
+    const size_t i = ((size_t)k * V + v) * C + c;
+    atab[i] = acc;
+    atab32[i] = (float)acc;
+    mx = fmaxf(mx, __double2float_ru(fabs(acc)));          // rounded up
   }
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    amax[(size_t)k * V + v] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
 }
 
 // embT[d][v] = (double) E[v][d]: coalesced reads for k_gtab
@@ -299,6 +333,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
   uint32_t* s_key = reinterpret_cast<uint32_t*>(s_bal + 256 * (NW + 1));   // [256][H]
   uint32_t* s_tok = s_key + 256 * L.H;                                  // [256 + 16]
   __shared__ uint32_t s_cnt[4];
+  __shared__ float s_bound[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = L.n;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
@@ -306,16 +341,46 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
     for (int i = threadIdx.x; i < 256 + n - 1; i += 256) s_tok[i] = c.tok[p0 + i];
     for (int i = threadIdx.x; i < 256; i += 256) s_bal[i * (NW + 1) + NW] = 0;
     __syncthreads();
-    // phase 1: threads are projection columns
-    for (int ch0 = 0; ch0 < L.C; ch0 += 256) {
+    {
+      // per window: the float32 decision bound, or -1 when the window needs float64
+      const int w = threadIdx.x;
+      float m = 0.0f;
+      bool f64 = L.atab32 == nullptr;
+      for (int k = 0; k < n; ++k) {
+        const uint32_t id = s_tok[w + k];
+        if (id & FS_OOV_FLAG) f64 = true; else m += L.amax[(size_t)k * L.V + id];
+      }
+      s_bound[w] = f64 ? -1.0f : L.bound_scale * m;
+    }
+    __syncthreads();
+    // phase 1: threads are projection columns.  Only the sign of a projection
+    // matters, so the float32 copy of the tables decides it whenever the float32
+    // sum is farther from zero than its worst-case distance to the canonical
+    // float64 sum:  |s32 - s64| <= n * 2^-23 * sum_k max_c|A[k][t_k][c]|  (rounding
+    // of the n table entries to float32 plus n-1 float32 additions; the float64
+    // additions contribute 2^-53 terms).  A window with any column inside twice
+    // that distance, or with an out-of-vocabulary token, is redone in float64.
+    for (int ch0 = 0; ch0 < L.C && L.diag != 2; ch0 += 256) {
       const int col = ch0 + threadIdx.x;
       const bool active = col < L.C;
       const int cc = active ? col : 0;
 #pragma unroll 4
       for (int w = 0; w < 256; ++w) {
-        double acc = a_value(L, 0, s_tok[w], cc);
-        for (int k = 1; k < n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_tok[w + k], cc));
-        const uint64_t b = __ballot(active && acc > 0.0);
+        bool bit;
+        bool slow = s_bound[w] < 0.0f;                   // no float32 tables, or an OOV token
+        if (!slow) {
+          float acc = L.atab32[(size_t)s_tok[w] * L.C + cc];
+          for (int k = 1; k < n; ++k)
+            acc = __fadd_rn(acc, L.atab32[((size_t)k * L.V + s_tok[w + k]) * L.C + cc]);
+          bit = acc > 0.0f;
+          slow = __any(active && !(fabsf(acc) > s_bound[w]));   // wave-uniform
+        }
+        if (slow) {
+          double acc = a_value(L, 0, s_tok[w], cc);
+          for (int k = 1; k < n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_tok[w + k], cc));
+          bit = acc > 0.0;
+        }
+        const uint64_t b = __ballot(active && bit);
         if (lane == 0 && ch0 + wave * 64 < L.C) s_bal[w * (NW + 1) + (ch0 >> 6) + wave] = b;
       }
     }
@@ -329,7 +394,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
     // is bitmap word j of the sub-tile
     const int w = 4 * lane + wave;
     bool flag = false;
-    if (p0 + w + n <= c.n_tok)
+    if (p0 + w + n <= c.n_tok && L.diag != 1)
       flag = lsh_neighbours<true>(L, s_key + w * L.H, s_tok + w, nullptr, nullptr) != 0;
     const uint64_t b = __ballot(flag);
     if (lane == 0) {
@@ -354,6 +419,7 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
   __shared__ uint32_t s_top_s[4][64];
   __shared__ double s_top_d[4][64];
   __shared__ uint32_t s_lev[4][64];
+  __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];
   __shared__ uint32_t s_f[4][FS_MAX_WINDOW];
   __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];
   __shared__ int s_n[4];
@@ -402,10 +468,14 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
       if (lane == 0) cg[i] = FS_NONE;
       continue;
     }
-    // Levenshtein of every kept match, one lane each (search.py:189-190)
-    if (lane < cnt)
-      s_lev[wave][lane] = lev_device(g, s_top_s[wave][lane], s_fs[wave], c.chars, c.coff, c.n_str, st);
-    __builtin_amdgcn_wave_barrier();
+    // Levenshtein of every kept match (search.py:189-190), the wave working on one
+    // match at a time
+    for (int r = 0; r < cnt; ++r) {
+      const uint32_t lv = lev_wave(g, s_top_s[wave][r], s_fs[wave], c.chars, c.coff, c.n_str, st,
+                                   s_la[wave], s_lb[wave]);
+      if (lane == 0) s_lev[wave][r] = lv;
+      __builtin_amdgcn_wave_barrier();
+    }
     if (lane == 0) {
       fs_best b;
       b.pad = 0.0;
@@ -435,12 +505,33 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.atab = ix->d_atab.p; L.nt = ix->d_nt.p; L.boff = ix->d_boff.p; L.bids = ix->d_bids.p;
   L.ss = ix->d_ss.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
+  L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
   L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
   L.nn = (int)ix->cfg.nearest_n; L.unique = ix->cfg.unique_filter ? 1 : 0;
   L.thr = ix->cfg.distance_threshold;
   L.cmax = ix->lsh_cmax;
+  {
+    // n * 2^-22; FS_LSH_F32_SLACK multiplies it (tests force the float64 fallback),
+    // FS_LSH_F32=0 disables the float32 path
+    double scale = (double)ix->cfg.window_size * ldexp(1.0, -22);
+    if (const char* e = getenv("FS_LSH_F32_SLACK")) scale *= atof(e);
+    L.bound_scale = (float)scale;
+    if (const char* e = getenv("FS_LSH_F32")) if (e[0] == '0') L.atab32 = nullptr;
+    // smallest number of identical slots that can reach cos >= 1 - thr - 1e-6
+    L.m_min = 0;
+    const double qmin = ix->info.norm_min * ix->info.norm_min, qmax = ix->info.norm_max * ix->info.norm_max;
+    if (qmin > 0.0 && ix->lsh_cmax < 1.0) {
+      const double lim = (1.0 - L.thr - 1e-6) * L.n * qmin * (1.0 - 1e-9);
+      int m = 0;
+      while (m <= L.n && (m + (L.n - m) * ix->lsh_cmax) * qmax < lim) ++m;
+      L.m_min = m;          // n + 1 would mean "nothing can match": exact windows still do
+      if (L.m_min > L.n) L.m_min = L.n;
+    }
+    L.diag = 0;
+    if (const char* e = getenv("FS_LSH_DIAG")) L.diag = atoi(e);
+  }
   return L;
 }
 
@@ -454,11 +545,13 @@ int fs_lsh_build(fs_index* ix) {
   const uint64_t V = ix->n_vec, W = ix->n_windows;
   FS_TRY(ix->d_nt.reserve((size_t)n * D * C));
   FS_TRY(ix->d_atab.reserve((size_t)n * V * C));
+  FS_TRY(ix->d_atab32.reserve((size_t)n * V * C + 1));
+  FS_TRY(ix->d_amax.reserve((size_t)n * V + 1));
   FS_TRY(ix->d_ss.reserve(W));
   hipLaunchKernelGGL(k_nt, dim3(1024), dim3(256), 0, s, ix->d_normals.p, n, D, C, ix->d_nt.p);
   if (V)
     hipLaunchKernelGGL(k_atab, dim3((uint32_t)V, n), dim3(256), 0, s, ix->d_nt.p, ix->d_emb.p,
-                       (uint32_t)V, D, C, ix->d_atab.p);
+                       (uint32_t)V, D, C, ix->d_atab.p, ix->d_atab32.p, ix->d_amax.p);
   FS_HIP(hipGetLastError());
   // pair dot products g(script row, table row): one 8-byte lookup per window slot
   // instead of D multiply-adds when a candidate's exact distance is needed.  Capped

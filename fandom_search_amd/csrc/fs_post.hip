@@ -186,35 +186,41 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
 }
 
 // Per (gram, rank) Levenshtein table for corpora whose string id == vector id:
-// the fan text of a hit is then a function of the gram alone.
-__global__ void k_levtab(GramIndexDev g, CorpusDev c, uint32_t* __restrict__ levtab,
-                         fs_status* st) {
+// the fan text of a hit is then a function of the gram alone.  One wave per entry.
+__global__ __launch_bounds__(256) void k_levtab(GramIndexDev g, CorpusDev c,
+                                                uint32_t* __restrict__ levtab, fs_status* st) {
+  __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = g.n_grams * (uint32_t)g.nn;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += gridDim.x * blockDim.x) {
+  for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
     const uint32_t gram = i / g.nn, r = i % g.nn;
     uint32_t v = 0;
-    if (r < g.gcnt[gram]) {
-      const uint32_t s = g.gpos[i];
+    if (r < g.gcnt[gram]) {                              // wave-uniform
       const uint32_t first = g.gpos[(size_t)gram * g.nn];
-      v = lev_device(g, s, g.stok + first, c.chars, c.coff, c.n_str, st);
+      v = lev_wave(g, g.gpos[i], g.stok + first, c.chars, c.coff, c.n_str, st, s_a[wave], s_b[wave]);
     }
-    levtab[i] = v;
+    if (lane == 0) levtab[i] = v;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
 // Per (candidate, rank) Levenshtein when fan tokens carry their own string ids.
-__global__ void k_matchlev(GramIndexDev g, CorpusDev c, const uint32_t* __restrict__ cpos,
-                           const uint32_t* __restrict__ cg, NSrc nc_nn,
-                           uint32_t* __restrict__ mlev, fs_status* st) {
+__global__ __launch_bounds__(256) void k_matchlev(GramIndexDev g, CorpusDev c,
+                                                  const uint32_t* __restrict__ cpos,
+                                                  const uint32_t* __restrict__ cg, NSrc nc_nn,
+                                                  uint32_t* __restrict__ mlev, fs_status* st) {
+  __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = nc_nn.get();
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += gridDim.x * blockDim.x) {
+  for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
     const uint32_t cand = i / g.nn, r = i % g.nn;
     const uint32_t gram = cg[cand];
-    if (gram == FS_NONE || r >= g.gcnt[gram]) continue;
+    if (gram == FS_NONE || r >= g.gcnt[gram]) continue;  // wave-uniform
     const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
-    mlev[i] = lev_device(g, s, c.str + cpos[cand], c.chars, c.coff, c.n_str, st);
+    const uint32_t v = lev_wave(g, s, c.str + cpos[cand], c.chars, c.coff, c.n_str, st, s_a[wave],
+                                s_b[wave]);
+    if (lane == 0) mlev[i] = v;
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -512,8 +518,8 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   FS_TRY(c->d_levtab.reserve(total));
   FS_TRY(c->d_gbest.reserve(ix->n_grams));
   if (total) {
-    const uint32_t blocks = (uint32_t)((total + 255) / 256);
-    hipLaunchKernelGGL(k_levtab, dim3(blocks > 1024 ? 1024 : blocks), dim3(256), 0, s,
+    const uint32_t blocks = (uint32_t)((total + 3) / 4);
+    hipLaunchKernelGGL(k_levtab, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s,
                        ix->gram_dev(), c->dev(), c->d_levtab.p, ix->d_status.p);
     const uint32_t gb = (ix->n_grams + 255) / 256;
     hipLaunchKernelGGL(k_gbest, dim3(gb > 1024 ? 1024 : gb), dim3(256), 0, s, ix->gram_dev(),

@@ -176,3 +176,25 @@ def test_oov_corpus_on_an_exact_index(synth_base):
     clean, off2 = util.ragged_corpus([800] * 6, script)
     got2, st2 = ix.search(ix.corpus(clean, off2, synth_base["chars"], synth_base["off"]))
     assert st2.path == abi.FS_MODE_EXACT and len(got2) >= len(got)
+
+
+@pytest.mark.parametrize("env", [{}, {"FS_LSH_F32_SLACK": "2e5"}, {"FS_LSH_F32": "0"}],
+                         ids=["f32-sign-path", "forced-f64-fallbacks", "f64-only"])
+def test_lsh_key_paths_agree(synth_base, env, monkeypatch):
+    """The float32 sign fast path of the LSH keys (with its float64 fallback for
+    windows inside the error bound) must give the canonical float64 keys: same rows
+    as the oracle with the fast path on, with the bound inflated so that most
+    windows fall back, and with the fast path off."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(2500)
+    tok, off = util.ragged_corpus([900] * 10 + [0, 7, 2000], script)
+    tok = tok.copy()
+    tok[11::131] = abi.FS_OOV_FLAG | ((3 * 300 + 4) * 300 + 250)      # windows with an OOV token
+    strings = list(words) + ["Oov"]
+    tok_str = np.where(tok & abi.FS_OOV_FLAG, len(words), tok).astype(np.uint32)
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config(window_size=8)
+    _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(8), tok, off,
+         chars, coff, tok_str=tok_str)
