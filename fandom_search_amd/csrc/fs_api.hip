@@ -483,7 +483,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   fs_corpus* c = sl.c;
   const uint32_t nn = ix->cfg.nearest_n;
   const uint32_t n_bm = sl.n_bm;
-  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * 4));
+  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * sl.tpl));
   FS_TRY(ix->w_qcnt.reserve(n_bm));
   FS_TRY(ix->w_cpos.reserve(sl.ccap));
   FS_TRY(ix->w_cg.reserve(sl.ccap));
@@ -501,11 +501,11 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
   if (sl.exact) {
     FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, sl.ev_scan0, sl.ev_scan1));
-    FS_TRY(fs_launch_post(ix, c, n_bm, ccap32, rcap32, d_rows, packed, s));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, s));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, sl.ev_scan0,
                               sl.ev_scan1));
-    FS_TRY(fs_launch_expand(ix, n_bm, ccap32, s));
+    FS_TRY(fs_launch_expand(ix, n_bm, ccap32, 4, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
     FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, s));
   }
@@ -541,8 +541,9 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
       }
   const uint64_t T = c->n_tok;
   sl.c = c; sl.rows = rows; sl.cap = cap; sl.mode = rows_mode; sl.launches = 0;
-  sl.n_bm = (uint32_t)((T + 255) / 256);
   sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
+  sl.tpl = sl.exact ? fs_scan_tpl(ix, T) : 4;
+  sl.n_bm = (uint32_t)((T + 64 * sl.tpl - 1) / (64 * sl.tpl));
   if (rows_mode == FS_ROWS_DEVICE_PACKED && !sl.exact) {
     fs_set_error("packed rows exist for the exact n-gram pipeline only (there the distance is a "
                  "function of the matched script window)");
@@ -636,8 +637,9 @@ extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, doub
   if (!ix || !c || c->ix != ix || !avg_ms || reps == 0) return FS_E_INVALID;
   FS_HIP(hipSetDevice(ix->device));
   hipStream_t s = ix->stream;
-  const uint32_t n_bm = (uint32_t)((c->n_tok + 255) / 256);
-  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * 4));
+  const int tpl = fs_scan_tpl(ix, c->n_tok);
+  const uint32_t n_bm = (uint32_t)((c->n_tok + 64 * tpl - 1) / (64 * tpl));
+  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * tpl));
   FS_TRY(ix->w_qcnt.reserve(n_bm));
   FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));   // warm
   FS_HIP(hipEventRecord(ix->ev_scan0, s));

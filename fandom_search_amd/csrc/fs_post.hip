@@ -87,6 +87,9 @@ __global__ __launch_bounds__(kThreads) void k_hitrows(HitRowsF f, NSrc ns,
 
 // ---- kernels --------------------------------------------------------------------
 
+// TPL = tokens per lane of the scan that wrote the bitmap: TPL ballot words per
+// sub-tile of 64*TPL tokens, bit L of word j <-> window 64*TPL*i + TPL*L + j.
+template <int TPL>
 __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict__ qbm,
                                                      const uint32_t* __restrict__ qcnt,
                                                      uint32_t n_sub,
@@ -105,20 +108,24 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
     uint32_t tile_total;
     uint32_t idx = carry + block_excl_scan(cnt, s_w, &tile_total);
     if (cnt) {
-      // windows in position order: lane L (tokens 4L..4L+3), then j
-      const uint4* w = reinterpret_cast<const uint4*>(qbm + (size_t)sub * 4);   // 32 B aligned
-      const uint4 lo4 = w[0], hi4 = w[1];
-      const uint64_t b0 = lo4.x | ((uint64_t)lo4.y << 32), b1 = lo4.z | ((uint64_t)lo4.w << 32);
-      const uint64_t b2 = hi4.x | ((uint64_t)hi4.y << 32), b3 = hi4.z | ((uint64_t)hi4.w << 32);
-      uint64_t any = b0 | b1 | b2 | b3;
+      // windows in position order: lane L (tokens TPL*L ..), then j
+      const uint4* w = reinterpret_cast<const uint4*>(qbm + (size_t)sub * TPL);   // 16-B aligned
+      uint64_t b[TPL];
+      uint64_t any = 0;
+#pragma unroll
+      for (int h = 0; h < TPL / 2; ++h) {
+        const uint4 q = w[h];
+        b[2 * h] = q.x | ((uint64_t)q.y << 32);
+        b[2 * h + 1] = q.z | ((uint64_t)q.w << 32);
+        any |= b[2 * h] | b[2 * h + 1];
+      }
       while (any) {
         const int L = __ffsll((unsigned long long)any) - 1;
         any &= any - 1;
-        const uint32_t base = sub * 256u + 4u * (uint32_t)L;
-        if ((b0 >> L) & 1) { if (idx < ccap) cpos[idx] = base; ++idx; }
-        if ((b1 >> L) & 1) { if (idx < ccap) cpos[idx] = base + 1; ++idx; }
-        if ((b2 >> L) & 1) { if (idx < ccap) cpos[idx] = base + 2; ++idx; }
-        if ((b3 >> L) & 1) { if (idx < ccap) cpos[idx] = base + 3; ++idx; }
+        const uint32_t base = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L;
+#pragma unroll
+        for (int j = 0; j < TPL; ++j)
+          if ((b[j] >> L) & 1) { if (idx < ccap) cpos[idx] = base + j; ++idx; }
       }
     }
     carry += tile_total;
@@ -530,12 +537,16 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 }
 
 // bitmap + counts -> candidate positions (w_cpos), n_cands in the status block
-int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, hipStream_t s) {
+int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, int tpl, hipStream_t s) {
   uint32_t* bsum32 = ix->w_bsum.p;
   hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
                      SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32);
-  hipLaunchKernelGGL(k_expand, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p, n_sub,
-                     bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
+  if (tpl == 8)
+    hipLaunchKernelGGL(k_expand<8>, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p,
+                       n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
+  else
+    hipLaunchKernelGGL(k_expand<4>, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p,
+                       n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -570,8 +581,8 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
   return FS_OK;
 }
 
-int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, uint32_t rcap,
-                   fs_row* d_rows, bool packed, hipStream_t s) {
+int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
+                   uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->d_status.p;
@@ -579,7 +590,7 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, ui
   const uint32_t nn = ix->cfg.nearest_n;
   const bool per_cand = c->has_str;
 
-  FS_TRY(fs_launch_expand(ix, n_sub, ccap, s));
+  FS_TRY(fs_launch_expand(ix, n_sub, ccap, tpl, s));
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->w_cpos.p, nc,
                      ix->w_cg.p, ix->w_cw.p, bmatch);

@@ -67,6 +67,13 @@ def test_scan_unroll_variants(synth_base, unroll):
     _case(synth_base, [1500] * 40 + [77, 5000], 4000, FS_SCAN_UNROLL=unroll)
 
 
+@pytest.mark.parametrize("tpl", [4, 8])
+@pytest.mark.parametrize("n", [2, 5, 6])
+def test_scan_tokens_per_lane_layouts(synth_base, tpl, n):
+    """Both bitmap layouts of the scan: 4 or 8 tokens per lane."""
+    _case(synth_base, [1500] * 20 + [0, 511, 512, 513, 1, 4000], 4000, n=n, FS_SCAN_TPL=tpl)
+
+
 def test_scan_simple_variant(synth_base):
     _case(synth_base, [1500] * 40, 4000, FS_SCAN_VARIANT="simple")
 
