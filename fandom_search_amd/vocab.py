@@ -146,12 +146,21 @@ class Vocab(object):
         return oov_vector(vid, self.dim)
 
     def encode(self, texts):
-        """(string ids, vector ids) uint32 arrays for a list of token texts."""
-        sids = np.fromiter((self.string_id(t) for t in texts), dtype=np.uint32,
-                           count=len(texts))
-        vids = np.fromiter((self._vec_id[s] for s in sids), dtype=np.uint32,
-                           count=len(texts))
-        return sids, vids
+        """(string ids, vector ids) uint32 arrays for a list of token texts.
+        The list is factorised first, so the vocabulary is consulted once per
+        distinct string, not once per token."""
+        if len(texts) == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        try:
+            import pandas as pd
+            codes, uniques = pd.factorize(np.asarray(texts, dtype=object), sort=False)
+        except ImportError:
+            uniques, codes = np.unique(np.asarray(texts, dtype=object), return_inverse=True)
+        usid = np.fromiter((self.string_id(t) for t in uniques), dtype=np.uint32,
+                           count=len(uniques))
+        uvid = np.fromiter((self._vec_id[s] for s in usid), dtype=np.uint32,
+                           count=len(uniques))
+        return usid[codes], uvid[codes]
 
     def string_table(self):
         """UTF-32 code points of all strings + offsets (n_strings + 1)."""
