@@ -56,10 +56,8 @@ CorpusDev fs_corpus::dev() const {
 }
 
 fs_index::~fs_index() {
-  if (ev_begin) (void)hipEventDestroy(ev_begin);
   if (ev_scan0) (void)hipEventDestroy(ev_scan0);
   if (ev_scan1) (void)hipEventDestroy(ev_scan1);
-  if (ev_end) (void)hipEventDestroy(ev_end);
   if (h_status) (void)hipHostFree(h_status);
   for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
     Slot& sl = slots[i];
@@ -243,10 +241,8 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   FS_HIP(hipGetDeviceProperties(&prop, cfg->device));
   ix->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   FS_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
-  FS_HIP(hipEventCreate(&ix->ev_begin));
-  FS_HIP(hipEventCreate(&ix->ev_scan0));
+  FS_HIP(hipEventCreate(&ix->ev_scan0));      // fs_scan_benchmark
   FS_HIP(hipEventCreate(&ix->ev_scan1));
-  FS_HIP(hipEventCreate(&ix->ev_end));
   FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
   for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
     fs_index::Slot& sl = ix->slots[i];

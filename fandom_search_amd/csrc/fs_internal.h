@@ -118,7 +118,7 @@ struct fs_index {
   fs_config cfg;
   int device = 0;
   hipStream_t stream = nullptr;
-  hipEvent_t ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_end = nullptr;
+  hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr;   // fs_scan_benchmark
   fs_index_info info{};
   uint64_t n_script = 0, n_windows = 0, n_vec = 0;
   uint32_t n_grams = 0;

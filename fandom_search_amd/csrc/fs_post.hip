@@ -2,17 +2,22 @@
 // records: five launches behind the scan, no host round trip.
 //
 //   k_reduce<SubTileCount>   per-block partial sums of the scan's sub-tile counts
-//   k_expand                 bitmap -> candidate window positions, in position
+//   k_expand<TPL>            bitmap -> candidate window positions, in position
 //                            order (block prefix from the partial sums + an
-//                            in-block scan; one wave expands one sub-tile)
+//                            in-block scan; one thread expands one sub-tile)
 //   k_verify                 candidate -> (n-gram id, work id) or FS_NONE: exact
 //                            id-for-id comparison with the script n-gram found
 //                            through the open-addressing table; windows that
 //                            cross a work boundary are dropped
-//   k_reduce<HitRows>        per-block (hits, records) partial sums
-//   k_rows                   per hit, the fan words it is first to cover; each
-//                            word's record is the first minimum of dist*lev
-//                            over all (hit, rank) pairs covering it
+//   k_hitrows                per candidate (hit?, fan words first covered), kept
+//                            for k_rows, and their per-block partial sums
+//   k_rows                   per 256-candidate tile a block scan gives every hit
+//                            its record offset, then one thread per record: the
+//                            first minimum of dist*lev over all hits covering
+//                            the word (each hit offers its best rank)
+// plus the Levenshtein kernels (per (n-gram, rank) once per corpus, or per
+// (candidate, rank) when fan tokens carry their own strings), the wire-record
+// unpack, the `format` histogram and corpus-build helpers.
 //
 // Reference semantics reproduced here (file:line in /root/reference):
 //   search.py:182-184  keep candidates with distance < threshold: in the exact

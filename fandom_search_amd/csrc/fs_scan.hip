@@ -15,6 +15,8 @@
 //   * four __ballot words per sub-tile: bit L of word 4 i + j says "the window
 //     starting at token 256 i + 4 L + j may be a script n-gram"; lanes 0..3
 //     store them, lane 0 also stores the sub-tile's popcount
+//   * k_scan8 is the same loop with eight tokens per lane (512-token sub-tiles,
+//     eight ballot words), used while the ids fit the Infinity Cache
 // No atomics, no inter-workgroup traffic, the output position is a function of
 // the token position, so the result is deterministic; exact verification
 // happens downstream on the (rare) flagged windows.  Algorithmic HBM traffic:
