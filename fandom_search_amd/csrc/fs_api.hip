@@ -491,22 +491,23 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   if (sl.mode == FS_ROWS_HOST) { FS_TRY(ix->w_rows.reserve(sl.rcap)); d_rows = ix->w_rows.p; }
   const bool packed = sl.mode == FS_ROWS_DEVICE_PACKED;
 
-  FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), s));
+  // the status block is cleared by the chain's first kernel (k_reduce) and its final
+  // state is written to sl.h_status by the last one (k_rows)
   FS_HIP(hipEventRecord(sl.ev_begin, s));
+  sl.timed = ix->scan_timing_period <= 1 || (ix->searches++ % ix->scan_timing_period) == 0;
+  hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
   if (sl.exact) {
-    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, sl.ev_scan0, sl.ev_scan1));
-    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, s));
+    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, e0, e1));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s));
   } else {
-    FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, sl.ev_scan0,
-                              sl.ev_scan1));
+    FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, e0, e1));
     FS_TRY(fs_launch_expand(ix, n_bm, ccap32, 4, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
-    FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, s));
+    FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
   }
   ++sl.launches;
-  FS_HIP(hipMemcpyAsync(sl.h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, s));
   FS_HIP(hipEventRecord(sl.ev_end, s));
   return FS_OK;
 }
@@ -569,7 +570,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
   for (int attempt = 0;; ++attempt) {
     FS_HIP(hipEventSynchronize(sl.ev_end));
     scan_ms = 0;
-    if (sl.n_bm) FS_HIP(hipEventElapsedTime(&scan_ms, sl.ev_scan0, sl.ev_scan1));
+    if (sl.n_bm && sl.timed) FS_HIP(hipEventElapsedTime(&scan_ms, sl.ev_scan0, sl.ev_scan1));
     FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
     const fs_status& hs = *sl.h_status;
     if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }
@@ -693,5 +694,11 @@ extern "C" int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint6
   FS_TRY(fs_launch_histogram(nullptr, nullptr, d_rows, n_rows, ix->n_script, d_thr.p, n_thr, d_counts,
                              ix->stream));
   FS_HIP(hipStreamSynchronize(ix->stream));
+  return FS_OK;
+}
+
+extern "C" int fs_index_set_scan_timing(fs_index* ix, uint32_t period) {
+  if (!ix) return FS_E_INVALID;
+  ix->scan_timing_period = period ? period : 1;
   return FS_OK;
 }

@@ -75,9 +75,16 @@ __device__ __forceinline__ void chunk_of_block(uint32_t n, uint32_t* lo, uint32_
   *hi = h < n ? (uint32_t)h : n;
 }
 
+// `zero` (optional): the per-search status block, cleared here because this is the
+// first kernel of the chain that may touch it (saves a memset node per search)
 template <class F, class V>
-__global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict__ bsum) {
+__global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict__ bsum,
+                                                     fs_status* zero) {
   __shared__ V s_w[4];
+  if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
+    zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
+    zero->reserved0 = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
+  }
   uint32_t lo, hi;
   chunk_of_block(ns.get(), &lo, &hi);
   V acc = 0;

@@ -158,10 +158,13 @@ struct fs_index {
     int mode = 0;
     bool exact = false;
     uint32_t n_bm = 0, launches = 0;
+    bool timed = false;               // this search's scan carries timing events
     int tpl = 4;                      // tokens per lane of the bitmap layout
   };
   Slot slots[FS_SEARCH_SLOTS];
   uint32_t next_slot = 0;
+  uint32_t scan_timing_period = 1;    // attach timing events to every k-th scan
+  uint64_t searches = 0;
 
   GramIndexDev gram_dev() const;
   ~fs_index();
@@ -193,11 +196,12 @@ uint32_t fs_scan_pad_tokens();
 int fs_scan_tpl(const fs_index* ix, uint64_t n_tok);   // tokens per lane (bitmap layout)
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
-                   uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s);
+                   uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st, hipStream_t s);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, int tpl, hipStream_t s);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
-                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s);
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
+                   hipStream_t s);
 int fs_lsh_build(fs_index* ix);
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                        uint32_t n_sub, hipStream_t s, hipEvent_t e0 = nullptr,

@@ -288,7 +288,8 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
                                                    const uint32_t* __restrict__ bmatch,
                                                    const fs_best* __restrict__ best_tab,
                                                    int best_per_cand, NSrc nc, uint32_t rcap,
-                                                   fs_row* __restrict__ rows, fs_status* st) {
+                                                   fs_row* __restrict__ rows, fs_status* st,
+                                                   fs_status* host_st) {
   __shared__ uint64_t s_w[4];
   __shared__ uint32_t s_w32[4];
   __shared__ uint32_t s_roff[kThreads];
@@ -299,9 +300,14 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
     for (int i = threadIdx.x; i < kNB; i += kThreads) m += bmatch[i];
     block_excl_scan(m, s_w32, &mt);
     if (threadIdx.x == 0) {
-      st->n_hits = (uint32_t)total;
-      st->n_rows = (uint32_t)(total >> 32);
-      st->n_matches = mt;
+      // every earlier kernel of the chain has finished: publish the totals and
+      // flags straight into the caller's pinned block (no copy node afterwards)
+      fs_status out = *st;
+      out.n_hits = (uint32_t)total;
+      out.n_rows = (uint32_t)(total >> 32);
+      out.n_matches = mt;
+      *st = out;
+      *host_st = out;
     }
   }
   const uint32_t NC = nc.get();
@@ -545,7 +551,8 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, int tpl, hipStream_t s) {
   uint32_t* bsum32 = ix->w_bsum.p;
   hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
-                     SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32);
+                     SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
+                     ix->d_status.p);
   if (tpl == 8)
     hipLaunchKernelGGL(k_expand<8>, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p,
                        n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
@@ -567,7 +574,8 @@ int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows,
 }
 
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
-                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s) {
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
+                   hipStream_t s) {
   fs_status* st = ix->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   uint32_t* bmatch = ix->w_bsum.p + kNB;
@@ -577,17 +585,18 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
   if (packed)
     hipLaunchKernelGGL(k_rows<true>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
                        ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
-                       best_per_cand, nc, rcap, d_rows, st);
+                       best_per_cand, nc, rcap, d_rows, st, host_st);
   else
     hipLaunchKernelGGL(k_rows<false>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
                        ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
-                       best_per_cand, nc, rcap, d_rows, st);
+                       best_per_cand, nc, rcap, d_rows, st, host_st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
-                   uint32_t rcap, fs_row* d_rows, bool packed, hipStream_t s) {
+                   uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
+                   hipStream_t s) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->d_status.p;
@@ -608,5 +617,5 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   }
   FS_HIP(hipGetLastError());
   return fs_launch_rows(ix, c, per_cand ? ix->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
-                        rcap, d_rows, packed, s);
+                        rcap, d_rows, packed, host_st, s);
 }

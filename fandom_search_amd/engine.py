@@ -195,6 +195,11 @@ class ScriptIndex(object):
         _lib.check(rc, "fs_search_corpus")
         return int(n.value), st
 
+    def set_scan_timing(self, period):
+        """Attach timing events to every `period`-th scan launch only."""
+        _lib.check(_lib.load().fs_index_set_scan_timing(self._h, int(period)),
+                   "fs_index_set_scan_timing")
+
     def search_begin(self, corpus, rows_ptr, cap, packed=False):
         """Queue a search (rows to the device buffer at `rows_ptr`) and return a
         ticket for search_end; up to four may be in flight per index."""

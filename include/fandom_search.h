@@ -94,7 +94,7 @@ typedef struct fs_stats {
   uint64_t candidates;         /* scan: filter positives; LSH: bucket entries */
   uint64_t matches;            /* (window, script window) pairs kept          */
   uint64_t rows;               /* records after per-word dedupe               */
-  double   scan_ms;            /* dominant kernel, HIP-event time, last call  */
+  double   scan_ms;            /* dominant kernel, HIP-event time; 0 if untimed */
   double   total_ms;           /* all device work of the call, HIP events     */
   uint32_t path;               /* FS_MODE_GENERAL or FS_MODE_EXACT            */
   uint32_t scan_launches;      /* launches of the dominant kernel in the call */
@@ -221,6 +221,11 @@ int fs_reuse_histogram(int device, const uint32_t* orig_ix, const double* comb, 
  * gather); d_counts is a device buffer of n_script * (n_thr + 1) uint32. */
 int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint64_t n_rows,
                             const double* thresholds, uint32_t n_thr, uint32_t* d_counts);
+
+/* Timing events ride on every `period`-th scan launch only (default 1 = every
+ * launch); searches in between report scan_ms = 0.  The events cost a few
+ * microseconds of stream time per launch, which matters for sub-100 us searches. */
+int fs_index_set_scan_timing(fs_index* ix, uint32_t period);
 
 /* Diagnostics: `reps` back-to-back launches of the scan kernel alone over `c`,
  * timed with one pair of HIP events; *avg_ms = time per launch.  Used by
