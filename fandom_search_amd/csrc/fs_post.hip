@@ -94,6 +94,9 @@ __global__ __launch_bounds__(kThreads) void k_hitrows(HitRowsF f, NSrc ns,
 
 // TPL = tokens per lane of the scan that wrote the bitmap: TPL ballot words per
 // sub-tile of 64*TPL tokens, bit L of word j <-> window 64*TPL*i + TPL*L + j.
+// One thread per ballot word; candidates are numbered in position order (L, then
+// j), so a window's index is the sub-tile's base + the set bits of all words below
+// lane L + the set bits of the earlier words at lane L.
 template <int TPL>
 __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict__ qbm,
                                                      const uint32_t* __restrict__ qcnt,
@@ -101,38 +104,50 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
                                                      const uint32_t* __restrict__ bsum,
                                                      uint32_t* __restrict__ cpos, uint32_t ccap,
                                                      fs_status* st) {
+  constexpr int SUBS = kThreads / TPL;          // sub-tiles per block iteration
   __shared__ uint32_t s_w[4];
+  __shared__ uint32_t s_base[SUBS];
   uint32_t total;
   uint32_t carry = block_prefix(bsum, s_w, &total);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->n_cands = total;
   uint32_t lo, hi;
   chunk_of_block(n_sub, &lo, &hi);
-  for (uint32_t t0 = lo; t0 < hi; t0 += kThreads) {
-    const uint32_t sub = t0 + threadIdx.x;
-    const uint32_t cnt = sub < hi ? qcnt[sub] : 0;
+  const int j = threadIdx.x % TPL, sl = threadIdx.x / TPL;
+  for (uint32_t t0 = lo; t0 < hi; t0 += SUBS) {
+    const uint32_t sub = t0 + sl;
+    const bool live = sub < hi;
+    const uint32_t cnt = (live && j == 0) ? qcnt[sub] : 0;
     uint32_t tile_total;
-    uint32_t idx = carry + block_excl_scan(cnt, s_w, &tile_total);
-    if (cnt) {
-      // windows in position order: lane L (tokens TPL*L ..), then j
+    const uint32_t ex = block_excl_scan(cnt, s_w, &tile_total);
+    if (j == 0) s_base[sl] = carry + ex;
+    __syncthreads();
+    if (live) {
       const uint4* w = reinterpret_cast<const uint4*>(qbm + (size_t)sub * TPL);   // 16-B aligned
       uint64_t b[TPL];
-      uint64_t any = 0;
 #pragma unroll
       for (int h = 0; h < TPL / 2; ++h) {
         const uint4 q = w[h];
         b[2 * h] = q.x | ((uint64_t)q.y << 32);
         b[2 * h + 1] = q.z | ((uint64_t)q.w << 32);
-        any |= b[2 * h] | b[2 * h + 1];
       }
-      while (any) {
-        const int L = __ffsll((unsigned long long)any) - 1;
-        any &= any - 1;
-        const uint32_t base = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L;
+      uint64_t mine = b[0];
 #pragma unroll
-        for (int j = 0; j < TPL; ++j)
-          if ((b[j] >> L) & 1) { if (idx < ccap) cpos[idx] = base + j; ++idx; }
+      for (int k = 1; k < TPL; ++k) mine = j == k ? b[k] : mine;
+      const uint32_t base = s_base[sl];
+      while (mine) {
+        const int L = __ffsll((unsigned long long)mine) - 1;
+        mine &= mine - 1;
+        const uint64_t below = (1ull << L) - 1;
+        uint32_t idx = base;
+#pragma unroll
+        for (int k = 0; k < TPL; ++k) {
+          idx += __popcll(b[k] & below);
+          if (k < j) idx += (uint32_t)((b[k] >> L) & 1);
+        }
+        if (idx < ccap) cpos[idx] = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L + (uint32_t)j;
       }
     }
+    __syncthreads();
     carry += tile_total;
   }
 }
