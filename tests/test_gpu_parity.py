@@ -215,3 +215,75 @@ def test_searches_in_flight(synth_base):
         ix.search_end(t)
     assert e.value.code == abi.FS_E_CAPACITY and e.value.required == len(want[1])
     assert ix.search(corpora[1])[0].tobytes() == want[1].tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 3, 7, 9, 11, 12, 16])
+def test_window_sizes_on_a_one_hot_table(n):
+    """Orthogonal vectors (c_max = 0) and threshold 0.05: one substituted token
+    gives cos = (n-1)/n <= 0.9375 < 0.95, so the exact-scan proof holds for every
+    window size up to 16, including those without a specialised scan kernel
+    (n = 1, 9, 11, 16 use the generic one).  (At the default threshold 0.1 the proof
+    rightly fails from n = 10 on: 10/11 > 0.9 is a genuine approximate match.)"""
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+    from oracle import c_oracle
+    rng = np.random.default_rng(n)
+    V, D = 40, 48
+    emb = np.zeros((V, D), dtype=np.float32)
+    emb[np.arange(V), rng.permutation(D)[:V]] = 1.0
+    words = ["t%d" % i for i in range(V)]
+    script = rng.integers(0, V, size=900).astype(np.uint32)
+    works = []
+    for w in range(12):
+        t = rng.integers(0, V, size=700).astype(np.uint32)
+        for _ in range(5):
+            ln = int(rng.integers(n, 3 * n + 2))
+            src = int(rng.integers(0, len(script) - ln))
+            dst = int(rng.integers(0, 700 - ln))
+            t[dst:dst + ln] = script[src:src + ln]
+        works.append(t)
+    works += [np.zeros(0, np.uint32), script[:n].copy(), script[5:5 + max(n - 1, 0)].copy()]
+    off = np.zeros(len(works) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(w) for w in works])
+    tok = np.concatenate(works)
+    chars, coff = pack_strings(words)
+    cfg = abi.make_config(window_size=n, emb_dim=D, number_of_hashes=4, hash_dimensions=6,
+                          distance_threshold=0.05)
+    normals = rng.standard_normal((4, 6, D * n))
+    swords = [words[int(t)] for t in script]
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    assert ix.info["proof_ok"] == 1 and ix.info["path"] == abi.FS_MODE_EXACT
+    got, st = ix.search(ix.corpus(tok, off, chars, coff))
+    sch, so = pack_strings(swords)
+    oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
+    want, ost = oi.search(tok, off, chars, coff)
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and len(got) > 0
+    assert st.path == abi.FS_MODE_EXACT
+
+
+def test_one_very_long_work(synth_base):
+    """A single work of 3M tokens (many tiles, one work offset pair)."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(3000)
+    rng = np.random.default_rng(77)
+    tok = synth._draw(rng, 3_000_000, len(words))
+    for _ in range(3000):
+        ln = int(rng.integers(6, 25))
+        src = int(rng.integers(0, len(script) - ln))
+        dst = int(rng.integers(0, len(tok) - ln))
+        tok[dst:dst + ln] = script[src:src + ln]
+    off = np.array([0, len(tok)], dtype=np.uint64)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    got, st = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    assert st.windows_processed == len(tok) - 5
+    # oracle on the first 60k tokens as its own work: the rows that lie fully inside agree
+    cut = 60_000
+    oi = util.oracle_index(abi.make_config(), script, words, emb, synth.lsh_normals(6))
+    want, _ = oi.search(tok[:cut], np.array([0, cut], np.uint64), synth_base["chars"],
+                        synth_base["off"])
+    inside = got[got["fan_ix"] < cut - 12]
+    util.assert_rows_equal(inside, want[want["fan_ix"] < cut - 12])
+    assert np.all(np.diff(got["fan_ix"].astype(np.int64)) > 0) and len(got) > 5000
