@@ -503,7 +503,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, e0, e1));
-    FS_TRY(fs_launch_expand(ix, n_bm, ccap32, 4, s));
+    FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
     FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
   }

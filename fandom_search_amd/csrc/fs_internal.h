@@ -198,7 +198,8 @@ int fs_scan_tpl(const fs_index* ix, uint64_t n_tok);   // tokens per lane (bitma
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
                    uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st, hipStream_t s);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
-int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, int tpl, hipStream_t s);
+int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
+                     bool verify, hipStream_t s);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
                    hipStream_t s);

@@ -37,6 +37,8 @@
 // with larger buffers if a total exceeded it.
 #include "fs_device.h"
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 namespace {
@@ -92,19 +94,73 @@ __global__ __launch_bounds__(kThreads) void k_hitrows(HitRowsF f, NSrc ns,
 
 // ---- kernels --------------------------------------------------------------------
 
+// ids of a window: two (n <= 8) or four 16-byte loads.  The window start is only
+// 4-byte aligned; gfx950 global loads accept that (unaligned access mode), and
+// the token buffers are padded, so reading up to 16 ids is always in bounds.
+struct Ids16 { uint32_t v[16]; };
+__device__ __forceinline__ void load_ids(const uint32_t* p, int n, Ids16* out) {
+  __builtin_memcpy(out->v, p, 32);
+  if (n > 8) __builtin_memcpy(out->v + 8, p + 8, 32);
+}
+
+// Exact check of the window at token p: the script n-gram with the same n vector
+// ids (found through the open-addressing table, compared id for id), or FS_NONE;
+// FS_NONE also for a window that crosses a work boundary (windows are built per
+// file, search.py:170-173).  *w = the work, *kept = NearestFilter entries it has.
+__device__ __forceinline__ uint32_t verify_window(const CorpusDev& c, const GramIndexDev& g,
+                                                  uint64_t p, uint32_t* w_out, uint32_t* kept) {
+  if (p + g.n > c.n_tok) return FS_NONE;
+  const uint32_t slot_mask = (1u << g.log2_slots) - 1;
+  // {gram + 1 (0 = empty), first position, occurrences kept, 0}
+  const uint4* table = reinterpret_cast<const uint4*>(g.table);
+  // two independent chains: ids -> table -> script ids, and block -> work
+  Ids16 f;
+  load_ids(c.tok + p, g.n, &f);
+  const uint32_t w = work_of_token(c, p);
+  const bool inside = p + g.n <= c.work_off[w + 1];
+  uint32_t h = 0;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_WINDOW; ++k)
+    if (k < g.n) h ^= fs_rotl(fs_premix(f.v[k]), fs_rot_of(g.n - 1 - k));
+  uint32_t slot = fs_table_slot(h, g.log2_slots);
+  for (;;) {
+    const uint4 e = table[slot];
+    if (e.x == 0) return FS_NONE;
+    Ids16 sc;
+    load_ids(g.stok + e.y, g.n, &sc);
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < FS_MAX_WINDOW; ++k)
+      if (k < g.n) same = same && (sc.v[k] == f.v[k]);
+    if (same) {
+      if (!inside) return FS_NONE;
+      *w_out = w;
+      *kept = e.z;
+      return e.x - 1;
+    }
+    slot = (slot + 1) & slot_mask;
+  }
+}
+
 // TPL = tokens per lane of the scan that wrote the bitmap: TPL ballot words per
 // sub-tile of 64*TPL tokens, bit L of word j <-> window 64*TPL*i + TPL*L + j.
 // One thread per ballot word; candidates are numbered in position order (L, then
 // j), so a window's index is the sub-tile's base + the set bits of all words below
 // lane L + the set bits of the earlier words at lane L.
-template <int TPL>
+// VERIFY (diagnostics, FS_POST_FUSED): the thread that finds a candidate also
+// verifies it; slower than the separate k_verify launch, see fs_launch_post.
+template <int TPL, bool VERIFY>
 __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict__ qbm,
                                                      const uint32_t* __restrict__ qcnt,
                                                      uint32_t n_sub,
                                                      const uint32_t* __restrict__ bsum,
                                                      uint32_t* __restrict__ cpos, uint32_t ccap,
-                                                     fs_status* st) {
+                                                     fs_status* st, CorpusDev c, GramIndexDev g,
+                                                     uint32_t* __restrict__ cg,
+                                                     uint32_t* __restrict__ cw,
+                                                     uint32_t* __restrict__ bmatch) {
   constexpr int SUBS = kThreads / TPL;          // sub-tiles per block iteration
+  uint32_t matches = 0;
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_base[SUBS];
   uint32_t total;
@@ -144,23 +200,30 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
           idx += __popcll(b[k] & below);
           if (k < j) idx += (uint32_t)((b[k] >> L) & 1);
         }
-        if (idx < ccap) cpos[idx] = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L + (uint32_t)j;
+        const uint32_t p = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L + (uint32_t)j;
+        if (idx < ccap) {
+          cpos[idx] = p;
+          if (VERIFY) {
+            uint32_t w = 0, kept = 0;
+            const uint32_t gram = verify_window(c, g, p, &w, &kept);
+            cg[idx] = gram;
+            if (gram != FS_NONE) { cw[idx] = w; matches += kept; }
+          }
+        }
       }
     }
     __syncthreads();
     carry += tile_total;
   }
+  if (VERIFY) {
+    // (window, script window) pairs of this block; summed by k_rows
+    uint32_t tot;
+    block_excl_scan(matches, s_w, &tot);
+    if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+  }
 }
 
-// ids of a window: two (n <= 8) or four 16-byte loads.  The window start is only
-// 4-byte aligned; gfx950 global loads accept that (unaligned access mode), and
-// the token buffers are padded, so reading up to 16 ids is always in bounds.
-struct Ids16 { uint32_t v[16]; };
-__device__ __forceinline__ void load_ids(const uint32_t* p, int n, Ids16* out) {
-  __builtin_memcpy(out->v, p, 32);
-  if (n > 8) __builtin_memcpy(out->v + 8, p + 8, 32);
-}
-
+// Verification of the candidate list, one thread per candidate.
 __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g,
                                                      const uint32_t* __restrict__ cpos,
                                                      NSrc nc, uint32_t* __restrict__ cg,
@@ -168,45 +231,14 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
                                                      uint32_t* __restrict__ bmatch) {
   __shared__ uint32_t s_w[4];
   const uint32_t total = nc.get();
-  const uint32_t slot_mask = (1u << g.log2_slots) - 1;
-  // {gram + 1 (0 = empty), first position, occurrences kept, 0}
-  const uint4* table = reinterpret_cast<const uint4*>(g.table);
   uint32_t matches = 0;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += gridDim.x * blockDim.x) {
-    const uint64_t p = cpos[i];
-    uint32_t gram = FS_NONE;
-    if (p + g.n <= c.n_tok) {
-      // two independent chains: ids -> table -> script ids, and block -> work
-      Ids16 f;
-      load_ids(c.tok + p, g.n, &f);
-      const uint32_t w = work_of_token(c, p);
-      const bool inside = p + g.n <= c.work_off[w + 1];   // a window never crosses works
-      uint32_t h = 0;
-#pragma unroll
-      for (int k = 0; k < FS_MAX_WINDOW; ++k)
-        if (k < g.n) h ^= fs_rotl(fs_premix(f.v[k]), fs_rot_of(g.n - 1 - k));
-      uint32_t slot = fs_table_slot(h, g.log2_slots);
-      for (;;) {
-        const uint4 e = table[slot];
-        if (e.x == 0) break;
-        Ids16 sc;
-        load_ids(g.stok + e.y, g.n, &sc);
-        bool same = true;
-#pragma unroll
-        for (int k = 0; k < FS_MAX_WINDOW; ++k)
-          if (k < g.n) same = same && (sc.v[k] == f.v[k]);
-        if (same) {
-          if (inside) { gram = e.x - 1; cw[i] = w; matches += e.z; }
-          break;
-        }
-        slot = (slot + 1) & slot_mask;
-      }
-    }
+    uint32_t w = 0, kept = 0;
+    const uint32_t gram = verify_window(c, g, cpos[i], &w, &kept);
     cg[i] = gram;
+    if (gram != FS_NONE) { cw[i] = w; matches += kept; }
   }
-  // (window, script window) pairs of this block; summed by k_rows (a single
-  // counter would serialise thousands of same-address atomics)
   uint32_t tot;
   block_excl_scan(matches, s_w, &tot);
   if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
@@ -563,17 +595,22 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 }
 
 // bitmap + counts -> candidate positions (w_cpos), n_cands in the status block
-int fs_launch_expand(fs_index* ix, uint32_t n_sub, uint32_t ccap, int tpl, hipStream_t s) {
+int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
+                     bool verify, hipStream_t s) {
   uint32_t* bsum32 = ix->w_bsum.p;
   hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
                      SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
                      ix->d_status.p);
-  if (tpl == 8)
-    hipLaunchKernelGGL(k_expand<8>, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p,
-                       n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
-  else
-    hipLaunchKernelGGL(k_expand<4>, dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p, ix->w_qcnt.p,
-                       n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p);
+  const CorpusDev cd = c->dev();
+  const GramIndexDev g = ix->gram_dev();
+  uint32_t* bmatch = ix->w_bsum.p + kNB;
+#define FS_EXPAND(T, V)                                                                      \
+  hipLaunchKernelGGL((k_expand<T, V>), dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p,         \
+                     ix->w_qcnt.p, n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p, cd, g, \
+                     ix->w_cg.p, ix->w_cw.p, bmatch)
+  if (tpl == 8) { if (verify) FS_EXPAND(8, true); else FS_EXPAND(8, false); }
+  else { if (verify) FS_EXPAND(4, true); else FS_EXPAND(4, false); }
+#undef FS_EXPAND
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -619,10 +656,15 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   const uint32_t nn = ix->cfg.nearest_n;
   const bool per_cand = c->has_str;
 
-  FS_TRY(fs_launch_expand(ix, n_sub, ccap, tpl, s));
+  // Verifying inside k_expand (FS_POST_FUSED=1) saves a launch but measured slower
+  // (110 vs 84 us per C2 step): the thread that decodes a ballot word then runs the
+  // dependent-load chain of each of its candidates one after the other.
+  const bool fused = getenv("FS_POST_FUSED") != nullptr;
+  FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s));
   const NSrc nc{&st->n_cands, 1, ccap, 0};
-  hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->w_cpos.p, nc,
-                     ix->w_cg.p, ix->w_cw.p, bmatch);
+  if (!fused)
+    hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->w_cpos.p, nc,
+                       ix->w_cg.p, ix->w_cw.p, bmatch);
   if (per_cand) {
     const NSrc nc_nn{&st->n_cands, nn, ccap, 0};
     hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->w_cpos.p,
