@@ -14,7 +14,9 @@ Prints ONE JSON line (rank 0) with the driver's contract plus
   roofline     scan kernel: algorithmic bytes (4 B per fan token)
                / HIP-event duration of the kernel, against 8 TB/s HBM
   cpu_baseline the plain-C oracle (the reference's LSH algorithm) on a bounded
-               sample of the same workload on the host cores (N=1 only)
+               sample of the same workload on the host cores (N=1 only), and as
+               `reference_shaped` the literal Python restatement on configs[0] in
+               a 4-process pool, the way search.py:381-385 runs the original
 """
 
 import argparse
@@ -46,6 +48,8 @@ def parse():
                     help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: every rank "
                          "computes on GPU 0, rows gathered through host memory)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-reference-shaped", action="store_true",
+                    help="skip the Python reference-shaped leg of cpu_baseline")
     return ap.parse_args()
 
 
@@ -89,8 +93,60 @@ def cpu_baseline(cfg, script, swords, words, emb, normals, tokens_per_work,
                       % (n, tokens_per_work, dt)}
 
 
+_REF = {}
+
+
+def _ref_search(w):
+    """One fan work through the literal restatement (pool worker)."""
+    return len(_REF["idx"].search("w%07d.txt" % w, _REF["toks"](_REF["works"][w])))
+
+
+def cpu_reference_shaped(window):
+    """the literal Python/numpy restatement of search.py driven the
+    way search.py:381-385 drives the original: Pool(4).map(..., chunksize=31) over the
+    works of configs[0] (c1: 50 works x 1000 tokens, 5000-token script).  Runs before
+    anything touches the GPU (the pool forks)."""
+    import multiprocessing as mp
+    from fandom_search_amd import synth, vocab
+    from oracle import nearpy_restated as nr
+    from oracle import search_restated as sr
+    conf = synth.CONFIGS["c1"]
+    words, emb = synth.vocab_words(), synth.embedding()
+    voc = vocab.Vocab(words, emb)
+    normals = synth.lsh_normals(window)
+    script = synth.script_tokens(conf["script_tokens"])
+    scene, char = synth.script_columns(len(script))
+    tok, off = synth.corpus_tokens(conf["n_works"], conf["tokens_per_work"], script)
+
+    def toks(ids):
+        return [sr.Tok(words[i], voc.orth(i), words[i], voc.orth(i), emb[i]) for i in ids]
+
+    rows = [[words[t], voc.orth(t), int(scene[i]), char[i]] for i, t in enumerate(script)]
+    t0 = time.perf_counter()
+    _REF["idx"] = sr.AnnIndexSearch(rows, toks(script), window, 15, 14, 0.1, normals,
+                                    arith=nr.LiteralArith(), unique_filter=True)
+    t_index = time.perf_counter() - t0
+    _REF["toks"] = toks
+    _REF["works"] = [tok[int(off[w]):int(off[w + 1])] for w in range(conf["n_works"])]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(processes=4) as pool:
+        n_rows = sum(pool.map(_ref_search, range(conf["n_works"]), chunksize=31))
+    dt = time.perf_counter() - t0
+    _REF.clear()
+    return {"value": conf["n_works"] / dt, "unit": "fanworks/s", "processes": 4,
+            "chunksize": 31, "workload": "c1", "rows": n_rows, "index_s": round(t_index, 2),
+            "sample": "all %d works of c1 (%d tokens each), %.1f s, literal Python/numpy "
+                      "restatement (oracle/search_restated.py) in Pool(4), chunksize 31 "
+                      "= %d busy workers" % (conf["n_works"], conf["tokens_per_work"], dt,
+                                             -(-conf["n_works"] // 31))}
+
+
 def main():
     args = parse()
+    ref_shaped = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline
+            and not args.no_reference_shaped):
+        ref_shaped = cpu_reference_shaped(args.window)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -338,6 +394,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, script, swords, words, emb, normals, tpw,
                                                chars, coff, args.cpu_seconds)
+            if ref_shaped is not None:
+                out["cpu_baseline"]["reference_shaped"] = ref_shaped
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
