@@ -28,9 +28,11 @@
 //                  best rank -> per-candidate record for k_rows
 //
 // A candidate's exact distance is skipped only when a sound upper bound on its
-// cosine is already below 1 - threshold (matching slots contribute q, other
-// slots at most c_max * (q_f + q_s) / 2); skipped candidates can never be in the
-// output, so the result equals the oracle's, which computes every distance.
+// cosine is already below 1 - threshold: too few identical slots for the table's
+// c_max (integer test), or, slot by slot, the partial canonical sum plus the
+// Cauchy-Schwarz bound of the remaining slots (window_distance).  Skipped
+// candidates can never be in the output, so the result equals the oracle's, which
+// computes every distance.
 #include "fs_device.h"
 
 #include <hip/hip_ext.h>
@@ -143,40 +145,43 @@ __device__ __forceinline__ uint32_t assemble_key(const uint64_t* bal, int h, int
 }
 
 // CosineDistance of fan window f[] to script window s (canonical), with the
-// sound skip described in the file header.  Returns false when skipped or NaN.
+// sound skips described in the file header.  Returns false when skipped or NaN.
 __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, double ff,
                                 double* out) {
   // stage 0: integer only.  With all table norms in [sqrt(q_min), sqrt(q_max)] and
   // no OOV vector involved, m identical slots bound the cosine by
   // (m q_max + (n-m) c_max q_max) / (n q_min); m_min is the smallest m for which that
   // reaches 1 - threshold (host side, lsh_dev).
-  uint32_t sid[FS_MAX_WINDOW];
-  {
+  if (L.m_min > 0) {
     int same = 0;
     uint32_t anyoov = 0;
     for (int k = 0; k < L.n; ++k) {
-      sid[k] = L.stok[s + k];
-      same += sid[k] == f[k];
-      anyoov |= sid[k] | f[k];
+      const uint32_t u = L.stok[s + k];
+      same += u == f[k];
+      anyoov |= u | f[k];
     }
     if (same < L.m_min && !(anyoov & FS_OOV_FLAG)) return false;
   }
+  // stage 1: the canonical sum SF slot by slot, leaving as soon as the slots still to
+  // come cannot lift it to the threshold.  By Cauchy-Schwarz the remaining slots add
+  // at most sqrt(SS_rem * FF_rem) (SS_rem, FF_rem = squared norms of the remaining
+  // slots), so  SF_k + sqrt(SS_rem FF_rem) < (1 - thr - 1e-6) sqrt(SS FF)  proves
+  // distance > thr + 1e-6, far outside the rounding of the canonical expression.  A
+  // bucket collision between unrelated windows leaves after its first slot.
   const double ss = L.ss[s];
-  // upper bound on SF
-  double ub = 0.0;
+  const double need = (1.0 - L.thr - 1e-6) * sqrt(ss * ff) * (1.0 - 1e-9);
+  double sf = 0.0, ssr = ss, ffr = ff;
   for (int k = 0; k < L.n; ++k) {
-    const uint32_t u = sid[k], v = f[k];
+    const uint32_t u = L.stok[s + k], v = f[k];
     const double qu = q_of(L, u);
-    if (u == v) { ub += qu; continue; }
-    const double c = ((u | v) & FS_OOV_FLAG) ? 1.0 : L.cmax;
-    ub += c * 0.5 * (qu + q_of(L, v));
-  }
-  const double lim = (1.0 - L.thr - 1e-6);
-  if (ub <= 0.0 || ub * ub < lim * lim * ss * ff * (1.0 - 1e-9)) return false;
-  double sf = 0.0;
-  for (int k = 0; k < L.n; ++k) {
-    const uint32_t u = sid[k], v = f[k];
-    sf = __dadd_rn(sf, u == v ? q_of(L, u) : g_of(L, u, v));
+    sf = __dadd_rn(sf, u == v ? qu : g_of(L, u, v));
+    if (k + 1 < L.n) {
+      ssr -= qu;
+      ffr -= u == v ? qu : q_of(L, v);
+      const double t = need - sf;
+      const double rem = fmax(ssr, 0.0) * fmax(ffr, 0.0) * (1.0 + 1e-9);
+      if (t > 0.0 && t * t > rem) return false;
+    }
   }
   const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(__dsqrt_rn(ss), __dsqrt_rn(ff))));
   if (d != d) return false;
