@@ -40,11 +40,12 @@ def main():
     ap.add_argument("--tokens", type=int, default=2000)
     ap.add_argument("--script-tokens", type=int, default=20000)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--oracle-works", type=int, default=0, help="also check N works against the oracle")
+    ap.add_argument("--rows", type=int, default=8192, help="rows of the clustered table")
     a = ap.parse_args()
     words = synth.vocab_words()
+    words += ["zz%x" % i for i in range(len(words), a.rows)]
     if a.table == "clustered":
-        emb, perm = clustered_table()
+        emb, perm = clustered_table(clusters=a.rows // 8)
         inv = np.argsort(perm)
     else:
         emb = synth.embedding()
@@ -74,16 +75,6 @@ def main():
            "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()),
            "fanworks_per_s": a.works / (best * 1e-3),
            "windows_per_s": st.windows_processed / (best * 1e-3)}
-    if a.oracle_works:
-        from oracle import c_oracle
-        sch, so = vocab.pack_strings([words[int(t)] for t in script])
-        oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, synth.lsh_normals(a.window), threads=16)
-        cut = int(off[a.oracle_works])
-        t0 = time.time()
-        want, _ = oi.search(tok[:cut], off[:a.oracle_works + 1], chars, coff)
-        out["oracle_s"] = round(time.time() - t0, 2)
-        got = rows[rows["work"] < a.oracle_works]
-        out["oracle_equal"] = bool(got.tobytes() == want.tobytes())
     print(json.dumps(out), flush=True)
 
 
