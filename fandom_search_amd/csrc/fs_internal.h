@@ -114,6 +114,16 @@ struct CorpusDev {
   uint32_t n_str;
 };
 
+// LSH pipeline: per script window, everything the first slot of a candidate's
+// distance needs, in one 32-byte record
+struct alignas(32) fs_swin {
+  double ss;       // sum of q over the window's slots
+  double rss;      // sqrt(ss), correctly rounded
+  double qu0;      // q of the first slot's vector
+  uint32_t u0;     // first slot's vector id
+  int32_t r0;      // its row in the pair table, -1: none
+};
+
 struct fs_index {
   fs_config cfg;
   int device = 0;
@@ -133,6 +143,7 @@ struct fs_index {
 
   // general (LSH) pipeline, built on demand (fs_lsh_build)
   DBuf<double> d_nt, d_atab, d_ss, d_gtab;
+  DBuf<fs_swin> d_sw;            // per script window: what a bucket candidate's first slot needs
   DBuf<int32_t> d_sidx;
   DBuf<float> d_atab32, d_amax;
   DBuf<uint32_t> d_boff, d_bids;

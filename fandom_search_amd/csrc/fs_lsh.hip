@@ -53,18 +53,21 @@ struct LshDev {
   const uint32_t* boff;    // [H][2^B + 1]
   const uint32_t* bids;    // [H][W]
   const double* ss;        // [W] sum of q over script window
+  const fs_swin* sw;       // [W] first-slot record per script window
   const double* q;         // [V]
   const float* emb;        // [V][D]
   const uint32_t* stok;    // script vector ids
-  const float* atab32;     // [n][V][C] float32 copy of atab, or nullptr
+  const float* atab32;     // [n][V][Cp] float32 copy of atab (rows padded to Cp = 4*ceil(C/4)
+                           // floats with zeros, 16-byte aligned), or nullptr
   const float* amax;       // [n][V] >= max_c |atab[k][v][c]|
   float bound_scale;       // n * 2^-22 (times a test factor)
   int m_min;               // fewer id-identical slots than this cannot reach the threshold
-  int diag;                // diagnostics: 1 = skip candidate walk, 2 = skip key computation
+  int diag;                // diagnostics: 1 = skip candidate walk, 2 = skip key computation,
+                           // 3 = walk the buckets but skip the distances
   const double* gtab;      // [n_srow][V] g(script row, table row), or nullptr
   const int32_t* sidx;     // [V] row of gtab for a table id, -1 if not a script word
   uint32_t V, W;
-  int n, H, B, D, C, nn, unique;
+  int n, H, B, D, C, Cp, nn, unique;
   double thr, cmax;
 };
 
@@ -147,7 +150,7 @@ __device__ __forceinline__ uint32_t assemble_key(const uint64_t* bal, int h, int
 // CosineDistance of fan window f[] to script window s (canonical), with the
 // sound skips described in the file header.  Returns false when skipped or NaN.
 __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, double ff,
-                                double* out) {
+                                double rff, double* out) {
   // stage 0: integer only.  With all table norms in [sqrt(q_min), sqrt(q_max)] and
   // no OOV vector involved, m identical slots bound the cosine by
   // (m q_max + (n-m) c_max q_max) / (n q_min); m_min is the smallest m for which that
@@ -165,16 +168,22 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
   // stage 1: the canonical sum SF slot by slot, leaving as soon as the slots still to
   // come cannot lift it to the threshold.  By Cauchy-Schwarz the remaining slots add
   // at most sqrt(SS_rem * FF_rem) (SS_rem, FF_rem = squared norms of the remaining
-  // slots), so  SF_k + sqrt(SS_rem FF_rem) < (1 - thr - 1e-6) sqrt(SS FF)  proves
+  // slots), so  SF_k + sqrt(SS_rem FF_rem) < (1 - thr - 1e-6) sqrt(SS) sqrt(FF)  proves
   // distance > thr + 1e-6, far outside the rounding of the canonical expression.  A
-  // bucket collision between unrelated windows leaves after its first slot.
-  const double ss = L.ss[s];
-  const double need = (1.0 - L.thr - 1e-6) * sqrt(ss * ff) * (1.0 - 1e-9);
-  double sf = 0.0, ssr = ss, ffr = ff;
+  // bucket collision between unrelated windows leaves after its first slot, which
+  // costs one 32-byte record of the script window and one pair-table entry.
+  const fs_swin sw = L.sw[s];
+  const double norm = __dmul_rn(sw.rss, rff);
+  const double need = (1.0 - L.thr - 1e-6) * norm * (1.0 - 1e-9);
+  double sf = 0.0, ssr = sw.ss, ffr = ff;
   for (int k = 0; k < L.n; ++k) {
-    const uint32_t u = L.stok[s + k], v = f[k];
-    const double qu = q_of(L, u);
-    sf = __dadd_rn(sf, u == v ? qu : g_of(L, u, v));
+    const uint32_t u = k ? L.stok[s + k] : sw.u0, v = f[k];
+    const double qu = k ? q_of(L, u) : sw.qu0;
+    double g;
+    if (u == v) g = qu;
+    else if (k == 0 && sw.r0 >= 0 && !(v & FS_OOV_FLAG)) g = L.gtab[(size_t)sw.r0 * L.V + v];
+    else g = g_of(L, u, v);
+    sf = __dadd_rn(sf, g);
     if (k + 1 < L.n) {
       ssr -= qu;
       ffr -= u == v ? qu : q_of(L, v);
@@ -183,7 +192,7 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
       if (t > 0.0 && t * t > rem) return false;
     }
   }
-  const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(__dsqrt_rn(ss), __dsqrt_rn(ff))));
+  const double d = __dsub_rn(1.0, __ddiv_rn(sf, norm));
   if (d != d) return false;
   *out = d;
   return true;
@@ -197,6 +206,7 @@ __device__ int lsh_neighbours(const LshDev& L, const uint32_t* keys, const uint3
                               uint32_t* top_s, double* top_d) {
   double ff = 0.0;
   for (int k = 0; k < L.n; ++k) ff = __dadd_rn(ff, q_of(L, f[k]));
+  const double rff = __dsqrt_rn(ff);
   const uint32_t nb1 = (1u << L.B) + 1;
   int cnt = 0;
   for (int h = 0; h < L.H; ++h) {
@@ -210,7 +220,8 @@ __device__ int lsh_neighbours(const LshDev& L, const uint32_t* keys, const uint3
         if (seen) continue;
       }
       double d;
-      if (!window_distance(L, s, f, ff, &d)) continue;
+      if (L.diag == 3) { cnt += s == 0xFFFFFFFFu; continue; }          // diagnostics: bucket walk only
+      if (!window_distance(L, s, f, ff, rff, &d)) continue;
       if (!(d < L.thr)) continue;
       if (ANY) return 1;
       // stable insertion: behind every entry with distance <= d
@@ -243,7 +254,7 @@ __global__ void k_nt(const double* __restrict__ normals, int n, int D, int C,
 // A[k][v][c] = seqsum_d nt[k][d][c] * (double)E[v][d]; block = one (k, v)
 __global__ __launch_bounds__(256) void k_atab(const double* __restrict__ nt,
                                               const float* __restrict__ emb, uint32_t V, int D,
-                                              int C, double* __restrict__ atab,
+                                              int C, int Cp, double* __restrict__ atab,
                                               float* __restrict__ atab32,
                                               float* __restrict__ amax) {
   __shared__ float s_m[4];
@@ -256,11 +267,12 @@ __global__ __launch_bounds__(256) void k_atab(const double* __restrict__ nt,
     double acc = 0.0;
     for (int d = 0; d < D; ++d)
       acc = __dadd_rn(acc, __dmul_rn(ntk[(size_t)d * C + c], (double)e[d]));
-    const size_t i = ((size_t)k * V + v) * C + c;
-    atab[i] = acc;
-    atab32[i] = (float)acc;
+    const size_t r = (size_t)k * V + v;
+    atab[r * C + c] = acc;
+    atab32[r * Cp + c] = (float)acc;
     mx = fmaxf(mx, __double2float_ru(fabs(acc)));          // rounded up
   }
+  for (int c = C + threadIdx.x; c < Cp; c += blockDim.x) atab32[((size_t)k * V + v) * Cp + c] = 0.0f;
   for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
   if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
   __syncthreads();
@@ -294,12 +306,19 @@ __global__ __launch_bounds__(256) void k_gtab(const float* __restrict__ emb,
 }
 
 __global__ void k_ss(const uint32_t* __restrict__ stok, uint32_t W, LshDev L,
-                     double* __restrict__ ss) {
+                     double* __restrict__ ss, fs_swin* __restrict__ sw) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= W) return;
   double acc = 0.0;
   for (int k = 0; k < L.n; ++k) acc = __dadd_rn(acc, q_of(L, stok[w + k]));
   ss[w] = acc;
+  fs_swin r;
+  r.ss = acc;
+  r.rss = __dsqrt_rn(acc);
+  r.u0 = stok[w];
+  r.qu0 = q_of(L, r.u0);
+  r.r0 = (L.gtab && !(r.u0 & FS_OOV_FLAG)) ? L.sidx[r.u0] : -1;
+  sw[w] = r;
 }
 
 // keys of the windows of a token stream; one wave per window
@@ -358,35 +377,76 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
       s_bound[w] = f64 ? -1.0f : L.bound_scale * m;
     }
     __syncthreads();
-    // phase 1: threads are projection columns.  Only the sign of a projection
-    // matters, so the float32 copy of the tables decides it whenever the float32
-    // sum is farther from zero than its worst-case distance to the canonical
+    // phase 1: a wave takes four windows at a time; lane l holds projection columns
+    // 4l .. 4l+3 of each, so one 16-byte load per lane fetches a whole table row
+    // (848 B at the default 210 columns) per wave instruction.  Only the sign of a
+    // projection matters, so the float32 copy of the tables decides it whenever the
+    // float32 sum is farther from zero than its worst-case distance to the canonical
     // float64 sum:  |s32 - s64| <= n * 2^-23 * sum_k max_c|A[k][t_k][c]|  (rounding
     // of the n table entries to float32 plus n-1 float32 additions; the float64
     // additions contribute 2^-53 terms).  A window with any column inside twice
     // that distance, or with an out-of-vocabulary token, is redone in float64.
-    for (int ch0 = 0; ch0 < L.C && L.diag != 2; ch0 += 256) {
-      const int col = ch0 + threadIdx.x;
-      const bool active = col < L.C;
-      const int cc = active ? col : 0;
-#pragma unroll 4
-      for (int w = 0; w < 256; ++w) {
-        bool bit;
-        bool slow = s_bound[w] < 0.0f;                   // no float32 tables, or an OOV token
-        if (!slow) {
-          float acc = L.atab32[(size_t)s_tok[w] * L.C + cc];
-          for (int k = 1; k < n; ++k)
-            acc = __fadd_rn(acc, L.atab32[((size_t)k * L.V + s_tok[w + k]) * L.C + cc]);
-          bit = acc > 0.0f;
-          slow = __any(active && !(fabsf(acc) > s_bound[w]));   // wave-uniform
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bal);           // [256][2 (NW + 1)]
+    for (int c0 = 0; c0 < L.C && L.diag != 2; c0 += 256) {
+      const int col = c0 + 4 * lane;
+      const int left = L.C - col;                                    // columns this lane owns
+      const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
+      const int colc = left > 0 ? col : 0;
+      const bool store = (lane & 7) == 0 && (c0 >> 5) + (lane >> 3) < 2 * NW;
+      for (int i = 0; i < 64; i += 4) {
+        const int w0 = wave * 64 + i;
+        float bnd[4];
+        bool fast = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { bnd[u] = s_bound[w0 + u]; fast = fast && bnd[u] >= 0.0f; }
+        uint32_t nib[4];
+        bool redo[4] = {true, true, true, true};
+        if (fast) {                                                  // wave-uniform
+          float4 acc[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            acc[u] = *reinterpret_cast<const float4*>(L.atab32 + (size_t)s_tok[w0 + u] * L.Cp + colc);
+          for (int k = 1; k < n; ++k) {
+            float4 r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              r[u] = *reinterpret_cast<const float4*>(
+                  L.atab32 + ((size_t)k * L.V + s_tok[w0 + u + k]) * L.Cp + colc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              acc[u].x = __fadd_rn(acc[u].x, r[u].x); acc[u].y = __fadd_rn(acc[u].y, r[u].y);
+              acc[u].z = __fadd_rn(acc[u].z, r[u].z); acc[u].w = __fadd_rn(acc[u].w, r[u].w);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t sure = (fabsf(acc[u].x) > bnd[u] ? 1u : 0u) | (fabsf(acc[u].y) > bnd[u] ? 2u : 0u) |
+                                  (fabsf(acc[u].z) > bnd[u] ? 4u : 0u) | (fabsf(acc[u].w) > bnd[u] ? 8u : 0u);
+            nib[u] = ((acc[u].x > 0.0f ? 1u : 0u) | (acc[u].y > 0.0f ? 2u : 0u) |
+                      (acc[u].z > 0.0f ? 4u : 0u) | (acc[u].w > 0.0f ? 8u : 0u)) & cmask;
+            redo[u] = __any((~sure & cmask) != 0u);                  // wave-uniform
+          }
         }
-        if (slow) {
-          double acc = a_value(L, 0, s_tok[w], cc);
-          for (int k = 1; k < n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_tok[w + k], cc));
-          bit = acc > 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (redo[u]) {
+            uint32_t bits = 0;
+            for (int j = 0; j < 4; ++j) {
+              if (!((cmask >> j) & 1u)) continue;
+              double acc = a_value(L, 0, s_tok[w0 + u], col + j);
+              for (int k = 1; k < n; ++k)
+                acc = __dadd_rn(acc, a_value(L, k, s_tok[w0 + u + k], col + j));
+              bits |= acc > 0.0 ? 1u << j : 0u;
+            }
+            nib[u] = bits;
+          }
+          // eight lanes -> one 32-bit piece of the window's column bit string
+          uint32_t x = nib[u];
+          x |= (uint32_t)__shfl_down((int)x, 1) << 4;
+          x |= (uint32_t)__shfl_down((int)x, 2) << 8;
+          x |= (uint32_t)__shfl_down((int)x, 4) << 16;
+          if (store) s_bits[(size_t)(w0 + u) * 2 * (NW + 1) + (c0 >> 5) + (lane >> 3)] = x;
         }
-        const uint64_t b = __ballot(active && bit);
-        if (lane == 0 && ch0 + wave * 64 < L.C) s_bal[w * (NW + 1) + (ch0 >> 6) + wave] = b;
       }
     }
     __syncthreads();
@@ -508,12 +568,13 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
 static LshDev lsh_dev(const fs_index* ix) {
   LshDev L;
   L.atab = ix->d_atab.p; L.nt = ix->d_nt.p; L.boff = ix->d_boff.p; L.bids = ix->d_bids.p;
-  L.ss = ix->d_ss.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
+  L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
   L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
+  L.Cp = (L.C + 3) & ~3;
   L.nn = (int)ix->cfg.nearest_n; L.unique = ix->cfg.unique_filter ? 1 : 0;
   L.thr = ix->cfg.distance_threshold;
   L.cmax = ix->lsh_cmax;
@@ -550,13 +611,15 @@ int fs_lsh_build(fs_index* ix) {
   const uint64_t V = ix->n_vec, W = ix->n_windows;
   FS_TRY(ix->d_nt.reserve((size_t)n * D * C));
   FS_TRY(ix->d_atab.reserve((size_t)n * V * C));
-  FS_TRY(ix->d_atab32.reserve((size_t)n * V * C + 1));
+  const int Cp = (C + 3) & ~3;
+  FS_TRY(ix->d_atab32.reserve((size_t)n * V * Cp + 4));
   FS_TRY(ix->d_amax.reserve((size_t)n * V + 1));
   FS_TRY(ix->d_ss.reserve(W));
+  FS_TRY(ix->d_sw.reserve(W));
   hipLaunchKernelGGL(k_nt, dim3(1024), dim3(256), 0, s, ix->d_normals.p, n, D, C, ix->d_nt.p);
   if (V)
     hipLaunchKernelGGL(k_atab, dim3((uint32_t)V, n), dim3(256), 0, s, ix->d_nt.p, ix->d_emb.p,
-                       (uint32_t)V, D, C, ix->d_atab.p, ix->d_atab32.p, ix->d_amax.p);
+                       (uint32_t)V, D, C, Cp, ix->d_atab.p, ix->d_atab32.p, ix->d_amax.p);
   FS_HIP(hipGetLastError());
   // pair dot products g(script row, table row): one 8-byte lookup per window slot
   // instead of D multiply-adds when a candidate's exact distance is needed.  Capped
@@ -595,7 +658,7 @@ int fs_lsh_build(fs_index* ix) {
   if (W) {
     LshDev L = lsh_dev(ix);
     hipLaunchKernelGGL(k_ss, dim3((uint32_t)((W + 255) / 256)), dim3(256), 0, s, ix->d_stok.p,
-                       (uint32_t)W, L, ix->d_ss.p);
+                       (uint32_t)W, L, ix->d_ss.p, ix->d_sw.p);
     DBuf<uint32_t> d_keys;
     FS_TRY(d_keys.reserve(W * H));
     hipLaunchKernelGGL(k_keys, dim3((uint32_t)std::min<uint64_t>((W + 3) / 4, 4096)), dim3(256), 0,
