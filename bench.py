@@ -189,11 +189,18 @@ def main():
     # 16-byte wire records (half the gather bytes); rank 0 expands them again.
     packed = world > 1 and ix.info["path"] == abi.FS_MODE_EXACT
     rec_bytes = 16 if packed else 32
+    # every row buffer starts with a 32-byte header whose first 8 bytes carry the
+    # row count of the step: count and records travel in ONE gather per step
+    HDR = 32
     cap = max(4096, corpus.n_tok // 16)
+
+    def row_buffer():
+        return torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
+
     while True:
-        bufs = [torch.zeros(cap * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        bufs = [row_buffer() for _ in range(2)]
         try:
-            n_rows, st = ix.search_device(corpus, bufs[0].data_ptr(), cap, packed=packed)
+            n_rows, st = ix.search_device(corpus, bufs[0].data_ptr() + HDR, cap, packed=packed)
             break
         except _lib.FsError as e:
             if e.code != abi.FS_E_CAPACITY:
@@ -206,14 +213,13 @@ def main():
         pad = int(t.item())
         if pad != cap:
             cap = pad
-            bufs = [torch.zeros(cap * rec_bytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        counts = [torch.zeros(world, dtype=torch.int64, device=cdev) for _ in range(2)]
-        mine = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(2)]
+            bufs = [row_buffer() for _ in range(2)]
         gathered = full_rows = None
         if rank == 0:
-            # one contiguous landing buffer per slot; rank r's records at [r*cap, ...)
-            gathered = [torch.zeros(world * cap * rec_bytes, dtype=torch.uint8, device=cdev)
-                        for _ in range(2)]
+            # one contiguous landing buffer per slot; rank r's header + records at
+            # [r * (HDR + cap * rec_bytes), ...)
+            gathered = [torch.zeros(world * (HDR + cap * rec_bytes), dtype=torch.uint8,
+                                    device=cdev) for _ in range(2)]
             if packed:
                 full_rows = torch.empty(world * cap * 32, dtype=torch.uint8, device="cuda")
 
@@ -222,14 +228,11 @@ def main():
     # than one rank the gather of step i-1 runs beside the search of step i.
     NB = 3
     while len(bufs) < NB:
-        bufs.append(torch.zeros(cap * rec_bytes, dtype=torch.uint8, device="cuda"))
-    if world > 1:
-        while len(counts) < NB:
-            counts.append(torch.zeros(world, dtype=torch.int64, device=cdev))
-            mine.append(torch.zeros(1, dtype=torch.int64, device=cdev))
-            if rank == 0:
-                gathered.append(torch.zeros(world * cap * rec_bytes, dtype=torch.uint8,
-                                            device=cdev))
+        bufs.append(row_buffer())
+    if world > 1 and rank == 0:
+        while len(gathered) < NB:
+            gathered.append(torch.zeros(world * (HDR + cap * rec_bytes), dtype=torch.uint8,
+                                        device=cdev))
     pending = [None] * NB       # gathers in flight, per buffer
     tickets = {}                # step -> (ticket, buffer)
     scan_ms = []
@@ -266,17 +269,16 @@ def main():
         total_rows = n
         last_st[0] = st
         if world > 1:
-            mine[b].fill_(n)
-            h1 = dist.all_gather_into_tensor(counts[b], mine[b], async_op=True)
+            bufs[b][:8].view(torch.int64).fill_(n)       # header: rows of this step
             send = bufs[b].cpu() if rehearsal else bufs[b]
-            h2 = dist.gather(send, list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
-                             async_op=True)
-            pending[b] = (h1, h2)
+            h = dist.gather(send, list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
+                            async_op=True)
+            pending[b] = (h,)
 
     def step(i):
         b = i % NB
         finish(b)
-        tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr(), cap, packed=packed), b)
+        tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr() + HDR, cap, packed=packed), b)
         if i - 1 in tickets:
             complete(i - 1)
 
@@ -319,13 +321,16 @@ def main():
         if rank == 0:
             last = last_gathered[0]
             crcs = crcs.cpu().tolist()
-            cnts = counts[last].cpu().tolist()
+            stride = HDR + cap * rec_bytes
+            src = gathered[last].cuda() if rehearsal else gathered[last]
+            cnts = src.view(world, stride)[:, :8].contiguous().view(torch.int64).flatten().cpu().tolist()
             if packed:
-                src = gathered[last].cuda() if rehearsal else gathered[last]
-                ix.unpack_device(src.data_ptr(), world * cap, full_rows.data_ptr())
+                for r in range(world):
+                    ix.unpack_device(src.data_ptr() + r * stride + HDR, min(cnts[r], cap),
+                                     full_rows.data_ptr() + r * cap * 32)
                 landed = full_rows.cpu().numpy()
             else:
-                landed = gathered[last].cpu().numpy()
+                landed = src.view(world, stride)[:, HDR:].contiguous().cpu().numpy().reshape(-1)
             gather_verified = True
             for r in range(world):
                 chunk = landed[r * cap * 32:(r * cap + cnts[r]) * 32]
@@ -345,8 +350,8 @@ def main():
             # LSH pipeline: per window n rows of H*B float64 projections are gathered
             # (L2 / Infinity Cache resident table, so 'hbm' is nominal here)
             kernel = "k_lsh_scan"
-            algo_bytes = float(st.windows_processed) * args.window * 15 * 14 * 8
-            note = "n*H*B*8 B of projection-table rows per window (cache-served gather)"
+            algo_bytes = float(st.windows_processed) * args.window * 212 * 4
+            note = "n rows of 212 float32 projections (848 B) per window (cache-served gather)"
         achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
