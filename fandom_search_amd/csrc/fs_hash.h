@@ -55,15 +55,16 @@ FS_HD uint32_t fs_gram_hash(const uint32_t* t, int n) {
 
 // Blocked Bloom filter: one 32-bit word, three bit positions, all taken from
 // disjoint bit fields of the hash (word index: top `log2_words` bits; bit
-// positions: bits 0-4, 5-9, 10-14).
+// positions: bits 0-4, 8-12 and 13-17 -- the second field sits in byte 1 so that
+// the scan can use it as a shift amount through an SDWA byte select).
 FS_HD uint32_t fs_bloom_word(uint32_t h, int log2_words) { return h >> (32 - log2_words); }
 FS_HD uint32_t fs_bloom_mask(uint32_t h) {
-  return (1u << (h & 31)) | (1u << ((h >> 5) & 31)) | (1u << ((h >> 10) & 31));
+  return (1u << (h & 31)) | (1u << ((h >> 8) & 31)) | (1u << ((h >> 13) & 31));
 }
 // the same test written as three shifts of the filter word (a 32-bit shift uses
 // the low five bits of its amount)
 FS_HD uint32_t fs_bloom_test(uint32_t word, uint32_t h) {
-  return (word >> (h & 31)) & (word >> ((h >> 5) & 31)) & (word >> ((h >> 10) & 31)) & 1u;
+  return (word >> (h & 31)) & (word >> ((h >> 8) & 31)) & (word >> ((h >> 13) & 31)) & 1u;
 }
 
 // slot of the exact (verification) table, 2^log2_slots entries

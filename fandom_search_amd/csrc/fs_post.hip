@@ -142,11 +142,14 @@ __device__ __forceinline__ uint32_t verify_window(const CorpusDev& c, const Gram
   }
 }
 
-// TPL = tokens per lane of the scan that wrote the bitmap: TPL ballot words per
-// sub-tile of 64*TPL tokens, bit L of word j <-> window 64*TPL*i + TPL*L + j.
-// One thread per ballot word; candidates are numbered in position order (L, then
-// j), so a window's index is the sub-tile's base + the set bits of all words below
-// lane L + the set bits of the earlier words at lane L.
+// TPL = tokens per lane of the scan that wrote the bitmap.
+//   TPL 4  four ballot words per sub-tile of 256 tokens, bit L of word j <-> window
+//          256 i + 4 L + j.  Candidates are numbered in position order (L, then j):
+//          a window's index is the sub-tile's base + the set bits of all words below
+//          lane L + the set bits of the earlier words at lane L.
+//   TPL 8  eight words per sub-tile of 512 tokens in natural order, bit L of word j
+//          <-> window 512 i + 64 j + L.
+// One thread per word.
 // VERIFY (diagnostics, FS_POST_FUSED): the thread that finds a candidate also
 // verifies it; slower than the separate k_verify launch, see fs_launch_post.
 template <int TPL, bool VERIFY>
@@ -189,18 +192,29 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
       uint64_t mine = b[0];
 #pragma unroll
       for (int k = 1; k < TPL; ++k) mine = j == k ? b[k] : mine;
+      const uint64_t mine_all = mine;
+      (void)mine_all;
       const uint32_t base = s_base[sl];
       while (mine) {
         const int L = __ffsll((unsigned long long)mine) - 1;
         mine &= mine - 1;
         const uint64_t below = (1ull << L) - 1;
         uint32_t idx = base;
+        uint32_t p;
+        if constexpr (TPL == 8) {
 #pragma unroll
-        for (int k = 0; k < TPL; ++k) {
-          idx += __popcll(b[k] & below);
-          if (k < j) idx += (uint32_t)((b[k] >> L) & 1);
+          for (int k = 0; k < TPL; ++k)
+            if (k < j) idx += __popcll(b[k]);
+          idx += __popcll(mine_all & below);
+          p = sub * 512u + 64u * (uint32_t)j + (uint32_t)L;
+        } else {
+#pragma unroll
+          for (int k = 0; k < TPL; ++k) {
+            idx += __popcll(b[k] & below);
+            if (k < j) idx += (uint32_t)((b[k] >> L) & 1);
+          }
+          p = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L + (uint32_t)j;
         }
-        const uint32_t p = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L + (uint32_t)j;
         if (idx < ccap) {
           cpos[idx] = p;
           if (VERIFY) {

@@ -195,33 +195,72 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
 // ---- eight tokens per lane ---------------------------------------------------
 // The same scan with lane L owning tokens [8L, 8L+8) of a 512-token sub-tile: the
 // n-1 halo tokens are shuffled in once per 8 windows instead of once per 4, 13
-// premixes serve 8 windows and the full fold is paid once per 8.  Bitmap layout:
-// eight ballot words per sub-tile, bit L of word j <-> window 512 i + 8 L + j.
-// For n <= 9 (the halo fits in the next lane's eight tokens).
-template <int N, bool TAIL>
-__device__ __forceinline__ void window_ballots8(const uint32_t* m, const uint32_t* s_filter,
-                                                int word_shift, uint32_t p0, uint32_t n_tok,
-                                                uint64_t* b) {
+// premixes serve 8 windows and the full fold is paid once per 8.  A lane's eight
+// answers are one byte, so the sub-tile's bitmap is written as 64 consecutive
+// bytes in natural order (bit p of the 512-bit string <-> window 512 i + p): no
+// ballots, no per-lane word selection.  For n <= 9 (the halo fits in the next
+// lane's eight tokens).
+//
+// VALU work per window (the kernel is VALU-issue bound): premix 1; slide
+//   x' = rotl(x, 7) ^ rotl(m_out, 7n) ^ m_in            alignbit, alignbit, xor3
+// Bloom test: word address 1 (SDWA word select, 64 KB filter) or 2, three shifts of
+// the filter word (one through an SDWA byte select, one needs h >> 13 first), and3,
+// and one alignbit that shifts the answer into the lane's flag byte.
+__device__ __forceinline__ uint32_t fs_shr_by_byte1(uint32_t word, uint32_t h) {
+  uint32_t r;     // word >> (bits 8..12 of h)
+  asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD"
+      : "=v"(r) : "v"(h), "v"(word));
+  return r;
+}
+__device__ __forceinline__ uint32_t fs_word_offset14(uint32_t h, uint32_t mask_fffc) {
+  uint32_t r;     // byte offset of filter word h >> 18:  (h >> 16) & 0xFFFC
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+      : "=v"(r) : "v"(h), "v"(mask_fffc));
+  return r;
+}
+
+// sum over the wave, complete in lane 63 (six DPP adds)
+__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);   // row_mirror
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+  return x;
+}
+
+template <int N, bool TAIL, bool LW14>
+__device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint32_t* s_filter,
+                                                  int word_shift, uint32_t mask_fffc,
+                                                  uint32_t p0, uint32_t n_tok) {
   uint32_t x = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) x ^= fs_rotl(m[k], fs_rot_of(N - 1 - k));
   uint32_t flags = 0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    if (j) x = fs_rotl(x ^ fs_rotl(m[j - 1], fs_rot_of(N - 1)), 7) ^ m[j - 1 + N];
-    const uint32_t word = s_filter[x >> word_shift];
-    flags |= fs_bloom_test(word, x) << j;
+    if (j) x = (uint32_t)__builtin_amdgcn_bitop3_b32(fs_rotl(x, 7), fs_rotl(m[j - 1], fs_rot_of(N)),
+                                                      m[j - 1 + N], 0x96);   // three-way xor
+    uint32_t word;
+    if constexpr (LW14)
+      word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filter) +
+                                                fs_word_offset14(x, mask_fffc));
+    else
+      word = s_filter[x >> word_shift];
+    const uint32_t t = (word >> (x & 31)) & fs_shr_by_byte1(word, x) & (word >> ((x >> 13) & 31));
+    flags = __builtin_amdgcn_alignbit(t, flags, 1);       // bit 0 of t enters at bit 31
   }
+  flags >>= 24;                                           // window j at bit j
   if (TAIL) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
   }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) b[j] = __ballot(flags & (1u << j));
+  return flags;
 }
 
-template <int N, int U, bool NT>
+template <int N, int U, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok, uint32_t n_tok,
                                                 const uint32_t* __restrict__ filter,
                                                 int log2_words, uint64_t* __restrict__ qbm,
@@ -243,6 +282,9 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
   const int src = (lane + 1) & 63;
+  uint32_t mask_fffc = 0xFFFCu;
+  asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
+  uint8_t* bm_bytes = reinterpret_cast<uint8_t*>(qbm);
 
   for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
     const uint32_t base = tile * (uint32_t)(SUB * U);
@@ -280,23 +322,16 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
 #pragma unroll
       for (int i = 0; i < 8 + HALO; ++i) a[i] = fs_premix(a[i]);
       const uint32_t p0 = base + u * SUB + 8 * lane;
-      uint64_t b[8];
+      uint32_t flags;
       if (base + (uint32_t)(SUB * U) + HALO > n_tok)
-        window_ballots8<N, true>(a, s_filter, word_shift, p0, n_tok, b);
+        flags = window_flags8<N, true, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
       else
-        window_ballots8<N, false>(a, s_filter, word_shift, p0, n_tok, b);
-      const uint32_t word = tile * U + u;
-      if (word < n_bm_words && lane < 8) {
-        uint64_t mine = b[0];
-#pragma unroll
-        for (int j = 1; j < 8; ++j) mine = lane == j ? b[j] : mine;
-        qbm[(size_t)word * 8 + lane] = mine;
-        if (lane == 0) {
-          uint32_t cnt = 0;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) cnt += __popcll(b[j]);
-          qcnt[word] = cnt;
-        }
+        flags = window_flags8<N, false, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
+      const uint32_t word = tile * U + u;                     // sub-tile index, wave-uniform
+      if (word < n_bm_words) {
+        bm_bytes[(size_t)word * 64 + lane] = (uint8_t)flags;
+        const uint32_t cnt = wave_sum_lane63(__popc(flags));
+        if (lane == 63) qcnt[word] = cnt;
       }
     }
   }
@@ -375,7 +410,7 @@ int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   uint32_t blocks_per_cu = lds <= 64 * 1024 ? 2 : 1;
   uint32_t blocks = (n_tiles + 15) / 16;
   if (blocks > ix->num_cu * blocks_per_cu) blocks = ix->num_cu * blocks_per_cu;
-  auto kern = k_scan8<N, U, NT>;
+  auto kern = ix->log2_words == 14 ? k_scan8<N, U, NT, true> : k_scan8<N, U, NT, false>;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
