@@ -59,6 +59,8 @@ fs_index::~fs_index() {
   if (ev_scan0) (void)hipEventDestroy(ev_scan0);
   if (ev_scan1) (void)hipEventDestroy(ev_scan1);
   if (h_status) (void)hipHostFree(h_status);
+  for (int l = 0; l < FS_LANES; ++l)
+    if (lanes[l].stream) (void)hipStreamDestroy(lanes[l].stream);
   for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
     Slot& sl = slots[i];
     if (sl.ev_begin) (void)hipEventDestroy(sl.ev_begin);
@@ -67,8 +69,8 @@ fs_index::~fs_index() {
     if (sl.ev_end) (void)hipEventDestroy(sl.ev_end);
     if (sl.h_status) (void)hipHostFree(sl.h_status);
   }
-  if (stream) (void)hipStreamDestroy(stream);
-}
+}   // `stream` is lanes[0].stream
+
 
 static int ceil_log2(uint64_t x) {
   int l = 0;
@@ -240,7 +242,10 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   hipDeviceProp_t prop;
   FS_HIP(hipGetDeviceProperties(&prop, cfg->device));
   ix->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  FS_HIP(hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking));
+  for (int l = 0; l < FS_LANES; ++l)
+    FS_HIP(hipStreamCreateWithFlags(&ix->lanes[l].stream, hipStreamNonBlocking));
+  ix->stream = ix->lanes[0].stream;
+  if (const char* e = getenv("FS_LANES")) ix->n_lanes = atoi(e) >= 2 ? FS_LANES : 1;
   FS_HIP(hipEventCreate(&ix->ev_scan0));      // fs_scan_benchmark
   FS_HIP(hipEventCreate(&ix->ev_scan1));
   FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
@@ -252,9 +257,11 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     FS_HIP(hipEventCreate(&sl.ev_end));
     FS_HIP(hipHostMalloc((void**)&sl.h_status, sizeof(fs_status), hipHostMallocDefault));
   }
-  FS_TRY(ix->d_status.reserve(1));
-  FS_TRY(ix->w_bsum.reserve(4096));
-  FS_TRY(ix->w_bsum64.reserve(2048));
+  for (int l = 0; l < FS_LANES; ++l) {
+    FS_TRY(ix->lanes[l].d_status.reserve(1));
+    FS_TRY(ix->lanes[l].w_bsum.reserve(4096));
+    FS_TRY(ix->lanes[l].w_bsum64.reserve(2048));
+  }
 
   // script ids padded by n so that device code may read a full window anywhere
   std::vector<uint32_t> stok(n_script + FS_MAX_WINDOW + 1, 0u);
@@ -307,7 +314,8 @@ extern "C" int fs_index_info_get(const fs_index* ix, fs_index_info* info) {
 extern "C" void fs_index_destroy(fs_index* ix) {
   if (!ix) return;
   (void)hipSetDevice(ix->device);
-  if (ix->stream) (void)hipStreamSynchronize(ix->stream);
+  for (int l = 0; l < FS_LANES; ++l)
+    if (ix->lanes[l].stream) (void)hipStreamSynchronize(ix->lanes[l].stream);
   delete ix;
 }
 
@@ -398,9 +406,10 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
   if (c->has_oov && ix->info.path == FS_MODE_EXACT) FS_TRY(fs_lsh_build(ix));
   if (!c->has_str && !c->has_oov && ix->info.path == FS_MODE_EXACT && !c->levtab_ready) {
     // string id == vector id: Levenshtein per (n-gram, rank), once per string table
-    FS_HIP(hipMemsetAsync(ix->d_status.p, 0, sizeof(fs_status), ix->stream));
+    ix->cur = &ix->lanes[0];
+    FS_HIP(hipMemsetAsync(ix->cur->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
-    FS_HIP(hipMemcpyAsync(ix->h_status, ix->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
+    FS_HIP(hipMemcpyAsync(ix->h_status, ix->cur->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     if (ix->h_status->bad_string) { fs_set_error("script vector id without a string"); return FS_E_INVALID; }
     if (ix->h_status->lev_overflow) {
@@ -462,33 +471,37 @@ extern "C" void fs_corpus_destroy(fs_corpus* c) {
   if (c->ix) {
     (void)hipSetDevice(c->ix->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    (void)hipStreamSynchronize(c->ix->stream);
+    for (int l = 0; l < FS_LANES; ++l) (void)hipStreamSynchronize(c->ix->lanes[l].stream);
   }
   delete c;
 }
 
 // ---- search: enqueue / finish ---------------------------------------------------
-// A search is queued on the index's stream into one of FS_SEARCH_SLOTS slots and
-// finished later; the synchronous entry point is begin + end.  All queued
-// searches share the workspaces and the device status block: they run in stream
-// order, and each one's status is copied to its slot's pinned block before the
-// next one's memset.
+// A search is queued into one of FS_SEARCH_SLOTS slots and finished later; the
+// synchronous entry point is begin + end.  Slot i runs on lane i % 2 (a stream with
+// its own workspaces and device status block), so two consecutive searches overlap
+// on the GPU: the dependent-load chain after the scan leaves most of the machine
+// idle, and the next search's scan fills it.  Searches on the same lane run in
+// stream order; each one's status goes to its slot's pinned block (written by the
+// chain's last kernel).  FS_LANES=1 puts every search on one stream.
 
 static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
-  hipStream_t s = ix->stream;
+  fs_index::Lane& ln = ix->lanes[sl.lane];
+  ix->cur = &ln;                       // the launchers enqueue into this lane
+  hipStream_t s = ln.stream;
   fs_corpus* c = sl.c;
   const uint32_t nn = ix->cfg.nearest_n;
   const uint32_t n_bm = sl.n_bm;
-  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * sl.tpl));
-  FS_TRY(ix->w_qcnt.reserve(n_bm));
-  FS_TRY(ix->w_cpos.reserve(sl.ccap));
-  FS_TRY(ix->w_cg.reserve(sl.ccap));
-  FS_TRY(ix->w_cw.reserve(sl.ccap));
-  FS_TRY(ix->w_hv.reserve(sl.ccap));
-  FS_TRY(ix->w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
-  FS_TRY(ix->w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
+  FS_TRY(ln.w_qbm.reserve((size_t)n_bm * sl.tpl));
+  FS_TRY(ln.w_qcnt.reserve(n_bm));
+  FS_TRY(ln.w_cpos.reserve(sl.ccap));
+  FS_TRY(ln.w_cg.reserve(sl.ccap));
+  FS_TRY(ln.w_cw.reserve(sl.ccap));
+  FS_TRY(ln.w_hv.reserve(sl.ccap));
+  FS_TRY(ln.w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
+  FS_TRY(ln.w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
   fs_row* d_rows = sl.rows;
-  if (sl.mode == FS_ROWS_HOST) { FS_TRY(ix->w_rows.reserve(sl.rcap)); d_rows = ix->w_rows.p; }
+  if (sl.mode == FS_ROWS_HOST) { FS_TRY(ln.w_rows.reserve(sl.rcap)); d_rows = ln.w_rows.p; }
   const bool packed = sl.mode == FS_ROWS_DEVICE_PACKED;
 
   // the status block is cleared by the chain's first kernel (k_reduce) and its final
@@ -499,16 +512,17 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
   if (sl.exact) {
-    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, e0, e1));
+    FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s));
   } else {
-    FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s, e0, e1));
+    FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
-    FS_TRY(fs_launch_rows(ix, c, ix->w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
+    FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
   }
   ++sl.launches;
   FS_HIP(hipEventRecord(sl.ev_end, s));
+  ix->cur = &ix->lanes[0];
   return FS_OK;
 }
 
@@ -538,6 +552,8 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
       }
   const uint64_t T = c->n_tok;
   sl.c = c; sl.rows = rows; sl.cap = cap; sl.mode = rows_mode; sl.launches = 0;
+  sl.lane = (int)(id % (uint32_t)ix->n_lanes);
+  const fs_index::Lane& ln = ix->lanes[sl.lane];
   sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   sl.tpl = sl.exact ? fs_scan_tpl(ix, T) : 4;
   sl.n_bm = (uint32_t)((T + 64 * sl.tpl - 1) / (64 * sl.tpl));
@@ -547,10 +563,10 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
     return FS_E_UNSUPPORTED;
   }
   // capacities: grown from the device totals when a stage overflows
-  sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_cpos.n);
+  sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ln.w_cpos.n);
   sl.rcap = rows_mode != FS_ROWS_HOST
                 ? cap
-                : std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->w_rows.n);
+                : std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ln.w_rows.n);
   FS_TRY(search_enqueue(ix, sl));
   sl.busy = true;
   *ticket = id;
@@ -604,9 +620,10 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
   }
   if (hs.n_rows > sl.cap) return FS_E_CAPACITY;
   if (sl.mode == FS_ROWS_HOST && hs.n_rows) {
-    FS_HIP(hipMemcpyAsync(sl.rows, ix->w_rows.p, (size_t)hs.n_rows * sizeof(fs_row),
-                          hipMemcpyDeviceToHost, ix->stream));
-    FS_HIP(hipStreamSynchronize(ix->stream));
+    fs_index::Lane& ln = ix->lanes[sl.lane];
+    FS_HIP(hipMemcpyAsync(sl.rows, ln.w_rows.p, (size_t)hs.n_rows * sizeof(fs_row),
+                          hipMemcpyDeviceToHost, ln.stream));
+    FS_HIP(hipStreamSynchronize(ln.stream));
   }
   return FS_OK;
 }
@@ -636,12 +653,12 @@ extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, doub
   hipStream_t s = ix->stream;
   const int tpl = fs_scan_tpl(ix, c->n_tok);
   const uint32_t n_bm = (uint32_t)((c->n_tok + 64 * tpl - 1) / (64 * tpl));
-  FS_TRY(ix->w_qbm.reserve((size_t)n_bm * tpl));
-  FS_TRY(ix->w_qcnt.reserve(n_bm));
-  FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));   // warm
+  FS_TRY(ix->cur->w_qbm.reserve((size_t)n_bm * tpl));
+  FS_TRY(ix->cur->w_qcnt.reserve(n_bm));
+  FS_TRY(fs_launch_scan(ix, c->dev(), ix->cur->w_qbm.p, ix->cur->w_qcnt.p, n_bm, s));   // warm
   FS_HIP(hipEventRecord(ix->ev_scan0, s));
   for (uint32_t r = 0; r < reps; ++r)
-    FS_TRY(fs_launch_scan(ix, c->dev(), ix->w_qbm.p, ix->w_qcnt.p, n_bm, s));
+    FS_TRY(fs_launch_scan(ix, c->dev(), ix->cur->w_qbm.p, ix->cur->w_qcnt.p, n_bm, s));
   FS_HIP(hipEventRecord(ix->ev_scan1, s));
   FS_HIP(hipStreamSynchronize(s));
   float ms = 0;

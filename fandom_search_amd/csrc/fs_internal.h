@@ -11,6 +11,7 @@
 
 #define FS_MAX_WINDOW 16          // n <= 16: at most 4 neighbour vectors of halo
 #define FS_NONE 0xFFFFFFFFu
+#define FS_LANES 2
 #define FS_SEARCH_SLOTS 4         // searches that may be in flight on one index
 #define FS_LEV_MAX 512            // code points per side handled by lev_device
 
@@ -150,12 +151,22 @@ struct fs_index {
   bool lsh_ready = false;
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors
 
-  // workspaces (grow on demand)
-  DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
-  DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
-  DBuf<fs_best> w_cbest;
-  DBuf<fs_row> w_rows;
-  DBuf<fs_status> d_status;
+  // Two lanes, each a stream with its own workspaces (grown on demand) and status
+  // block.  Consecutive searches alternate between them, so the latency-bound
+  // verify / rows chain of one search runs beside the scan of the next.  `cur` is
+  // the lane the launchers enqueue into (host-side, set by search_enqueue); `stream`
+  // is lane 0's stream, used by everything that is not a search.
+  struct Lane {
+    hipStream_t stream = nullptr;
+    DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
+    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
+    DBuf<fs_best> w_cbest;
+    DBuf<fs_row> w_rows;
+    DBuf<fs_status> d_status;
+  };
+  Lane lanes[FS_LANES];
+  Lane* cur = &lanes[0];
+  int n_lanes = FS_LANES;
   fs_status* h_status = nullptr;   // pinned
 
   // searches in flight (fs_search_corpus_begin / _end)
@@ -171,6 +182,7 @@ struct fs_index {
     uint32_t n_bm = 0, launches = 0;
     bool timed = false;               // this search's scan carries timing events
     int tpl = 4;                      // tokens per lane of the bitmap layout
+    int lane = 0;                     // the lane (stream + workspaces) it was queued on
   };
   Slot slots[FS_SEARCH_SLOTS];
   uint32_t next_slot = 0;

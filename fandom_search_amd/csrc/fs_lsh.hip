@@ -700,11 +700,11 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
 
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s) {
   const LshDev L = lsh_dev(ix);
-  fs_status* st = ix->d_status.p;
+  fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
-                     ix->w_cpos.p, nc, ix->w_cg.p, ix->w_cw.p, ix->w_cbest.p,
-                     ix->w_bsum.p + kNB, st);
+                     ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
+                     ix->cur->w_bsum.p + kNB, st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

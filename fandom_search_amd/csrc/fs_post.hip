@@ -599,7 +599,7 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   if (total) {
     const uint32_t blocks = (uint32_t)((total + 3) / 4);
     hipLaunchKernelGGL(k_levtab, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s,
-                       ix->gram_dev(), c->dev(), c->d_levtab.p, ix->d_status.p);
+                       ix->gram_dev(), c->dev(), c->d_levtab.p, ix->cur->d_status.p);
     const uint32_t gb = (ix->n_grams + 255) / 256;
     hipLaunchKernelGGL(k_gbest, dim3(gb > 1024 ? 1024 : gb), dim3(256), 0, s, ix->gram_dev(),
                        c->d_levtab.p, c->d_gbest.p);
@@ -611,17 +611,17 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 // bitmap + counts -> candidate positions (w_cpos), n_cands in the status block
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
                      bool verify, hipStream_t s) {
-  uint32_t* bsum32 = ix->w_bsum.p;
+  uint32_t* bsum32 = ix->cur->w_bsum.p;
   hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
-                     SubTileCountF{ix->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
-                     ix->d_status.p);
+                     SubTileCountF{ix->cur->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
+                     ix->cur->d_status.p);
   const CorpusDev cd = c->dev();
   const GramIndexDev g = ix->gram_dev();
-  uint32_t* bmatch = ix->w_bsum.p + kNB;
+  uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
 #define FS_EXPAND(T, V)                                                                      \
-  hipLaunchKernelGGL((k_expand<T, V>), dim3(kNB), dim3(kThreads), 0, s, ix->w_qbm.p,         \
-                     ix->w_qcnt.p, n_sub, bsum32, ix->w_cpos.p, ccap, ix->d_status.p, cd, g, \
-                     ix->w_cg.p, ix->w_cw.p, bmatch)
+  hipLaunchKernelGGL((k_expand<T, V>), dim3(kNB), dim3(kThreads), 0, s, ix->cur->w_qbm.p,         \
+                     ix->cur->w_qcnt.p, n_sub, bsum32, ix->cur->w_cpos.p, ccap, ix->cur->d_status.p, cd, g, \
+                     ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch)
   if (tpl == 8) { if (verify) FS_EXPAND(8, true); else FS_EXPAND(8, false); }
   else { if (verify) FS_EXPAND(4, true); else FS_EXPAND(4, false); }
 #undef FS_EXPAND
@@ -642,19 +642,19 @@ int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows,
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
                    hipStream_t s) {
-  fs_status* st = ix->d_status.p;
+  fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
-  uint32_t* bmatch = ix->w_bsum.p + kNB;
-  uint64_t* bsum64 = ix->w_bsum64.p;
+  uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
+  uint64_t* bsum64 = ix->cur->w_bsum64.p;
   hipLaunchKernelGGL(k_hitrows, dim3(kNB), dim3(kThreads), 0, s,
-                     HitRowsF{ix->w_cpos.p, ix->w_cg.p, ix->cfg.window_size}, nc, ix->w_hv.p, bsum64);
+                     HitRowsF{ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cfg.window_size}, nc, ix->cur->w_hv.p, bsum64);
   if (packed)
     hipLaunchKernelGGL(k_rows<true>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
-                       ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
+                       ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p, bsum64, bmatch, best_tab,
                        best_per_cand, nc, rcap, d_rows, st, host_st);
   else
     hipLaunchKernelGGL(k_rows<false>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
-                       ix->w_cpos.p, ix->w_cg.p, ix->w_cw.p, ix->w_hv.p, bsum64, bmatch, best_tab,
+                       ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p, bsum64, bmatch, best_tab,
                        best_per_cand, nc, rcap, d_rows, st, host_st);
   FS_HIP(hipGetLastError());
   return FS_OK;
@@ -665,8 +665,8 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
                    hipStream_t s) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
-  fs_status* st = ix->d_status.p;
-  uint32_t* bmatch = ix->w_bsum.p + kNB;
+  fs_status* st = ix->cur->d_status.p;
+  uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
   const uint32_t nn = ix->cfg.nearest_n;
   const bool per_cand = c->has_str;
 
@@ -677,16 +677,16 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s));
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   if (!fused)
-    hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->w_cpos.p, nc,
-                       ix->w_cg.p, ix->w_cw.p, bmatch);
+    hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,
+                       ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
   if (per_cand) {
     const NSrc nc_nn{&st->n_cands, nn, ccap, 0};
-    hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->w_cpos.p,
-                       ix->w_cg.p, nc_nn, ix->w_mlev.p, st);
-    hipLaunchKernelGGL(k_cbest, dim3(kNB), dim3(kThreads), 0, s, g, ix->w_cg.p, ix->w_mlev.p, nc,
-                       ix->w_cbest.p);
+    hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->cur->w_cpos.p,
+                       ix->cur->w_cg.p, nc_nn, ix->cur->w_mlev.p, st);
+    hipLaunchKernelGGL(k_cbest, dim3(kNB), dim3(kThreads), 0, s, g, ix->cur->w_cg.p, ix->cur->w_mlev.p, nc,
+                       ix->cur->w_cbest.p);
   }
   FS_HIP(hipGetLastError());
-  return fs_launch_rows(ix, c, per_cand ? ix->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
+  return fs_launch_rows(ix, c, per_cand ? ix->cur->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
                         rcap, d_rows, packed, host_st, s);
 }
