@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="c2",
                     help="per-rank shard: c2 (default), c3shard, c3, c1")
     ap.add_argument("--works", type=int, default=0, help="override works per rank")
@@ -48,6 +48,8 @@ def parse():
                     help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: every rank "
                          "computes on GPU 0, rows gathered through host memory)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="searches kept in flight (the library overlaps them on its lanes)")
     ap.add_argument("--no-reference-shaped", action="store_true",
                     help="skip the Python reference-shaped leg of cpu_baseline")
     return ap.parse_args()
@@ -226,7 +228,7 @@ def main():
     # Software pipeline over NB row buffers: the search of step i is queued while
     # the GPU still finishes step i-1 (fs_search_corpus_begin / _end), and with more
     # than one rank the gather of step i-1 runs beside the search of step i.
-    NB = 3
+    NB = args.inflight + 1
     while len(bufs) < NB:
         bufs.append(row_buffer())
     if world > 1 and rank == 0:
@@ -279,8 +281,8 @@ def main():
         b = i % NB
         finish(b)
         tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr() + HDR, cap, packed=packed), b)
-        if i - 1 in tickets:
-            complete(i - 1)
+        if i - (args.inflight - 1) in tickets:
+            complete(i - (args.inflight - 1))
 
     def drain():
         for i in sorted(tickets):
@@ -343,7 +345,11 @@ def main():
         scan_avg_ms = float(np.mean(scan_ms))
         exact = st.path == abi.FS_MODE_EXACT
         if exact:
-            kernel = "k_scan<%d,U,shuffle>" % args.window
+            # fs_scan_tpl: eight tokens per lane (byte bitmap) while the ids fit 256 MiB
+            if corpus.n_tok * 4 <= (256 << 20) and 2 <= args.window <= 8:
+                kernel = "k_scan8<%d,1>" % args.window
+            else:
+                kernel = "k_scan<%d,4,shuffle,nt>" % args.window
             algo_bytes = 4.0 * corpus.n_tok       # 4 B per fan token
             note = "4 B per fan token"
         else:
@@ -384,8 +390,11 @@ def main():
                        "rows_per_gpu_step": int(total_rows),
                        "wire_record_bytes": rec_bytes if world > 1 else None,
                        "gather_verified": gather_verified,
-                       "pipeline": "search of step i queued while step i-1 completes "
-                                   "(fs_search_corpus_begin/_end, %d row buffers)" % NB,
+                       "pipeline": "%d searches in flight (fs_search_corpus_begin/_end, %d row "
+                                   "buffers); the library alternates them over %s lanes "
+                                   "(streams), so one search's verify/rows chain runs beside "
+                                   "the next one's scan" % (args.inflight, NB,
+                                                            os.environ.get("FS_LANES", "2")),
                        "gather": ("%s gather to rank 0, overlapped" % ("gloo (rehearsal)" if rehearsal
                                                                         else "rccl")) if world > 1 else "none",
                        "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh"},

@@ -67,6 +67,7 @@ fs_index::~fs_index() {
     if (sl.ev_scan0) (void)hipEventDestroy(sl.ev_scan0);
     if (sl.ev_scan1) (void)hipEventDestroy(sl.ev_scan1);
     if (sl.ev_end) (void)hipEventDestroy(sl.ev_end);
+    if (sl.ev_scan_done) (void)hipEventDestroy(sl.ev_scan_done);
     if (sl.h_status) (void)hipHostFree(sl.h_status);
   }
 }   // `stream` is lanes[0].stream
@@ -245,7 +246,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   for (int l = 0; l < FS_LANES; ++l)
     FS_HIP(hipStreamCreateWithFlags(&ix->lanes[l].stream, hipStreamNonBlocking));
   ix->stream = ix->lanes[0].stream;
-  if (const char* e = getenv("FS_LANES")) ix->n_lanes = atoi(e) >= 2 ? FS_LANES : 1;
+  if (const char* e = getenv("FS_LANES")) ix->n_lanes = std::min(FS_LANES, std::max(1, atoi(e)));
   FS_HIP(hipEventCreate(&ix->ev_scan0));      // fs_scan_benchmark
   FS_HIP(hipEventCreate(&ix->ev_scan1));
   FS_HIP(hipHostMalloc((void**)&ix->h_status, sizeof(fs_status), hipHostMallocDefault));
@@ -255,6 +256,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     FS_HIP(hipEventCreate(&sl.ev_scan0));
     FS_HIP(hipEventCreate(&sl.ev_scan1));
     FS_HIP(hipEventCreate(&sl.ev_end));
+    FS_HIP(hipEventCreateWithFlags(&sl.ev_scan_done, hipEventDisableTiming));
     FS_HIP(hipHostMalloc((void**)&sl.h_status, sizeof(fs_status), hipHostMallocDefault));
   }
   for (int l = 0; l < FS_LANES; ++l) {
@@ -511,16 +513,24 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
+  // Scans of different lanes do not run side by side (two scans would only halve each
+  // other's bandwidth): a search's scan is ordered behind the scan of the search
+  // queued before it.  What overlaps is a scan with the other lanes' chains.
+  const bool stagger = ix->n_lanes > 1 && ix->last_scan_ev && !getenv("FS_NO_STAGGER");
+  if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact) {
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+    FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+    FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
     FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
   }
   ++sl.launches;
+  ix->last_scan_ev = sl.ev_scan_done;
   FS_HIP(hipEventRecord(sl.ev_end, s));
   ix->cur = &ix->lanes[0];
   return FS_OK;

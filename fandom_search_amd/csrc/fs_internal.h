@@ -11,7 +11,8 @@
 
 #define FS_MAX_WINDOW 16          // n <= 16: at most 4 neighbour vectors of halo
 #define FS_NONE 0xFFFFFFFFu
-#define FS_LANES 2
+#define FS_LANES 4                // streams (with workspaces) searches are spread over; see fs_index::Lane
+#define FS_LANES_DEFAULT 2
 #define FS_SEARCH_SLOTS 4         // searches that may be in flight on one index
 #define FS_LEV_MAX 512            // code points per side handled by lev_device
 
@@ -166,12 +167,14 @@ struct fs_index {
   };
   Lane lanes[FS_LANES];
   Lane* cur = &lanes[0];
-  int n_lanes = FS_LANES;
+  hipEvent_t last_scan_ev = nullptr;   // scan of the most recently queued search
+  int n_lanes = FS_LANES_DEFAULT;
   fs_status* h_status = nullptr;   // pinned
 
   // searches in flight (fs_search_corpus_begin / _end)
   struct Slot {
     hipEvent_t ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_end = nullptr;
+    hipEvent_t ev_scan_done = nullptr;   // no timing: orders the next search's scan behind this one's
     fs_status* h_status = nullptr;    // pinned
     bool busy = false;
     fs_corpus* c = nullptr;
