@@ -184,12 +184,15 @@ int fs_search_corpus(fs_index* ix, fs_corpus* c,
                      fs_row* rows, uint64_t cap, int rows_on_device,
                      uint64_t* n_rows, fs_stats* st);
 
-/* The same in two halves: _begin queues the search on the index's stream and returns
- * a ticket, _end waits for it and delivers what fs_search_corpus delivers.  Up to
- * four searches may be in flight per index (they execute in order); the host can
- * queue the next batch while the GPU still works on the previous one.  Device
- * row modes only while another search is in flight; a corpus must not be updated
- * while a search on it is in flight. */
+/* The same in two halves: _begin queues the search and returns a ticket, _end waits
+ * for it and delivers what fs_search_corpus delivers.  Up to four searches may be in
+ * flight per index; consecutive ones go to alternating streams of the index, so the
+ * verify / rows chain of one runs beside the scan of the next (searches are
+ * independent: every one writes only its own rows buffer), and the host can queue
+ * the next batch while the GPU still works on the previous ones.  Device row modes
+ * only while another search is in flight; the rows buffers of searches in flight
+ * must be distinct; a corpus must not be updated while a search on it is in
+ * flight. */
 int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap,
                            int rows_mode, uint32_t* ticket);
 int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_rows, fs_stats* st);
