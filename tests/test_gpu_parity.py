@@ -287,3 +287,38 @@ def test_one_very_long_work(synth_base):
     inside = got[got["fan_ix"] < cut - 12]
     util.assert_rows_equal(inside, want[want["fan_ix"] < cut - 12])
     assert np.all(np.diff(got["fan_ix"].astype(np.int64)) > 0) and len(got) > 5000
+
+
+@pytest.mark.parametrize("mode", [abi.FS_MODE_AUTO, abi.FS_MODE_GENERAL])
+def test_overlapping_searches_stress(synth_base, mode):
+    """Searches alternate between the index's lanes (streams with their own
+    workspaces), so consecutive ones run side by side on the GPU.  Many rounds
+    of four searches in flight over corpora of different sizes, collected in
+    changing order, must reproduce the synchronous rows every time."""
+    import torch
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(6000)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config(mode=mode))
+    sizes = [(400, 2000), (40, 700), (900, 1500), (150, 3000)] if mode == abi.FS_MODE_AUTO else \
+            [(60, 900), (10, 400), (90, 700), (30, 1200)]
+    corpora, want = [], []
+    for k, (works, tokens) in enumerate(sizes):
+        tok, off = synth.corpus_tokens(works, tokens, script, first_work=1000 * k)
+        c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        corpora.append(c)
+        want.append(ix.search(c)[0])
+    bufs = [torch.zeros((len(w) + 8) * 32, dtype=torch.uint8, device="cuda") for w in want]
+    rounds = 25 if mode == abi.FS_MODE_AUTO else 6
+    for r in range(rounds):
+        order = [(r + j) % 4 for j in range(4)]
+        for b in bufs:
+            b.zero_()
+        tickets = {k: ix.search_begin(corpora[k], bufs[k].data_ptr(), len(want[k]) + 8) for k in order}
+        for k in reversed(order) if r % 2 else order:
+            n, st = ix.search_end(tickets[k])
+            assert n == len(want[k])
+            got = bufs[k].cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
+            assert got.tobytes() == want[k].tobytes(), (r, k)
+    ix.close()
