@@ -42,6 +42,8 @@ GramIndexDev fs_index::gram_dev() const {
   g.stok = d_stok.p; g.filter = d_filter.p; g.table = d_table.p; g.gpos = d_gpos.p;
   g.gcnt = d_gcnt.p; g.selfdist = d_selfdist.p; g.schars = d_schars.p; g.soff = d_soff.p;
   g.log2_words = log2_words; g.log2_slots = log2_slots;
+  g.tstride = (int)((2 + cfg.window_size + 3) & ~3u);
+  g.disp = d_disp.p; g.log2_buckets = log2_buckets;
   g.n = (int)cfg.window_size; g.nn = (int)cfg.nearest_n; g.n_grams = n_grams;
   return g;
 }
@@ -49,7 +51,7 @@ GramIndexDev fs_index::gram_dev() const {
 CorpusDev fs_corpus::dev() const {
   CorpusDev c;
   c.tok = d_tok.p; c.str = has_str ? d_str.p : nullptr; c.work_off = d_work_off.p;
-  c.blk_work = d_blk_work.p;
+  c.blk_work = reinterpret_cast<const uint2*>(d_blk_work.p);
   c.chars = d_chars.p; c.coff = d_coff.p;
   c.n_tok = (uint32_t)n_tok; c.n_works = (uint32_t)n_works; c.n_str = (uint32_t)n_str;
   return c;
@@ -116,17 +118,60 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
   ix->log2_words = lw;
   ix->log2_slots = std::max(4, ceil_log2((uint64_t)G * 2 + 1));
   if (ix->log2_slots > 31) { fs_set_error("script too large"); return FS_E_UNSUPPORTED; }
-  std::vector<uint32_t> filter(1u << lw, 0u), table((size_t)4 << ix->log2_slots, 0u);
+  const size_t ts = (2 + n + 3) & ~(size_t)3;       // words per table entry
+  std::vector<uint32_t> filter(1u << lw, 0u), table(ts << ix->log2_slots, 0u);
   const uint32_t slot_mask = (1u << ix->log2_slots) - 1;
+  // hash-and-displace (fs_hash.h): about four n-grams per bucket, largest buckets first
+  ix->log2_buckets = std::max(2, ceil_log2(std::max<uint64_t>(1, (uint64_t)G / 4)));
+  const uint32_t n_buckets = 1u << ix->log2_buckets;
+  std::vector<uint32_t> disp(n_buckets, 0u), ghash(G);
+  std::vector<std::vector<uint32_t>> members(n_buckets);
   for (uint32_t g = 0; g < G; ++g) {
-    const uint32_t h = fs_gram_hash(stok + gpos[(size_t)g * nn], (int)n);
-    filter[fs_bloom_word(h, lw)] |= fs_bloom_mask(h);
-    uint32_t slot = fs_table_slot(h, ix->log2_slots);
-    while (table[4 * (size_t)slot]) slot = (slot + 1) & slot_mask;
-    table[4 * (size_t)slot] = g + 1;            // {gram + 1, first position, kept occurrences, 0}
-    table[4 * (size_t)slot + 1] = gpos[(size_t)g * nn];
-    table[4 * (size_t)slot + 2] = gkept[g];
+    ghash[g] = fs_gram_hash(stok + gpos[(size_t)g * nn], (int)n);
+    filter[fs_bloom_word(ghash[g], lw)] |= fs_bloom_mask(ghash[g]);
+    members[fs_table_bucket(ghash[g], ix->log2_buckets)].push_back(g);
   }
+  auto put = [&](uint32_t g, uint32_t slot) {
+    uint32_t* e = &table[ts * slot];                // {gram + 1, kept occurrences, ids[n], pad}
+    e[0] = g + 1;
+    e[1] = gkept[g];
+    memcpy(e + 2, stok + gpos[(size_t)g * nn], n * sizeof(uint32_t));
+  };
+  std::vector<uint32_t> border(n_buckets);
+  for (uint32_t b = 0; b < n_buckets; ++b) border[b] = b;
+  std::stable_sort(border.begin(), border.end(), [&](uint32_t a, uint32_t b) {
+    return members[a].size() > members[b].size();
+  });
+  std::vector<uint32_t> overflow;                   // buckets left for linear probing
+  std::vector<uint32_t> trial;
+  for (uint32_t b : border) {
+    const std::vector<uint32_t>& mem = members[b];
+    if (mem.empty()) continue;
+    bool placed = false;
+    for (uint32_t d = 0; d < 4096 && !placed; ++d) {
+      trial.clear();
+      bool ok = true;
+      for (uint32_t g : mem) {
+        const uint32_t slot = fs_table_slot_d(ghash[g], d, ix->log2_slots);
+        if (table[ts * slot] || std::find(trial.begin(), trial.end(), slot) != trial.end()) { ok = false; break; }
+        trial.push_back(slot);
+      }
+      if (!ok) continue;
+      for (size_t i = 0; i < mem.size(); ++i) put(mem[i], trial[i]);
+      disp[b] = d;
+      placed = true;
+    }
+    if (!placed) overflow.push_back(b);
+  }
+  for (uint32_t b : overflow) {                     // after every separable bucket has its slots
+    disp[b] = FS_DISP_OVERFLOW;
+    for (uint32_t g : members[b]) {
+      uint32_t slot = fs_table_slot_d(ghash[g], 0, ix->log2_slots);
+      while (table[ts * slot]) slot = (slot + 1) & slot_mask;
+      put(g, slot);
+    }
+  }
+  FS_TRY(ix->d_disp.upload(disp.data(), disp.size(), ix->stream));
   FS_TRY(ix->d_filter.upload(filter.data(), filter.size(), ix->stream));
   FS_TRY(ix->d_table.upload(table.data(), table.size(), ix->stream));
   FS_TRY(ix->d_gpos.upload(gpos.data(), gpos.size(), ix->stream));
@@ -366,8 +411,9 @@ extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
   }
   FS_TRY(c->d_work_off.upload(work_off, n_works + 1, cs));
   const uint32_t n_blocks = (uint32_t)((T + 255) / 256);
-  FS_TRY(c->d_blk_work.reserve(n_blocks));
-  FS_TRY(fs_launch_blk_work(c->d_work_off.p, (uint32_t)n_works, n_blocks, c->d_blk_work.p, cs));
+  FS_TRY(c->d_blk_work.reserve(2 * (size_t)n_blocks));
+  FS_TRY(fs_launch_blk_work(c->d_work_off.p, (uint32_t)n_works, n_blocks,
+                            reinterpret_cast<uint2*>(c->d_blk_work.p), cs));
   FS_TRY(c->d_check.reserve(4));
   FS_HIP(hipMemsetAsync(c->d_check.p, 0, 4 * sizeof(uint32_t), cs));
   FS_TRY(fs_launch_corpus_check(c->d_tok.p, tok_str ? c->d_str.p : nullptr, (uint32_t)T,
@@ -508,8 +554,10 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
 
   // the status block is cleared by the chain's first kernel (k_reduce) and its final
   // state is written to sl.h_status by the last one (k_rows)
-  FS_HIP(hipEventRecord(sl.ev_begin, s));
+  // timing events only on timed searches: every event record is a barrier packet
+  // in the queue (about 1.5 us of bubble each)
   sl.timed = ix->scan_timing_period <= 1 || (ix->searches++ % ix->scan_timing_period) == 0;
+  if (sl.timed) FS_HIP(hipEventRecord(sl.ev_begin, s));
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
@@ -522,17 +570,17 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact) {
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
-    FS_HIP(hipEventRecord(sl.ev_scan_done, s));
+    if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
-    FS_HIP(hipEventRecord(sl.ev_scan_done, s));
+    if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
     FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
   }
   ++sl.launches;
-  ix->last_scan_ev = sl.ev_scan_done;
+  if (ix->n_lanes == 2) ix->last_scan_ev = sl.ev_scan_done;
   FS_HIP(hipEventRecord(sl.ev_end, s));
   ix->cur = &ix->lanes[0];
   return FS_OK;
@@ -599,7 +647,8 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     FS_HIP(hipEventSynchronize(sl.ev_end));
     scan_ms = 0;
     if (sl.n_bm && sl.timed) FS_HIP(hipEventElapsedTime(&scan_ms, sl.ev_scan0, sl.ev_scan1));
-    FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
+    total_ms = 0;
+    if (sl.timed) FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
     const fs_status& hs = *sl.h_status;
     if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }
     if (hs.lev_overflow) {

@@ -95,10 +95,14 @@ __global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict
 }
 
 
-// work of token p: start from the work of its 256-token block
-__device__ __forceinline__ uint32_t work_of_token(const CorpusDev& c, uint64_t p) {
-  uint32_t w = c.blk_work[p >> 8];
-  while (c.work_off[w + 1] <= p) ++w;
+// work of token p and the end of that work: one 8-byte read of the block table
+// unless a work boundary lies between the block's first token and p
+__device__ __forceinline__ uint32_t work_of_token(const CorpusDev& c, uint64_t p, uint64_t* end) {
+  const uint2 e = c.blk_work[p >> 8];
+  uint32_t w = e.x;
+  uint64_t we = e.y;
+  while (we <= p) { ++w; we = c.work_off[w + 1]; }
+  *end = we;
   return w;
 }
 

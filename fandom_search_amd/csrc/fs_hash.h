@@ -67,7 +67,17 @@ FS_HD uint32_t fs_bloom_test(uint32_t word, uint32_t h) {
   return (word >> (h & 31)) & (word >> ((h >> 8) & 31)) & (word >> ((h >> 13) & 31)) & 1u;
 }
 
-// slot of the exact (verification) table, 2^log2_slots entries
-FS_HD uint32_t fs_table_slot(uint32_t h, int log2_slots) {
-  return (h * 0xC2B2AE35u) >> (32 - log2_slots);
+// Exact (verification) table, hash-and-displace: 2^log2_buckets buckets, each with a
+// displacement seed d; an n-gram with hash h lives in slot fs_table_slot_d(h, d).
+// The seed of a bucket is chosen at build time so that all its n-grams fall into
+// free slots of their own.  FS_DISP_OVERFLOW marks a bucket that could not be
+// separated (different n-grams with the same 32-bit hash): its members were placed
+// by linear probing from their slot.
+#define FS_DISP_OVERFLOW 0x80000000u
+#define FS_DISP_MASK 0x7FFFFFFFu
+FS_HD uint32_t fs_table_bucket(uint32_t h, int log2_buckets) {
+  return (h * 0x85EBCA6Bu) >> (32 - log2_buckets);
+}
+FS_HD uint32_t fs_table_slot_d(uint32_t h, uint32_t d, int log2_slots) {
+  return ((h ^ (d * 0x9E3779B9u)) * 0xC2B2AE35u) >> (32 - log2_slots);
 }

@@ -12,7 +12,7 @@
 #define FS_MAX_WINDOW 16          // n <= 16: at most 4 neighbour vectors of halo
 #define FS_NONE 0xFFFFFFFFu
 #define FS_LANES 4                // streams (with workspaces) searches are spread over; see fs_index::Lane
-#define FS_LANES_DEFAULT 2
+#define FS_LANES_DEFAULT 1
 #define FS_SEARCH_SLOTS 4         // searches that may be in flight on one index
 #define FS_LEV_MAX 512            // code points per side handled by lev_device
 
@@ -91,7 +91,7 @@ struct alignas(16) fs_best {
 struct GramIndexDev {
   const uint32_t* stok;      // [n_script] script vector ids
   const uint32_t* filter;    // [1 << log2_words] blocked Bloom filter
-  const uint32_t* table;     // [1 << log2_slots][4] {gram id + 1 (0 = empty), first position, kept occurrences, 0}
+  const uint32_t* table;     // [1 << log2_slots][tstride] {gram id + 1 (0 = empty), kept occurrences, the n vector ids, pad}
   const uint32_t* gpos;      // [n_grams][nn] first <= nn script positions, ascending
   const uint32_t* gcnt;      // [n_grams] min(occurrences, nn)
   const double*   selfdist;  // [n_windows] canonical distance of a window to itself
@@ -99,6 +99,9 @@ struct GramIndexDev {
   const uint64_t* soff;      // [n_script + 1]
   int log2_words;
   int log2_slots;
+  int tstride;               // words per table entry: 2 + n rounded up to a multiple of 4
+  const uint32_t* disp;      // [1 << log2_buckets] displacement seed per bucket (fs_hash.h)
+  int log2_buckets;
   int n;                     // window size
   int nn;                    // NearestFilter N
   uint32_t n_grams;
@@ -108,7 +111,7 @@ struct CorpusDev {
   const uint32_t* tok;       // [n_tok + pad] vector ids
   const uint32_t* str;       // [n_tok] string ids or nullptr (== vector ids)
   const uint64_t* work_off;  // [n_works + 1]
-  const uint32_t* blk_work;  // [ceil(n_tok / 256)] work of token 256*i
+  const uint2* blk_work;     // [ceil(n_tok / 256)] {work of token 256*i, end of that work}
   const uint32_t* chars;     // fan-side string table
   const uint64_t* coff;      // [n_str + 1]
   uint32_t n_tok;
@@ -134,10 +137,10 @@ struct fs_index {
   fs_index_info info{};
   uint64_t n_script = 0, n_windows = 0, n_vec = 0;
   uint32_t n_grams = 0;
-  int log2_words = 0, log2_slots = 0;
+  int log2_words = 0, log2_slots = 0, log2_buckets = 0;
   int num_cu = 256;
 
-  DBuf<uint32_t> d_stok, d_filter, d_table, d_gpos, d_gcnt, d_schars;
+  DBuf<uint32_t> d_stok, d_filter, d_table, d_disp, d_gpos, d_gcnt, d_schars;
   DBuf<uint64_t> d_soff;
   DBuf<double> d_q, d_selfdist;
   DBuf<float> d_emb;
@@ -240,7 +243,7 @@ int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_r
                         uint64_t n_rows, uint64_t n_script, const double* d_thr, uint32_t n_thr,
                         uint32_t* d_counts, hipStream_t s);
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
-                       uint32_t* blk_work, hipStream_t s);
+                       uint2* blk_work, hipStream_t s);
 
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 

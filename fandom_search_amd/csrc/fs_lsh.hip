@@ -498,8 +498,9 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
     bool ok = p + L.n <= c.n_tok;
     uint32_t w = 0;
     if (ok) {
-      w = work_of_token(c, p);
-      ok = p + L.n <= c.work_off[w + 1];        // a window never crosses a work boundary
+      uint64_t work_end;
+      w = work_of_token(c, p, &work_end);
+      ok = p + L.n <= work_end;                 // a window never crosses a work boundary
     }
     if (!ok) {                                  // wave-uniform
       if (lane == 0) cg[i] = FS_NONE;

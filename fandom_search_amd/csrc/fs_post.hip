@@ -111,33 +111,46 @@ __device__ __forceinline__ uint32_t verify_window(const CorpusDev& c, const Gram
                                                   uint64_t p, uint32_t* w_out, uint32_t* kept) {
   if (p + g.n > c.n_tok) return FS_NONE;
   const uint32_t slot_mask = (1u << g.log2_slots) - 1;
-  // {gram + 1 (0 = empty), first position, occurrences kept, 0}
-  const uint4* table = reinterpret_cast<const uint4*>(g.table);
-  // two independent chains: ids -> table -> script ids, and block -> work
+  // two independent chains of two reads each: ids -> table entry (which carries the
+  // script n-gram's ids), and block -> work
   Ids16 f;
   load_ids(c.tok + p, g.n, &f);
-  const uint32_t w = work_of_token(c, p);
-  const bool inside = p + g.n <= c.work_off[w + 1];
+  uint64_t work_end;
+  const uint32_t w = work_of_token(c, p, &work_end);
+  const bool inside = p + g.n <= work_end;
   uint32_t h = 0;
 #pragma unroll
   for (int k = 0; k < FS_MAX_WINDOW; ++k)
     if (k < g.n) h ^= fs_rotl(fs_premix(f.v[k]), fs_rot_of(g.n - 1 - k));
-  uint32_t slot = fs_table_slot(h, g.log2_slots);
+  // hash-and-displace: the bucket's displacement seed sends every script n-gram of the
+  // bucket to a slot of its own, so one entry read decides (hit, or not a script
+  // n-gram).  Only buckets holding n-grams with identical 32-bit hashes carry the
+  // overflow flag and continue by linear probing.
+  const uint32_t d = g.disp[fs_table_bucket(h, g.log2_buckets)];
+  uint32_t slot = fs_table_slot_d(h, d & FS_DISP_MASK, g.log2_slots);
+  const int quads = g.tstride >> 2;              // 16-byte pieces of an entry: 2 (n <= 6) .. 5
   for (;;) {
-    const uint4 e = table[slot];
-    if (e.x == 0) return FS_NONE;
-    Ids16 sc;
-    load_ids(g.stok + e.y, g.n, &sc);
+    // {gram + 1 (0 = empty), occurrences kept, ids[n], pad}
+    const uint4* e = reinterpret_cast<const uint4*>(g.table + (size_t)slot * g.tstride);
+    uint32_t ew[20];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (q < quads) {
+        const uint4 t = e[q];
+        ew[4 * q] = t.x; ew[4 * q + 1] = t.y; ew[4 * q + 2] = t.z; ew[4 * q + 3] = t.w;
+      }
+    if (ew[0] == 0) return FS_NONE;
     bool same = true;
 #pragma unroll
     for (int k = 0; k < FS_MAX_WINDOW; ++k)
-      if (k < g.n) same = same && (sc.v[k] == f.v[k]);
+      if (k < g.n) same = same && (ew[2 + k] == f.v[k]);
     if (same) {
       if (!inside) return FS_NONE;
       *w_out = w;
-      *kept = e.z;
-      return e.x - 1;
+      *kept = ew[1];
+      return ew[0] - 1;
     }
+    if (!(d & FS_DISP_OVERFLOW)) return FS_NONE;
     slot = (slot + 1) & slot_mask;
   }
 }
@@ -507,9 +520,10 @@ __global__ void k_hist_cumulate(uint32_t* __restrict__ counts, uint64_t n_script
   for (uint32_t b = 0; b <= n_thr; ++b) { acc += c[b]; c[b] = acc; }
 }
 
-// work id of the first token of every 256-token block (corpus build time)
+// work of the first token of every 256-token block and where that work ends
+// (corpus build time)
 __global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_works,
-                           uint32_t n_blocks, uint32_t* __restrict__ blk_work) {
+                           uint32_t n_blocks, uint2* __restrict__ blk_work) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_blocks) return;
   const uint64_t p = (uint64_t)b * 256;
@@ -518,7 +532,7 @@ __global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_wor
     const uint32_t mid = lo + ((hi - lo) >> 1);
     if (work_off[mid] <= p) lo = mid; else hi = mid;
   }
-  blk_work[b] = lo;
+  blk_work[b] = make_uint2(lo, (uint32_t)work_off[lo + 1]);      // a batch holds < 2^32 tokens
 }
 
 // validation of an uploaded batch: largest embedding row id + 1, "any OOV id",
@@ -584,7 +598,7 @@ int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_r
 }
 
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
-                       uint32_t* blk_work, hipStream_t s) {
+                       uint2* blk_work, hipStream_t s) {
   if (!n_blocks || !n_works) return FS_OK;
   hipLaunchKernelGGL(k_blk_work, dim3((n_blocks + 255) / 256), dim3(256), 0, s, work_off, n_works,
                      n_blocks, blk_work);

@@ -322,3 +322,47 @@ def test_overlapping_searches_stress(synth_base, mode):
             got = bufs[k].cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
             assert got.tobytes() == want[k].tobytes(), (r, k)
     ix.close()
+
+
+def test_table_overflow_buckets_with_colliding_hashes(synth_base):
+    """The verification table is hash-and-displace; n-grams whose 32-bit hashes
+    are identical cannot be separated by a displacement seed and fall back to
+    linear probing inside an overflow bucket.  A long script of 2-grams holds
+    such pairs (checked here with the hash restated in numpy); rows must still
+    equal the oracle's."""
+    words, emb = synth_base["words"], synth_base["emb"]
+    rng = np.random.default_rng(5)
+    script = rng.integers(0, len(words), size=120_000).astype(np.uint32)
+    m = (script.astype(np.uint64) * 0x9E3779) & 0xFFFFFFFF
+    x = (((m[:-1] << 7) | (m[:-1] >> 25)) & 0xFFFFFFFF) ^ m[1:]
+    grams = np.unique(np.stack([script[:-1], script[1:]], axis=1), axis=0)
+    gm = (grams.astype(np.uint64) * 0x9E3779) & 0xFFFFFFFF
+    gx = (((gm[:, 0] << 7) | (gm[:, 0] >> 25)) & 0xFFFFFFFF) ^ gm[:, 1]
+    assert len(np.unique(gx)) < len(grams), "no colliding 2-gram hashes: pick another seed"
+    # fan works: random tokens with script spans planted, among them the colliding 2-grams
+    _, first, counts = np.unique(gx, return_index=True, return_counts=True)
+    dup_hash = gx[first[counts > 1]]
+    dup = grams[np.isin(gx, dup_hash)]
+    works = []
+    for w in range(12):
+        t = rng.integers(0, len(words), size=400).astype(np.uint32)
+        for _ in range(6):
+            a = int(rng.integers(0, len(script) - 12))
+            b = int(rng.integers(0, len(t) - 12))
+            t[b:b + 8] = script[a:a + 8]
+        for j, g in enumerate(dup[:40]):
+            t[10 + 9 * j:12 + 9 * j] = g
+        works.append(t)
+    off = np.zeros(len(works) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(t) for t in works])
+    tok = np.concatenate(works)
+    cfg = abi.make_config(window_size=2)
+    from fandom_search_amd.engine import ScriptIndex
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(2), cfg=cfg)
+    assert ix.info["path"] == abi.FS_MODE_EXACT
+    got, st = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
+    oi = util.oracle_index(cfg, script, words, emb, synth.lsh_normals(2), threads=8)
+    want, ost = oi.search(tok, off, synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and len(got) > 100
+    ix.close()
