@@ -33,7 +33,9 @@ class FsError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_PKG, LIB_NAME)
+    # FS_LIB_FILE: another build of the same library (A/B measurements of two builds
+    # in one GPU session); it must sit next to the regular one
+    return os.path.join(_PKG, os.path.basename(os.environ.get("FS_LIB_FILE", LIB_NAME)))
 
 
 def build(verbose=False):
