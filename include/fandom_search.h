@@ -187,10 +187,11 @@ int fs_search_corpus(fs_index* ix, fs_corpus* c,
 
 /* The same in two halves: _begin queues the search and returns a ticket, _end waits
  * for it and delivers what fs_search_corpus delivers.  Up to four searches may be in
- * flight per index; consecutive ones go to alternating streams of the index, so the
- * verify / rows chain of one runs beside the scan of the next (searches are
- * independent: every one writes only its own rows buffer), and the host can queue
- * the next batch while the GPU still works on the previous ones.  Device row modes
+ * flight per index, so the host can queue the next batch while the GPU still works
+ * on the previous ones.  With FS_LANES=2..4 in the environment consecutive searches
+ * go to alternating streams of the index and overlap on the GPU (the verify / rows
+ * chain of one beside the scan of the next; searches are independent, every one
+ * writes only its own rows buffer); by default they run in order.  Device row modes
  * only while another search is in flight; the rows buffers of searches in flight
  * must be distinct; a corpus must not be updated while a search on it is in
  * flight. */
