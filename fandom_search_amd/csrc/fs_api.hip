@@ -526,12 +526,13 @@ extern "C" void fs_corpus_destroy(fs_corpus* c) {
 
 // ---- search: enqueue / finish ---------------------------------------------------
 // A search is queued into one of FS_SEARCH_SLOTS slots and finished later; the
-// synchronous entry point is begin + end.  Slot i runs on lane i % 2 (a stream with
-// its own workspaces and device status block), so two consecutive searches overlap
-// on the GPU: the dependent-load chain after the scan leaves most of the machine
-// idle, and the next search's scan fills it.  Searches on the same lane run in
-// stream order; each one's status goes to its slot's pinned block (written by the
-// chain's last kernel).  FS_LANES=1 puts every search on one stream.
+// synchronous entry point is begin + end.  Slot i runs on lane i % n_lanes (a lane =
+// a stream with its own workspaces and device status block).  One lane by default:
+// searches run in queue order.  With FS_LANES=2..4 consecutive searches overlap on
+// the GPU: the dependent-load chain after the scan leaves most of the machine idle,
+// and the next search's scan fills it (DESIGN.md section 6 has the measured
+// trade-off).  Each search's status goes to its slot's pinned block, written by the
+// chain's last kernel.
 
 static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   fs_index::Lane& ln = ix->lanes[sl.lane];

@@ -155,11 +155,12 @@ struct fs_index {
   bool lsh_ready = false;
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors
 
-  // Two lanes, each a stream with its own workspaces (grown on demand) and status
-  // block.  Consecutive searches alternate between them, so the latency-bound
-  // verify / rows chain of one search runs beside the scan of the next.  `cur` is
-  // the lane the launchers enqueue into (host-side, set by search_enqueue); `stream`
-  // is lane 0's stream, used by everything that is not a search.
+  // Lanes: a stream with its own workspaces (grown on demand) and status block.
+  // Searches are spread over n_lanes of them (FS_LANES in the environment, default
+  // one); with more than one, the latency-bound verify / rows chain of a search runs
+  // beside the scan of the next.  `cur` is the lane the launchers enqueue into
+  // (host-side, set by search_enqueue); `stream` is lane 0's stream, used by
+  // everything that is not a search.
   struct Lane {
     hipStream_t stream = nullptr;
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
