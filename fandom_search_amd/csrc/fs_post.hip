@@ -179,29 +179,40 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
   uint32_t matches = 0;
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_base[SUBS];
-  uint32_t total;
-  uint32_t carry = block_prefix(bsum, s_w, &total);
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->n_cands = total;
   uint32_t lo, hi;
   chunk_of_block(n_sub, &lo, &hi);
   const int j = threadIdx.x % TPL, sl = threadIdx.x / TPL;
-  for (uint32_t t0 = lo; t0 < hi; t0 += SUBS) {
+  // loads of one tile: requested before the barriers of the prefix sums, so that
+  // they are in flight together with the partial sums
+  uint32_t cnt = 0;
+  uint64_t b[TPL] = {};
+  auto load_tile = [&](uint32_t t0) {
     const uint32_t sub = t0 + sl;
     const bool live = sub < hi;
-    const uint32_t cnt = (live && j == 0) ? qcnt[sub] : 0;
-    uint32_t tile_total;
-    const uint32_t ex = block_excl_scan(cnt, s_w, &tile_total);
-    if (j == 0) s_base[sl] = carry + ex;
-    __syncthreads();
+    cnt = (live && j == 0) ? qcnt[sub] : 0;
     if (live) {
       const uint4* w = reinterpret_cast<const uint4*>(qbm + (size_t)sub * TPL);   // 16-B aligned
-      uint64_t b[TPL];
 #pragma unroll
       for (int h = 0; h < TPL / 2; ++h) {
         const uint4 q = w[h];
         b[2 * h] = q.x | ((uint64_t)q.y << 32);
         b[2 * h + 1] = q.z | ((uint64_t)q.w << 32);
       }
+    }
+  };
+  if (lo < hi) load_tile(lo);
+  uint32_t total;
+  uint32_t carry = block_prefix(bsum, s_w, &total);
+  if (blockIdx.x == 0 && threadIdx.x == 0) st->n_cands = total;
+  for (uint32_t t0 = lo; t0 < hi; t0 += SUBS) {
+    if (t0 != lo) load_tile(t0);
+    const uint32_t sub = t0 + sl;
+    const bool live = sub < hi;
+    uint32_t tile_total;
+    const uint32_t ex = block_excl_scan(cnt, s_w, &tile_total);
+    if (j == 0) s_base[sl] = carry + ex;
+    __syncthreads();
+    if (live) {
       uint64_t mine = b[0];
 #pragma unroll
       for (int k = 1; k < TPL; ++k) mine = j == k ? b[k] : mine;
@@ -367,6 +378,12 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
   __shared__ uint64_t s_w[4];
   __shared__ uint32_t s_w32[4];
   __shared__ uint32_t s_roff[kThreads];
+  const uint32_t NC = nc.get();
+  const uint32_t n = g.n;
+  uint32_t lo, hi;
+  chunk_of_block(NC, &lo, &hi);
+  // first tile's values requested before the barriers of the prefix sums
+  uint64_t v_first = lo + threadIdx.x < hi ? hv[lo + threadIdx.x] : 0;
   uint64_t total;
   uint64_t carry = block_prefix(bsum, s_w, &total);
   if (blockIdx.x == 0) {
@@ -384,13 +401,9 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
       *host_st = out;
     }
   }
-  const uint32_t NC = nc.get();
-  const uint32_t n = g.n;
-  uint32_t lo, hi;
-  chunk_of_block(NC, &lo, &hi);
   for (uint32_t t0 = lo; t0 < hi; t0 += kThreads) {
     const uint32_t i = t0 + threadIdx.x;
-    const uint64_t v = i < hi ? hv[i] : 0;
+    const uint64_t v = t0 == lo ? v_first : (i < hi ? hv[i] : 0);
     uint64_t tile_total;
     const uint64_t ex = block_excl_scan(v, s_w, &tile_total);
     s_roff[threadIdx.x] = (uint32_t)(ex >> 32);
