@@ -547,6 +547,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   FS_TRY(ln.w_cg.reserve(sl.ccap));
   FS_TRY(ln.w_cw.reserve(sl.ccap));
   FS_TRY(ln.w_hv.reserve(sl.ccap));
+  FS_TRY(ln.w_hcomb.reserve(sl.ccap));
   FS_TRY(ln.w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
   FS_TRY(ln.w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
   fs_row* d_rows = sl.rows;

@@ -51,19 +51,16 @@ __device__ __forceinline__ V block_excl_scan(V v, V* s_w, V* total) {
   return base + inc - v;
 }
 
-// sum of the partial sums of all blocks before this one, and of all blocks
+// Sum of the partial sums of all blocks before this one: block b reads b values.
+// Kernels that also need the grand total are launched with kNB + 1 blocks; the
+// extra block (index kNB) has an empty chunk, its prefix is the total, and it does
+// the bookkeeping beside the others instead of in front of block 0's work.
 template <class V>
-__device__ __forceinline__ V block_prefix(const V* __restrict__ bsum, V* s_w, V* total) {
-  V pre = 0, all = 0;
-  for (int i = threadIdx.x; i < kNB; i += kThreads) {
-    const V x = bsum[i];
-    all += x;
-    if (i < (int)blockIdx.x) pre += x;
-  }
-  V t_all, t_pre;
-  block_excl_scan(all, s_w, &t_all);
+__device__ __forceinline__ V block_prefix(const V* __restrict__ bsum, V* s_w) {
+  V pre = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x && i < kNB; i += kThreads) pre += bsum[i];
+  V t_pre;
   block_excl_scan(pre, s_w, &t_pre);
-  *total = t_all;
   return t_pre;
 }
 

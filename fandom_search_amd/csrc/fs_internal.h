@@ -166,6 +166,7 @@ struct fs_index {
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
     DBuf<fs_best> w_cbest;
+    DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
     DBuf<fs_row> w_rows;
     DBuf<fs_status> d_status;
   };

@@ -76,13 +76,22 @@ struct HitRowsF {
 // (hits, records) partial sums; the per-candidate value is kept for k_rows so that
 // the backward walk is done once
 __global__ __launch_bounds__(kThreads) void k_hitrows(HitRowsF f, NSrc ns,
+                                                      const fs_best* __restrict__ best_tab,
+                                                      int best_per_cand,
                                                       uint64_t* __restrict__ hv,
+                                                      double* __restrict__ hcomb,
                                                       uint64_t* __restrict__ bsum) {
   __shared__ uint64_t s_w[4];
   uint32_t lo, hi;
   chunk_of_block(ns.get(), &lo, &hi);
   uint64_t acc = 0;
   for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
+    // what this candidate offers to the words it covers: the combined distance of its
+    // best rank, +inf when it is not a hit.  k_rows then walks 8-byte neighbours
+    // instead of chasing candidate -> n-gram -> 32-byte record for every covering hit.
+    const uint32_t gram = f.cg[i];
+    hcomb[i] = gram == FS_NONE ? __longlong_as_double(0x7FF0000000000000ll)
+                               : best_tab[best_per_cand ? i : gram].comb;
     const uint64_t v = f(i);
     hv[i] = v;
     acc += v;
@@ -201,9 +210,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
     }
   };
   if (lo < hi) load_tile(lo);
-  uint32_t total;
-  uint32_t carry = block_prefix(bsum, s_w, &total);
-  if (blockIdx.x == 0 && threadIdx.x == 0) st->n_cands = total;
+  uint32_t carry = block_prefix(bsum, s_w);
+  if (blockIdx.x == kNB && threadIdx.x == 0) st->n_cands = carry;    // the extra block: total
   for (uint32_t t0 = lo; t0 < hi; t0 += SUBS) {
     if (t0 != lo) load_tile(t0);
     const uint32_t sub = t0 + sl;
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
     // (window, script window) pairs of this block; summed by k_rows
     uint32_t tot;
     block_excl_scan(matches, s_w, &tot);
-    if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+    if (threadIdx.x == 0 && blockIdx.x < kNB) bmatch[blockIdx.x] = tot;
   }
 }
 
@@ -369,6 +377,7 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
                                                    const uint32_t* __restrict__ cg,
                                                    const uint32_t* __restrict__ cw,
                                                    const uint64_t* __restrict__ hv,
+                                                   const double* __restrict__ hcomb,
                                                    const uint64_t* __restrict__ bsum,
                                                    const uint32_t* __restrict__ bmatch,
                                                    const fs_best* __restrict__ best_tab,
@@ -384,9 +393,9 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
   chunk_of_block(NC, &lo, &hi);
   // first tile's values requested before the barriers of the prefix sums
   uint64_t v_first = lo + threadIdx.x < hi ? hv[lo + threadIdx.x] : 0;
-  uint64_t total;
-  uint64_t carry = block_prefix(bsum, s_w, &total);
-  if (blockIdx.x == 0) {
+  uint64_t carry = block_prefix(bsum, s_w);
+  if (blockIdx.x == kNB) {                 // the extra block: its prefix is the total
+    const uint64_t total = carry;
     uint32_t m = 0, mt;
     for (int i = threadIdx.x; i < kNB; i += kThreads) m += bmatch[i];
     block_excl_scan(m, s_w32, &mt);
@@ -430,24 +439,23 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
       const uint32_t next_off = a + 1 < kThreads ? s_roff[a + 1] : tile_rows;
       const uint32_t cnt = next_off - s_roff[a];
       const uint32_t x = p + n - cnt + k;          // global token position of the word
-      bool have = false;
-      fs_row out;
-      uint32_t koff = 0;
-      for (uint32_t j = own; j < NC; ++j) {
+      // first minimum of the combined distance over the hits covering x (candidates
+      // own, own+1, ... while they start at or before x; non-hits carry +inf)
+      uint32_t jbest = own, pbest = p;
+      double cbest = hcomb[own];
+      for (uint32_t j = own + 1; j < NC; ++j) {
         const uint32_t p2 = cpos[j];
         if (p2 > x) break;
-        const uint32_t gram = cg[j];
-        if (gram == FS_NONE) continue;
-        const fs_best bb = best_tab[best_per_cand ? j : gram];
-        if (!have || bb.comb < out.comb) {
-          have = true;
-          out.orig_ix = bb.s + (x - p2);
-          out.lev = bb.lev;
-          out.dist = bb.dist;
-          out.comb = bb.comb;
-          koff = x - p2;
-        }
+        const double cj = hcomb[j];
+        if (cj < cbest) { cbest = cj; jbest = j; pbest = p2; }
       }
+      const fs_best bb = best_tab[best_per_cand ? jbest : cg[jbest]];
+      fs_row out;
+      const uint32_t koff = x - pbest;
+      out.orig_ix = bb.s + koff;
+      out.lev = bb.lev;
+      out.dist = bb.dist;
+      out.comb = bb.comb;
       out.work = w;
       out.fan_ix = (uint32_t)((uint64_t)x - wbase);
       if (PACKED) {
@@ -646,7 +654,7 @@ int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, 
   const GramIndexDev g = ix->gram_dev();
   uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
 #define FS_EXPAND(T, V)                                                                      \
-  hipLaunchKernelGGL((k_expand<T, V>), dim3(kNB), dim3(kThreads), 0, s, ix->cur->w_qbm.p,         \
+  hipLaunchKernelGGL((k_expand<T, V>), dim3(kNB + 1), dim3(kThreads), 0, s, ix->cur->w_qbm.p,         \
                      ix->cur->w_qcnt.p, n_sub, bsum32, ix->cur->w_cpos.p, ccap, ix->cur->d_status.p, cd, g, \
                      ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch)
   if (tpl == 8) { if (verify) FS_EXPAND(8, true); else FS_EXPAND(8, false); }
@@ -674,15 +682,15 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
   uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
   uint64_t* bsum64 = ix->cur->w_bsum64.p;
   hipLaunchKernelGGL(k_hitrows, dim3(kNB), dim3(kThreads), 0, s,
-                     HitRowsF{ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cfg.window_size}, nc, ix->cur->w_hv.p, bsum64);
-  if (packed)
-    hipLaunchKernelGGL(k_rows<true>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
-                       ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p, bsum64, bmatch, best_tab,
-                       best_per_cand, nc, rcap, d_rows, st, host_st);
-  else
-    hipLaunchKernelGGL(k_rows<false>, dim3(kNB), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),
-                       ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p, bsum64, bmatch, best_tab,
-                       best_per_cand, nc, rcap, d_rows, st, host_st);
+                     HitRowsF{ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cfg.window_size}, nc, best_tab,
+                     best_per_cand, ix->cur->w_hv.p, ix->cur->w_hcomb.p, bsum64);
+#define FS_ROWS(P)                                                                           \
+  hipLaunchKernelGGL(k_rows<P>, dim3(kNB + 1), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),   \
+                     ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p,   \
+                     ix->cur->w_hcomb.p, bsum64, bmatch, best_tab, best_per_cand, nc, rcap,  \
+                     d_rows, st, host_st)
+  if (packed) FS_ROWS(true); else FS_ROWS(false);
+#undef FS_ROWS
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
