@@ -571,9 +571,12 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && !getenv("FS_NO_STAGGER");
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact) {
-    FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+    bool counted = false;
+    FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, ln.w_bsum.p,
+                          ln.d_status.p, &counted));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s,
+                          counted));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));

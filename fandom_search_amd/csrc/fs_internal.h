@@ -222,15 +222,17 @@ struct fs_corpus {
 // ---- kernel launchers (fs_scan.hip / fs_post.hip / fs_build.hip) ----------
 int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                    uint32_t n_bm_words, hipStream_t s, hipEvent_t e0 = nullptr,
-                   hipEvent_t e1 = nullptr);
+                   hipEvent_t e1 = nullptr, uint32_t* bsum = nullptr, fs_status* zero = nullptr,
+                   bool* counted = nullptr);
 uint32_t fs_scan_pad_tokens();
 int fs_scan_tpl(const fs_index* ix, uint64_t n_tok);   // tokens per lane (bitmap layout)
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
-                   uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st, hipStream_t s);
+                   uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st, hipStream_t s,
+                   bool counted);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
-                     bool verify, hipStream_t s);
+                     bool verify, hipStream_t s, bool counted = false);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
                    hipStream_t s);

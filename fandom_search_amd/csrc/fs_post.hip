@@ -644,12 +644,14 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 }
 
 // bitmap + counts -> candidate positions (w_cpos), n_cands in the status block
+// counted: the scan already wrote the chunk sums and cleared the status block
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
-                     bool verify, hipStream_t s) {
+                     bool verify, hipStream_t s, bool counted) {
   uint32_t* bsum32 = ix->cur->w_bsum.p;
-  hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
-                     SubTileCountF{ix->cur->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
-                     ix->cur->d_status.p);
+  if (!counted)
+    hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
+                       SubTileCountF{ix->cur->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
+                       ix->cur->d_status.p);
   const CorpusDev cd = c->dev();
   const GramIndexDev g = ix->gram_dev();
   uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
@@ -697,7 +699,7 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
                    uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
-                   hipStream_t s) {
+                   hipStream_t s, bool counted) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->cur->d_status.p;
@@ -709,7 +711,7 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   // (110 vs 84 us per C2 step): the thread that decodes a ballot word then runs the
   // dependent-load chain of each of its candidates one after the other.
   const bool fused = getenv("FS_POST_FUSED") != nullptr;
-  FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s));
+  FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s, counted));
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   if (!fused)
     hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,

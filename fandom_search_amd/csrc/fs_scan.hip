@@ -22,9 +22,12 @@
 // happens downstream on the (rare) flagged windows.  Algorithmic HBM traffic:
 // 4 B read per token + 36 B written per 256 tokens.
 #include "fs_internal.h"
+#include "fs_device.h"
 
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+
+#include <algorithm>
 
 namespace {
 
@@ -260,14 +263,37 @@ __device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint3
   return flags;
 }
 
-template <int N, int U, bool NT, bool LW14>
+// Work assignment: the expand kernel that follows cuts the sub-tiles into kNB chunks
+// and needs the candidate count of every chunk.  Workgroup b therefore takes the
+// kChunksPerBlock consecutive chunks [4b, 4b+4) (its 16 waves interleaved over their
+// sub-tiles: 160 KB of ids per workgroup on C2), adds the sub-tile counts of each chunk
+// in LDS and writes the four sums itself: no counting kernel between scan and expand,
+// no global atomics.  Workgroup 0 also clears the search's status block.
+constexpr int kScanBlocks = 512;
+constexpr int kChunksPerBlock = fsdev::kNB / kScanBlocks;
+
+template <int N, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok, uint32_t n_tok,
                                                 const uint32_t* __restrict__ filter,
                                                 int log2_words, uint64_t* __restrict__ qbm,
-                                                uint32_t* __restrict__ qcnt,
-                                                uint32_t n_bm_words, uint32_t n_tiles) {
+                                                uint32_t* __restrict__ qcnt, uint32_t n_sub,
+                                                uint32_t chunk, uint32_t* __restrict__ bsum,
+                                                fs_status* __restrict__ zero) {
   static_assert(N <= 9, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
+  __shared__ uint32_t s_csum[kChunksPerBlock];
+  if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
+    zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
+    zero->reserved0 = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
+  }
+  const uint32_t span = chunk * kChunksPerBlock;               // sub-tiles of this workgroup
+  const uint64_t first64 = (uint64_t)blockIdx.x * span;
+  if (first64 >= n_sub) {                                      // nothing to scan: empty chunks
+    if (bsum && threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = 0;
+    return;
+  }
+  const uint32_t first = (uint32_t)first64;
+  if (threadIdx.x < kChunksPerBlock) s_csum[threadIdx.x] = 0;
   {
     const uint32_t vecs = (1u << log2_words) / 4;
     const uint4* src = reinterpret_cast<const uint4*>(filter);
@@ -279,61 +305,62 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   constexpr int SUB = 512;
   const int word_shift = 32 - log2_words;
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t wave = threadIdx.x >> 6;
   const int src = (lane + 1) & 63;
   uint32_t mask_fffc = 0xFFFCu;
   asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
   uint8_t* bm_bytes = reinterpret_cast<uint8_t*>(qbm);
 
-  for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-    const uint32_t base = tile * (uint32_t)(SUB * U);
-    uint4 v[U + 1][2];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint4* p = reinterpret_cast<const uint4*>(tok + base + u * SUB + 8 * lane);
+  for (uint32_t i = wave; i < span; i += 16) {
+    const uint32_t sub = first + i;
+    if (sub >= n_sub) break;
+    const uint32_t base = sub * (uint32_t)SUB;
+    uint4 v[2][2];
+    {
+      const uint4* p = reinterpret_cast<const uint4*>(tok + base + 8 * lane);
       if constexpr (NT) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          v[u][h].x = __builtin_nontemporal_load(&p[h].x); v[u][h].y = __builtin_nontemporal_load(&p[h].y);
-          v[u][h].z = __builtin_nontemporal_load(&p[h].z); v[u][h].w = __builtin_nontemporal_load(&p[h].w);
+          v[0][h].x = __builtin_nontemporal_load(&p[h].x); v[0][h].y = __builtin_nontemporal_load(&p[h].y);
+          v[0][h].z = __builtin_nontemporal_load(&p[h].z); v[0][h].w = __builtin_nontemporal_load(&p[h].w);
         }
       } else {
-        v[u][0] = p[0]; v[u][1] = p[1];
+        v[0][0] = p[0]; v[0][1] = p[1];
       }
     }
-    {  // first eight tokens of the next tile, needed by lane 63 only (the buffer is padded)
-      const uint4* p = reinterpret_cast<const uint4*>(tok + base + U * SUB);
-      v[U][0] = p[0]; v[U][1] = p[1];
+    {  // first eight tokens of the next sub-tile, needed by lane 63 only (the buffer is padded)
+      const uint4* p = reinterpret_cast<const uint4*>(tok + base + SUB);
+      v[1][0] = p[0]; v[1][1] = p[1];
     }
+    uint32_t a[16];
+    a[0] = v[0][0].x; a[1] = v[0][0].y; a[2] = v[0][0].z; a[3] = v[0][0].w;
+    a[4] = v[0][1].x; a[5] = v[0][1].y; a[6] = v[0][1].z; a[7] = v[0][1].w;
+    // halo: first HALO tokens of lane L+1; lane 0 publishes the next sub-tile's
+    const bool wrap = lane == 0;
+    const uint32_t n0[8] = {wrap ? v[1][0].x : v[0][0].x, wrap ? v[1][0].y : v[0][0].y,
+                            wrap ? v[1][0].z : v[0][0].z, wrap ? v[1][0].w : v[0][0].w,
+                            wrap ? v[1][1].x : v[0][1].x, wrap ? v[1][1].y : v[0][1].y,
+                            wrap ? v[1][1].z : v[0][1].z, wrap ? v[1][1].w : v[0][1].w};
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      uint32_t a[16];
-      a[0] = v[u][0].x; a[1] = v[u][0].y; a[2] = v[u][0].z; a[3] = v[u][0].w;
-      a[4] = v[u][1].x; a[5] = v[u][1].y; a[6] = v[u][1].z; a[7] = v[u][1].w;
-      // halo: first HALO tokens of lane L+1; lane 0 publishes the next sub-tile's
-      const bool wrap = lane == 0;
-      const uint32_t n0[8] = {wrap ? v[u + 1][0].x : v[u][0].x, wrap ? v[u + 1][0].y : v[u][0].y,
-                              wrap ? v[u + 1][0].z : v[u][0].z, wrap ? v[u + 1][0].w : v[u][0].w,
-                              wrap ? v[u + 1][1].x : v[u][1].x, wrap ? v[u + 1][1].y : v[u][1].y,
-                              wrap ? v[u + 1][1].z : v[u][1].z, wrap ? v[u + 1][1].w : v[u][1].w};
+    for (int h = 0; h < HALO; ++h) a[8 + h] = __shfl(n0[h], src);
 #pragma unroll
-      for (int h = 0; h < HALO; ++h) a[8 + h] = __shfl(n0[h], src);
-#pragma unroll
-      for (int i = 0; i < 8 + HALO; ++i) a[i] = fs_premix(a[i]);
-      const uint32_t p0 = base + u * SUB + 8 * lane;
-      uint32_t flags;
-      if (base + (uint32_t)(SUB * U) + HALO > n_tok)
-        flags = window_flags8<N, true, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
-      else
-        flags = window_flags8<N, false, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
-      const uint32_t word = tile * U + u;                     // sub-tile index, wave-uniform
-      if (word < n_bm_words) {
-        bm_bytes[(size_t)word * 64 + lane] = (uint8_t)flags;
-        const uint32_t cnt = wave_sum_lane63(__popc(flags));
-        if (lane == 63) qcnt[word] = cnt;
-      }
+    for (int k = 0; k < 8 + HALO; ++k) a[k] = fs_premix(a[k]);
+    const uint32_t p0 = base + 8 * lane;
+    uint32_t flags;
+    if (base + (uint32_t)SUB + HALO > n_tok)
+      flags = window_flags8<N, true, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
+    else
+      flags = window_flags8<N, false, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
+    bm_bytes[(size_t)sub * 64 + lane] = (uint8_t)flags;
+    const uint32_t cnt = wave_sum_lane63(__popc(flags));
+    if (lane == 63) {
+      qcnt[sub] = cnt;
+      if (cnt) atomicAdd(&s_csum[i / chunk], cnt);               // LDS
     }
+  }
+  if (bsum) {
+    __syncthreads();
+    if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = s_csum[threadIdx.x];
   }
 }
 
@@ -400,39 +427,33 @@ int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   return FS_OK;
 }
 
-template <int N, int U, bool NT>
+template <int N, bool NT>
 int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  const uint32_t tile_tok = 512 * U;
-  const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
-  if (n_tiles == 0) return FS_OK;
+                  uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1, uint32_t* bsum,
+                  fs_status* zero) {
+  if (n_bm_words == 0 && !bsum) return FS_OK;
   const size_t lds = (size_t)4 << ix->log2_words;
-  uint32_t blocks_per_cu = lds <= 64 * 1024 ? 2 : 1;
-  uint32_t blocks = (n_tiles + 15) / 16;
-  if (blocks > ix->num_cu * blocks_per_cu) blocks = ix->num_cu * blocks_per_cu;
-  auto kern = ix->log2_words == 14 ? k_scan8<N, U, NT, true> : k_scan8<N, U, NT, false>;
+  // the expand kernel's chunking (chunk_of_block): kNB chunks of `chunk` sub-tiles
+  const uint32_t chunk = std::max<uint32_t>(1, (n_bm_words + fsdev::kNB - 1) / fsdev::kNB);
+  auto kern = ix->log2_words == 14 ? k_scan8<N, NT, true> : k_scan8<N, NT, false>;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
+  hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
                         c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
-                        n_bm_words, n_tiles);
+                        n_bm_words, chunk, bsum, zero);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 template <int N>
 int launch_tpl8(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1, uint32_t* bsum,
+                fs_status* zero) {
   const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
-  int unroll = big ? 2 : 1;
-  if (const char* u = getenv("FS_SCAN_UNROLL")) unroll = atoi(u) >= 4 ? 2 : 1;
   const char* e = getenv("FS_SCAN_FLAGS");
   const bool nt = (e && e[0] == 'n') || (!e && big);
-  if (unroll == 2)
-    return nt ? launch_tpl8_k<N, 2, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1)
-              : launch_tpl8_k<N, 2, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-  return nt ? launch_tpl8_k<N, 1, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1)
-            : launch_tpl8_k<N, 1, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+  return nt ? launch_tpl8_k<N, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero)
+            : launch_tpl8_k<N, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
 }
 
 template <int N, int U, bool HL>
@@ -492,8 +513,13 @@ int fs_scan_tpl(const fs_index* ix, uint64_t n_tok) {
 // tile loads of the last wave never leave the allocation
 uint32_t fs_scan_pad_tokens() { return 512 * 8 + 64; }
 
+// bsum / zero / counted (optional): the eight-tokens-per-lane kernel also writes the
+// expand kernel's kNB chunk sums to bsum and clears *zero, and reports that through
+// *counted; the other kernels leave both to k_reduce (fs_launch_expand).
 int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1, uint32_t* bsum,
+                   fs_status* zero, bool* counted) {
+  if (counted) *counted = false;
   const int n = ix->cfg.window_size;
   const char* var = getenv("FS_SCAN_VARIANT");
   const bool simple = var && var[0] == 's';
@@ -505,13 +531,13 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   if (const char* h = getenv("FS_SCAN_HALO")) halo_loads = h[0] == 'l';   // "loads"
   if (fs_scan_tpl(ix, c.n_tok) == 8) {
     switch (n) {
-      case 2: return launch_tpl8<2>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 3: return launch_tpl8<3>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 4: return launch_tpl8<4>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 5: return launch_tpl8<5>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 6: return launch_tpl8<6>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 7: return launch_tpl8<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 8: return launch_tpl8<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+      case 2: if (counted) *counted = bsum != nullptr; return launch_tpl8<2>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 3: if (counted) *counted = bsum != nullptr; return launch_tpl8<3>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 4: if (counted) *counted = bsum != nullptr; return launch_tpl8<4>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 5: if (counted) *counted = bsum != nullptr; return launch_tpl8<5>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 6: if (counted) *counted = bsum != nullptr; return launch_tpl8<6>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 7: if (counted) *counted = bsum != nullptr; return launch_tpl8<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 8: if (counted) *counted = bsum != nullptr; return launch_tpl8<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
       default: break;
     }
   }
