@@ -541,8 +541,13 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   fs_corpus* c = sl.c;
   const uint32_t nn = ix->cfg.nearest_n;
   const uint32_t n_bm = sl.n_bm;
-  FS_TRY(ln.w_qbm.reserve((size_t)n_bm * sl.tpl));
-  FS_TRY(ln.w_qcnt.reserve(n_bm));
+  if (sl.capw) {                       // direct path: records instead of a bitmap
+    FS_TRY(ln.w_recs.reserve((size_t)FS_CHUNKS * 4 * sl.capw));
+    FS_TRY(ln.w_info.reserve((size_t)FS_CHUNKS * 4));
+  } else {
+    FS_TRY(ln.w_qbm.reserve((size_t)n_bm * sl.tpl));
+    FS_TRY(ln.w_qcnt.reserve(n_bm));
+  }
   FS_TRY(ln.w_cpos.reserve(sl.ccap));
   FS_TRY(ln.w_cg.reserve(sl.ccap));
   FS_TRY(ln.w_cw.reserve(sl.ccap));
@@ -571,12 +576,12 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && !getenv("FS_NO_STAGGER");
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact) {
-    bool counted = false;
-    FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, ln.w_bsum.p,
-                          ln.d_status.p, &counted));
+    fs_scan_extra ex;
+    ex.bsum = ln.w_bsum.p; ex.zero = ln.d_status.p;
+    if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
+    FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s,
-                          counted));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s, ex));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
@@ -627,6 +632,13 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
                  "function of the matched script window)");
     return FS_E_UNSUPPORTED;
   }
+  // direct path (the scan writes candidate records per wave range): 64 records per
+  // range to start with (C2 needs about 20), more once a search has asked for it
+  sl.capw = 0;
+  if (sl.exact && fs_scan_direct_ok(ix, T)) {
+    sl.capw = std::max<uint32_t>(64, ln.capw_hint);
+    if (const char* e = getenv("FS_SCAN_CAPW")) sl.capw = std::max(1, atoi(e));   // tests: force the growth path
+  }
   // capacities: grown from the device totals when a stage overflows
   sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ln.w_cpos.n);
   sl.rcap = rows_mode != FS_ROWS_HOST
@@ -662,6 +674,11 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     }
     bool again = false;
     if (hs.n_cands > sl.ccap) { sl.ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
+    if (sl.capw && hs.max_recs > sl.capw) {
+      sl.capw = (hs.max_recs + hs.max_recs / 4 + 7) & ~7u;
+      ix->lanes[sl.lane].capw_hint = sl.capw;
+      again = true;
+    }
     else if (sl.mode == FS_ROWS_HOST && hs.n_rows > sl.rcap && hs.n_rows <= sl.cap) {
       sl.rcap = hs.n_rows; again = true;
     }

@@ -4,7 +4,7 @@
 
 namespace fsdev {
 
-constexpr int kNB = 2048;        // blocks of every chunked kernel (and partial sums)
+constexpr int kNB = FS_CHUNKS;        // blocks of every chunked kernel (and partial sums)
 constexpr int kThreads = 256;
 
 struct NSrc {               // element count, known on the host or on the device
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict
   __shared__ V s_w[4];
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
     zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
-    zero->reserved0 = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
+    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
   }
   uint32_t lo, hi;
   chunk_of_block(ns.get(), &lo, &hi);

@@ -13,6 +13,7 @@
 #define FS_NONE 0xFFFFFFFFu
 #define FS_LANES 4                // streams (with workspaces) searches are spread over; see fs_index::Lane
 #define FS_LANES_DEFAULT 1
+#define FS_CHUNKS 2048             // = fsdev::kNB: chunks of the chained kernels (and partial sums)
 #define FS_SEARCH_SLOTS 4         // searches that may be in flight on one index
 #define FS_LEV_MAX 512            // code points per side handled by lev_device
 
@@ -71,7 +72,7 @@ struct fs_status {
   uint32_t n_hits;       // verified (window, n-gram) hits inside a work
   uint32_t n_matches;    // (window, script window) pairs
   uint32_t n_rows;       // output records
-  uint32_t reserved0;
+  uint32_t max_recs;     // direct path: largest record count of a wave range beyond its capacity
   uint32_t lev_overflow; // a Levenshtein operand exceeded FS_LEV_MAX
   uint32_t bad_string;   // string id outside the string table
   uint32_t pad;
@@ -165,6 +166,8 @@ struct fs_index {
     hipStream_t stream = nullptr;
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
+    DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
+    uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<fs_best> w_cbest;
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
     DBuf<fs_row> w_rows;
@@ -191,6 +194,7 @@ struct fs_index {
     bool timed = false;               // this search's scan carries timing events
     int tpl = 4;                      // tokens per lane of the bitmap layout
     int lane = 0;                     // the lane (stream + workspaces) it was queued on
+    uint32_t capw = 0;                // direct path: record capacity per wave range (0: bitmap path)
   };
   Slot slots[FS_SEARCH_SLOTS];
   uint32_t next_slot = 0;
@@ -220,16 +224,34 @@ struct fs_corpus {
 };
 
 // ---- kernel launchers (fs_scan.hip / fs_post.hip / fs_build.hip) ----------
+// What a scan launch may produce beyond the bitmap (eight-tokens-per-lane kernel only):
+//   bsum/zero  the FS_CHUNKS chunk sums the next kernel needs and a cleared status block
+//              -> counted: no counting kernel
+//   recs/info  the direct path.  A chunk is scanned by four waves, each over a contiguous
+//              quarter of its sub-tiles (a "wave range").  A lane that finds candidates
+//              among its eight windows appends ONE record {position/8 << 8 | flag byte,
+//              rank of its first candidate inside the wave range} to the wave range's
+//              list (capacity capw records); info[range] = {records, candidates}.
+//              -> direct: no bitmap in global memory, no expand kernel; block b of
+//              k_verify_direct takes chunk b, wave q its q-th wave range.
+struct fs_scan_extra {
+  uint32_t* bsum = nullptr;
+  fs_status* zero = nullptr;
+  uint2* recs = nullptr;
+  uint2* info = nullptr;
+  uint32_t capw = 0;
+  bool counted = false, direct = false;    // out
+};
 int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                    uint32_t n_bm_words, hipStream_t s, hipEvent_t e0 = nullptr,
-                   hipEvent_t e1 = nullptr, uint32_t* bsum = nullptr, fs_status* zero = nullptr,
-                   bool* counted = nullptr);
+                   hipEvent_t e1 = nullptr, fs_scan_extra* extra = nullptr);
+bool fs_scan_direct_ok(const fs_index* ix, uint64_t n_tok);   // the direct path applies
 uint32_t fs_scan_pad_tokens();
 int fs_scan_tpl(const fs_index* ix, uint64_t n_tok);   // tokens per lane (bitmap layout)
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
                    uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st, hipStream_t s,
-                   bool counted);
+                   const fs_scan_extra& scan);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
                      bool verify, hipStream_t s, bool counted = false);

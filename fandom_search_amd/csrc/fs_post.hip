@@ -290,6 +290,99 @@ __global__ __launch_bounds__(kThreads) void k_verify(CorpusDev c, GramIndexDev g
   if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
 }
 
+// Verification on the direct path (fs_scan_extra): the scan left, per wave range, a list
+// of records {(position / 8) << 8 | flag byte, rank of the first candidate in the range}
+// and info[range] = {records, candidates}.  Block b takes chunk b: its candidates start
+// at the sum of the chunk sums before it.  Stage 1 turns the chunk's records (four wave
+// ranges, back to back over the threads) into (position, index) pairs in LDS; stage 2
+// verifies one candidate per thread exactly like k_verify.  (Verifying inside the
+// record loop instead measured 36 us against 10 us: the staged form keeps full waves
+// on the dependent-load chains.)  Writes the dense per-candidate arrays of the later
+// kernels; the extra block publishes the total.
+// (launch bounds: all kNB blocks must be resident at once, i.e. eight waves per SIMD)
+__global__ __launch_bounds__(kThreads, 8) void k_verify_direct(CorpusDev c, GramIndexDev g,
+                                                            const uint32_t* __restrict__ bsum,
+                                                            const uint2* __restrict__ recs,
+                                                            const uint2* __restrict__ info,
+                                                            uint32_t capw, uint32_t ccap,
+                                                            uint32_t* __restrict__ cpos,
+                                                            uint32_t* __restrict__ cg,
+                                                            uint32_t* __restrict__ cw,
+                                                            uint32_t* __restrict__ bmatch,
+                                                            fs_status* st) {
+  __shared__ uint32_t s_w[4];
+  // requested before the barriers of the prefix sum
+  uint2 inf[4] = {};
+  if (blockIdx.x < kNB) {
+    const uint4* src = reinterpret_cast<const uint4*>(info + (size_t)blockIdx.x * 4);
+    const uint4 a = src[0], b = src[1];
+    inf[0] = make_uint2(a.x, a.y); inf[1] = make_uint2(a.z, a.w);
+    inf[2] = make_uint2(b.x, b.y); inf[3] = make_uint2(b.z, b.w);
+  }
+  const uint32_t base = block_prefix(bsum, s_w);
+  if (blockIdx.x == kNB) {                       // the extra block: its prefix is the total
+    if (threadIdx.x == 0) st->n_cands = base;
+    return;
+  }
+  // the records of the chunk's four wave ranges, back to back over the block's threads
+  uint32_t nr[4], roff[5], coff[4];
+  roff[0] = 0; coff[0] = base;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    nr[k] = inf[k].x;
+    if (nr[k] > capw) {                          // the host repeats the search with longer lists
+      if (threadIdx.x == 0) atomicMax(&st->max_recs, nr[k]);
+      nr[k] = capw;
+    }
+    roff[k + 1] = roff[k] + nr[k];
+    if (k < 3) coff[k + 1] = coff[k] + inf[k].y;
+  }
+  const uint2* lists = recs + (size_t)blockIdx.x * 4 * capw;
+  // stage 1: records -> positions of the chunk's candidates, in candidate order, in LDS
+  // (1024 at a time; a slot stays FS_NONE when its record did not fit the list)
+  __shared__ uint32_t s_p[1024];
+  const uint32_t n_c = coff[3] + inf[3].y - base;          // candidates of the chunk
+  uint32_t matches = 0;
+  for (uint32_t c0 = 0; c0 < n_c; c0 += 1024) {
+    const uint32_t m = n_c - c0 < 1024 ? n_c - c0 : 1024;
+    for (uint32_t t = threadIdx.x; t < m; t += kThreads) s_p[t] = FS_NONE;
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < roff[4]; t += kThreads) {
+      const int k = (t >= roff[1]) + (t >= roff[2]) + (t >= roff[3]);
+      const uint32_t r = t - (k == 0 ? 0u : k == 1 ? roff[1] : k == 2 ? roff[2] : roff[3]);
+      const uint32_t cb = k == 0 ? coff[0] : k == 1 ? coff[1] : k == 2 ? coff[2] : coff[3];
+      const uint2 rec = lists[(size_t)k * capw + r];
+      uint32_t flags = rec.x & 0xFFu;
+      const uint32_t p0 = (rec.x >> 8) << 3;
+      uint32_t li = cb + rec.y - base;                      // index inside the chunk
+      while (flags) {
+        const int bb = __ffs(flags) - 1;
+        flags &= flags - 1;
+        if (li >= c0 && li - c0 < m) s_p[li - c0] = p0 + (uint32_t)bb;
+        ++li;
+      }
+    }
+    __syncthreads();
+    // stage 2: one candidate per thread, as in k_verify.  Every index below the total
+    // is written (the later kernels read them all): a candidate whose record was cut
+    // off is marked as no hit, and the host repeats the search with longer lists.
+    for (uint32_t t = threadIdx.x; t < m; t += kThreads) {
+      const uint32_t i = base + c0 + t;
+      if (i >= ccap) continue;
+      const uint32_t p = s_p[t];
+      uint32_t w = 0, kept = 0, gram = FS_NONE;
+      if (p != FS_NONE) gram = verify_window(c, g, p, &w, &kept);
+      cpos[i] = p;
+      cg[i] = gram;
+      if (gram != FS_NONE) { cw[i] = w; matches += kept; }
+    }
+    __syncthreads();
+  }
+  uint32_t tot;
+  block_excl_scan(matches, s_w, &tot);
+  if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+}
+
 // Per (gram, rank) Levenshtein table for corpora whose string id == vector id:
 // the fan text of a hit is then a function of the gram alone.  One wave per entry.
 __global__ __launch_bounds__(256) void k_levtab(GramIndexDev g, CorpusDev c,
@@ -699,23 +792,29 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
                    uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
-                   hipStream_t s, bool counted) {
+                   hipStream_t s, const fs_scan_extra& scan) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->cur->d_status.p;
   uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
   const uint32_t nn = ix->cfg.nearest_n;
   const bool per_cand = c->has_str;
-
-  // Verifying inside k_expand (FS_POST_FUSED=1) saves a launch but measured slower
-  // (110 vs 84 us per C2 step): the thread that decodes a ballot word then runs the
-  // dependent-load chain of each of its candidates one after the other.
-  const bool fused = getenv("FS_POST_FUSED") != nullptr;
-  FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s, counted));
   const NSrc nc{&st->n_cands, 1, ccap, 0};
-  if (!fused)
-    hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,
-                       ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
+  if (scan.direct) {
+    // the scan wrote candidate records per wave range: no expand kernel
+    hipLaunchKernelGGL(k_verify_direct, dim3(kNB + 1), dim3(kThreads), 0, s, cd, g, scan.bsum,
+                       scan.recs, scan.info, scan.capw, ccap, ix->cur->w_cpos.p,
+                       ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch, st);
+  } else {
+    // Verifying inside k_expand (FS_POST_FUSED=1) saves a launch but measured slower
+    // (110 vs 84 us per C2 step): the thread that decodes a ballot word then runs the
+    // dependent-load chain of each of its candidates one after the other.
+    const bool fused = getenv("FS_POST_FUSED") != nullptr;
+    FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s, scan.counted));
+    if (!fused)
+      hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,
+                         ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
+  }
   if (per_cand) {
     const NSrc nc_nn{&st->n_cands, nn, ccap, 0};
     hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->cur->w_cpos.p,

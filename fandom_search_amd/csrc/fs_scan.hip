@@ -233,6 +233,18 @@ __device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x) {
   return x;
 }
 
+// inclusive prefix sum over the wave (four row_shr adds inside each row of 16 lanes,
+// then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+  return x;
+}
+
 template <int N, bool TAIL, bool LW14>
 __device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint32_t* s_filter,
                                                   int word_shift, uint32_t mask_fffc,
@@ -263,14 +275,21 @@ __device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint3
   return flags;
 }
 
-// Work assignment: the expand kernel that follows cuts the sub-tiles into kNB chunks
-// and needs the candidate count of every chunk.  Workgroup b therefore takes the
-// kChunksPerBlock consecutive chunks [4b, 4b+4) (its 16 waves interleaved over their
-// sub-tiles: 160 KB of ids per workgroup on C2), adds the sub-tile counts of each chunk
-// in LDS and writes the four sums itself: no counting kernel between scan and expand,
-// no global atomics.  Workgroup 0 also clears the search's status block.
+// Work assignment: the kernels that follow cut the sub-tiles into kNB chunks and need the
+// candidate count of every chunk.  Workgroup b takes the kChunksPerBlock consecutive
+// chunks [4b, 4b+4); inside a chunk each of four waves scans a contiguous quarter of the
+// sub-tiles (a "wave range", 10 KB of ids on C2).  The waves add their counts per chunk in
+// LDS and the workgroup writes the four sums: no counting kernel, no global atomics.
+// Workgroup 0 also clears the search's status block.
+//
+// Direct path (recs != nullptr): no bitmap leaves the kernel.  A lane whose eight windows
+// hold candidates appends one 8-byte record {(position / 8) << 8 | flag byte, rank of its
+// first candidate inside the wave range} to the wave range's list; ranks come from a wave
+// prefix sum of the flag popcounts (six DPP adds, in place of the wave sum) and the record
+// slot from a ballot.  k_verify_direct reads the lists: block = chunk, wave = wave range.
 constexpr int kScanBlocks = 512;
 constexpr int kChunksPerBlock = fsdev::kNB / kScanBlocks;
+static_assert(kChunksPerBlock * 4 == 16, "four waves per chunk, sixteen waves per workgroup");
 
 template <int N, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok, uint32_t n_tok,
@@ -278,21 +297,31 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
                                                 int log2_words, uint64_t* __restrict__ qbm,
                                                 uint32_t* __restrict__ qcnt, uint32_t n_sub,
                                                 uint32_t chunk, uint32_t* __restrict__ bsum,
-                                                fs_status* __restrict__ zero) {
+                                                fs_status* __restrict__ zero,
+                                                uint2* __restrict__ recs, uint2* __restrict__ info,
+                                                uint32_t capw) {
   static_assert(N <= 9, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   __shared__ uint32_t s_csum[kChunksPerBlock];
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
     zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
-    zero->reserved0 = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
+    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
   }
-  const uint32_t span = chunk * kChunksPerBlock;               // sub-tiles of this workgroup
-  const uint64_t first64 = (uint64_t)blockIdx.x * span;
-  if (first64 >= n_sub) {                                      // nothing to scan: empty chunks
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t kc = wave >> 2, q = wave & 3;                 // chunk of the workgroup, quarter
+  const uint32_t range_id = (blockIdx.x * kChunksPerBlock + kc) * 4 + q;
+  const uint32_t per = (chunk + 3) >> 2;                       // sub-tiles per wave range
+  const uint64_t chunk_first = ((uint64_t)blockIdx.x * kChunksPerBlock + kc) * chunk;
+  uint32_t j0 = q * per, j1 = j0 + per;
+  if (j1 > chunk) j1 = chunk;
+  if (j0 > j1) j0 = j1;
+  if (chunk_first + j1 > n_sub) j1 = chunk_first + j0 < n_sub ? (uint32_t)(n_sub - chunk_first) : j0;
+  if ((uint64_t)blockIdx.x * kChunksPerBlock * chunk >= n_sub) {   // nothing to scan: empty chunks
     if (bsum && threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = 0;
+    if (info && lane == 0) info[range_id] = make_uint2(0, 0);
     return;
   }
-  const uint32_t first = (uint32_t)first64;
   if (threadIdx.x < kChunksPerBlock) s_csum[threadIdx.x] = 0;
   {
     const uint32_t vecs = (1u << log2_words) / 4;
@@ -304,16 +333,15 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   constexpr int HALO = N - 1;
   constexpr int SUB = 512;
   const int word_shift = 32 - log2_words;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = threadIdx.x >> 6;
   const int src = (lane + 1) & 63;
   uint32_t mask_fffc = 0xFFFCu;
   asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
   uint8_t* bm_bytes = reinterpret_cast<uint8_t*>(qbm);
+  uint2* list = recs ? recs + (size_t)range_id * capw : nullptr;
+  uint32_t cand_run = 0, rec_run = 0;          // candidates / records of this wave range so far
 
-  for (uint32_t i = wave; i < span; i += 16) {
-    const uint32_t sub = first + i;
-    if (sub >= n_sub) break;
+  for (uint32_t j = j0; j < j1; ++j) {
+    const uint32_t sub = (uint32_t)chunk_first + j;
     const uint32_t base = sub * (uint32_t)SUB;
     uint4 v[2][2];
     {
@@ -351,12 +379,25 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
       flags = window_flags8<N, true, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
     else
       flags = window_flags8<N, false, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
-    bm_bytes[(size_t)sub * 64 + lane] = (uint8_t)flags;
-    const uint32_t cnt = wave_sum_lane63(__popc(flags));
-    if (lane == 63) {
-      qcnt[sub] = cnt;
-      if (cnt) atomicAdd(&s_csum[i / chunk], cnt);               // LDS
+    if (recs) {
+      const uint32_t c = __popc(flags);
+      const uint32_t inc = wave_incl_scan(c);
+      const uint64_t has = __ballot(flags != 0);
+      const uint32_t slot = rec_run + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+      if (flags != 0 && slot < capw) list[slot] = make_uint2(((p0 >> 3) << 8) | flags, cand_run + inc - c);
+      rec_run += (uint32_t)__popcll(has);
+      cand_run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    } else {
+      bm_bytes[(size_t)sub * 64 + lane] = (uint8_t)flags;
+      const uint32_t cnt = wave_sum_lane63(__popc(flags));
+      if (lane == 63) qcnt[sub] = cnt;
+      cand_run += (uint32_t)__builtin_amdgcn_readlane((int)cnt, 63);
     }
+  }
+  if (lane == 0) {
+    if (info) info[range_id] = make_uint2(rec_run, cand_run);
+    if (cand_run) atomicAdd(&s_csum[kc], cand_run);              // LDS
   }
   if (bsum) {
     __syncthreads();
@@ -429,31 +470,36 @@ int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
 
 template <int N, bool NT>
 int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1, uint32_t* bsum,
-                  fs_status* zero) {
+                  uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                  fs_scan_extra* ex) {
+  uint32_t* bsum = ex ? ex->bsum : nullptr;
   if (n_bm_words == 0 && !bsum) return FS_OK;
   const size_t lds = (size_t)4 << ix->log2_words;
-  // the expand kernel's chunking (chunk_of_block): kNB chunks of `chunk` sub-tiles
+  // the chained kernels' chunking (chunk_of_block): kNB chunks of `chunk` sub-tiles
   const uint32_t chunk = std::max<uint32_t>(1, (n_bm_words + fsdev::kNB - 1) / fsdev::kNB);
+  const bool direct = ex && ex->bsum && ex->recs && ex->info && ex->capw && fs_scan_direct_ok(ix, c.n_tok);
   auto kern = ix->log2_words == 14 ? k_scan8<N, NT, true> : k_scan8<N, NT, false>;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
                         c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
-                        n_bm_words, chunk, bsum, zero);
+                        n_bm_words, chunk, bsum, ex ? ex->zero : nullptr,
+                        direct ? ex->recs : nullptr, direct ? ex->info : nullptr,
+                        direct ? ex->capw : 0u);
   FS_HIP(hipGetLastError());
+  if (ex) { ex->counted = bsum != nullptr; ex->direct = direct; }
   return FS_OK;
 }
 
 template <int N>
 int launch_tpl8(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1, uint32_t* bsum,
-                fs_status* zero) {
+                uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                fs_scan_extra* ex) {
   const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
   const char* e = getenv("FS_SCAN_FLAGS");
   const bool nt = (e && e[0] == 'n') || (!e && big);
-  return nt ? launch_tpl8_k<N, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero)
-            : launch_tpl8_k<N, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+  return nt ? launch_tpl8_k<N, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, ex)
+            : launch_tpl8_k<N, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, ex);
 }
 
 template <int N, int U, bool HL>
@@ -513,13 +559,19 @@ int fs_scan_tpl(const fs_index* ix, uint64_t n_tok) {
 // tile loads of the last wave never leave the allocation
 uint32_t fs_scan_pad_tokens() { return 512 * 8 + 64; }
 
-// bsum / zero / counted (optional): the eight-tokens-per-lane kernel also writes the
-// expand kernel's kNB chunk sums to bsum and clears *zero, and reports that through
-// *counted; the other kernels leave both to k_reduce (fs_launch_expand).
+// The direct path packs (position / 8) << 8 | flags into 32 bits: positions below 2^26,
+// which is also the limit of the eight-tokens-per-lane kernel unless it is forced.
+bool fs_scan_direct_ok(const fs_index* ix, uint64_t n_tok) {
+  if (const char* e = getenv("FS_SCAN_DIRECT")) if (e[0] == '0') return false;
+  return fs_scan_tpl(ix, n_tok) == 8 && n_tok + 1024 < (1ull << 26);
+}
+
+// extra (optional, see fs_scan_extra): honoured by the eight-tokens-per-lane kernel
+// only; the other kernels leave counting and expansion to k_reduce / k_expand.
 int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1, uint32_t* bsum,
-                   fs_status* zero, bool* counted) {
-  if (counted) *counted = false;
+                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                   fs_scan_extra* extra) {
+  if (extra) { extra->counted = false; extra->direct = false; }
   const int n = ix->cfg.window_size;
   const char* var = getenv("FS_SCAN_VARIANT");
   const bool simple = var && var[0] == 's';
@@ -531,13 +583,13 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
   if (const char* h = getenv("FS_SCAN_HALO")) halo_loads = h[0] == 'l';   // "loads"
   if (fs_scan_tpl(ix, c.n_tok) == 8) {
     switch (n) {
-      case 2: if (counted) *counted = bsum != nullptr; return launch_tpl8<2>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
-      case 3: if (counted) *counted = bsum != nullptr; return launch_tpl8<3>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
-      case 4: if (counted) *counted = bsum != nullptr; return launch_tpl8<4>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
-      case 5: if (counted) *counted = bsum != nullptr; return launch_tpl8<5>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
-      case 6: if (counted) *counted = bsum != nullptr; return launch_tpl8<6>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
-      case 7: if (counted) *counted = bsum != nullptr; return launch_tpl8<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
-      case 8: if (counted) *counted = bsum != nullptr; return launch_tpl8<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, bsum, zero);
+      case 2: return launch_tpl8<2>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
+      case 3: return launch_tpl8<3>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
+      case 4: return launch_tpl8<4>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
+      case 5: return launch_tpl8<5>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
+      case 6: return launch_tpl8<6>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
+      case 7: return launch_tpl8<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
+      case 8: return launch_tpl8<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
       default: break;
     }
   }

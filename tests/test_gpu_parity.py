@@ -366,3 +366,36 @@ def test_table_overflow_buckets_with_colliding_hashes(synth_base):
     util.assert_rows_equal(got, want)
     assert st.matches == ost.matches and len(got) > 100
     ix.close()
+
+
+def test_direct_and_bitmap_paths_agree(synth_base, monkeypatch):
+    """Up to 256 MiB of ids the scan writes candidate records per wave range and
+    k_verify_direct reads them (no bitmap, no expand kernel); FS_SCAN_DIRECT=0
+    keeps the bitmap + k_expand path.  Same rows, same statistics, also when the
+    record lists start far too short (FS_SCAN_CAPW=2) and are grown."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(5000)
+    # a work that quotes a long stretch of the script: every lane of several sub-tiles
+    # holds candidates, the worst case for the record lists
+    tok, off = util.ragged_corpus([1500] * 40 + [0, 5, 6, 3000], script)
+    tok = tok.copy()
+    tok[int(off[3]):int(off[3]) + 1400] = script[100:1500]
+    results = []
+    for env in ({}, {"FS_SCAN_DIRECT": "0"}, {"FS_SCAN_CAPW": "2"}):
+        for k in ("FS_SCAN_DIRECT", "FS_SCAN_CAPW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                         cfg=abi.make_config())
+        c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        rows, st = ix.search(c)
+        rows2, st2 = ix.search(c)                 # second search starts with the grown lists
+        assert rows.tobytes() == rows2.tobytes()
+        results.append((rows.tobytes(), st.candidates, st.matches, st.rows))
+        ix.close()
+    assert results[0] == results[1] == results[2]
+    oi = util.oracle_index(abi.make_config(), script, words, emb, synth.lsh_normals(6))
+    want, ost = oi.search(tok, off, synth_base["chars"], synth_base["off"])
+    assert results[0][0] == want.tobytes() and results[0][2] == ost.matches
