@@ -77,7 +77,7 @@ def c2(synth_base):
     return script, tok, off
 
 
-def test_c2_full_properties_and_pipeline_equality(c2, synth_base):
+def test_c2_full_properties_and_pipeline_equality(c2, synth_base, monkeypatch):
     """BASELINE.json configs[1]: 10k works x 2k tokens vs a 20k-token script."""
     from fandom_search_amd.engine import ScriptIndex
     script, tok, off = c2
@@ -95,6 +95,12 @@ def test_c2_full_properties_and_pipeline_equality(c2, synth_base):
     # idempotence
     rows2, _ = ix.search(corpus)
     assert rows.tobytes() == rows2.tobytes()
+    # the bitmap + expand form of the exact pipeline gives the same bytes as the
+    # candidate-record form used above
+    monkeypatch.setenv("FS_SCAN_DIRECT", "0")
+    brows, bst = ix.search(corpus)
+    monkeypatch.delenv("FS_SCAN_DIRECT")
+    assert brows.tobytes() == rows.tobytes() and bst.candidates == st.candidates
     # the LSH pipeline over the same 20M windows gives the same bytes
     gx = ScriptIndex(script, swords, emb, normals, cfg=abi.make_config(mode=abi.FS_MODE_GENERAL))
     grows, gst = gx.search(gx.corpus(tok, off, synth_base["chars"], synth_base["off"]))
