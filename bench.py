@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--lanes", type=int, default=0,
                     help="streams the library spreads searches over (FS_LANES; library "
                          "default 1): 2 or 4 trade the scan kernel's own speed for step rate")
+    ap.add_argument("--wire", type=int, default=0, help="N > 1: force 16-byte wire records")
     ap.add_argument("--inflight", type=int, default=2,
                     help="searches kept in flight (the library overlaps them on its lanes)")
     ap.add_argument("--no-reference-shaped", action="store_true",
@@ -191,11 +192,15 @@ def main():
     ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
     corpus = ix.corpus(tok, off, chars, coff)
 
-    # row buffers in HBM (two, so a gather may still read one while the next
-    # step writes the other).  With more than one rank the exact pipeline emits
-    # 16-byte wire records (half the gather bytes); rank 0 expands them again.
-    packed = world > 1 and ix.info["path"] == abi.FS_MODE_EXACT
-    rec_bytes = 16 if packed else 32
+    # row buffers in HBM.  With more than one rank the exact pipeline emits wire
+    # records for the gather, which rank 0 expands again without loss: 8 bytes each
+    # (token position + packed script position / offset / Levenshtein; rank 0 needs the
+    # ranks' work offsets for them, gathered once below), or 16 bytes for scripts of
+    # 2^18 tokens and more.
+    packed = False
+    if world > 1 and ix.info["path"] == abi.FS_MODE_EXACT:
+        packed = 8 if len(script) < abi.PACKED8_MAX_SCRIPT and args.wire != 16 else 16
+    rec_bytes = packed if packed else 32
     # every row buffer starts with a 32-byte header whose first 8 bytes carry the
     # row count of the step: count and records travel in ONE gather per step
     HDR = 32
@@ -229,6 +234,13 @@ def main():
                                     device=cdev) for _ in range(2)]
             if packed:
                 full_rows = torch.empty(world * cap * 32, dtype=torch.uint8, device="cuda")
+        all_off = None
+        if packed == 8:
+            # the batch layout of every rank, once per corpus: (n_works + 1) offsets
+            mine_off = torch.from_numpy(off.astype(np.int64)).to(cdev)
+            all_off = torch.zeros(world * len(off), dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(all_off, mine_off)
+            all_off = all_off.cuda() if rank == 0 else None
 
     # Software pipeline over NB row buffers: the search of step i is queued while
     # the GPU still finishes step i-1 (fs_search_corpus_begin / _end), and with more
@@ -336,8 +348,13 @@ def main():
             cnts = src.view(world, stride)[:, :8].contiguous().view(torch.int64).flatten().cpu().tolist()
             if packed:
                 for r in range(world):
-                    ix.unpack_device(src.data_ptr() + r * stride + HDR, min(cnts[r], cap),
-                                     full_rows.data_ptr() + r * cap * 32)
+                    if packed == 8:
+                        ix.unpack8_device(src.data_ptr() + r * stride + HDR, min(cnts[r], cap),
+                                          all_off.data_ptr() + r * len(off) * 8, len(off) - 1,
+                                          full_rows.data_ptr() + r * cap * 32)
+                    else:
+                        ix.unpack_device(src.data_ptr() + r * stride + HDR, min(cnts[r], cap),
+                                         full_rows.data_ptr() + r * cap * 32)
                 landed = full_rows.cpu().numpy()
             else:
                 landed = src.view(world, stride)[:, HDR:].contiguous().cpu().numpy().reshape(-1)

@@ -18,7 +18,7 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_index_info_get", "fs_index_destroy", "fs_corpus_create",
            "fs_corpus_destroy", "fs_search_corpus", "fs_search",
            "fs_scan_benchmark", "fs_corpus_update_begin", "fs_corpus_update_end",
-           "fs_host_alloc", "fs_host_free", "fs_rows_unpack",
+           "fs_host_alloc", "fs_host_free", "fs_rows_unpack", "fs_rows_unpack8",
            "fs_reuse_histogram", "fs_reuse_histogram_rows",
            "fs_search_corpus_begin", "fs_search_corpus_end", "fs_index_set_scan_timing")
 
@@ -106,6 +106,9 @@ def load():
     L.fs_host_free.argtypes = [C.c_void_p]
     L.fs_rows_unpack.restype = C.c_int
     L.fs_rows_unpack.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.fs_rows_unpack8.restype = C.c_int
+    L.fs_rows_unpack8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64,
+                                  C.c_void_p]
     L.fs_reuse_histogram.restype = C.c_int
     L.fs_reuse_histogram.argtypes = [C.c_int, u32p, C.POINTER(C.c_double), C.c_uint64, C.c_uint64,
                                      C.POINTER(C.c_double), C.c_uint32, u32p]

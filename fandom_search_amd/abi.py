@@ -21,7 +21,10 @@ FS_OOV_FLAG = 0x80000000
 FS_ROWS_HOST = 0
 FS_ROWS_DEVICE = 1
 FS_ROWS_DEVICE_PACKED = 2
+FS_ROWS_DEVICE_PACKED8 = 3
 PACKED_ROW_BYTES = 16
+PACKED8_ROW_BYTES = 8
+PACKED8_MAX_SCRIPT = 1 << 18
 
 
 class FsConfig(C.Structure):

@@ -557,7 +557,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   FS_TRY(ln.w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
   fs_row* d_rows = sl.rows;
   if (sl.mode == FS_ROWS_HOST) { FS_TRY(ln.w_rows.reserve(sl.rcap)); d_rows = ln.w_rows.p; }
-  const bool packed = sl.mode == FS_ROWS_DEVICE_PACKED;
+  const int wire = sl.mode == FS_ROWS_DEVICE_PACKED ? 16 : sl.mode == FS_ROWS_DEVICE_PACKED8 ? 8 : 0;
 
   // the status block is cleared by the chain's first kernel (k_reduce) and its final
   // state is written to sl.h_status by the last one (k_rows)
@@ -581,13 +581,13 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, packed, sl.h_status, s, ex));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
-    FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, false, sl.h_status, s));
+    FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, 0, sl.h_status, s));
   }
   ++sl.launches;
   if (ix->n_lanes == 2) ix->last_scan_ev = sl.ev_scan_done;
@@ -602,8 +602,10 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
     fs_set_error("null or mismatched handle");
     return FS_E_INVALID;
   }
-  if (rows_mode != FS_ROWS_HOST && rows_mode != FS_ROWS_DEVICE && rows_mode != FS_ROWS_DEVICE_PACKED) {
-    fs_set_error("rows_mode must be FS_ROWS_HOST, FS_ROWS_DEVICE or FS_ROWS_DEVICE_PACKED");
+  if (rows_mode != FS_ROWS_HOST && rows_mode != FS_ROWS_DEVICE &&
+      rows_mode != FS_ROWS_DEVICE_PACKED && rows_mode != FS_ROWS_DEVICE_PACKED8) {
+    fs_set_error("rows_mode must be FS_ROWS_HOST, FS_ROWS_DEVICE, FS_ROWS_DEVICE_PACKED or "
+                 "FS_ROWS_DEVICE_PACKED8");
     return FS_E_INVALID;
   }
   FS_HIP(hipSetDevice(ix->device));
@@ -627,6 +629,10 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   sl.tpl = sl.exact ? fs_scan_tpl(ix, T) : 4;
   sl.n_bm = (uint32_t)((T + 64 * sl.tpl - 1) / (64 * sl.tpl));
+  if (rows_mode == FS_ROWS_DEVICE_PACKED8 && (!sl.exact || ix->n_script >= (1ull << 18))) {
+    fs_set_error("8-byte rows exist for the exact n-gram pipeline and scripts below 2^18 tokens");
+    return FS_E_UNSUPPORTED;
+  }
   if (rows_mode == FS_ROWS_DEVICE_PACKED && !sl.exact) {
     fs_set_error("packed rows exist for the exact n-gram pipeline only (there the distance is a "
                  "function of the matched script window)");
@@ -747,6 +753,19 @@ extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, doub
   float ms = 0;
   FS_HIP(hipEventElapsedTime(&ms, ix->ev_scan0, ix->ev_scan1));
   *avg_ms = (double)ms / reps;
+  return FS_OK;
+}
+
+extern "C" int fs_rows_unpack8(fs_index* ix, const void* packed, uint64_t n,
+                               const uint64_t* work_off, uint64_t n_works, fs_row* rows) {
+  if (!ix || (n && (!packed || !rows || !work_off || !n_works))) { fs_set_error("null argument"); return FS_E_INVALID; }
+  if (ix->info.path != FS_MODE_EXACT || ix->n_script >= (1ull << 18)) {
+    fs_set_error("8-byte rows exist for the exact n-gram pipeline and scripts below 2^18 tokens");
+    return FS_E_UNSUPPORTED;
+  }
+  FS_HIP(hipSetDevice(ix->device));
+  FS_TRY(fs_launch_unpack8(ix, packed, n, work_off, n_works, rows, ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
   return FS_OK;
 }
 

@@ -250,14 +250,16 @@ uint32_t fs_scan_pad_tokens();
 int fs_scan_tpl(const fs_index* ix, uint64_t n_tok);   // tokens per lane (bitmap layout)
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
-                   uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st, hipStream_t s,
+                   uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st, hipStream_t s,
                    const fs_scan_extra& scan);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
                      bool verify, hipStream_t s, bool counted = false);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
-                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
                    hipStream_t s);
+int fs_launch_unpack8(fs_index* ix, const void* packed, uint64_t n, const uint64_t* work_off,
+                      uint64_t n_works, fs_row* rows, hipStream_t s);
 int fs_lsh_build(fs_index* ix);
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                        uint32_t n_sub, hipStream_t s, hipEvent_t e0 = nullptr,

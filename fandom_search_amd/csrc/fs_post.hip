@@ -464,7 +464,8 @@ __global__ void k_cbest(GramIndexDev g, const uint32_t* __restrict__ cg,
 // hit whose window covers the word, in the reference's insertion order
 // (ascending window position; search.py:176-218, 224-225), each hit offering
 // its best rank (best_of_ranks).
-template <bool PACKED>
+// WIRE: 0 = 32-byte fs_row records, 16 / 8 = wire records (include/fandom_search.h)
+template <int WIRE>
 __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
                                                    const uint32_t* __restrict__ cpos,
                                                    const uint32_t* __restrict__ cg,
@@ -551,12 +552,17 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
       out.comb = bb.comb;
       out.work = w;
       out.fan_ix = (uint32_t)((uint64_t)x - wbase);
-      if (PACKED) {
+      if (WIRE == 16) {
         // 16-byte wire record {work, fan_ix, orig_ix, lev | k << 16}: k = offset of the
         // word inside the matched window, so that dist = selfdist[orig_ix - k]
         uint4 q;
         q.x = out.work; q.y = out.fan_ix; q.z = out.orig_ix; q.w = out.lev | (koff << 16);
         reinterpret_cast<uint4*>(rows)[ridx] = q;
+        continue;
+      }
+      if (WIRE == 8) {
+        // 8-byte wire record {token position, orig_ix | k << 18 | lev << 22}
+        reinterpret_cast<uint2*>(rows)[ridx] = make_uint2(x, out.orig_ix | (koff << 18) | (out.lev << 22));
         continue;
       }
       // one 32-byte record = two 16-byte stores (row buffers are 16-byte aligned)
@@ -584,6 +590,32 @@ __global__ void k_unpack(const uint4* __restrict__ packed, uint64_t n,
     const double comb = __dmul_rn(dist, (double)lev);
     uint4 q0, q1;
     q0.x = q.x; q0.y = q.y; q0.z = q.z; q0.w = lev;
+    const uint64_t db = (uint64_t)__double_as_longlong(dist);
+    const uint64_t cb = (uint64_t)__double_as_longlong(comb);
+    q1.x = (uint32_t)db; q1.y = (uint32_t)(db >> 32); q1.z = (uint32_t)cb; q1.w = (uint32_t)(cb >> 32);
+    uint4* dst = reinterpret_cast<uint4*>(rows + i);
+    dst[0] = q0; dst[1] = q1;
+  }
+}
+
+// 8-byte wire records -> full records: the work is the last one starting at or
+// before the token position (binary search over the batch's offsets)
+__global__ void k_unpack8(const uint2* __restrict__ packed, uint64_t n,
+                          const uint64_t* __restrict__ work_off, uint32_t n_works,
+                          const double* __restrict__ selfdist, fs_row* __restrict__ rows) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint2 q = packed[i];
+    const uint32_t x = q.x, orig = q.y & 0x3FFFFu, k = (q.y >> 18) & 0xFu, lev = q.y >> 22;
+    uint32_t lo = 0, hi = n_works;               // work_off[lo] <= x < work_off[hi]
+    while (hi - lo > 1) {
+      const uint32_t mid = lo + ((hi - lo) >> 1);
+      if (work_off[mid] <= x) lo = mid; else hi = mid;
+    }
+    const double dist = selfdist[orig - k];
+    const double comb = __dmul_rn(dist, (double)lev);
+    uint4 q0, q1;
+    q0.x = lo; q0.y = (uint32_t)(x - work_off[lo]); q0.z = orig; q0.w = lev;
     const uint64_t db = (uint64_t)__double_as_longlong(dist);
     const uint64_t cb = (uint64_t)__double_as_longlong(comb);
     q1.x = (uint32_t)db; q1.y = (uint32_t)(db >> 32); q1.z = (uint32_t)cb; q1.w = (uint32_t)(cb >> 32);
@@ -769,8 +801,20 @@ int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows,
   return FS_OK;
 }
 
+int fs_launch_unpack8(fs_index* ix, const void* packed, uint64_t n, const uint64_t* work_off,
+                      uint64_t n_works, fs_row* rows, hipStream_t s) {
+  if (!n) return FS_OK;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_unpack8, dim3(blocks), dim3(256), 0, s,
+                     reinterpret_cast<const uint2*>(packed), n, work_off, (uint32_t)n_works,
+                     ix->d_selfdist.p, rows);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+// wire: 0 (fs_row), 16 or 8 bytes per record
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
-                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
+                   uint32_t ccap, uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
                    hipStream_t s) {
   fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
@@ -780,18 +824,18 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
                      HitRowsF{ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cfg.window_size}, nc, best_tab,
                      best_per_cand, ix->cur->w_hv.p, ix->cur->w_hcomb.p, bsum64);
 #define FS_ROWS(P)                                                                           \
-  hipLaunchKernelGGL(k_rows<P>, dim3(kNB + 1), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),   \
+  hipLaunchKernelGGL((k_rows<P>), dim3(kNB + 1), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),   \
                      ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p,   \
                      ix->cur->w_hcomb.p, bsum64, bmatch, best_tab, best_per_cand, nc, rcap,  \
                      d_rows, st, host_st)
-  if (packed) FS_ROWS(true); else FS_ROWS(false);
+  if (wire == 16) FS_ROWS(16); else if (wire == 8) FS_ROWS(8); else FS_ROWS(0);
 #undef FS_ROWS
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
-                   uint32_t rcap, fs_row* d_rows, bool packed, fs_status* host_st,
+                   uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
                    hipStream_t s, const fs_scan_extra& scan) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
@@ -824,5 +868,5 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   }
   FS_HIP(hipGetLastError());
   return fs_launch_rows(ix, c, per_cand ? ix->cur->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
-                        rcap, d_rows, packed, host_st, s);
+                        rcap, d_rows, wire, host_st, s);
 }

@@ -176,16 +176,24 @@ class ScriptIndex(object):
             _lib.check(rc, "fs_search_corpus")
             return rows[:n.value], st
 
+    @staticmethod
+    def _rows_mode(packed):
+        """packed: False (32-byte fs_row), True or 16 (16-byte wire records), 8
+        (8-byte wire records)."""
+        if packed == 8:
+            return abi.FS_ROWS_DEVICE_PACKED8
+        return abi.FS_ROWS_DEVICE_PACKED if packed else abi.FS_ROWS_DEVICE
+
     def search_device(self, corpus, rows_ptr, cap, packed=False):
         """Rows written to a caller-owned device buffer (`rows_ptr`: 16-byte
         aligned address on this index's device, `cap` records of 32 bytes, or of
-        16 bytes when `packed`: the wire format of the exact pipeline, see
-        unpack_device).  Returns (n_rows, stats); raises FsError(FS_E_CAPACITY)
-        with .required when the buffer is too small."""
+        16 / 8 bytes when `packed` is True / 8: the wire formats of the exact
+        pipeline, see unpack_device / unpack8_device).  Returns (n_rows, stats);
+        raises FsError(FS_E_CAPACITY) with .required when the buffer is too small."""
         L = _lib.load()
         st = abi.FsStats()
         n = C.c_uint64(0)
-        mode = abi.FS_ROWS_DEVICE_PACKED if packed else abi.FS_ROWS_DEVICE
+        mode = self._rows_mode(packed)
         rc = L.fs_search_corpus(self._h, corpus._h, C.c_void_p(rows_ptr),
                                 int(cap), mode, C.byref(n), C.byref(st))
         if rc == abi.FS_E_CAPACITY:
@@ -204,7 +212,7 @@ class ScriptIndex(object):
         """Queue a search (rows to the device buffer at `rows_ptr`) and return a
         ticket for search_end; up to four may be in flight per index."""
         t = C.c_uint32(0)
-        mode = abi.FS_ROWS_DEVICE_PACKED if packed else abi.FS_ROWS_DEVICE
+        mode = self._rows_mode(packed)
         _lib.check(_lib.load().fs_search_corpus_begin(
             self._h, corpus._h, C.c_void_p(rows_ptr), int(cap), mode, C.byref(t)),
             "fs_search_corpus_begin")
@@ -228,6 +236,13 @@ class ScriptIndex(object):
         fs_row records at `rows_ptr` (both on this index's device)."""
         _lib.check(_lib.load().fs_rows_unpack(self._h, C.c_void_p(packed_ptr), int(n),
                                               C.c_void_p(rows_ptr)), "fs_rows_unpack")
+
+    def unpack8_device(self, packed_ptr, n, work_off_ptr, n_works, rows_ptr):
+        """Expand `n` 8-byte wire records; `work_off_ptr`: device address of the
+        n_works + 1 uint64 work offsets of the batch the records come from."""
+        _lib.check(_lib.load().fs_rows_unpack8(self._h, C.c_void_p(packed_ptr), int(n),
+                                               C.c_void_p(work_off_ptr), int(n_works),
+                                               C.c_void_p(rows_ptr)), "fs_rows_unpack8")
 
     def reuse_histogram_device(self, rows_ptr, n_rows, thresholds):
         """`format` aggregation over device-resident fs_row records (after a

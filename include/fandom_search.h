@@ -171,10 +171,15 @@ void fs_host_free(void* p);
 enum {
   FS_ROWS_HOST = 0,           /* `rows` is a host buffer of fs_row                        */
   FS_ROWS_DEVICE = 1,         /* `rows` is a device buffer of fs_row                      */
-  FS_ROWS_DEVICE_PACKED = 2   /* `rows` is a device buffer of 16-byte wire records
+  FS_ROWS_DEVICE_PACKED = 2,  /* `rows` is a device buffer of 16-byte wire records
                                  {work, fan_ix, orig_ix, lev | k << 16} (exact n-gram
                                  pipeline only, else FS_E_UNSUPPORTED): half the bytes
                                  for the gather; fs_rows_unpack restores fs_row          */
+  FS_ROWS_DEVICE_PACKED8 = 3  /* 8-byte wire records {token position in the batch,
+                                 orig_ix | k << 18 | lev << 22}: a quarter of the bytes.
+                                 Exact pipeline and scripts below 2^18 tokens only
+                                 (else FS_E_UNSUPPORTED); fs_rows_unpack8 restores fs_row
+                                 given the batch's work offsets                          */
 };
 
 /* Search every work of `c`.  `rows` is a host buffer of `cap` records, or,
@@ -203,6 +208,11 @@ int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_rows, fs_sta
  * built from the same script, vectors and config: dist = the matched script
  * window's self distance, comb = dist * lev. */
 int fs_rows_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows);
+
+/* The same for n 8-byte wire records: work_off (device, n_works + 1 offsets of the
+ * batch the records come from) turns a token position back into (work, fan_ix). */
+int fs_rows_unpack8(fs_index* ix, const void* packed, uint64_t n, const uint64_t* work_off,
+                    uint64_t n_works, fs_row* rows);
 
 /* fs_corpus_create + fs_search_corpus + fs_corpus_destroy. */
 int fs_search(fs_index* ix,

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_functions():
     text = open(os.path.join(ROOT, "include", "fandom_search.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fs_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(fs_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_declares_the_documented_entry_points():

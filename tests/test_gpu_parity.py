@@ -399,3 +399,31 @@ def test_direct_and_bitmap_paths_agree(synth_base, monkeypatch):
     oi = util.oracle_index(abi.make_config(), script, words, emb, synth.lsh_normals(6))
     want, ost = oi.search(tok, off, synth_base["chars"], synth_base["off"])
     assert results[0][0] == want.tobytes() and results[0][2] == ost.matches
+
+
+def test_eight_byte_wire_rows_round_trip(synth_base):
+    """8-byte wire records {token position, orig_ix | k << 18 | lev << 22} expand,
+    with the batch's work offsets, to the same fs_row bytes (ragged and empty works
+    included)."""
+    import torch
+    from fandom_search_amd import _lib
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(6000)
+    tok, off = util.ragged_corpus([1200] * 40 + [0, 5, 0, 0, 3000, 7], script)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    want, _ = ix.search(corpus)
+    cap = len(want) + 10
+    packed = torch.zeros(cap * 8, dtype=torch.uint8, device="cuda")
+    n, st = ix.search_device(corpus, packed.data_ptr(), cap, packed=8)
+    assert n == len(want)
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    full = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    ix.unpack8_device(packed.data_ptr(), n, d_off.data_ptr(), len(off) - 1, full.data_ptr())
+    got = full.cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
+    assert got.tobytes() == want.tobytes()
+    with pytest.raises(_lib.FsError) as e:
+        ix.search_device(corpus, packed.data_ptr(), 10, packed=8)
+    assert e.value.code == abi.FS_E_CAPACITY and e.value.required == len(want)
