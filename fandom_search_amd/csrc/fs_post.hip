@@ -1,16 +1,21 @@
-// fs_post.hip -- everything between the scan's window bitmap and the output
-// records: five launches behind the scan, no host round trip.
+// fs_post.hip -- everything between the scan's output and the records: three launches
+// behind the scan on the direct path, five on the bitmap paths, no host round trip.
 //
-//   k_reduce<SubTileCount>   per-block partial sums of the scan's sub-tile counts
+//   k_verify_direct          direct path: the scan's candidate records (per wave range)
+//                            -> positions in LDS -> (n-gram id, work id) or FS_NONE per
+//                            candidate, dense arrays in position order
+//   k_reduce<SubTileCount>   bitmap paths: per-block partial sums of the scan's sub-tile
+//                            counts (the 8-tokens-per-lane scan writes them itself)
 //   k_expand<TPL>            bitmap -> candidate window positions, in position
 //                            order (block prefix from the partial sums + an
-//                            in-block scan; one thread expands one sub-tile)
+//                            in-block scan; one thread expands one bitmap word)
 //   k_verify                 candidate -> (n-gram id, work id) or FS_NONE: exact
 //                            id-for-id comparison with the script n-gram found
-//                            through the open-addressing table; windows that
+//                            through the hash-and-displace table; windows that
 //                            cross a work boundary are dropped
-//   k_hitrows                per candidate (hit?, fan words first covered), kept
-//                            for k_rows, and their per-block partial sums
+//   k_hitrows                per candidate (hit?, fan words first covered) and the
+//                            combined distance of its best rank, kept for k_rows,
+//                            and their per-block partial sums
 //   k_rows                   per 256-candidate tile a block scan gives every hit
 //                            its record offset, then one thread per record: the
 //                            first minimum of dist*lev over all hits covering

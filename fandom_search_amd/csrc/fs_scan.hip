@@ -5,22 +5,26 @@
 // (/root/reference/search.py:176-178): every fan window's n vector ids are
 // hashed and tested against the script's n-gram set.
 //
-// Data flow per wave (64 lanes), per 256-token sub-tile:
-//   * one coalesced global_load_dwordx4 per lane: tokens [4L, 4L+4)
-//   * the n-1 halo tokens come from lanes L+1.. by ds_bpermute (no second
-//     global read); the wrap into the next sub-tile is folded into the same
-//     permute by letting the low lanes publish the next vector
-//   * per window: rolling fold of premixed ids, finalise, one ds_read_b32 of
-//     the LDS-resident blocked Bloom filter, three-bit test
-//   * four __ballot words per sub-tile: bit L of word 4 i + j says "the window
-//     starting at token 256 i + 4 L + j may be a script n-gram"; lanes 0..3
-//     store them, lane 0 also stores the sub-tile's popcount
-//   * k_scan8 is the same loop with eight tokens per lane (512-token sub-tiles,
-//     eight ballot words), used while the ids fit the Infinity Cache
-// No atomics, no inter-workgroup traffic, the output position is a function of
-// the token position, so the result is deterministic; exact verification
-// happens downstream on the (rare) flagged windows.  Algorithmic HBM traffic:
-// 4 B read per token + 36 B written per 256 tokens.
+// Two kernels.  k_scan8 (n <= 8, ids up to 256 MiB: the benchmark's case), per wave and
+// 512-token sub-tile:
+//   * two coalesced global_load_dwordx4 per lane: tokens [8L, 8L+8)
+//   * the n-1 halo tokens come from lane L+1 by ds_bpermute (no second global read);
+//     the wrap into the next sub-tile is folded into the same permute by letting
+//     lane 0 publish the next sub-tile's first tokens
+//   * per window: sliding fold of premixed ids, one ds_read_b32 of the LDS-resident
+//     blocked Bloom filter, three-bit test; a lane's eight answers are one byte
+//   * direct path: a lane whose byte is not zero appends one 8-byte record to the
+//     list of its wave range (see the comment at k_scan8); the workgroup writes the
+//     candidate counts of its four chunks.  Bitmap path (FS_SCAN_DIRECT=0): the 64
+//     bytes of a sub-tile go out in natural order with the sub-tile's count.
+// k_scan (other n, larger corpora): four tokens per lane, 256-token sub-tiles, four
+// __ballot words per sub-tile (bit L of word j <-> window 256 i + 4 L + j) and the
+// sub-tile's popcount; counting and expansion are left to k_reduce / k_expand.
+// No global atomics, no inter-workgroup traffic, the output position is a function of
+// the token position, so the result is deterministic; exact verification happens
+// downstream on the (rare) flagged windows.  Algorithmic HBM traffic: 4 B read per
+// token; written: 8 B per lane with candidates (direct), 68 B per 512 tokens or 36 B
+// per 256 tokens (bitmap forms).
 #include "fs_internal.h"
 #include "fs_device.h"
 
