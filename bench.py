@@ -93,7 +93,15 @@ def cpu_baseline(cfg, script, swords, words, emb, normals, tokens_per_work,
     t0 = time.perf_counter()
     rows, st = oi.search(tok, off, chars, coff)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "fanworks/s", "cores": cores, "kind": "port",
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": n / dt, "unit": "fanworks/s", "cores": cores, "cpu_model": model, "kind": "port",
             "sample": "first %d works (%d tokens each) of the workload, %.1f s, "
                       "oracle/fs_oracle.c with OpenMP over works"
                       % (n, tokens_per_work, dt)}
