@@ -217,7 +217,7 @@ def test_searches_in_flight(synth_base):
     assert ix.search(corpora[1])[0].tobytes() == want[1].tobytes()
 
 
-@pytest.mark.parametrize("n", [1, 3, 7, 9, 11, 12, 16])
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 16])
 def test_window_sizes_on_a_one_hot_table(n):
     """Orthogonal vectors (c_max = 0) and threshold 0.05: one substituted token
     gives cos = (n-1)/n <= 0.9375 < 0.95, so the exact-scan proof holds for every
