@@ -298,7 +298,6 @@ def main():
         total_rows = n
         last_st[0] = st
         if world > 1:
-            bufs[b][:8].view(torch.int64).fill_(n)       # header: rows of this step
             send = bufs[b].cpu() if rehearsal else bufs[b]
             h = dist.gather(send, list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
                             async_op=True)
@@ -307,7 +306,9 @@ def main():
     def step(i):
         b = i % NB
         finish(b)
-        tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr() + HDR, cap, packed=packed), b)
+        # the library writes the step's row count into the buffer's header itself
+        tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr(), cap, packed=packed,
+                                      header=True), b)
         if i - (args.inflight - 1) in tickets:
             complete(i - (args.inflight - 1))
 

@@ -22,6 +22,8 @@ FS_ROWS_HOST = 0
 FS_ROWS_DEVICE = 1
 FS_ROWS_DEVICE_PACKED = 2
 FS_ROWS_DEVICE_PACKED8 = 3
+FS_ROWS_HEADER = 0x100
+ROWS_HEADER_BYTES = 32
 PACKED_ROW_BYTES = 16
 PACKED8_ROW_BYTES = 8
 PACKED8_MAX_SCRIPT = 1 << 18

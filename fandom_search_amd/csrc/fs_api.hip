@@ -556,6 +556,11 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   FS_TRY(ln.w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
   FS_TRY(ln.w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
   fs_row* d_rows = sl.rows;
+  uint64_t* count_out = nullptr;
+  if (sl.header) {                     // 32-byte header in front of the records
+    count_out = reinterpret_cast<uint64_t*>(sl.rows);
+    d_rows = reinterpret_cast<fs_row*>(reinterpret_cast<char*>(sl.rows) + 32);
+  }
   if (sl.mode == FS_ROWS_HOST) { FS_TRY(ln.w_rows.reserve(sl.rcap)); d_rows = ln.w_rows.p; }
   const int wire = sl.mode == FS_ROWS_DEVICE_PACKED ? 16 : sl.mode == FS_ROWS_DEVICE_PACKED8 ? 8 : 0;
 
@@ -581,13 +586,13 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
-    FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, 0, sl.h_status, s));
+    FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, 0, sl.h_status, s, count_out));
   }
   ++sl.launches;
   if (ix->n_lanes == 2) ix->last_scan_ev = sl.ev_scan_done;
@@ -600,6 +605,12 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
                                       int rows_mode, uint32_t* ticket) {
   if (!ix || !c || c->ix != ix || !ticket || (cap && !rows)) {
     fs_set_error("null or mismatched handle");
+    return FS_E_INVALID;
+  }
+  const bool header = (rows_mode & FS_ROWS_HEADER) != 0;
+  rows_mode &= ~FS_ROWS_HEADER;
+  if (header && rows_mode == FS_ROWS_HOST) {
+    fs_set_error("FS_ROWS_HEADER goes with the device row modes");
     return FS_E_INVALID;
   }
   if (rows_mode != FS_ROWS_HOST && rows_mode != FS_ROWS_DEVICE &&
@@ -624,6 +635,7 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
       }
   const uint64_t T = c->n_tok;
   sl.c = c; sl.rows = rows; sl.cap = cap; sl.mode = rows_mode; sl.launches = 0;
+  sl.header = header;
   sl.lane = (int)(id % (uint32_t)ix->n_lanes);
   const fs_index::Lane& ln = ix->lanes[sl.lane];
   sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;

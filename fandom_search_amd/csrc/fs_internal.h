@@ -189,6 +189,7 @@ struct fs_index {
     fs_row* rows = nullptr;
     uint64_t cap = 0, ccap = 0, rcap = 0;
     int mode = 0;
+    bool header = false;              // FS_ROWS_HEADER: rows = 32-byte header + records
     bool exact = false;
     uint32_t n_bm = 0, launches = 0;
     bool timed = false;               // this search's scan carries timing events
@@ -251,13 +252,13 @@ int fs_scan_tpl(const fs_index* ix, uint64_t n_tok);   // tokens per lane (bitma
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
                    uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st, hipStream_t s,
-                   const fs_scan_extra& scan);
+                   const fs_scan_extra& scan, uint64_t* count_out = nullptr);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
                      bool verify, hipStream_t s, bool counted = false);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
-                   hipStream_t s);
+                   hipStream_t s, uint64_t* count_out = nullptr);
 int fs_launch_unpack8(fs_index* ix, const void* packed, uint64_t n, const uint64_t* work_off,
                       uint64_t n_works, fs_row* rows, hipStream_t s);
 int fs_lsh_build(fs_index* ix);

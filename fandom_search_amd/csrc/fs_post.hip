@@ -482,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
                                                    const fs_best* __restrict__ best_tab,
                                                    int best_per_cand, NSrc nc, uint32_t rcap,
                                                    fs_row* __restrict__ rows, fs_status* st,
-                                                   fs_status* host_st) {
+                                                   fs_status* host_st, uint64_t* count_out) {
   __shared__ uint64_t s_w[4];
   __shared__ uint32_t s_w32[4];
   __shared__ uint32_t s_roff[kThreads];
@@ -507,6 +507,7 @@ __global__ __launch_bounds__(kThreads) void k_rows(GramIndexDev g, CorpusDev c,
       out.n_matches = mt;
       *st = out;
       *host_st = out;
+      if (count_out) *count_out = out.n_rows;    // FS_ROWS_HEADER
     }
   }
   for (uint32_t t0 = lo; t0 < hi; t0 += kThreads) {
@@ -820,7 +821,7 @@ int fs_launch_unpack8(fs_index* ix, const void* packed, uint64_t n, const uint64
 // wire: 0 (fs_row), 16 or 8 bytes per record
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
-                   hipStream_t s) {
+                   hipStream_t s, uint64_t* count_out) {
   fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
@@ -832,7 +833,7 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
   hipLaunchKernelGGL((k_rows<P>), dim3(kNB + 1), dim3(kThreads), 0, s, ix->gram_dev(), c->dev(),   \
                      ix->cur->w_cpos.p, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_hv.p,   \
                      ix->cur->w_hcomb.p, bsum64, bmatch, best_tab, best_per_cand, nc, rcap,  \
-                     d_rows, st, host_st)
+                     d_rows, st, host_st, count_out)
   if (wire == 16) FS_ROWS(16); else if (wire == 8) FS_ROWS(8); else FS_ROWS(0);
 #undef FS_ROWS
   FS_HIP(hipGetLastError());
@@ -841,7 +842,7 @@ int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best
 
 int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t ccap,
                    uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
-                   hipStream_t s, const fs_scan_extra& scan) {
+                   hipStream_t s, const fs_scan_extra& scan, uint64_t* count_out) {
   const GramIndexDev g = ix->gram_dev();
   const CorpusDev cd = c->dev();
   fs_status* st = ix->cur->d_status.p;
@@ -873,5 +874,5 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   }
   FS_HIP(hipGetLastError());
   return fs_launch_rows(ix, c, per_cand ? ix->cur->w_cbest.p : c->d_gbest.p, per_cand ? 1 : 0, ccap,
-                        rcap, d_rows, wire, host_st, s);
+                        rcap, d_rows, wire, host_st, s, count_out);
 }

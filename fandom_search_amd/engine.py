@@ -208,11 +208,13 @@ class ScriptIndex(object):
         _lib.check(_lib.load().fs_index_set_scan_timing(self._h, int(period)),
                    "fs_index_set_scan_timing")
 
-    def search_begin(self, corpus, rows_ptr, cap, packed=False):
+    def search_begin(self, corpus, rows_ptr, cap, packed=False, header=False):
         """Queue a search (rows to the device buffer at `rows_ptr`) and return a
-        ticket for search_end; up to four may be in flight per index."""
+        ticket for search_end; up to four may be in flight per index.  `header`:
+        the buffer starts with a 32-byte header whose first eight bytes receive the
+        record count, the `cap` records follow it."""
         t = C.c_uint32(0)
-        mode = self._rows_mode(packed)
+        mode = self._rows_mode(packed) | (abi.FS_ROWS_HEADER if header else 0)
         _lib.check(_lib.load().fs_search_corpus_begin(
             self._h, corpus._h, C.c_void_p(rows_ptr), int(cap), mode, C.byref(t)),
             "fs_search_corpus_begin")

@@ -175,11 +175,16 @@ enum {
                                  {work, fan_ix, orig_ix, lev | k << 16} (exact n-gram
                                  pipeline only, else FS_E_UNSUPPORTED): half the bytes
                                  for the gather; fs_rows_unpack restores fs_row          */
-  FS_ROWS_DEVICE_PACKED8 = 3  /* 8-byte wire records {token position in the batch,
+  FS_ROWS_DEVICE_PACKED8 = 3, /* 8-byte wire records {token position in the batch,
                                  orig_ix | k << 18 | lev << 22}: a quarter of the bytes.
                                  Exact pipeline and scripts below 2^18 tokens only
                                  (else FS_E_UNSUPPORTED); fs_rows_unpack8 restores fs_row
                                  given the batch's work offsets                          */
+  FS_ROWS_HEADER = 0x100      /* flag, with a device mode: `rows` points to a 32-byte
+                                 header followed by the `cap` records; the search writes
+                                 the record count (uint64) into the header's first eight
+                                 bytes, so that count and records can travel in one
+                                 collective without a host-side step in between          */
 };
 
 /* Search every work of `c`.  `rows` is a host buffer of `cap` records, or,

@@ -427,3 +427,26 @@ def test_eight_byte_wire_rows_round_trip(synth_base):
     with pytest.raises(_lib.FsError) as e:
         ix.search_device(corpus, packed.data_ptr(), 10, packed=8)
     assert e.value.code == abi.FS_E_CAPACITY and e.value.required == len(want)
+
+
+def test_rows_header_receives_the_count(synth_base):
+    """FS_ROWS_HEADER: the record count lands in the first eight bytes of a 32-byte
+    header in front of the records (all three device record formats)."""
+    import torch
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(4000)
+    tok, off = util.ragged_corpus([900] * 25 + [0, 4], script)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    want, _ = ix.search(corpus)
+    cap = len(want) + 5
+    for packed, size in ((False, 32), (True, 16), (8, 8)):
+        buf = torch.full((32 + cap * size,), 0xAB, dtype=torch.uint8, device="cuda")
+        n, st = ix.search_end(ix.search_begin(corpus, buf.data_ptr(), cap, packed=packed, header=True))
+        host = buf.cpu().numpy()
+        assert n == len(want) and int(host[:8].view(np.uint64)[0]) == n
+        if not packed:
+            assert host[32:32 + n * 32].tobytes() == want.tobytes()
+    ix.close()
