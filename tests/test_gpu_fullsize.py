@@ -101,6 +101,17 @@ def test_c2_full_properties_and_pipeline_equality(c2, synth_base, monkeypatch):
     brows, bst = ix.search(corpus)
     monkeypatch.delenv("FS_SCAN_DIRECT")
     assert brows.tobytes() == rows.tobytes() and bst.candidates == st.candidates
+    # the 8-byte wire records of the whole batch expand to the same bytes
+    import torch
+    cap = len(rows) + 16
+    wire = torch.zeros(32 + cap * 8, dtype=torch.uint8, device="cuda")
+    n8, _ = ix.search_end(ix.search_begin(corpus, wire.data_ptr(), cap, packed=8, header=True))
+    assert n8 == len(rows) and int(wire[:8].cpu().numpy().view(np.uint64)[0]) == n8
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    full = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    ix.unpack8_device(wire.data_ptr() + 32, n8, d_off.data_ptr(), len(off) - 1, full.data_ptr())
+    assert full.cpu().numpy()[:n8 * 32].tobytes() == rows.tobytes()
+    del wire, full
     # the LSH pipeline over the same 20M windows gives the same bytes
     gx = ScriptIndex(script, swords, emb, normals, cfg=abi.make_config(mode=abi.FS_MODE_GENERAL))
     grows, gst = gx.search(gx.corpus(tok, off, synth_base["chars"], synth_base["off"]))
