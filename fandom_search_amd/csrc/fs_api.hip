@@ -277,7 +277,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     fs_set_error("device %d of %d", cfg->device, ndev);
     return FS_E_INVALID;
   }
-  FS_HIP(hipSetDevice(cfg->device));
+  FS_ENTER(cfg->device);
   fs_index* ix = new (std::nothrow) fs_index();
   if (!ix) return FS_E_NOMEM;
   struct Guard { fs_index* p; ~Guard() { delete p; } } guard{ix};
@@ -395,7 +395,7 @@ extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
     const uint64_t len = work_off[w + 1] - work_off[w];
     if (len >= n) windows += len - n + 1;
   }
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   if (c->pending) FS_HIP(hipEventSynchronize(c->ev_ready));
   hipStream_t cs = c->copy_stream;
   c->n_tok = T; c->n_works = n_works; c->windows = windows;
@@ -430,7 +430,7 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
   if (!c) return FS_E_INVALID;
   if (!c->pending) return FS_OK;
   fs_index* ix = c->ix;
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   FS_HIP(hipEventSynchronize(c->ev_ready));
   c->pending = false;
   const uint32_t max_row_plus1 = c->h_check[0], any_oov = c->h_check[1], max_str_plus1 = c->h_check[2];
@@ -479,7 +479,7 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
   }
   *out = nullptr;
   if (n_str >= (1ull << 32)) { fs_set_error("string table too large"); return FS_E_UNSUPPORTED; }
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   fs_corpus* c = new (std::nothrow) fs_corpus();
   if (!c) return FS_E_NOMEM;
   struct Guard { fs_corpus* p; ~Guard() { delete p; } } guard{c};
@@ -619,7 +619,7 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
                  "FS_ROWS_DEVICE_PACKED8");
     return FS_E_INVALID;
   }
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   FS_TRY(fs_corpus_update_end(c));          // no-op unless an upload is in flight
   const uint32_t id = ix->next_slot % FS_SEARCH_SLOTS;
   fs_index::Slot& sl = ix->slots[id];
@@ -674,7 +674,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     fs_set_error("no such search in flight");
     return FS_E_INVALID;
   }
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   fs_index::Slot& sl = ix->slots[ticket];
   sl.busy = false;
   float scan_ms = 0, total_ms = 0;
@@ -750,7 +750,7 @@ extern "C" int fs_search(fs_index* ix, const uint32_t* tok_vec, const uint32_t* 
 
 extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms) {
   if (!ix || !c || c->ix != ix || !avg_ms || reps == 0) return FS_E_INVALID;
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   hipStream_t s = ix->stream;
   const int tpl = fs_scan_tpl(ix, c->n_tok);
   const uint32_t n_bm = (uint32_t)((c->n_tok + 64 * tpl - 1) / (64 * tpl));
@@ -775,7 +775,7 @@ extern "C" int fs_rows_unpack8(fs_index* ix, const void* packed, uint64_t n,
     fs_set_error("8-byte rows exist for the exact n-gram pipeline and scripts below 2^18 tokens");
     return FS_E_UNSUPPORTED;
   }
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   FS_TRY(fs_launch_unpack8(ix, packed, n, work_off, n_works, rows, ix->stream));
   FS_HIP(hipStreamSynchronize(ix->stream));
   return FS_OK;
@@ -783,7 +783,7 @@ extern "C" int fs_rows_unpack8(fs_index* ix, const void* packed, uint64_t n,
 
 extern "C" int fs_rows_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows) {
   if (!ix || (n && (!packed || !rows))) return FS_E_INVALID;
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   FS_TRY(fs_launch_unpack(ix, packed, n, rows, ix->stream));
   FS_HIP(hipStreamSynchronize(ix->stream));
   return FS_OK;
@@ -799,7 +799,7 @@ extern "C" int fs_reuse_histogram(int device, const uint32_t* orig_ix, const dou
   }
   for (uint32_t t = 1; t < n_thr; ++t)
     if (!(thresholds[t - 1] <= thresholds[t])) { fs_set_error("thresholds must ascend"); return FS_E_INVALID; }
-  FS_HIP(hipSetDevice(device));
+  FS_ENTER(device);
   DBuf<uint32_t> d_orig, d_counts;
   DBuf<double> d_comb, d_thr;
   FS_TRY(d_orig.upload(orig_ix, n_rows, nullptr));
@@ -819,7 +819,7 @@ extern "C" int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint6
   if (!ix || (n_rows && !d_rows) || !thresholds || !n_thr || n_thr > 64 || !d_counts) return FS_E_INVALID;
   for (uint32_t t = 1; t < n_thr; ++t)
     if (!(thresholds[t - 1] <= thresholds[t])) { fs_set_error("thresholds must ascend"); return FS_E_INVALID; }
-  FS_HIP(hipSetDevice(ix->device));
+  FS_ENTER(ix->device);
   DBuf<double> d_thr;
   FS_TRY(d_thr.upload(thresholds, n_thr, ix->stream));
   FS_TRY(fs_launch_histogram(nullptr, nullptr, d_rows, n_rows, ix->n_script, d_thr.p, n_thr, d_counts,

@@ -29,6 +29,15 @@ void fs_set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// At an entry point: select the device and drop an error another user of the same HIP
+// runtime (PyTorch in this process) may have left behind -- hipGetLastError() is how
+// launches are checked here, and it reports the thread's last error whoever caused it.
+#define FS_ENTER(dev)                 \
+  do {                                \
+    FS_HIP(hipSetDevice(dev));        \
+    (void)hipGetLastError();          \
+  } while (0)
+
 #define FS_TRY(call)                \
   do {                              \
     int rc_ = (call);               \

@@ -20,9 +20,10 @@
 // Two kernels use them:
 //   k_lsh_scan     one block per 256-window sub-tile: keys for all 256 windows
 //                  (threads = projection columns, coalesced 8-byte reads of A
-//                  rows), then one thread per window asks "is any candidate
-//                  within the threshold?" and the answers go out in the scan's
-//                  bitmap format, so k_expand / k_rows of fs_post.hip are shared
+//                  rows), then the (window, bucket candidate) pairs of the sub-tile
+//                  are dealt out evenly over the threads and each asks "within the
+//                  threshold?"; the per-window answers go out in the scan's bitmap
+//                  format, so k_expand / k_rows of fs_post.hip are shared
 //   k_lsh_verify   one wave per flagged window: keys again, the full
 //                  neighbours list, Levenshtein per kept match (one lane each),
 //                  best rank -> per-candidate record for k_rows
@@ -356,6 +357,9 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
   uint64_t* s_bal = reinterpret_cast<uint64_t*>(s_raw);                 // [256][NW + 1]
   uint32_t* s_key = reinterpret_cast<uint32_t*>(s_bal + 256 * (NW + 1));   // [256][H]
   uint32_t* s_tok = s_key + 256 * L.H;                                  // [256 + 16]
+  uint32_t* s_pref = s_tok + 256 + 16;                                  // [256 * H + 1] pair offsets
+  double* s_ff = reinterpret_cast<double*>(s_pref + ((256 * L.H + 2) & ~1));   // [256]
+  __shared__ uint32_t s_flag[256];
   __shared__ uint32_t s_cnt[4];
   __shared__ float s_bound[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -455,12 +459,58 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
       s_key[i] = assemble_key(s_bal + w * (NW + 1), h, L.B);
     }
     __syncthreads();
-    // phase 2: thread (wave j, lane l) owns window 4 l + j, so that wave j's ballot
-    // is bitmap word j of the sub-tile
-    const int w = 4 * lane + wave;
-    bool flag = false;
-    if (p0 + w + n <= c.n_tok && L.diag != 1)
-      flag = lsh_neighbours<true>(L, s_key + w * L.H, s_tok + w, nullptr, nullptr) != 0;
+    // phase 2: "is any bucket candidate of the window within the threshold?"  The 256 x H
+    // buckets of the sub-tile hold very different numbers of candidates, so they are not
+    // walked window by window: thread w looks up its window's H bucket ranges, a block
+    // scan turns the sizes into offsets, and the (window, candidate) pairs of the whole
+    // sub-tile are then dealt out evenly, pair j to thread j mod 256 (the bucket of a
+    // pair is found by binary search over the offsets in LDS).  A pair that is within
+    // the threshold sets its window's flag.
+    {
+      const int w = threadIdx.x;
+      const bool valid = p0 + w + n <= c.n_tok && L.diag != 1;
+      const uint32_t nb1 = (1u << L.B) + 1;
+      uint32_t sum = 0;
+      for (int h = 0; h < L.H; ++h) {
+        uint32_t e0 = 0, cntb = 0;
+        if (valid) {
+          const uint32_t* o = L.boff + (size_t)h * nb1 + s_key[w * L.H + h];
+          e0 = o[0];
+          cntb = o[1] - e0;
+        }
+        s_key[w * L.H + h] = e0;                 // the key is not needed again
+        s_pref[w * L.H + h] = sum;               // offset inside the window, for now
+        sum += cntb;
+      }
+      double ff = 0.0;
+      for (int k = 0; k < n; ++k) ff = __dadd_rn(ff, q_of(L, s_tok[w + k]));
+      s_ff[w] = ff;
+      s_flag[w] = 0;
+      uint32_t total;
+      const uint32_t base = block_excl_scan(sum, s_cnt, &total);
+      for (int h = 0; h < L.H; ++h) s_pref[w * L.H + h] += base;
+      if (w == 255) s_pref[256 * L.H] = total;
+      __syncthreads();
+      const uint32_t n_b = 256u * (uint32_t)L.H;
+      for (uint32_t j = threadIdx.x; j < total; j += 256) {
+        uint32_t lo = 0, hi = n_b;               // s_pref[lo] <= j < s_pref[hi]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pref[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t pw = lo / (uint32_t)L.H, ph = lo - pw * (uint32_t)L.H;
+        if (s_flag[pw]) continue;                // the window has its answer already
+        const uint32_t sidx = L.bids[(size_t)ph * L.W + s_key[lo] + (j - s_pref[lo])];
+        if (L.diag == 3) continue;               // diagnostics: bucket walk only
+        const double pff = s_ff[pw];
+        double d;
+        if (window_distance(L, sidx, s_tok + pw, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_flag[pw] = 1;
+      }
+      __syncthreads();
+    }
+    // thread (wave j, lane l) reports window 4 l + j, so that wave j's ballot is bitmap
+    // word j of the sub-tile
+    const bool flag = s_flag[4 * lane + wave] != 0;
     const uint64_t b = __ballot(flag);
     if (lane == 0) {
       qbm[(size_t)sub * 4 + wave] = b;
@@ -688,7 +738,8 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   if (!n_sub) return FS_OK;
   const LshDev L = lsh_dev(ix);
   const int NW = (L.C + 63) >> 6;
-  const size_t lds = (size_t)256 * (NW + 1) * 8 + (size_t)256 * L.H * 4 + (256 + 16) * 4;
+  const size_t lds = (size_t)256 * (NW + 1) * 8 + (size_t)256 * L.H * 4 + (256 + 16) * 4 +
+                     ((size_t)256 * L.H + 2) * 4 + 256 * 8;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsh_scan),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
