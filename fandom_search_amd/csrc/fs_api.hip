@@ -363,6 +363,9 @@ extern "C" void fs_index_destroy(fs_index* ix) {
   (void)hipSetDevice(ix->device);
   for (int l = 0; l < FS_LANES; ++l)
     if (ix->lanes[l].stream) (void)hipStreamSynchronize(ix->lanes[l].stream);
+  // corpora that outlive the index keep their own device buffers and are detached:
+  // they can still be destroyed, every other call on them is refused
+  for (fs_corpus* c : ix->corpora) c->ix = nullptr;
   delete ix;
 }
 
@@ -381,6 +384,7 @@ extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
                                       uint64_t n_works) {
   if (!c || !work_off) { fs_set_error("null argument"); return FS_E_INVALID; }
   fs_index* ix = c->ix;
+  if (!ix) { fs_set_error("the corpus's index has been destroyed"); return FS_E_INVALID; }
   if (work_off[0] != 0) { fs_set_error("work_off[0] must be 0"); return FS_E_INVALID; }
   const uint64_t T = work_off[n_works];
   if (T && !tok_vec) { fs_set_error("null token buffer"); return FS_E_INVALID; }
@@ -430,6 +434,7 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
   if (!c) return FS_E_INVALID;
   if (!c->pending) return FS_OK;
   fs_index* ix = c->ix;
+  if (!ix) { fs_set_error("the corpus's index has been destroyed"); return FS_E_INVALID; }
   FS_ENTER(ix->device);
   FS_HIP(hipEventSynchronize(c->ev_ready));
   c->pending = false;
@@ -497,6 +502,7 @@ extern "C" int fs_corpus_create(fs_index* ix, const uint32_t* tok_vec, const uin
   FS_TRY(fs_corpus_update_begin(c, tok_vec, tok_str, work_off, n_works));
   FS_TRY(fs_corpus_update_end(c));
   guard.p = nullptr;
+  ix->corpora.push_back(c);
   *out = c;
   return FS_OK;
 }
@@ -516,10 +522,17 @@ extern "C" void fs_host_free(void* p) {
 
 extern "C" void fs_corpus_destroy(fs_corpus* c) {
   if (!c) return;
-  if (c->ix) {
-    (void)hipSetDevice(c->ix->device);
+  if (c->ix) {                         // nullptr: the index went first (fs_index_destroy)
+    fs_index* ix = c->ix;
+    (void)hipSetDevice(ix->device);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
-    for (int l = 0; l < FS_LANES; ++l) (void)hipStreamSynchronize(c->ix->lanes[l].stream);
+    for (int l = 0; l < FS_LANES; ++l) (void)hipStreamSynchronize(ix->lanes[l].stream);
+    for (size_t i = 0; i < ix->corpora.size(); ++i)
+      if (ix->corpora[i] == c) { ix->corpora.erase(ix->corpora.begin() + (long)i); break; }
+    for (int i = 0; i < FS_SEARCH_SLOTS; ++i)
+      if (ix->slots[i].c == c) ix->slots[i].c = nullptr;
+  } else if (c->copy_stream) {
+    (void)hipStreamSynchronize(c->copy_stream);
   }
   delete c;
 }

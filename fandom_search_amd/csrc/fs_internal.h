@@ -139,6 +139,8 @@ struct alignas(32) fs_swin {
   int32_t r0;      // its row in the pair table, -1: none
 };
 
+struct fs_corpus;
+
 struct fs_index {
   fs_config cfg;
   int device = 0;
@@ -210,6 +212,10 @@ struct fs_index {
   uint32_t next_slot = 0;
   uint32_t scan_timing_period = 1;    // attach timing events to every k-th scan
   uint64_t searches = 0;
+
+  // corpora created on this index and still alive: fs_index_destroy detaches them, so that
+  // a corpus destroyed after its index does not touch freed memory
+  std::vector<fs_corpus*> corpora;
 
   GramIndexDev gram_dev() const;
   ~fs_index();

@@ -32,6 +32,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -443,6 +445,20 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
   }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is set once per kernel and size (per
+// device: the attribute belongs to the loaded code object), not on every launch
+static int ensure_dynamic_lds(const void* kern, int device, size_t lds) {
+  struct Seen { const void* k; int dev; size_t lds; };
+  static std::vector<Seen> seen;                  // a handful of entries
+  static std::mutex mu;                           // handles of different devices may be driven from different threads
+  std::lock_guard<std::mutex> lock(mu);
+  for (const Seen& e : seen)
+    if (e.k == kern && e.dev == device && e.lds >= lds) return FS_OK;
+  FS_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  seen.push_back({kern, device, lds});
+  return FS_OK;
+}
+
 template <int N, int U, bool HL, bool DIRECT, bool NT>
 int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
@@ -461,8 +477,7 @@ int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   uint32_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > max_blocks) blocks = max_blocks;
   auto kern = k_scan<N, U, HL, DIRECT, NT>;
-  FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   // start/stop events attached to the dispatch itself: their difference is the
   // kernel's execution time (what rocprofv3 reports), not kernel + marker gaps
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), (uint32_t)lds, s, e0, e1, 0u, c.tok,
@@ -483,8 +498,7 @@ int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   const uint32_t chunk = std::max<uint32_t>(1, (n_bm_words + fsdev::kNB - 1) / fsdev::kNB);
   const bool direct = ex && ex->bsum && ex->recs && ex->info && ex->capw && fs_scan_direct_ok(ix, c.n_tok);
   auto kern = ix->log2_words == 14 ? k_scan8<N, NT, true> : k_scan8<N, NT, false>;
-  FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
                         c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
                         n_bm_words, chunk, bsum, ex ? ex->zero : nullptr,

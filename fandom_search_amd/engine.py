@@ -8,11 +8,28 @@ numeric half of the records (abi.ROW_DTYPE), sorted by (work, fan word index).
 """
 
 import ctypes as C
+import weakref
 
 import numpy as np
 
+import atexit
+
 from . import _lib, abi
 from .vocab import pack_strings
+
+# Handles still open when the interpreter exits are closed before the HIP runtime's
+# own teardown (a __del__ that runs after it would call into a runtime that is gone).
+_LIVE = weakref.WeakSet()
+
+
+@atexit.register
+def _close_all():
+    for obj in sorted(_LIVE, key=lambda o: 0 if isinstance(o, ScriptIndex) else 1):
+        try:
+            obj.close()            # an index closes its corpora first
+        except Exception:
+            pass
+
 
 
 class Corpus(object):
@@ -36,6 +53,8 @@ class Corpus(object):
             abi.ptr(self.work_off, C.c_uint64), self.n_works,
             abi.ptr(chars, C.c_uint32), abi.ptr(off, C.c_uint64),
             len(off) - 1, C.byref(self._h)), "fs_corpus_create")
+        index._corpora.add(self)
+        _LIVE.add(self)
 
     def update_begin(self, tok_vec, work_off, tok_str=None):
         """Queue the upload of a new batch of works into this corpus (copy
@@ -144,6 +163,8 @@ class ScriptIndex(object):
                 * self.cfg.emb_dim * self.cfg.window_size)
         if normals.size != want:
             raise ValueError("normals must hold H*B*D*n = %d values" % want)
+        self._corpora = weakref.WeakSet()      # live Corpus objects of this index
+        _LIVE.add(self)
         self._h = C.c_void_p()
         _lib.check(L.fs_index_create(
             C.byref(self.cfg), abi.ptr(sv, C.c_uint32),
@@ -267,6 +288,10 @@ class ScriptIndex(object):
         return ms.value
 
     def close(self):
+        """Destroys the index; corpora created on it are closed first (the library
+        would only detach them)."""
+        for c in list(getattr(self, "_corpora", ())):
+            c.close()
         if self._h:
             _lib.load().fs_index_destroy(self._h)
             self._h = C.c_void_p()

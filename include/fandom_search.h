@@ -150,6 +150,8 @@ int fs_corpus_create(fs_index* ix,
                      const uint32_t* str_chars, const uint64_t* str_off,
                      uint64_t n_str,
                      fs_corpus** out);
+/* A corpus may be destroyed before or after its index: fs_index_destroy detaches
+ * the corpora that are still alive (a detached corpus can only be destroyed). */
 void fs_corpus_destroy(fs_corpus* c);
 
 /* Streaming (BASELINE configs[4]: corpora larger than one batch, streamed from

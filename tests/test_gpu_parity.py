@@ -450,3 +450,34 @@ def test_rows_header_receives_the_count(synth_base):
         if not packed:
             assert host[32:32 + n * 32].tobytes() == want.tobytes()
     ix.close()
+
+
+def test_corpus_may_outlive_its_index(synth_base):
+    """Destroying an index before its corpora must be harmless: through the Python
+    wrapper (closes the corpora first) and at the C ABI (the index detaches them, a
+    detached corpus can only be destroyed)."""
+    import ctypes as C
+    from fandom_search_amd import _lib
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(2000)
+    tok, off = util.ragged_corpus([500] * 6, script)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    rows, _ = ix.search(c)
+    ix.close()                                   # closes c as well
+    assert not c._h
+    # C ABI order: index first, then the corpus
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    L = _lib.load()
+    ix._corpora.discard(c)
+    L.fs_index_destroy(ix._h)
+    ix._h = C.c_void_p()
+    assert L.fs_corpus_update_end(c._h) == abi.FS_OK          # nothing pending: no-op
+    rc = L.fs_corpus_update_begin(c._h, abi.ptr(c.tok_vec, C.c_uint32), None,
+                                  abi.ptr(c.work_off, C.c_uint64), c.n_works)
+    assert rc == abi.FS_E_INVALID
+    c.close()
