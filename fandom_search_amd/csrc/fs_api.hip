@@ -690,6 +690,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
   FS_ENTER(ix->device);
   fs_index::Slot& sl = ix->slots[ticket];
   sl.busy = false;
+  if (!sl.c) { fs_set_error("the corpus of this search has been destroyed"); return FS_E_INVALID; }
   float scan_ms = 0, total_ms = 0;
   for (int attempt = 0;; ++attempt) {
     FS_HIP(hipEventSynchronize(sl.ev_end));
