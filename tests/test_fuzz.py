@@ -5,6 +5,8 @@ selects."""
 
 import numpy as np
 import pytest
+import os
+
 from hypothesis import HealthCheck, given, settings, strategies as st
 
 from fandom_search_amd import abi
@@ -79,7 +81,8 @@ def test_c_oracle_equals_python_oracle(p):
 
 
 @pytest.mark.gpu
-@settings(max_examples=400, deadline=None, suppress_health_check=list(HealthCheck))
+@settings(max_examples=int(os.environ.get("FS_FUZZ_EXAMPLES", "400")), deadline=None,
+          suppress_health_check=list(HealthCheck))
 @given(CASE)
 def test_hip_equals_c_oracle(p):
     from fandom_search_amd.engine import ScriptIndex

@@ -289,14 +289,16 @@ def test_one_very_long_work(synth_base):
     assert np.all(np.diff(got["fan_ix"].astype(np.int64)) > 0) and len(got) > 5000
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
 @pytest.mark.parametrize("mode", [abi.FS_MODE_AUTO, abi.FS_MODE_GENERAL])
-def test_overlapping_searches_stress(synth_base, mode):
-    """Searches alternate between the index's lanes (streams with their own
-    workspaces), so consecutive ones run side by side on the GPU.  Many rounds
-    of four searches in flight over corpora of different sizes, collected in
-    changing order, must reproduce the synchronous rows every time."""
+def test_overlapping_searches_stress(synth_base, mode, lanes, monkeypatch):
+    """With FS_LANES > 1 searches alternate between the index's lanes (streams with
+    their own workspaces), so consecutive ones run side by side on the GPU.  Many
+    rounds of four searches in flight over corpora of different sizes, collected
+    in changing order, must reproduce the synchronous rows every time."""
     import torch
     from fandom_search_amd.engine import ScriptIndex
+    monkeypatch.setenv("FS_LANES", str(lanes))
     words, emb = synth_base["words"], synth_base["emb"]
     script = synth.script_tokens(6000)
     ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
