@@ -483,3 +483,38 @@ def test_corpus_may_outlive_its_index(synth_base):
                                   abi.ptr(c.work_off, C.c_uint64), c.n_works)
     assert rc == abi.FS_E_INVALID
     c.close()
+
+
+def test_dense_chunks_span_several_verify_tiles(synth_base, monkeypatch):
+    """3.3 M tokens: a chunk of the direct path is three sub-tiles (1536 windows).
+    Works that quote 1900 script tokens in a row fill whole chunks with candidates,
+    so k_verify_direct stages more than one 1024-candidate tile per chunk and the
+    record lists grow; the bitmap form of the pipeline must give the same bytes, and
+    the quoted works alone must equal the oracle."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(20000)
+    tok, off = synth.corpus_tokens(1650, 2000, script)
+    tok = tok.copy()
+    dense = [3, 400, 401, 1649]
+    for j, w in enumerate(dense):
+        a = int(off[w]) + 17 * j
+        tok[a:a + 1900] = script[500 + 1000 * j:2400 + 1000 * j]
+    swords = [words[int(t)] for t in script]
+    ix = ScriptIndex(script, swords, emb, synth.lsh_normals(6), cfg=abi.make_config())
+    c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    rows, st = ix.search(c)
+    monkeypatch.setenv("FS_SCAN_DIRECT", "0")
+    brows, bst = ix.search(c)
+    monkeypatch.delenv("FS_SCAN_DIRECT")
+    assert rows.tobytes() == brows.tobytes() and st.candidates == bst.candidates
+    ix.close()
+    # the dense works on their own against the oracle
+    sub_tok = np.concatenate([tok[int(off[w]):int(off[w + 1])] for w in dense])
+    sub_off = np.arange(len(dense) + 1, dtype=np.uint64) * np.uint64(2000)
+    oi = util.oracle_index(abi.make_config(), script, words, emb, synth.lsh_normals(6))
+    want, _ = oi.search(sub_tok, sub_off, synth_base["chars"], synth_base["off"])
+    got = rows[np.isin(rows["work"], dense)].copy()
+    got["work"] = np.searchsorted(dense, got["work"])
+    util.assert_rows_equal(got, want)
+    assert len(want) > 4 * 1800
