@@ -285,7 +285,8 @@ def main():
         last_gathered[0] = b
 
     # the scan kernel is timed (events attached to its dispatch) on every 4th step
-    ix.set_scan_timing(4 if args.steps >= 16 else 1)
+    # (a timed search carries extra event records, about 15 us: time few of them)
+    ix.set_scan_timing(4 if args.steps >= 8 else 2 if args.steps >= 4 else 1)
 
     def complete(i):
         """Finish the search of step i and hand its rows to the gather."""
