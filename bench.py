@@ -440,7 +440,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "avg_launch_ms": scan_avg_ms, "timed_launches": len(scan_ms)},
-            "device_total_ms": float(np.mean(total_ms)) if total_ms else None,
+            "device_total_ms": float(np.mean(total_ms)) if total_ms and np.mean(total_ms) > 0 else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, script, swords, words, emb, normals, tpw,

@@ -582,7 +582,10 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   // timing events only on timed searches: every event record is a barrier packet
   // in the queue (about 1.5 us of bubble each)
   sl.timed = ix->scan_timing_period <= 1 || (ix->searches++ % ix->scan_timing_period) == 0;
-  if (sl.timed) FS_HIP(hipEventRecord(sl.ev_begin, s));
+  // the whole-search time only when every search is timed (the synchronous use)
+  const bool whole = sl.timed && ix->scan_timing_period <= 1;
+  if (whole) FS_HIP(hipEventRecord(sl.ev_begin, s));
+  sl.whole_timed = whole;
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
@@ -697,7 +700,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     scan_ms = 0;
     if (sl.n_bm && sl.timed) FS_HIP(hipEventElapsedTime(&scan_ms, sl.ev_scan0, sl.ev_scan1));
     total_ms = 0;
-    if (sl.timed) FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
+    if (sl.whole_timed) FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
     const fs_status& hs = *sl.h_status;
     if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }
     if (hs.lev_overflow) {

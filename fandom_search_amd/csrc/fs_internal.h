@@ -204,6 +204,7 @@ struct fs_index {
     bool exact = false;
     uint32_t n_bm = 0, launches = 0;
     bool timed = false;               // this search's scan carries timing events
+    bool whole_timed = false;         // ... and ev_begin / ev_end bracket the whole search
     int tpl = 4;                      // tokens per lane of the bitmap layout
     int lane = 0;                     // the lane (stream + workspaces) it was queued on
     uint32_t capw = 0;                // direct path: record capacity per wave range (0: bitmap path)
