@@ -11,6 +11,11 @@ import pytest
 from fandom_search_amd import search
 from tests import util
 
+def _bytes(path):
+    with open(path, "rb") as fh:
+        return fh.read()
+
+
 
 def _script(tmp_path):
     p = tmp_path / "script.txt"
@@ -63,11 +68,11 @@ def test_format_command_equals_restatement(tmp_path, monkeypatch):
     assert main(["format", matches, script, "-o", "out.csv", "--lexicon", str(lex)]) == 0
     fr.format_data(matches, search.load_markup_script(script), lambda w: LEX.get(w, set()),
                    "want.csv")
-    assert open("out.csv", "rb").read() == open("want.csv", "rb").read()
+    assert _bytes("out.csv") == _bytes("want.csv")
     # default output name, no lexicon
     assert main(["format", matches, script]) == 0
     fr.format_data(matches, search.load_markup_script(script), lambda w: set(), "want2.csv")
-    assert open("js-data.csv", "rb").read() == open("want2.csv", "rb").read()
+    assert _bytes("js-data.csv") == _bytes("want2.csv")
 
 
 @pytest.mark.gpu
@@ -88,7 +93,7 @@ def test_format_on_search_output(tmp_path, monkeypatch, synth_base):
         fh.write(util.golden_text("synthetic_small", "canonical"))
     fmt.format_data(types.SimpleNamespace(matches="m.csv", script="script.txt", output="o.csv"))
     fr.format_data("m.csv", search.load_markup_script("script.txt"), lambda w: set(), "w.csv")
-    assert open("o.csv", "rb").read() == open("w.csv", "rb").read()
+    assert _bytes("o.csv") == _bytes("w.csv")
     # fused: histogram of device rows right after the search
     cfg = util.case_config(case)
     ix = ScriptIndex(script, [words[int(t)] for t in script], synth_base["emb"],

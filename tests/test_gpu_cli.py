@@ -58,5 +58,6 @@ def test_ao3_search_c1(tmp_path, monkeypatch, synth_base, capsys):
 
     # matrix over the result
     assert main(["matrix", "match-6gram-%s.csv" % today, "synth"]) == 0
-    m = list(csv.reader(open("synth-most-common-perfect-matches-no-overlap-6-gram-match-matrix.csv")))
+    with open("synth-most-common-perfect-matches-no-overlap-6-gram-match-matrix.csv") as fh:
+        m = list(csv.reader(fh))
     assert m[0][0] == "FILENAME" and m[1][0] == "(total)" and len(m[0]) > 1
