@@ -386,7 +386,7 @@ def main():
         if exact:
             # fs_scan_tpl: eight tokens per lane (byte bitmap) while the ids fit 256 MiB
             if corpus.n_tok * 4 <= (256 << 20) and 2 <= args.window <= 8:
-                kernel = "k_scan8<%d,1>" % args.window
+                kernel = "k_scan8<%d>" % args.window
             else:
                 kernel = "k_scan<%d,4,shuffle,nt>" % args.window
             algo_bytes = 4.0 * corpus.n_tok       # 4 B per fan token
