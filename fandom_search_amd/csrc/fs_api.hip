@@ -75,6 +75,25 @@ fs_index::~fs_index() {
 }   // `stream` is lanes[0].stream
 
 
+// FS_* diagnostic switches -> fs_switches (fs_internal.h)
+void fs_read_switches(fs_switches* sw) {
+  *sw = fs_switches();
+  auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
+  sw->scan_blocks_per_cu = num("FS_SCAN_BLOCKS_PER_CU");
+  if (const char* e = getenv("FS_SCAN_FLAGS")) sw->scan_flags = e[0] ? e[0] : '-';
+  if (const char* e = getenv("FS_SCAN_VARIANT")) sw->scan_simple = e[0] == 's';
+  sw->scan_tpl = num("FS_SCAN_TPL");
+  if (const char* e = getenv("FS_SCAN_DIRECT")) sw->scan_direct = e[0] != '0';
+  sw->scan_unroll = num("FS_SCAN_UNROLL");
+  if (const char* e = getenv("FS_SCAN_HALO")) sw->scan_halo_loads = e[0] == 'l';
+  sw->no_stagger = getenv("FS_NO_STAGGER") != nullptr;
+  sw->scan_capw = num("FS_SCAN_CAPW");
+  sw->post_fused = getenv("FS_POST_FUSED") != nullptr;
+  if (const char* e = getenv("FS_POST_RANGES")) sw->post_ranges = e[0] != '0';
+  if (const char* e = getenv("FS_SCAN_ROWS")) sw->scan_rows = e[0] != '0';
+  sw->ranges_caprow = num("FS_RANGES_CAPROW");
+}
+
 static int ceil_log2(uint64_t x) {
   int l = 0;
   while ((1ull << l) < x) ++l;
@@ -282,6 +301,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   if (!ix) return FS_E_NOMEM;
   struct Guard { fs_index* p; ~Guard() { delete p; } } guard{ix};
   ix->cfg = *cfg;
+  fs_read_switches(&ix->sw);
   ix->device = cfg->device;
   ix->n_script = n_script; ix->n_vec = n_vec;
   ix->n_windows = n_script >= cfg->window_size ? n_script - cfg->window_size + 1 : 0;
@@ -355,6 +375,14 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
 extern "C" int fs_index_info_get(const fs_index* ix, fs_index_info* info) {
   if (!ix || !info) return FS_E_INVALID;
   *info = ix->info;
+  return FS_OK;
+}
+
+// Diagnostics: the FS_* switches are read at fs_index_create; a test or sweep that
+// changes them on a live index calls this (never needed on the search path).
+extern "C" int fs_index_reload_switches(fs_index* ix) {
+  if (!ix) return FS_E_INVALID;
+  fs_read_switches(&ix->sw);
   return FS_OK;
 }
 
@@ -462,6 +490,7 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
     ix->cur = &ix->lanes[0];
     FS_HIP(hipMemsetAsync(ix->cur->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
+    FS_TRY(fs_launch_sbest(ix, c, ix->stream));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->cur->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     if (ix->h_status->bad_string) { fs_set_error("script vector id without a string"); return FS_E_INVALID; }
@@ -554,20 +583,23 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   fs_corpus* c = sl.c;
   const uint32_t nn = ix->cfg.nearest_n;
   const uint32_t n_bm = sl.n_bm;
-  if (sl.capw) {                       // direct path: records instead of a bitmap
+  if (sl.fused_waves) {                // k_scan_rows: nothing between scan and records
+  } else if (sl.capw) {                // direct path: records instead of a bitmap
     FS_TRY(ln.w_recs.reserve((size_t)FS_CHUNKS * 4 * sl.capw));
     FS_TRY(ln.w_info.reserve((size_t)FS_CHUNKS * 4));
   } else {
     FS_TRY(ln.w_qbm.reserve((size_t)n_bm * sl.tpl));
     FS_TRY(ln.w_qcnt.reserve(n_bm));
   }
-  FS_TRY(ln.w_cpos.reserve(sl.ccap));
-  FS_TRY(ln.w_cg.reserve(sl.ccap));
-  FS_TRY(ln.w_cw.reserve(sl.ccap));
-  FS_TRY(ln.w_hv.reserve(sl.ccap));
-  FS_TRY(ln.w_hcomb.reserve(sl.ccap));
-  FS_TRY(ln.w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
-  FS_TRY(ln.w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
+  if (!sl.caprow) {                    // the per-candidate arrays of the chained kernels
+    FS_TRY(ln.w_cpos.reserve(sl.ccap));
+    FS_TRY(ln.w_cg.reserve(sl.ccap));
+    FS_TRY(ln.w_cw.reserve(sl.ccap));
+    FS_TRY(ln.w_hv.reserve(sl.ccap));
+    FS_TRY(ln.w_hcomb.reserve(sl.ccap));
+    FS_TRY(ln.w_mlev.reserve(sl.exact && c->has_str ? sl.ccap * nn : 1));
+    FS_TRY(ln.w_cbest.reserve(!sl.exact || c->has_str ? sl.ccap : 1));
+  }
   fs_row* d_rows = sl.rows;
   uint64_t* count_out = nullptr;
   if (sl.header) {                     // 32-byte header in front of the records
@@ -594,15 +626,22 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   // before it, and what overlaps is a scan with the other lane's chain.  With three or
   // four lanes (FS_LANES, throughput over everything else) the order is left to the GPU:
   // measured on C2, 47 us per step with four lanes against 58 us with the ordering.
-  const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && !getenv("FS_NO_STAGGER");
+  const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && !ix->sw.no_stagger;
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
-  if (sl.exact) {
+  if (sl.exact && sl.fused_waves) {
+    FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,
+                               e0, e1, count_out));
+    if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
+  } else if (sl.exact) {
     fs_scan_extra ex;
     ex.bsum = ln.w_bsum.p; ex.zero = ln.d_status.p;
     if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
+    if (ex.direct && sl.caprow)
+      FS_TRY(fs_launch_ranges(ix, c, n_bm, rcap32, d_rows, wire, sl.caprow, sl.h_status, s, ex, count_out));
+    else
+      FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
@@ -671,8 +710,20 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   sl.capw = 0;
   if (sl.exact && fs_scan_direct_ok(ix, T)) {
     sl.capw = std::max<uint32_t>(64, ln.capw_hint);
-    if (const char* e = getenv("FS_SCAN_CAPW")) sl.capw = std::max(1, atoi(e));   // tests: force the growth path
+    if (ix->sw.scan_capw > 0) sl.capw = (uint32_t)ix->sw.scan_capw;   // tests: force the growth path
   }
+  // k_ranges (scan records -> output records in one kernel): staged records per wave
+  // range, 128 to start with (C2 averages 36), more once a search has asked for it
+  sl.caprow = 0;
+  sl.fused_waves = sl.exact ? fs_scan_rows_waves(ix, c) : 0;
+  if (sl.fused_waves || (sl.capw && fs_ranges_ok(ix, c))) {
+    const uint32_t ranges = sl.fused_waves ? fs_scan_rows_blocks(ix) * sl.fused_waves : FS_CHUNKS * 4;
+    // 128 for the 8192 ranges of a C2 scan (36 on average), in proportion for longer ranges
+    const uint32_t dflt = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(128, T / ranges / 16), 1u << 20);
+    sl.caprow = std::max<uint32_t>(dflt, ln.caprow_hint);
+    if (ix->sw.ranges_caprow > 0) sl.caprow = (uint32_t)ix->sw.ranges_caprow;
+  }
+  if (sl.fused_waves) { sl.capw = 0; sl.tpl = 8; sl.n_bm = (uint32_t)((T + 511) / 512); }
   // capacities: grown from the device totals when a stage overflows
   sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ln.w_cpos.n);
   sl.rcap = rows_mode != FS_ROWS_HOST
@@ -708,7 +759,12 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
       return FS_E_UNSUPPORTED;
     }
     bool again = false;
-    if (hs.n_cands > sl.ccap) { sl.ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
+    if (!sl.caprow && hs.n_cands > sl.ccap) { sl.ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
+    if (sl.caprow && hs.max_rows > sl.caprow) {
+      sl.caprow = (hs.max_rows + hs.max_rows / 4 + 7) & ~7u;
+      ix->lanes[sl.lane].caprow_hint = sl.caprow;
+      again = true;
+    }
     if (sl.capw && hs.max_recs > sl.capw) {
       sl.capw = (hs.max_recs + hs.max_recs / 4 + 7) & ~7u;
       ix->lanes[sl.lane].capw_hint = sl.capw;

@@ -19,6 +19,31 @@ struct NSrc {               // element count, known on the host or on the device
   }
 };
 
+// ---- wave-wide helpers (DPP) -------------------------------------------------
+
+// sum over the wave, complete in lane 63 (six DPP adds)
+__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);   // row_mirror
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+  return x;
+}
+
+// inclusive prefix sum over the wave (four row_shr adds inside each row of 16 lanes,
+// then the two row broadcasts)
+__device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
+  return x;
+}
+
 // ---- block-wide helpers ----------------------------------------------------
 
 template <class V>
@@ -80,7 +105,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict
   __shared__ V s_w[4];
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
     zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
-    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
+    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->max_rows = 0;
   }
   uint32_t lo, hi;
   chunk_of_block(ns.get(), &lo, &hi);

@@ -84,7 +84,7 @@ struct fs_status {
   uint32_t max_recs;     // direct path: largest record count of a wave range beyond its capacity
   uint32_t lev_overflow; // a Levenshtein operand exceeded FS_LEV_MAX
   uint32_t bad_string;   // string id outside the string table
-  uint32_t pad;
+  uint32_t max_rows;     // k_ranges: largest record count of a wave range beyond its staging capacity
 };
 
 // what one hit offers to the fan words of its window (first-minimum rank)
@@ -141,8 +141,28 @@ struct alignas(32) fs_swin {
 
 struct fs_corpus;
 
+// Diagnostic switches (FS_* environment variables), read once at fs_index_create and
+// again only on fs_index_reload_switches: nothing on the per-search path calls getenv.
+struct fs_switches {
+  int scan_blocks_per_cu = 0;     // FS_SCAN_BLOCKS_PER_CU (k_scan)
+  char scan_flags = 0;            // FS_SCAN_FLAGS: 'd' direct ballots, 'n' non-temporal loads, other: neither
+  bool scan_simple = false;       // FS_SCAN_VARIANT=simple
+  int scan_tpl = 0;               // FS_SCAN_TPL: tokens per lane (4 or 8)
+  bool scan_direct = true;        // FS_SCAN_DIRECT=0: bitmap + k_expand instead of candidate records
+  int scan_unroll = 0;            // FS_SCAN_UNROLL
+  bool scan_halo_loads = false;   // FS_SCAN_HALO=loads
+  bool no_stagger = false;        // FS_NO_STAGGER
+  int scan_capw = 0;              // FS_SCAN_CAPW: records per wave range to start with (tests)
+  bool post_fused = false;        // FS_POST_FUSED
+  bool post_ranges = true;        // FS_POST_RANGES=0: the k_verify_direct / k_hitrows / k_rows chain
+  bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
+  int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range to start with (tests)
+};
+void fs_read_switches(fs_switches* sw);
+
 struct fs_index {
   fs_config cfg;
+  fs_switches sw;
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev_scan0 = nullptr, ev_scan1 = nullptr;   // fs_scan_benchmark
@@ -179,6 +199,9 @@ struct fs_index {
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
+    DBuf<uint8_t> w_stage;         // k_ranges: staged records, caprow per wave range
+    DBuf<uint4> w_rinfo, w_csum;   //           {records, hits, pairs} per wave range / per chunk
+    uint32_t caprow_hint = 0;      //           staged records per wave range the last searches needed
     DBuf<fs_best> w_cbest;
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
     DBuf<fs_row> w_rows;
@@ -208,6 +231,8 @@ struct fs_index {
     int tpl = 4;                      // tokens per lane of the bitmap layout
     int lane = 0;                     // the lane (stream + workspaces) it was queued on
     uint32_t capw = 0;                // direct path: record capacity per wave range (0: bitmap path)
+    uint32_t caprow = 0;              // k_ranges / k_scan_rows: staged records per wave range
+    uint32_t fused_waves = 0;         // k_scan_rows: waves per workgroup (0: separate kernels)
   };
   Slot slots[FS_SEARCH_SLOTS];
   uint32_t next_slot = 0;
@@ -235,6 +260,7 @@ struct fs_corpus {
   bool pending = false;                // an upload is queued and not yet waited for
   DBuf<uint64_t> d_work_off, d_coff;
   DBuf<fs_best> d_gbest;
+  DBuf<fs_best> d_sbest;               // d_gbest by table slot (k_ranges reads it beside the table entry)
   bool levtab_ready = false;
   CorpusDev dev() const;
   ~fs_corpus();
@@ -291,6 +317,23 @@ int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_bl
                        uint2* blk_work, hipStream_t s);
 
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
+
+// fs_ranges.hip: scan records -> output records in one kernel + a copy into place
+int fs_launch_sbest(fs_index* ix, fs_corpus* c, hipStream_t s);
+bool fs_ranges_ok(const fs_index* ix, const fs_corpus* c);
+int fs_launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, uint32_t caprow,
+                      int rec_bytes, uint32_t rcap, fs_row* d_rows, fs_status* host_st,
+                      hipStream_t s, uint64_t* count_out, bool fresh,
+                      const uint32_t* cand_sums = nullptr, uint32_t n_cand_sums = 0);
+// fs_scan.hip: scan + records in one kernel (k_scan_rows), then k_compact
+uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c);   // 0: does not apply
+uint32_t fs_scan_rows_blocks(const fs_index* ix);
+int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
+                        int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
+                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out);
+int fs_launch_ranges(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t rcap, fs_row* d_rows,
+                     int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
+                     const fs_scan_extra& scan, uint64_t* count_out = nullptr);
 
 int fs_launch_rownorms(const float* emb, uint64_t n_vec, int D, double* q, hipStream_t s);
 int fs_launch_selfdist(const uint32_t* stok, uint64_t n_windows, int n, int D,

@@ -859,7 +859,7 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
     // Verifying inside k_expand (FS_POST_FUSED=1) saves a launch but measured slower
     // (110 vs 84 us per C2 step): the thread that decodes a ballot word then runs the
     // dependent-load chain of each of its candidates one after the other.
-    const bool fused = getenv("FS_POST_FUSED") != nullptr;
+    const bool fused = ix->sw.post_fused;
     FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s, scan.counted));
     if (!fused)
       hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,

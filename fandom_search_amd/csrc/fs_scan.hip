@@ -27,6 +27,7 @@
 // per 256 tokens (bitmap forms).
 #include "fs_internal.h"
 #include "fs_device.h"
+#include "fs_ranges.h"
 
 #include <hip/hip_ext.h>
 #include <stdlib.h>
@@ -228,29 +229,6 @@ __device__ __forceinline__ uint32_t fs_word_offset14(uint32_t h, uint32_t mask_f
   return r;
 }
 
-// sum over the wave, complete in lane 63 (six DPP adds)
-__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);   // row_mirror
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
-  return x;
-}
-
-// inclusive prefix sum over the wave (four row_shr adds inside each row of 16 lanes,
-// then the two row broadcasts)
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x) {
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1, 3
-  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2, 3
-  return x;
-}
-
 template <int N, bool TAIL, bool LW14>
 __device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint32_t* s_filter,
                                                   int word_shift, uint32_t mask_fffc,
@@ -311,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   __shared__ uint32_t s_csum[kChunksPerBlock];
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
     zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
-    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->pad = 0;
+    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->max_rows = 0;
   }
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;
@@ -387,7 +365,7 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
       flags = window_flags8<N, false, LW14>(a, s_filter, word_shift, mask_fffc, p0, n_tok);
     if (recs) {
       const uint32_t c = __popc(flags);
-      const uint32_t inc = wave_incl_scan(c);
+      const uint32_t inc = fsdev::wave_incl_scan_dpp(c);
       const uint64_t has = __ballot(flags != 0);
       const uint32_t slot = rec_run + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
@@ -396,7 +374,7 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
       cand_run += (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
     } else {
       bm_bytes[(size_t)sub * 64 + lane] = (uint8_t)flags;
-      const uint32_t cnt = wave_sum_lane63(__popc(flags));
+      const uint32_t cnt = fsdev::wave_sum_lane63(__popc(flags));
       if (lane == 63) qcnt[sub] = cnt;
       cand_run += (uint32_t)__builtin_amdgcn_readlane((int)cnt, 63);
     }
@@ -408,6 +386,195 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   if (bsum) {
     __syncthreads();
     if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = s_csum[threadIdx.x];
+  }
+}
+
+// ---- scan and records in one kernel -------------------------------------------------
+// k_scan_rows: the scan loop of k_scan8 with the post-scan work of fs_ranges.hip inside
+// the same wave.  Tokens in, output records (staged per wave range) out; nothing else
+// touches global memory: no candidate records, no per-candidate arrays.
+//
+// One workgroup of `blockDim.x / 64` waves per CU (the 64 KB filter plus 3.5 KB of queue
+// and hit state per wave).  Wave r scans the contiguous sub-tiles [s0, s1) of range r.
+// A lane whose eight windows hold candidates appends one 4-byte record
+// {(position - range start) / 8 << 8 | flag byte} to the wave's queue in LDS.  Once
+// kRecFlush records are queued (about one full round of candidates), and at the end of
+// the range, the wave runs the rounds of fs_ranges.h over the queue: verification,
+// hits, records of the words up to the scan front.  The ids of the next sub-tile are
+// requested before that, so their latency and the rounds' dependent loads overlap;
+// the other waves of the SIMD keep scanning meanwhile (flushes fall at data-dependent
+// times, so the waves drift apart instead of queueing at the end of the kernel).
+constexpr uint32_t kRecQueue = 128;   // queued records per wave (a sub-tile adds at most 64)
+constexpr uint32_t kRecFlush = 40;    // flush threshold
+
+struct alignas(16) FusedLds {         // per wave
+  fsdev::RangeLds R;
+  uint32_t rec[kRecQueue];
+};
+
+template <int N, bool NT, bool LW14>
+__global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
+                                                    const fs_best* __restrict__ sbest,
+                                                    uint32_t n_sub, fsdev::RangeOut out,
+                                                    uint4* __restrict__ rinfo,
+                                                    uint32_t* __restrict__ csum) {
+  using namespace fsdev;
+  static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+  __shared__ uint32_t s_rows[16];
+  uint32_t* s_filter = s_dyn;
+  FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << g.log2_words));
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  FusedLds& W = s_wave[wave];
+  RangeLds& S = W.R;
+  const uint32_t range_id = blockIdx.x * n_waves + wave;
+  const uint32_t n_ranges = gridDim.x * n_waves;
+  {
+    const uint32_t vecs = (1u << g.log2_words) / 4;
+    const uint4* src = reinterpret_cast<const uint4*>(g.filter);
+    uint4* dst = reinterpret_cast<uint4*>(s_filter);
+    for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  // sub-tiles dealt out evenly: the first n_sub % n_ranges ranges take one more
+  const uint32_t per = n_sub / n_ranges, rem = n_sub % n_ranges;
+  const uint32_t s0 = range_id * per + (range_id < rem ? range_id : rem);
+  const uint32_t s1 = s0 + per + (range_id < rem ? 1u : 0u);
+
+  constexpr uint32_t HALO = N - 1, RS = 64 - HALO;
+  constexpr uint32_t SUB = 512;
+  const int word_shift = 32 - g.log2_words;
+  const int src_lane = (lane + 1) & 63;
+  uint32_t mask_fffc = 0xFFFCu;
+  asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
+  const uint32_t* __restrict__ tok = c.tok;
+  const uint32_t n_tok = c.n_tok;
+
+  RangeState R;
+  R.E = 0; R.hc = 0; R.rows_run = 0; R.hits_run = 0; R.match_acc = 0;
+  uint32_t cacc = 0;                           // per lane: candidates seen
+  if (s1 > s0) {
+    const uint32_t a = s0 * SUB, bnd = s1 * SUB;
+    R.E = a;
+    uint32_t rec_cnt = 0, halo_n = a ? HALO : 0;
+    uint4 t0, t1, h0, h1;                      // the sub-tile in flight: own eight ids, first eight of the next one
+    auto request = [&](uint32_t sub) {
+      const uint4* p = reinterpret_cast<const uint4*>(tok + sub * SUB + 8 * lane);
+      if constexpr (NT) {
+        t0.x = __builtin_nontemporal_load(&p[0].x); t0.y = __builtin_nontemporal_load(&p[0].y);
+        t0.z = __builtin_nontemporal_load(&p[0].z); t0.w = __builtin_nontemporal_load(&p[0].w);
+        t1.x = __builtin_nontemporal_load(&p[1].x); t1.y = __builtin_nontemporal_load(&p[1].y);
+        t1.z = __builtin_nontemporal_load(&p[1].z); t1.w = __builtin_nontemporal_load(&p[1].w);
+      } else {
+        t0 = p[0]; t1 = p[1];
+      }
+      const uint4* hp = reinterpret_cast<const uint4*>(tok + sub * SUB + SUB);   // the buffer is padded
+      h0 = hp[0]; h1 = hp[1];
+    };
+    request(s0);
+    for (uint32_t j = s0; j < s1; ++j) {
+      const uint32_t base = j * SUB;
+      const uint4 v00 = t0, v01 = t1, v10 = h0, v11 = h1;
+      if (j + 1 < s1) request(j + 1);          // in flight during this sub-tile's work
+      uint32_t aa[16];
+      aa[0] = v00.x; aa[1] = v00.y; aa[2] = v00.z; aa[3] = v00.w;
+      aa[4] = v01.x; aa[5] = v01.y; aa[6] = v01.z; aa[7] = v01.w;
+      // halo: first HALO tokens of lane L+1; lane 0 publishes the next sub-tile's
+      const bool wrap = lane == 0;
+      const uint32_t n0[8] = {wrap ? v10.x : v00.x, wrap ? v10.y : v00.y,
+                              wrap ? v10.z : v00.z, wrap ? v10.w : v00.w,
+                              wrap ? v11.x : v01.x, wrap ? v11.y : v01.y,
+                              wrap ? v11.z : v01.z, wrap ? v11.w : v01.w};
+#pragma unroll
+      for (int h = 0; h < (int)HALO; ++h) aa[8 + h] = __shfl(n0[h], src_lane);
+#pragma unroll
+      for (int k = 0; k < 8 + (int)HALO; ++k) aa[k] = fs_premix(aa[k]);
+      const uint32_t p0 = base + 8 * lane;
+      uint32_t flags;
+      if (base + SUB + HALO > n_tok)
+        flags = window_flags8<N, true, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+      else
+        flags = window_flags8<N, false, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+      const uint64_t has = __ballot(flags != 0);
+      const uint32_t slot = rec_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
+                                          __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
+      if (flags != 0) W.rec[slot] = ((((base - a) >> 3) + (uint32_t)lane) << 8) | flags;
+      rec_cnt += (uint32_t)__popcll(has);
+      cacc += __popc(flags);
+      const bool last_sub = j + 1 == s1;
+      if (rec_cnt >= kRecFlush || (last_sub && (rec_cnt | halo_n | R.hc))) {      // wave-uniform
+        wave_sync();
+        // ranks of the queued candidates: lane t holds records t and t + 64
+        const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
+        const uint32_t rb = (uint32_t)lane + 64 < rec_cnt ? W.rec[lane + 64] : 0u;
+        const uint32_t ca = __popc(ra & 0xFFu), cb = __popc(rb & 0xFFu);
+        const uint32_t ia = wave_incl_scan_dpp(ca);
+        const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+        uint32_t ib = 0, tb = 0;
+        if (rec_cnt > 64) {
+          ib = wave_incl_scan_dpp(cb);
+          tb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+        }
+        const uint32_t total = halo_n + ta + tb;
+        const uint32_t F_end = last_sub ? bnd : base + SUB;
+        uint32_t r0 = 0;
+        do {
+          const uint32_t left = total - r0;
+          const uint32_t m = left < RS ? left : RS;
+          S.cand[lane] = FS_NONE;
+          wave_sync();
+          if ((uint32_t)lane < halo_n && (uint32_t)lane >= r0 && (uint32_t)lane - r0 <= RS)
+            S.cand[lane - r0] = a - halo_n + lane;
+          {
+            uint32_t fl = ra & 0xFFu, li = halo_n + ia - ca;
+            const uint32_t q0 = a + ((ra >> 8) << 3);
+            while (fl) {
+              const int bb = __ffs(fl) - 1;
+              fl &= fl - 1;
+              if (li >= r0 && li - r0 <= RS) S.cand[li - r0] = q0 + (uint32_t)bb;
+              ++li;
+            }
+          }
+          if (rec_cnt > 64) {
+            uint32_t fl = rb & 0xFFu, li = halo_n + ta + ib - cb;
+            const uint32_t q0 = a + ((rb >> 8) << 3);
+            while (fl) {
+              const int bb = __ffs(fl) - 1;
+              fl &= fl - 1;
+              if (li >= r0 && li - r0 <= RS) S.cand[li - r0] = q0 + (uint32_t)bb;
+              ++li;
+            }
+          }
+          wave_sync();
+          uint32_t F = F_end;
+          if (r0 + RS < total) {
+            const uint32_t nx = S.cand[RS];
+            if (nx < F) F = nx;
+          }
+          range_round<N>(c, g, sbest, S, m, F, a, range_id, out, R);
+          r0 += RS;
+        } while (r0 < total);
+        rec_cnt = 0;
+        halo_n = 0;
+      }
+    }
+  }
+  // per range {records, hits, (window, script window) pairs, candidates}; per block: records
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) {
+    R.match_acc += (uint32_t)__shfl_xor((int)R.match_acc, d);
+    cacc += (uint32_t)__shfl_xor((int)cacc, d);
+  }
+  if (lane == 0) {
+    rinfo[range_id] = make_uint4(R.rows_run, R.hits_run, R.match_acc, cacc);
+    s_rows[wave] = R.rows_run;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+    for (uint32_t i = 0; i < n_waves; ++i) t += s_rows[i];
+    csum[blockIdx.x] = t;
   }
 }
 
@@ -469,10 +636,7 @@ int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   int threads = 1024;
   const uint32_t waves_per_block = threads / 64;
   uint32_t blocks_per_cu = lds <= 64 * 1024 ? 2 : 1;
-  if (const char* e = getenv("FS_SCAN_BLOCKS_PER_CU")) {
-    const int v = atoi(e);
-    if (v > 0) blocks_per_cu = v;
-  }
+  if (ix->sw.scan_blocks_per_cu > 0) blocks_per_cu = ix->sw.scan_blocks_per_cu;
   uint32_t max_blocks = ix->num_cu * blocks_per_cu;
   uint32_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -514,8 +678,8 @@ int launch_tpl8(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
                 uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
                 fs_scan_extra* ex) {
   const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
-  const char* e = getenv("FS_SCAN_FLAGS");
-  const bool nt = (e && e[0] == 'n') || (!e && big);
+  const char e = ix->sw.scan_flags;
+  const bool nt = e == 'n' || (!e && big);
   return nt ? launch_tpl8_k<N, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, ex)
             : launch_tpl8_k<N, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, ex);
 }
@@ -528,10 +692,10 @@ int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
   //          straight into the ballot ("direct")
   //   nt     non-temporal id loads: +6 % once the ids cannot stay in the 256 MiB
   //          Infinity Cache (2 GB), -7 % when a resident corpus is scanned again
-  const char* e = getenv("FS_SCAN_FLAGS");
+  const char e = ix->sw.scan_flags;
   const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
-  if (e && e[0] == 'd') return launch_fast_k<N, U, HL, true, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-  if ((e && e[0] == 'n') || (!e && big))
+  if (e == 'd') return launch_fast_k<N, U, HL, true, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+  if (e == 'n' || (!e && big))
     return launch_fast_k<N, U, HL, false, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
   return launch_fast_k<N, U, HL, false, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
 }
@@ -564,10 +728,9 @@ int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
 // slower at 2 GB (413 -> 438 us), where the 32-byte lane stride of its loads costs
 // more than the saved VALU work.
 int fs_scan_tpl(const fs_index* ix, uint64_t n_tok) {
-  const char* var = getenv("FS_SCAN_VARIANT");
-  if (var && var[0] == 's') return 4;
+  if (ix->sw.scan_simple) return 4;
   int tpl = n_tok * 4 <= (256ull << 20) ? 8 : 4;
-  if (const char* e = getenv("FS_SCAN_TPL")) tpl = atoi(e);
+  if (ix->sw.scan_tpl) tpl = ix->sw.scan_tpl;
   const int n = ix->cfg.window_size;
   const bool has8 = n == 2 || n == 3 || n == 4 || n == 5 || n == 6 || n == 7 || n == 8;
   return (tpl == 8 && has8) ? 8 : 4;
@@ -580,7 +743,7 @@ uint32_t fs_scan_pad_tokens() { return 512 * 8 + 64; }
 // The direct path packs (position / 8) << 8 | flags into 32 bits: positions below 2^26,
 // which is also the limit of the eight-tokens-per-lane kernel unless it is forced.
 bool fs_scan_direct_ok(const fs_index* ix, uint64_t n_tok) {
-  if (const char* e = getenv("FS_SCAN_DIRECT")) if (e[0] == '0') return false;
+  if (!ix->sw.scan_direct) return false;
   return fs_scan_tpl(ix, n_tok) == 8 && n_tok + 1024 < (1ull << 26);
 }
 
@@ -591,14 +754,12 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
                    fs_scan_extra* extra) {
   if (extra) { extra->counted = false; extra->direct = false; }
   const int n = ix->cfg.window_size;
-  const char* var = getenv("FS_SCAN_VARIANT");
-  const bool simple = var && var[0] == 's';
+  const bool simple = ix->sw.scan_simple;
   // measured on MI355X (tools/scan_sweep.py, profiles/): two sub-tiles per wave
   // iteration and the shuffle halo are fastest up to the Infinity Cache size, four beyond (2 GB of ids)
   int unroll = (uint64_t)c.n_tok * 4 > (256ull << 20) ? 4 : 2;
-  if (const char* u = getenv("FS_SCAN_UNROLL")) unroll = atoi(u);
-  bool halo_loads = false;
-  if (const char* h = getenv("FS_SCAN_HALO")) halo_loads = h[0] == 'l';   // "loads"
+  if (ix->sw.scan_unroll) unroll = ix->sw.scan_unroll;
+  const bool halo_loads = ix->sw.scan_halo_loads;
   if (fs_scan_tpl(ix, c.n_tok) == 8) {
     switch (n) {
       case 2: return launch_tpl8<2>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
@@ -637,4 +798,72 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
                         qcnt, n_bm_words);
   FS_HIP(hipGetLastError());
   return FS_OK;
+}
+
+// ---- k_scan_rows (scan + records) -----------------------------------------------------
+namespace {
+
+template <int N>
+int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
+                     const fsdev::RangeOut& out, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  fs_index::Lane& ln = *ix->cur;
+  const size_t lds = ((size_t)4 << ix->log2_words) + waves * sizeof(FusedLds);
+  const bool big = c->n_tok * 4 > (256ull << 20);
+  const char e = ix->sw.scan_flags;
+  const bool nt = e == 'n' || (!e && big);
+  const bool lw14 = ix->log2_words == 14;
+  auto kern = nt ? (lw14 ? k_scan_rows<N, true, true> : k_scan_rows<N, true, false>)
+                 : (lw14 ? k_scan_rows<N, false, true> : k_scan_rows<N, false, false>);
+  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
+  hipExtLaunchKernelGGL(kern, dim3(fs_scan_rows_blocks(ix)), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
+                        0u, c->dev(), ix->gram_dev(), (const fs_best*)c->d_sbest.p, n_sub, out,
+                        ln.w_rinfo.p, reinterpret_cast<uint32_t*>(ln.w_csum.p));
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
+}  // namespace
+
+// waves per workgroup of k_scan_rows: sixteen when filter + per-wave state fit the
+// 160 KB of LDS, eight with a 128 KB filter, 0: does not apply
+uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c) {
+  const uint32_t n = ix->cfg.window_size;
+  if (!ix->sw.scan_rows || n < 2 || n > 8 || c->has_str || !c->d_sbest.p) return 0;
+  // a switch that asks for one of the other scan kernels or paths
+  const fs_switches& sw = ix->sw;
+  if (sw.scan_simple || sw.scan_tpl == 4 || sw.scan_unroll || sw.scan_halo_loads || !sw.scan_direct ||
+      sw.scan_capw)
+    return 0;
+  const size_t filter = (size_t)4 << ix->log2_words;
+  for (uint32_t w : {16u, 8u})
+    if (filter + w * sizeof(FusedLds) + 256 <= 160 * 1024) return w;
+  return 0;
+}
+
+uint32_t fs_scan_rows_blocks(const fs_index* ix) { return (uint32_t)ix->num_cu; }
+
+// tokens -> staged records of fs_scan_rows_blocks() * waves wave ranges -> k_compact
+int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
+                        int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
+                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out) {
+  fs_index::Lane& ln = *ix->cur;
+  const uint32_t n_ranges = fs_scan_rows_blocks(ix) * waves;
+  const int rec_bytes = wire ? wire : 32;
+  const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
+  FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * rec_bytes));
+  FS_TRY(ln.w_rinfo.reserve(n_ranges));
+  FS_TRY(ln.w_csum.reserve(n_ranges));
+  const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
+  switch (ix->cfg.window_size) {
+    case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 3: FS_TRY(launch_scan_rows<3>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 4: FS_TRY(launch_scan_rows<4>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 5: FS_TRY(launch_scan_rows<5>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 6: FS_TRY(launch_scan_rows<6>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 7: FS_TRY(launch_scan_rows<7>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    default: fs_set_error("k_scan_rows covers n = 2..8"); return FS_E_UNSUPPORTED;
+  }
+  return fs_launch_compact(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st, s, count_out,
+                           /*fresh=*/true);
 }

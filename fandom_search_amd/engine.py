@@ -229,6 +229,10 @@ class ScriptIndex(object):
         _lib.check(_lib.load().fs_index_set_scan_timing(self._h, int(period)),
                    "fs_index_set_scan_timing")
 
+    def reload_switches(self):
+        """Diagnostics: re-read the FS_* environment switches (read at creation)."""
+        _lib.check(_lib.load().fs_index_reload_switches(self._h), "fs_index_reload_switches")
+
     def search_begin(self, corpus, rows_ptr, cap, packed=False, header=False):
         """Queue a search (rows to the device buffer at `rows_ptr`) and return a
         ticket for search_end; up to four may be in flight per index.  `header`:

@@ -249,6 +249,11 @@ int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint64_t n_rows,
  * microseconds of stream time per launch, which matters for sub-100 us searches. */
 int fs_index_set_scan_timing(fs_index* ix, uint32_t period);
 
+/* Diagnostics: the FS_* environment switches (kernel variants, forced capacities) are
+ * read once at fs_index_create; a test or sweep that changes them on a live index
+ * calls this to have them read again.  Not part of the search path. */
+int fs_index_reload_switches(fs_index* ix);
+
 /* Diagnostics: `reps` back-to-back launches of the scan kernel alone over `c`,
  * timed with one pair of HIP events; *avg_ms = time per launch.  Used by
  * tools/scan_sweep.py to compare kernel variants without per-launch event

@@ -98,8 +98,10 @@ def test_c2_full_properties_and_pipeline_equality(c2, synth_base, monkeypatch):
     # the bitmap + expand form of the exact pipeline gives the same bytes as the
     # candidate-record form used above
     monkeypatch.setenv("FS_SCAN_DIRECT", "0")
+    ix.reload_switches()
     brows, bst = ix.search(corpus)
     monkeypatch.delenv("FS_SCAN_DIRECT")
+    ix.reload_switches()
     assert brows.tobytes() == rows.tobytes() and bst.candidates == st.candidates
     # the 8-byte wire records of the whole batch expand to the same bytes
     import torch

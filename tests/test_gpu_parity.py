@@ -505,8 +505,10 @@ def test_dense_chunks_span_several_verify_tiles(synth_base, monkeypatch):
     c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
     rows, st = ix.search(c)
     monkeypatch.setenv("FS_SCAN_DIRECT", "0")
+    ix.reload_switches()
     brows, bst = ix.search(c)
     monkeypatch.delenv("FS_SCAN_DIRECT")
+    ix.reload_switches()
     assert rows.tobytes() == brows.tobytes() and st.candidates == bst.candidates
     ix.close()
     # the dense works on their own against the oracle
@@ -518,3 +520,70 @@ def test_dense_chunks_span_several_verify_tiles(synth_base, monkeypatch):
     got["work"] = np.searchsorted(dense, got["work"])
     util.assert_rows_equal(got, want)
     assert len(want) > 4 * 1800
+
+
+@pytest.mark.parametrize("n", [2, 4, 5, 6, 7, 8])
+def test_range_kernel_and_chain_agree(synth_base, monkeypatch, n):
+    """k_scan_rows (scan + records in one kernel, the default), k_scan8 + k_ranges
+    (FS_SCAN_ROWS=0: scan records -> output records per wave range, fs_ranges.hip), the
+    chain they replace (FS_POST_RANGES=0: k_verify_direct, k_hitrows, k_rows) and
+    the oracle: same bytes and statistics in all three record formats, also when
+    the staging area starts far too small (FS_RANGES_CAPROW=2), with works that quote
+    long stretches of the script (several rounds of candidates per wave, hits carried
+    from round to round), hits at range and work boundaries, ragged and empty works.
+    n = 7, 8 need a table the exact-n-gram proof accepts: 256 one-hot vectors."""
+    import torch
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+    if n <= 6:
+        words, emb, V = synth_base["words"], synth_base["emb"], synth.VOCAB_SIZE
+        chars, coff = synth_base["chars"], synth_base["off"]
+    else:
+        V = 256
+        words = synth.vocab_words(V)
+        emb = np.eye(V, synth.EMB_DIM, dtype=np.float32)
+        chars, coff = pack_strings(words)
+    script = synth.script_tokens(5000, vocab_size=V)
+    lengths = [1500] * 40 + [0, 5, n, n - 1, 3000, 511, 512, 513]
+    parts = [synth.fanwork_tokens(i, L, script, V) if L else np.zeros(0, np.uint32)
+             for i, L in enumerate(lengths)]
+    off = np.zeros(len(lengths) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(p) for p in parts])
+    tok = np.concatenate(parts).astype(np.uint32)
+    tok[int(off[3]):int(off[3]) + 1400] = script[100:1500]      # dense: every window a hit
+    tok[int(off[7]) + 1490:int(off[7]) + 1500] = script[40:50]  # hit at the end of a work ...
+    tok[int(off[8]):int(off[8]) + 10] = script[40:50]           # ... and at the start of the next
+    for k in range(9, 30):                                      # hits straddling 512-token borders
+        at = (int(off[k]) // 512 + 1) * 512 - (k % (n + 3))
+        tok[at:at + n + 2] = script[700 + k:700 + k + n + 2]
+    normals = synth.lsh_normals(n)
+    cfg = abi.make_config(window_size=n)
+    results = []
+    for env in ({}, {"FS_SCAN_ROWS": "0"}, {"FS_SCAN_ROWS": "0", "FS_POST_RANGES": "0"},
+                {"FS_RANGES_CAPROW": "2"}, {"FS_SCAN_ROWS": "0", "FS_RANGES_CAPROW": "2"}):
+        for k in ("FS_SCAN_ROWS", "FS_POST_RANGES", "FS_RANGES_CAPROW"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ix = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=cfg)
+        assert ix.info["path"] == abi.FS_MODE_EXACT
+        c = ix.corpus(tok, off, chars, coff)
+        rows, st = ix.search(c)
+        rows2, _ = ix.search(c)
+        assert rows.tobytes() == rows2.tobytes()
+        wires = []
+        cap = len(rows) + 3
+        for packed, size in ((True, 16), (8, 8)):
+            buf = torch.zeros(32 + cap * size, dtype=torch.uint8, device="cuda")
+            nw, _ = ix.search_end(ix.search_begin(c, buf.data_ptr(), cap, packed=packed, header=True))
+            host = buf.cpu().numpy()
+            assert nw == len(rows) and int(host[:8].view(np.uint64)[0]) == nw
+            wires.append(host[32:32 + nw * size].tobytes())
+        results.append((rows.tobytes(), st.candidates, st.matches, st.rows, wires))
+        ix.close()
+    assert all(r == results[0] for r in results[1:])
+    oi = util.oracle_index(cfg, script, words, emb, normals)
+    want, ost = oi.search(tok, off, chars, coff)
+    assert results[0][0] == want.tobytes() and results[0][2] == ost.matches
+    assert len(want) > 1400
+    oi.close()

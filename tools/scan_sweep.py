@@ -72,6 +72,7 @@ def main():
                 os.environ["FS_SCAN_UNROLL"] = str(un)
                 os.environ["FS_SCAN_BLOCKS_PER_CU"] = str(blk)
                 os.environ["FS_SCAN_FLAGS"] = fl
+                ix.reload_switches()
                 ms = ix.scan_benchmark(corpus, a.reps)
                 best.setdefault(v, []).append(ms)
         for v in variants:
