@@ -92,6 +92,8 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_POST_RANGES")) sw->post_ranges = e[0] != '0';
   if (const char* e = getenv("FS_SCAN_ROWS")) sw->scan_rows = e[0] != '0';
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
+  sw->diag = num("FS_DIAG");
+  sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
 }
 
 static int ceil_log2(uint64_t x) {

@@ -156,6 +156,8 @@ struct fs_switches {
   bool post_fused = false;        // FS_POST_FUSED
   bool post_ranges = true;        // FS_POST_RANGES=0: the k_verify_direct / k_hitrows / k_rows chain
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
+  int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
+  int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range to start with (tests)
 };
 void fs_read_switches(fs_switches* sw);

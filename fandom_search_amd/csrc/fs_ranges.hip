@@ -51,11 +51,11 @@ __global__ __launch_bounds__(kRangeWaves * 64) void k_ranges(
     CorpusDev c, GramIndexDev g, const fs_best* __restrict__ sbest,
     const uint2* __restrict__ recs, const uint2* __restrict__ info, uint32_t capw,
     uint32_t n_sub, uint32_t chunk, RangeOut out, uint4* __restrict__ rinfo,
-    uint32_t* __restrict__ csum, fs_status* st) {
+    uint4* __restrict__ csum, uint32_t* __restrict__ cmax, fs_status* st) {
   static_assert(N >= 2 && N <= 8, "the eight-tokens-per-lane scan covers n <= 8");
   constexpr uint32_t HALO = N - 1, RS = 64 - HALO;
   __shared__ RangeLds s_all[kRangeWaves];
-  __shared__ uint32_t s_sum[kRangeWaves];
+  __shared__ uint32_t s_sum[kRangeWaves][3];
   const int lane = threadIdx.x & 63;
   const uint32_t wv = threadIdx.x >> 6;
   RangeLds& S = s_all[wv];
@@ -114,19 +114,25 @@ __global__ __launch_bounds__(kRangeWaves * 64) void k_ranges(
     }
     if (R.rows_run > out.caprow && lane == 0) atomicMax(&st->max_rows, R.rows_run);
   }
-  // per range {records, hits, (window, script window) pairs, -}; per block: records
+  // {records, hits, (window, script window) pairs, -} per range and per block, and the
+  // block's largest record count of a range
   uint32_t match = R.match_acc;
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) match += (uint32_t)__shfl_xor((int)match, d);
   if (lane == 0) {
     rinfo[range_id] = make_uint4(R.rows_run, R.hits_run, match, 0);
-    s_sum[wv] = R.rows_run;
+    s_sum[wv][0] = R.rows_run; s_sum[wv][1] = R.hits_run; s_sum[wv][2] = match;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (int i = 0; i < kRangeWaves; ++i) t += s_sum[i];
+    uint4 t = make_uint4(0, 0, 0, 0);
+    uint32_t mx = 0;
+    for (int i = 0; i < kRangeWaves; ++i) {
+      t.x += s_sum[i][0]; t.y += s_sum[i][1]; t.z += s_sum[i][2];
+      mx = s_sum[i][0] > mx ? s_sum[i][0] : mx;
+    }
     csum[blockIdx.x] = t;
+    cmax[blockIdx.x] = mx;
   }
 }
 
@@ -142,35 +148,40 @@ __device__ __forceinline__ void compact_copy(const uint8_t* __restrict__ stage,
                                              uint8_t* __restrict__ rows, uint32_t caprow,
                                              uint32_t rec_bytes, uint32_t range0, uint32_t base,
                                              const uint32_t* s_off, const uint32_t* s_poff) {
-  constexpr int U = 4;
   const uint32_t P = s_poff[kCompactRanges];
-  for (uint32_t i0 = 0; i0 < P; i0 += kThreads * U) {
-    V v[U];
-    V* dst[U];
+  // piece i of the block: its place in the staging area and in the output
+  auto locate = [&](uint32_t i, const V** src, V** dst) {
+    uint32_t r = 0;                                        // last range with s_poff[r] <= i
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = i0 + u * kThreads + threadIdx.x;
-      dst[u] = nullptr;
-      if (i < P) {
-        uint32_t r = 0;                                    // last range with s_poff[r] <= i
-#pragma unroll
-        for (int step = kCompactRanges / 2; step > 0; step >>= 1)
-          if (s_poff[r + step] <= i) r += step;
-        const uint32_t k = i - s_poff[r];
-        const V* src = reinterpret_cast<const V*>(stage + (size_t)(range0 + r) * caprow * rec_bytes) + k;
-        v[u] = *src;
-        dst[u] = reinterpret_cast<V*>(rows + (size_t)(base + s_off[r]) * rec_bytes) + k;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (dst[u]) *dst[u] = v[u];
+    for (int step = kCompactRanges / 2; step > 0; step >>= 1)
+      if (s_poff[r + step] <= i) r += step;
+    const uint32_t k = i - s_poff[r];
+    *src = reinterpret_cast<const V*>(stage + (size_t)(range0 + r) * caprow * rec_bytes) + k;
+    *dst = reinterpret_cast<V*>(rows + (size_t)(base + s_off[r]) * rec_bytes) + k;
+  };
+  // four pieces per thread requested together (named registers: an array here is moved
+  // to LDS by the compiler, with a wait behind every load)
+  uint32_t i = threadIdx.x;
+  for (; i + 3 * kThreads < P; i += 4 * kThreads) {
+    const V *s0, *s1, *s2, *s3;
+    V *d0, *d1, *d2, *d3;
+    locate(i, &s0, &d0); locate(i + kThreads, &s1, &d1);
+    locate(i + 2 * kThreads, &s2, &d2); locate(i + 3 * kThreads, &s3, &d3);
+    const V v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3;
+    *d0 = v0; *d1 = v1; *d2 = v2; *d3 = v3;
+  }
+  for (; i < P; i += kThreads) {
+    const V* s0;
+    V* d0;
+    locate(i, &s0, &d0);
+    *d0 = *s0;
   }
 }
 
 __global__ __launch_bounds__(kThreads) void k_compact(
-    const uint4* __restrict__ rinfo, const uint32_t* __restrict__ csum, uint32_t csum_per,
-    uint32_t n_ranges, const uint32_t* __restrict__ cand_sums, uint32_t n_cand_sums, bool fresh,
+    const uint4* __restrict__ rinfo, const uint4* __restrict__ csum,
+    const uint32_t* __restrict__ cmax, uint32_t csum_per, uint32_t n_ranges,
+    const uint32_t* __restrict__ cand_sums, uint32_t n_cand_sums, bool fresh,
     const uint8_t* __restrict__ stage, uint32_t caprow, int rec_bytes, uint32_t rcap,
     uint8_t* __restrict__ rows, fs_status* st, fs_status* host_st, uint64_t* count_out) {
   __shared__ uint32_t s_w[4];
@@ -178,16 +189,27 @@ __global__ __launch_bounds__(kThreads) void k_compact(
   __shared__ uint32_t s_n[kCompactRanges], s_off[kCompactRanges + 1], s_poff[kCompactRanges + 1];
   const uint32_t n_blocks = n_ranges / kCompactRanges;
   if (blockIdx.x == n_blocks) {
-    // the extra block: totals over all ranges, largest range, status
+    // the extra block: totals over all block sums, largest range, status
+    const uint32_t n_csum = n_ranges / csum_per;
     uint32_t rws = 0, hits = 0, mt = 0, cands = 0, mx = 0;
-    for (uint32_t i = threadIdx.x; i < n_ranges; i += kThreads) {
-      const uint4 v = rinfo[i];
-      rws += v.x; hits += v.y; mt += v.z; cands += v.w;
-      mx = v.x > mx ? v.x : mx;
+    // eight loads requested together, in named registers (an array indexed in an
+    // unrolled loop is moved to LDS by the compiler, with a wait behind every load)
+    auto ld4 = [&](uint32_t i) { return i < n_csum ? csum[i] : make_uint4(0, 0, 0, 0); };
+    auto ldm = [&](uint32_t i) { return i < n_csum ? cmax[i] : 0u; };
+    auto ldc = [&](uint32_t i) { return i < n_cand_sums ? cand_sums[i] : 0u; };
+    for (uint32_t i0 = threadIdx.x; i0 < n_csum; i0 += kThreads * 4) {
+      const uint4 a = ld4(i0), b = ld4(i0 + kThreads), c = ld4(i0 + 2 * kThreads), d = ld4(i0 + 3 * kThreads);
+      const uint32_t ma = ldm(i0), mb = ldm(i0 + kThreads), mc = ldm(i0 + 2 * kThreads), md = ldm(i0 + 3 * kThreads);
+      rws += a.x + b.x + c.x + d.x; hits += a.y + b.y + c.y + d.y;
+      mt += a.z + b.z + c.z + d.z; cands += a.w + b.w + c.w + d.w;
+      const uint32_t m1 = ma > mb ? ma : mb, m2 = mc > md ? mc : md;
+      mx = mx > m1 ? mx : m1; mx = mx > m2 ? mx : m2;
     }
     if (cand_sums) {
       cands = 0;
-      for (uint32_t i = threadIdx.x; i < n_cand_sums; i += kThreads) cands += cand_sums[i];
+      for (uint32_t i0 = threadIdx.x; i0 < n_cand_sums; i0 += kThreads * 8)
+        cands += ldc(i0) + ldc(i0 + kThreads) + ldc(i0 + 2 * kThreads) + ldc(i0 + 3 * kThreads) +
+                 ldc(i0 + 4 * kThreads) + ldc(i0 + 5 * kThreads) + ldc(i0 + 6 * kThreads) + ldc(i0 + 7 * kThreads);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -221,7 +243,12 @@ __global__ __launch_bounds__(kThreads) void k_compact(
   if (threadIdx.x < kCompactRanges)
     s_n[threadIdx.x] = rinfo[blockIdx.x * kCompactRanges + threadIdx.x].x;
   uint32_t pre = 0;
-  for (uint32_t i = threadIdx.x; i < nb_before; i += kThreads) pre += csum[i];
+  {
+    auto ldx = [&](uint32_t i) { return i < nb_before ? csum[i].x : 0u; };
+    for (uint32_t i0 = threadIdx.x; i0 < nb_before; i0 += kThreads * 8)
+      pre += ldx(i0) + ldx(i0 + kThreads) + ldx(i0 + 2 * kThreads) + ldx(i0 + 3 * kThreads) +
+             ldx(i0 + 4 * kThreads) + ldx(i0 + 5 * kThreads) + ldx(i0 + 6 * kThreads) + ldx(i0 + 7 * kThreads);
+  }
   uint32_t base;
   block_excl_scan(pre, s_w, &base);
   const uint32_t piece = rec_bytes == 8 ? 8 : 16;
@@ -284,7 +311,8 @@ int fs_launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, uint32
     return FS_E_INVALID;
   }
   hipLaunchKernelGGL(k_compact, dim3(n_ranges / kCompactRanges + 1), dim3(kThreads), 0, s,
-                     ln.w_rinfo.p, reinterpret_cast<const uint32_t*>(ln.w_csum.p), csum_per,
+                     ln.w_rinfo.p, ln.w_csum.p,
+                     reinterpret_cast<const uint32_t*>(ln.w_csum.p + n_ranges / csum_per), csum_per,
                      n_ranges, cand_sums, n_cand_sums, fresh, ln.w_stage.p, caprow, rec_bytes, rcap,
                      reinterpret_cast<uint8_t*>(d_rows), ln.d_status.p, host_st, count_out);
   FS_HIP(hipGetLastError());
@@ -302,13 +330,14 @@ int fs_launch_ranges(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t rcap, 
   const uint32_t chunk = std::max<uint32_t>(1, (n_sub + FS_CHUNKS - 1) / FS_CHUNKS);
   FS_TRY(ln.w_stage.reserve((size_t)kRanges * caprow * rec_bytes));
   FS_TRY(ln.w_rinfo.reserve(kRanges));
-  FS_TRY(ln.w_csum.reserve(kRanges / kRangeWaves));
+  FS_TRY(ln.w_csum.reserve(2 * kRanges / kRangeWaves));
   const dim3 grid(kRanges / kRangeWaves), block(kRangeWaves * 64);
   const RangeOut out{ln.w_stage.p, caprow, wire};
 #define FS_RANGES(NN)                                                                           \
   hipLaunchKernelGGL((k_ranges<NN>), grid, block, 0, s, cd, g, c->d_sbest.p, scan.recs,         \
-                     scan.info, scan.capw, n_sub, chunk, out, ln.w_rinfo.p,                     \
-                     reinterpret_cast<uint32_t*>(ln.w_csum.p), ln.d_status.p)
+                     scan.info, scan.capw, n_sub, chunk, out, ln.w_rinfo.p, ln.w_csum.p,        \
+                     reinterpret_cast<uint32_t*>(ln.w_csum.p + kRanges / kRangeWaves),         \
+                     ln.d_status.p)
   switch (ix->cfg.window_size) {
     case 2: FS_RANGES(2); break;
     case 3: FS_RANGES(3); break;

@@ -417,11 +417,12 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     const fs_best* __restrict__ sbest,
                                                     uint32_t n_sub, fsdev::RangeOut out,
                                                     uint4* __restrict__ rinfo,
-                                                    uint32_t* __restrict__ csum) {
+                                                    uint4* __restrict__ csum,
+                                                    uint32_t* __restrict__ cmax, uint32_t diag) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  __shared__ uint32_t s_rows[16];
+  __shared__ uint32_t s_sum[16][4];
   uint32_t* s_filter = s_dyn;
   FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << g.log2_words));
   const int lane = threadIdx.x & 63;
@@ -431,10 +432,17 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   const uint32_t n_ranges = gridDim.x * n_waves;
   {
+    // the filter: four 16-byte pieces per thread requested together (64 KB, 1024 threads)
     const uint32_t vecs = (1u << g.log2_words) / 4;
     const uint4* src = reinterpret_cast<const uint4*>(g.filter);
     uint4* dst = reinterpret_cast<uint4*>(s_filter);
-    for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+    const uint32_t nt = blockDim.x;
+    uint32_t i = threadIdx.x;
+    for (; i + 3 * nt < vecs; i += 4 * nt) {
+      const uint4 q0 = src[i], q1 = src[i + nt], q2 = src[i + 2 * nt], q3 = src[i + 3 * nt];
+      dst[i] = q0; dst[i + nt] = q1; dst[i + 2 * nt] = q2; dst[i + 3 * nt] = q3;
+    }
+    for (; i < vecs; i += nt) dst[i] = src[i];
   }
   __syncthreads();
   // sub-tiles dealt out evenly: the first n_sub % n_ranges ranges take one more
@@ -458,25 +466,31 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     const uint32_t a = s0 * SUB, bnd = s1 * SUB;
     R.E = a;
     uint32_t rec_cnt = 0, halo_n = a ? HALO : 0;
-    uint4 t0, t1, h0, h1;                      // the sub-tile in flight: own eight ids, first eight of the next one
+    // two sub-tiles in flight: own eight ids (t*) and the first eight of the sub-tile
+    // behind (h*: lane 63's halo)
+    struct Tile { uint4 t0, t1, h0, h1; };
     auto request = [&](uint32_t sub) {
+      Tile r;
       const uint4* p = reinterpret_cast<const uint4*>(tok + sub * SUB + 8 * lane);
       if constexpr (NT) {
-        t0.x = __builtin_nontemporal_load(&p[0].x); t0.y = __builtin_nontemporal_load(&p[0].y);
-        t0.z = __builtin_nontemporal_load(&p[0].z); t0.w = __builtin_nontemporal_load(&p[0].w);
-        t1.x = __builtin_nontemporal_load(&p[1].x); t1.y = __builtin_nontemporal_load(&p[1].y);
-        t1.z = __builtin_nontemporal_load(&p[1].z); t1.w = __builtin_nontemporal_load(&p[1].w);
+        r.t0.x = __builtin_nontemporal_load(&p[0].x); r.t0.y = __builtin_nontemporal_load(&p[0].y);
+        r.t0.z = __builtin_nontemporal_load(&p[0].z); r.t0.w = __builtin_nontemporal_load(&p[0].w);
+        r.t1.x = __builtin_nontemporal_load(&p[1].x); r.t1.y = __builtin_nontemporal_load(&p[1].y);
+        r.t1.z = __builtin_nontemporal_load(&p[1].z); r.t1.w = __builtin_nontemporal_load(&p[1].w);
       } else {
-        t0 = p[0]; t1 = p[1];
+        r.t0 = p[0]; r.t1 = p[1];
       }
       const uint4* hp = reinterpret_cast<const uint4*>(tok + sub * SUB + SUB);   // the buffer is padded
-      h0 = hp[0]; h1 = hp[1];
+      r.h0 = hp[0]; r.h1 = hp[1];
+      return r;
     };
-    request(s0);
+    Tile ta = request(s0), tb = ta;
+    if (s0 + 1 < s1) tb = request(s0 + 1);
     for (uint32_t j = s0; j < s1; ++j) {
       const uint32_t base = j * SUB;
-      const uint4 v00 = t0, v01 = t1, v10 = h0, v11 = h1;
-      if (j + 1 < s1) request(j + 1);          // in flight during this sub-tile's work
+      const uint4 v00 = ta.t0, v01 = ta.t1, v10 = ta.h0, v11 = ta.h1;
+      ta = tb;
+      if (j + 2 < s1) tb = request(j + 2);     // in flight during the next two sub-tiles' work
       uint32_t aa[16];
       aa[0] = v00.x; aa[1] = v00.y; aa[2] = v00.z; aa[3] = v00.w;
       aa[4] = v01.x; aa[5] = v01.y; aa[6] = v01.z; aa[7] = v01.w;
@@ -503,6 +517,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       rec_cnt += (uint32_t)__popcll(has);
       cacc += __popc(flags);
       const bool last_sub = j + 1 == s1;
+      if ((diag & 2) && !last_sub) { if (rec_cnt >= kRecFlush) rec_cnt = 0; continue; }
       if (rec_cnt >= kRecFlush || (last_sub && (rec_cnt | halo_n | R.hc))) {      // wave-uniform
         wave_sync();
         // ranks of the queued candidates: lane t holds records t and t + 64
@@ -552,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
             const uint32_t nx = S.cand[RS];
             if (nx < F) F = nx;
           }
-          range_round<N>(c, g, sbest, S, m, F, a, range_id, out, R);
+          if (!(diag & 1)) range_round<N>(c, g, sbest, S, m, F, a, range_id, out, R);
           r0 += RS;
         } while (r0 < total);
         rec_cnt = 0;
@@ -560,7 +575,8 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       }
     }
   }
-  // per range {records, hits, (window, script window) pairs, candidates}; per block: records
+  // {records, hits, (window, script window) pairs, candidates} per range and per block,
+  // and the block's largest record count of a range
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     R.match_acc += (uint32_t)__shfl_xor((int)R.match_acc, d);
@@ -568,13 +584,19 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   }
   if (lane == 0) {
     rinfo[range_id] = make_uint4(R.rows_run, R.hits_run, R.match_acc, cacc);
-    s_rows[wave] = R.rows_run;
+    s_sum[wave][0] = R.rows_run; s_sum[wave][1] = R.hits_run; s_sum[wave][2] = R.match_acc;
+    s_sum[wave][3] = cacc;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t t = 0;
-    for (uint32_t i = 0; i < n_waves; ++i) t += s_rows[i];
+    uint4 t = make_uint4(0, 0, 0, 0);
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < n_waves; ++i) {
+      t.x += s_sum[i][0]; t.y += s_sum[i][1]; t.z += s_sum[i][2]; t.w += s_sum[i][3];
+      mx = s_sum[i][0] > mx ? s_sum[i][0] : mx;
+    }
     csum[blockIdx.x] = t;
+    cmax[blockIdx.x] = mx;
   }
 }
 
@@ -657,11 +679,14 @@ int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
                   fs_scan_extra* ex) {
   uint32_t* bsum = ex ? ex->bsum : nullptr;
   if (n_bm_words == 0 && !bsum) return FS_OK;
-  const size_t lds = (size_t)4 << ix->log2_words;
+  const size_t lds_filter = (size_t)4 << ix->log2_words;
   // the chained kernels' chunking (chunk_of_block): kNB chunks of `chunk` sub-tiles
   const uint32_t chunk = std::max<uint32_t>(1, (n_bm_words + fsdev::kNB - 1) / fsdev::kNB);
   const bool direct = ex && ex->bsum && ex->recs && ex->info && ex->capw && fs_scan_direct_ok(ix, c.n_tok);
   auto kern = ix->log2_words == 14 ? k_scan8<N, NT, true> : k_scan8<N, NT, false>;
+  // FS_SCAN_LDS_PAD: dynamic LDS beyond the filter, i.e. fewer workgroups per CU (leaves wave
+  // slots to the kernels of a search on another lane)
+  const size_t lds = lds_filter + (size_t)std::max(0, ix->sw.scan_lds_pad);
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
                         c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
@@ -817,7 +842,9 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(fs_scan_rows_blocks(ix)), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), (const fs_best*)c->d_sbest.p, n_sub, out,
-                        ln.w_rinfo.p, reinterpret_cast<uint32_t*>(ln.w_csum.p));
+                        ln.w_rinfo.p, ln.w_csum.p,
+                        reinterpret_cast<uint32_t*>(ln.w_csum.p + fs_scan_rows_blocks(ix)),
+                        (uint32_t)ix->sw.diag);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -852,7 +879,7 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rca
   const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
   FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * rec_bytes));
   FS_TRY(ln.w_rinfo.reserve(n_ranges));
-  FS_TRY(ln.w_csum.reserve(n_ranges));
+  FS_TRY(ln.w_csum.reserve(2 * (size_t)fs_scan_rows_blocks(ix)));
   const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
   switch (ix->cfg.window_size) {
     case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, out, s, e0, e1)); break;
