@@ -94,6 +94,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
   sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
+  if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
 }
 
 static int ceil_log2(uint64_t x) {
@@ -324,7 +325,9 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     FS_HIP(hipEventCreate(&sl.ev_scan1));
     FS_HIP(hipEventCreate(&sl.ev_end));
     FS_HIP(hipEventCreateWithFlags(&sl.ev_scan_done, hipEventDisableTiming));
-    FS_HIP(hipHostMalloc((void**)&sl.h_status, sizeof(fs_status), hipHostMallocDefault));
+    // the status block and, behind it, the "a wait gave up" word of finish_rows
+    FS_HIP(hipHostMalloc((void**)&sl.h_status, 2 * sizeof(fs_status), hipHostMallocDefault));
+    memset(sl.h_status, 0, 2 * sizeof(fs_status));
   }
   for (int l = 0; l < FS_LANES; ++l) {
     FS_TRY(ix->lanes[l].d_status.reserve(1));
@@ -761,6 +764,22 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
       return FS_E_UNSUPPORTED;
     }
     bool again = false;
+    uint32_t* gave_up = reinterpret_cast<uint32_t*>(sl.h_status + 1);
+    if (*gave_up) {
+      // finish_rows: a workgroup's wait for the workgroups in front of it ran out.  Run the
+      // search again through the chained kernels (no hand-off inside a launch).
+      *gave_up = 0;
+      if (!sl.caprow) { fs_set_error("in-launch wait flagged on a search without one"); return FS_E_DEVICE; }
+      const uint64_t T = sl.c->n_tok;
+      sl.caprow = 0; sl.fused_waves = 0;
+      sl.tpl = fs_scan_tpl(ix, T);
+      sl.n_bm = (uint32_t)((T + 64 * sl.tpl - 1) / (64 * sl.tpl));
+      sl.capw = fs_scan_direct_ok(ix, T) ? std::max<uint32_t>(64, ix->lanes[sl.lane].capw_hint) : 0;
+      sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->lanes[sl.lane].w_cpos.n);
+      ix->wait_fallbacks++;
+      FS_TRY(search_enqueue(ix, sl));
+      continue;
+    }
     if (!sl.caprow && hs.n_cands > sl.ccap) { sl.ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
     if (sl.caprow && hs.max_rows > sl.caprow) {
       sl.caprow = (hs.max_rows + hs.max_rows / 4 + 7) & ~7u;

@@ -16,6 +16,8 @@
 #define FS_CHUNKS 2048             // = fsdev::kNB: chunks of the chained kernels (and partial sums)
 #define FS_SEARCH_SLOTS 4         // searches that may be in flight on one index
 #define FS_LEV_MAX 512            // code points per side handled by lev_device
+#define FS_WAIT_GAVE_UP 0x80000000u   // fs_status.lev_overflow: an in-kernel wait gave up (finish_rows)
+#define FS_SYNC_BLOCKS 1024       // workgroups a records kernel may have (granules per lane)
 
 void fs_set_error(const char* fmt, ...);
 
@@ -158,6 +160,7 @@ struct fs_switches {
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
   int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
   int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
+  int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
   int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range to start with (tests)
 };
 void fs_read_switches(fs_switches* sw);
@@ -201,9 +204,11 @@ struct fs_index {
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
-    DBuf<uint8_t> w_stage;         // k_ranges: staged records, caprow per wave range
-    DBuf<uint4> w_rinfo, w_csum;   //           {records, hits, pairs} per wave range / per chunk
-    uint32_t caprow_hint = 0;      //           staged records per wave range the last searches needed
+    DBuf<uint8_t> w_stage;         // k_ranges / k_scan_rows: staged records, caprow per wave range
+    uint32_t caprow_hint = 0;      //   staged records per wave range the last searches needed
+    DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup
+    DBuf<uint4> w_bstat;           //   {hits, pairs, candidates, max records of a range} per workgroup
+    uint32_t sync_epoch = 0;
     DBuf<fs_best> w_cbest;
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
     DBuf<fs_row> w_rows;
@@ -240,6 +245,7 @@ struct fs_index {
   uint32_t next_slot = 0;
   uint32_t scan_timing_period = 1;    // attach timing events to every k-th scan
   uint64_t searches = 0;
+  uint64_t wait_fallbacks = 0;        // searches repeated through the chained kernels (finish_rows gave up)
 
   // corpora created on this index and still alive: fs_index_destroy detaches them, so that
   // a corpus destroyed after its index does not touch freed memory
@@ -323,11 +329,9 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 // fs_ranges.hip: scan records -> output records in one kernel + a copy into place
 int fs_launch_sbest(fs_index* ix, fs_corpus* c, hipStream_t s);
 bool fs_ranges_ok(const fs_index* ix, const fs_corpus* c);
-int fs_launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, uint32_t caprow,
-                      int rec_bytes, uint32_t rcap, fs_row* d_rows, fs_status* host_st,
-                      hipStream_t s, uint64_t* count_out, bool fresh,
-                      const uint32_t* cand_sums = nullptr, uint32_t n_cand_sums = 0);
-// fs_scan.hip: scan + records in one kernel (k_scan_rows), then k_compact
+// fs_scan.hip: scan + records in one kernel (k_scan_rows)
+namespace fsdev { struct RowSync; }
+int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
 uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c);   // 0: does not apply
 uint32_t fs_scan_rows_blocks(const fs_index* ix);
 int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,

@@ -213,4 +213,169 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   wave_sync();
 }
 
+// ---- records into place inside the launch ------------------------------------------
+// Workgroup b of k_ranges / k_scan_rows holds the wave ranges [b * waves, (b + 1) * waves).
+// When its waves are done it stores its statistics (write-through), then publishes its
+// record count as one 8-byte granule {epoch, count} (the data is the flag; epoch = launch
+// number of the lane, so nothing is cleared between launches), sums the granules of the
+// workgroups in front of it and copies its staged records to their final place.  The
+// last workgroup has then seen every other one and publishes totals and status.
+//
+// No atomic read-modify-write anywhere (one word serves about 88 of them per microsecond:
+// a ticket per workgroup or a counter update per wave would cost more than the whole
+// hand-off).  A workgroup waits only for workgroups with a smaller index.  The records
+// do not depend on timing or placement; that the wait ends relies on workgroups being
+// started in index order (every earlier one is then running or done).  The wait is
+// bounded: should it ever give up, the search is flagged and the host runs it again
+// through the chained kernels of fs_post.hip, which have no in-launch hand-off.
+struct RowSync {
+  unsigned long long* gran;  // [n_blocks] {epoch << 32 | records of the workgroup}
+  uint4* bstat;              // [n_blocks] {hits, pairs, candidates, max records of a range}
+  uint32_t epoch;            // >= 1
+  uint32_t n_blocks;
+  uint32_t spin_limit;       // polls of one batch of granules before the wait gives up
+};
+
+struct RowFinal {
+  uint8_t* rows;           // the caller's buffer
+  uint32_t rcap;           // records it holds
+  fs_status* st;           // device status block
+  fs_status* host_st;      // pinned host copy; the word behind it: set when a wait gave up
+  uint64_t* count_out;     // FS_ROWS_HEADER
+  bool fresh;              // nothing before this kernel wrote *st
+};
+
+// All threads of the workgroup call this once every wave has staged its records.
+//   range_id   the wave's range (blockIdx.x * waves + wave)
+//   my_rows    (wave-uniform) records of the wave's range; stats of the wave: hits, pairs,
+//              candidates
+//   s_cnt      LDS, 5 * n_waves + 2 words
+__device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& fin,
+                                            const RangeOut& out, uint32_t range_id,
+                                            uint32_t my_rows, uint32_t hits, uint32_t pairs,
+                                            uint32_t cands, uint32_t* s_cnt) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  const uint32_t L = blockIdx.x;
+  const uint32_t staged = my_rows < out.caprow ? my_rows : out.caprow;
+  if (lane == 0) {
+    s_cnt[wave] = staged;
+    s_cnt[n_waves + 2 + 4 * wave] = hits; s_cnt[n_waves + 3 + 4 * wave] = pairs;
+    s_cnt[n_waves + 4 + 4 * wave] = cands; s_cnt[n_waves + 5 + 4 * wave] = my_rows;
+  }
+  // the staged records of this wave have reached memory before anything reads them back
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  bool gave_up = false;
+  if (wave == 0) {
+    uint32_t total = 0;
+    uint4 bs = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = 0; i < n_waves; ++i) {
+      total += s_cnt[i];
+      bs.x += s_cnt[n_waves + 2 + 4 * i]; bs.y += s_cnt[n_waves + 3 + 4 * i];
+      bs.z += s_cnt[n_waves + 4 + 4 * i];
+      const uint32_t r = s_cnt[n_waves + 5 + 4 * i];
+      bs.w = r > bs.w ? r : bs.w;
+    }
+    if (lane == 0) {
+      uint32_t* b = reinterpret_cast<uint32_t*>(sy.bstat + L);
+      __hip_atomic_store(b + 0, bs.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(b + 1, bs.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(b + 2, bs.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(b + 3, bs.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // statistics before the granule
+      __hip_atomic_store(sy.gran + L, ((unsigned long long)sy.epoch << 32) | total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // records of the workgroups in front: every granule, once it carries this launch's epoch
+    uint32_t pre = 0;
+    for (uint32_t i0 = 0; i0 < L; i0 += 64) {
+      const uint32_t i = i0 + lane;
+      unsigned long long v = 0;
+      bool ok = i >= L;
+      for (uint32_t spins = 0; !__all(ok); ++spins) {
+        if (!ok) {
+          v = __hip_atomic_load(sy.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = (uint32_t)(v >> 32) == sy.epoch;
+        }
+        if (spins > 16) __builtin_amdgcn_s_sleep(1);
+        if (spins >= sy.spin_limit) { gave_up = true; break; }   // default: about a second
+      }
+      pre += (i < L && ok) ? (uint32_t)v : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) pre += (uint32_t)__shfl_xor((int)pre, d);
+    if (lane == 0) { s_cnt[n_waves] = pre; s_cnt[n_waves + 1] = total; }
+  }
+  __syncthreads();
+  // this wave's records: from the staging area to their place
+  uint32_t first = s_cnt[n_waves];
+  for (uint32_t i = 0; i < wave; ++i) first += s_cnt[i];
+  const uint32_t rec_bytes = out.wire ? (uint32_t)out.wire : 32u;
+  uint32_t n = staged;
+  if (first >= fin.rcap) n = 0;
+  else if (first + n > fin.rcap) n = fin.rcap - first;
+  const uint8_t* src = out.stage + (size_t)range_id * out.caprow * rec_bytes;
+  uint8_t* dst = fin.rows + (size_t)first * rec_bytes;
+  if (rec_bytes == 8) {
+    const uint2* sp = reinterpret_cast<const uint2*>(src);
+    uint2* dp = reinterpret_cast<uint2*>(dst);
+    for (uint32_t i = lane; i < n; i += 128) {
+      const uint2 v0 = sp[i];
+      const bool two = i + 64 < n;
+      const uint2 v1 = two ? sp[i + 64] : v0;
+      dp[i] = v0;
+      if (two) dp[i + 64] = v1;
+    }
+  } else {
+    const uint32_t pieces = n * (rec_bytes >> 4);
+    const uint4* sp = reinterpret_cast<const uint4*>(src);
+    uint4* dp = reinterpret_cast<uint4*>(dst);
+    for (uint32_t i = lane; i < pieces; i += 128) {
+      const uint4 v0 = sp[i];
+      const bool two = i + 64 < pieces;
+      const uint4 v1 = two ? sp[i + 64] : v0;
+      dp[i] = v0;
+      if (two) dp[i + 64] = v1;
+    }
+  }
+  if (wave != 0) return;
+  if (gave_up && lane == 0) {
+    // whoever gives up flags the search, in a word of its own that nothing else writes
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(fin.host_st + 1), FS_WAIT_GAVE_UP, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // the last workgroup: every other one has published; their statistics were stored
+  // write-through before their granules and are read past the caches
+  if (L + 1 == sy.n_blocks) {
+    uint32_t h = 0, pr = 0, cd = 0, mx = 0;
+    for (uint32_t i = lane; i < sy.n_blocks; i += 64) {
+      const uint32_t* b = reinterpret_cast<const uint32_t*>(sy.bstat + i);
+      h += __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pr += __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cd += __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t r = __hip_atomic_load(b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mx = r > mx ? r : mx;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      h += (uint32_t)__shfl_xor((int)h, d); pr += (uint32_t)__shfl_xor((int)pr, d);
+      cd += (uint32_t)__shfl_xor((int)cd, d);
+      const uint32_t o = (uint32_t)__shfl_xor((int)mx, d);
+      mx = o > mx ? o : mx;
+    }
+    if (lane == 0) {
+      fs_status o;
+      if (fin.fresh) { o.max_recs = 0; o.lev_overflow = 0; o.bad_string = 0; }
+      else o = *fin.st;
+      o.n_rows = s_cnt[n_waves] + s_cnt[n_waves + 1];
+      o.n_hits = h; o.n_matches = pr; o.n_cands = cd;
+      o.max_rows = mx > out.caprow ? mx : 0;
+      *fin.st = o;
+      *fin.host_st = o;
+      if (fin.count_out) *fin.count_out = o.n_rows;
+    }
+  }
+}
+
 }  // namespace fsdev

@@ -42,6 +42,22 @@ constexpr int kWave = 64;
 constexpr int kTokPerLane = 4;
 constexpr int kSubTile = kWave * kTokPerLane;   // 256 tokens per bitmap word
 
+// The Bloom filter into LDS: four 16-byte pieces per thread requested together (64 KB,
+// 1024 threads: one batch instead of four dependent round trips in front of the scan).
+__device__ __forceinline__ void copy_filter_to_lds(const uint32_t* __restrict__ filter,
+                                                   uint32_t* s_filter, int log2_words) {
+  const uint32_t vecs = (1u << log2_words) / 4;
+  const uint4* src = reinterpret_cast<const uint4*>(filter);
+  uint4* dst = reinterpret_cast<uint4*>(s_filter);
+  const uint32_t nt = blockDim.x;
+  uint32_t i = threadIdx.x;
+  for (; i + 3 * nt < vecs; i += 4 * nt) {
+    const uint4 q0 = src[i], q1 = src[i + nt], q2 = src[i + 2 * nt], q3 = src[i + 3 * nt];
+    dst[i] = q0; dst[i + nt] = q1; dst[i + 2 * nt] = q2; dst[i + 3 * nt] = q3;
+  }
+  for (; i < vecs; i += nt) dst[i] = src[i];
+}
+
 // b[j]: wave mask of "window 4*lane + j of sub-tile `word` is filter-positive"
 __device__ __forceinline__ void store_ballots(const uint64_t* b, int lane, uint32_t word,
                                               uint32_t n_bm_words, uint64_t* __restrict__ qbm,
@@ -114,10 +130,7 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
                                                uint32_t n_bm_words, uint32_t n_tiles) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   {
-    const uint32_t vecs = (1u << log2_words) / 4;
-    const uint4* src = reinterpret_cast<const uint4*>(filter);
-    uint4* dst = reinterpret_cast<uint4*>(s_filter);
-    for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+    copy_filter_to_lds(filter, s_filter, log2_words);
   }
   __syncthreads();
 
@@ -308,10 +321,7 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   }
   if (threadIdx.x < kChunksPerBlock) s_csum[threadIdx.x] = 0;
   {
-    const uint32_t vecs = (1u << log2_words) / 4;
-    const uint4* src = reinterpret_cast<const uint4*>(filter);
-    uint4* dst = reinterpret_cast<uint4*>(s_filter);
-    for (uint32_t i = threadIdx.x; i < vecs; i += blockDim.x) dst[i] = src[i];
+    copy_filter_to_lds(filter, s_filter, log2_words);
   }
   __syncthreads();
   constexpr int HALO = N - 1;
@@ -416,35 +426,22 @@ template <int N, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     const fs_best* __restrict__ sbest,
                                                     uint32_t n_sub, fsdev::RangeOut out,
-                                                    uint4* __restrict__ rinfo,
-                                                    uint4* __restrict__ csum,
-                                                    uint32_t* __restrict__ cmax, uint32_t diag) {
+                                                    fsdev::RowSync sy, fsdev::RowFinal fin,
+                                                    uint32_t diag) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  __shared__ uint32_t s_sum[16][4];
+  __shared__ uint32_t s_cnt[5 * 16 + 2];
   uint32_t* s_filter = s_dyn;
   FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << g.log2_words));
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
+  copy_filter_to_lds(g.filter, s_filter, g.log2_words);
+  __syncthreads();
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   const uint32_t n_ranges = gridDim.x * n_waves;
-  {
-    // the filter: four 16-byte pieces per thread requested together (64 KB, 1024 threads)
-    const uint32_t vecs = (1u << g.log2_words) / 4;
-    const uint4* src = reinterpret_cast<const uint4*>(g.filter);
-    uint4* dst = reinterpret_cast<uint4*>(s_filter);
-    const uint32_t nt = blockDim.x;
-    uint32_t i = threadIdx.x;
-    for (; i + 3 * nt < vecs; i += 4 * nt) {
-      const uint4 q0 = src[i], q1 = src[i + nt], q2 = src[i + 2 * nt], q3 = src[i + 3 * nt];
-      dst[i] = q0; dst[i + nt] = q1; dst[i + 2 * nt] = q2; dst[i + 3 * nt] = q3;
-    }
-    for (; i < vecs; i += nt) dst[i] = src[i];
-  }
-  __syncthreads();
   // sub-tiles dealt out evenly: the first n_sub % n_ranges ranges take one more
   const uint32_t per = n_sub / n_ranges, rem = n_sub % n_ranges;
   const uint32_t s0 = range_id * per + (range_id < rem ? range_id : rem);
@@ -575,29 +572,12 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       }
     }
   }
-  // {records, hits, (window, script window) pairs, candidates} per range and per block,
-  // and the block's largest record count of a range
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) {
     R.match_acc += (uint32_t)__shfl_xor((int)R.match_acc, d);
     cacc += (uint32_t)__shfl_xor((int)cacc, d);
   }
-  if (lane == 0) {
-    rinfo[range_id] = make_uint4(R.rows_run, R.hits_run, R.match_acc, cacc);
-    s_sum[wave][0] = R.rows_run; s_sum[wave][1] = R.hits_run; s_sum[wave][2] = R.match_acc;
-    s_sum[wave][3] = cacc;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint4 t = make_uint4(0, 0, 0, 0);
-    uint32_t mx = 0;
-    for (uint32_t i = 0; i < n_waves; ++i) {
-      t.x += s_sum[i][0]; t.y += s_sum[i][1]; t.z += s_sum[i][2]; t.w += s_sum[i][3];
-      mx = s_sum[i][0] > mx ? s_sum[i][0] : mx;
-    }
-    csum[blockIdx.x] = t;
-    cmax[blockIdx.x] = mx;
-  }
+  finish_rows(sy, fin, out, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt);
 }
 
 // Simple variant for any n <= FS_MAX_WINDOW: every lane reads its ids straight
@@ -830,8 +810,8 @@ namespace {
 
 template <int N>
 int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
-                     const fsdev::RangeOut& out, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  fs_index::Lane& ln = *ix->cur;
+                     const fsdev::RangeOut& out, const fsdev::RowSync& sy,
+                     const fsdev::RowFinal& fin, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const size_t lds = ((size_t)4 << ix->log2_words) + waves * sizeof(FusedLds);
   const bool big = c->n_tok * 4 > (256ull << 20);
   const char e = ix->sw.scan_flags;
@@ -842,9 +822,7 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(fs_scan_rows_blocks(ix)), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), (const fs_best*)c->d_sbest.p, n_sub, out,
-                        ln.w_rinfo.p, ln.w_csum.p,
-                        reinterpret_cast<uint32_t*>(ln.w_csum.p + fs_scan_rows_blocks(ix)),
-                        (uint32_t)ix->sw.diag);
+                        sy, fin, (uint32_t)ix->sw.diag);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -869,7 +847,7 @@ uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c) {
 
 uint32_t fs_scan_rows_blocks(const fs_index* ix) { return (uint32_t)ix->num_cu; }
 
-// tokens -> staged records of fs_scan_rows_blocks() * waves wave ranges -> k_compact
+// tokens -> output records: one launch of fs_scan_rows_blocks() workgroups of `waves` wave ranges
 int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
                         int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
                         hipEvent_t e0, hipEvent_t e1, uint64_t* count_out) {
@@ -878,19 +856,19 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rca
   const int rec_bytes = wire ? wire : 32;
   const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
   FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * rec_bytes));
-  FS_TRY(ln.w_rinfo.reserve(n_ranges));
-  FS_TRY(ln.w_csum.reserve(2 * (size_t)fs_scan_rows_blocks(ix)));
   const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
+  fsdev::RowSync sy;
+  FS_TRY(fs_row_sync(ix, fs_scan_rows_blocks(ix), &sy));
+  const fsdev::RowFinal fin{reinterpret_cast<uint8_t*>(d_rows), rcap, ln.d_status.p, host_st, count_out, true};
   switch (ix->cfg.window_size) {
-    case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, out, s, e0, e1)); break;
-    case 3: FS_TRY(launch_scan_rows<3>(ix, c, n_sub, waves, out, s, e0, e1)); break;
-    case 4: FS_TRY(launch_scan_rows<4>(ix, c, n_sub, waves, out, s, e0, e1)); break;
-    case 5: FS_TRY(launch_scan_rows<5>(ix, c, n_sub, waves, out, s, e0, e1)); break;
-    case 6: FS_TRY(launch_scan_rows<6>(ix, c, n_sub, waves, out, s, e0, e1)); break;
-    case 7: FS_TRY(launch_scan_rows<7>(ix, c, n_sub, waves, out, s, e0, e1)); break;
-    case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, out, s, e0, e1)); break;
+    case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 3: FS_TRY(launch_scan_rows<3>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 4: FS_TRY(launch_scan_rows<4>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 5: FS_TRY(launch_scan_rows<5>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 6: FS_TRY(launch_scan_rows<6>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 7: FS_TRY(launch_scan_rows<7>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
     default: fs_set_error("k_scan_rows covers n = 2..8"); return FS_E_UNSUPPORTED;
   }
-  return fs_launch_compact(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st, s, count_out,
-                           /*fresh=*/true);
+  return FS_OK;
 }

@@ -559,9 +559,12 @@ def test_range_kernel_and_chain_agree(synth_base, monkeypatch, n):
     normals = synth.lsh_normals(n)
     cfg = abi.make_config(window_size=n)
     results = []
+    # FS_WAIT_SPINS=0: the in-launch wait for the workgroups in front gives up at once, the
+    # search is flagged and repeated through the chained kernels
     for env in ({}, {"FS_SCAN_ROWS": "0"}, {"FS_SCAN_ROWS": "0", "FS_POST_RANGES": "0"},
-                {"FS_RANGES_CAPROW": "2"}, {"FS_SCAN_ROWS": "0", "FS_RANGES_CAPROW": "2"}):
-        for k in ("FS_SCAN_ROWS", "FS_POST_RANGES", "FS_RANGES_CAPROW"):
+                {"FS_RANGES_CAPROW": "2"}, {"FS_SCAN_ROWS": "0", "FS_RANGES_CAPROW": "2"},
+                {"FS_WAIT_SPINS": "0"}, {"FS_SCAN_ROWS": "0", "FS_WAIT_SPINS": "0"}):
+        for k in ("FS_SCAN_ROWS", "FS_POST_RANGES", "FS_RANGES_CAPROW", "FS_WAIT_SPINS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
