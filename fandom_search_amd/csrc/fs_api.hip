@@ -89,12 +89,12 @@ void fs_read_switches(fs_switches* sw) {
   sw->no_stagger = getenv("FS_NO_STAGGER") != nullptr;
   sw->scan_capw = num("FS_SCAN_CAPW");
   sw->post_fused = getenv("FS_POST_FUSED") != nullptr;
-  if (const char* e = getenv("FS_POST_RANGES")) sw->post_ranges = e[0] != '0';
   if (const char* e = getenv("FS_SCAN_ROWS")) sw->scan_rows = e[0] != '0';
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
   sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
+  sw->rows_finish = num("FS_ROWS_FINISH");
 }
 
 static int ceil_log2(uint64_t x) {
@@ -643,10 +643,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    if (ex.direct && sl.caprow)
-      FS_TRY(fs_launch_ranges(ix, c, n_bm, rcap32, d_rows, wire, sl.caprow, sl.h_status, s, ex, count_out));
-    else
-      FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
+    FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
   } else {
     FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
@@ -717,13 +714,13 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
     sl.capw = std::max<uint32_t>(64, ln.capw_hint);
     if (ix->sw.scan_capw > 0) sl.capw = (uint32_t)ix->sw.scan_capw;   // tests: force the growth path
   }
-  // k_ranges (scan records -> output records in one kernel): staged records per wave
-  // range, 128 to start with (C2 averages 36), more once a search has asked for it
+  // k_scan_rows (tokens -> records in one kernel): staged records per wave range, more once
+  // a search has asked for it
   sl.caprow = 0;
   sl.fused_waves = sl.exact ? fs_scan_rows_waves(ix, c) : 0;
-  if (sl.fused_waves || (sl.capw && fs_ranges_ok(ix, c))) {
-    const uint32_t ranges = sl.fused_waves ? fs_scan_rows_blocks(ix) * sl.fused_waves : FS_CHUNKS * 4;
-    // 128 for the 8192 ranges of a C2 scan (36 on average), in proportion for longer ranges
+  if (sl.fused_waves) {
+    const uint32_t ranges = fs_scan_rows_blocks(ix) * sl.fused_waves;
+    // staged records per wave range: a sixteenth of its tokens (C2: 305, 72 used on average)
     const uint32_t dflt = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(128, T / ranges / 16), 1u << 20);
     sl.caprow = std::max<uint32_t>(dflt, ln.caprow_hint);
     if (ix->sw.ranges_caprow > 0) sl.caprow = (uint32_t)ix->sw.ranges_caprow;

@@ -156,12 +156,12 @@ struct fs_switches {
   bool no_stagger = false;        // FS_NO_STAGGER
   int scan_capw = 0;              // FS_SCAN_CAPW: records per wave range to start with (tests)
   bool post_fused = false;        // FS_POST_FUSED
-  bool post_ranges = true;        // FS_POST_RANGES=0: the k_verify_direct / k_hitrows / k_rows chain
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
   int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
   int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
-  int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range to start with (tests)
+  int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
+  int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range of k_scan_rows to start with (tests)
 };
 void fs_read_switches(fs_switches* sw);
 
@@ -208,6 +208,7 @@ struct fs_index {
     uint32_t caprow_hint = 0;      //   staged records per wave range the last searches needed
     DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup
     DBuf<uint4> w_bstat;           //   {hits, pairs, candidates, max records of a range} per workgroup
+    DBuf<uint4> w_rinfo, w_csum;   // k_compact: {records, hits, pairs, candidates} per range / per workgroup
     uint32_t sync_epoch = 0;
     DBuf<fs_best> w_cbest;
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
@@ -238,7 +239,7 @@ struct fs_index {
     int tpl = 4;                      // tokens per lane of the bitmap layout
     int lane = 0;                     // the lane (stream + workspaces) it was queued on
     uint32_t capw = 0;                // direct path: record capacity per wave range (0: bitmap path)
-    uint32_t caprow = 0;              // k_ranges / k_scan_rows: staged records per wave range
+    uint32_t caprow = 0;              // k_scan_rows: staged records per wave range
     uint32_t fused_waves = 0;         // k_scan_rows: waves per workgroup (0: separate kernels)
   };
   Slot slots[FS_SEARCH_SLOTS];
@@ -326,12 +327,24 @@ int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_bl
 
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 
-// fs_ranges.hip: scan records -> output records in one kernel + a copy into place
+// fs_ranges.hip: helpers of the records path of k_scan_rows
 int fs_launch_sbest(fs_index* ix, fs_corpus* c, hipStream_t s);
-bool fs_ranges_ok(const fs_index* ix, const fs_corpus* c);
 // fs_scan.hip: scan + records in one kernel (k_scan_rows)
 namespace fsdev { struct RowSync; }
 int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
+int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
+                                      int rec_bytes, uint32_t rcap, fs_row* d_rows,
+                                      fs_status* host_st, hipStream_t s, uint64_t* count_out);
+uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c);   // 0: does not apply
+uint32_t fs_scan_rows_blocks(const fs_index* ix);
+int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
+                        int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
+                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out);
+namespace fsdev { struct RowSync; }
+int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
+int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
+                                      int rec_bytes, uint32_t rcap, fs_row* d_rows,
+                                      fs_status* host_st, hipStream_t s, uint64_t* count_out);
 uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c);   // 0: does not apply
 uint32_t fs_scan_rows_blocks(const fs_index* ix);
 int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,

@@ -1,7 +1,32 @@
-// fs_ranges.h -- one round of "candidates of a wave range -> output records", shared by
-// k_ranges (fs_ranges.hip: candidates from the scan's record lists in global memory) and
-// k_scan_rows (fs_scan.hip: the scan kernel itself, candidates from its LDS queue).
-// The head of fs_ranges.hip describes the scheme.
+// fs_ranges.h -- "candidates of a wave range -> output records" inside the scan kernel
+// (k_scan_rows, fs_scan.hip), and the hand-off that puts the records into place.
+//
+// Reference semantics (file:line in /root/reference), as in fs_post.hip:
+//   search.py:182-184  kept candidates = script windows with the fan window's ids
+//   search.py:192-218  n word records per match
+//   search.py:224-226  per fan word the FIRST record of minimal dist*lev over the
+//                      windows covering it, output ascending by word index
+//
+// A wave range is the contiguous run of 512-token sub-tiles one wave scans.  The record
+// of fan word x depends only on the hits among windows x-n+1 .. x, so a range's records
+// follow from its own candidates plus the n-1 windows in front of it (the "halo",
+// verified unconditionally): no data crosses ranges.  Per round of at most 64-(n-1)
+// candidates (one per lane, position order) the wave
+//   1. verifies every candidate: ids -> hash -> displacement -> table entry, compared id
+//      for id, and the work boundary (three levels of loads, every load of a level
+//      requested before any is used); the per-corpus table `sbest` (indexed by table slot,
+//      so fetched beside the entry) carries the best rank's record of the matched n-gram
+//   2. compacts the hits behind the <= n-1 hits carried over from the last round
+//   3. emits the records of the words in [E, F): E = words done so far, F = the first
+//      position whose hit status is not known yet (the next round's first candidate, or
+//      the scan front).  Hit j is the first to cover the words
+//      [max(p_j, p_{j-1} + n), p_j + n); one lane per word looks at the <= n-1 later hits
+//      that also cover it for the first minimum of the combined distance
+//   4. keeps the hits that may still cover words >= F.
+// Records go to a staging area of `caprow` records per range (position order inside a
+// range = output order) and from there into place: finish_rows below, or k_compact.
+// The records never depend on timing: values and order are functions of the token
+// positions alone.
 #pragma once
 #include "fs_device.h"
 
@@ -24,7 +49,6 @@ struct alignas(16) RangeLds {
   uint32_t w[64];             //       work
   uint32_t wbase[64];         //       first token of that work
   uint32_t lo[64];            // hit -> (first word it emits in this round) - (its first record)
-  uint32_t cand[64];          // candidates of the round; [RS] = first one of the next round
   uint8_t owner[64 * 8];      // record of the round -> hit
 };
 
@@ -42,24 +66,22 @@ struct RangeOut {
   int wire;            // 0: fs_row, 16 / 8: wire records
 };
 
-// One round over the candidates S.cand[0 .. m) (window positions in ascending order,
-// FS_NONE = no candidate), m <= 64 - (N-1).  F = first position whose hit status is not
-// known after this round; a = first token of the range.  A candidate lies inside the
-// token buffer (the scan masks windows that run past it; a halo window is in front of
-// the range).
+// One round: lane i < 64 - (N-1) holds candidate window position `p` (ascending over the
+// lanes; FS_NONE = none).  F = first position whose hit status is not known after this
+// round; a = first token of the range.  A candidate lies inside the token buffer (the
+// scan masks windows that run past it; a halo window is in front of the range).
 template <int N>
 __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexDev& g,
                                             const fs_best* __restrict__ sbest, RangeLds& S,
-                                            uint32_t m, uint32_t F, uint32_t a,
+                                            uint32_t p, uint32_t F, uint32_t a,
                                             uint32_t range_id, const RangeOut& out,
                                             RangeState& R) {
   constexpr int TS = (2 + N + 3) & ~3;             // words per table entry
   const int lane = threadIdx.x & 63;
   if (F < R.E) F = R.E;
-  // 2. verification, one candidate per lane: every load of a level is requested before
+  // 1. verification, one candidate per lane: every load of a level is requested before
   // anything of that level is looked at (ids + block table | displacement | entry + best
   // record + work start)
-  const uint32_t p = (uint32_t)lane < m ? S.cand[lane] : FS_NONE;
   bool hit = false;
   uint32_t kept = 0, w = 0, wbase = 0, bs = 0, blev = 0;
   double comb = 0.0, bdist = 0.0;
@@ -107,6 +129,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       uint32_t diff = 0;
 #pragma unroll
       for (int k = 0; k < N; ++k) diff |= ew[2 + k] ^ f[k];
+      asm volatile("" : "+v"(diff));       // one compare of the OR, not one compare per id
       bs = b0.x; blev = b0.y;
       bdist = __longlong_as_double((long long)(b0.z | ((uint64_t)b0.w << 32)));
       comb = __longlong_as_double((long long)(b1.x | ((uint64_t)b1.y << 32)));
@@ -121,7 +144,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       do slot = (slot + 1) & slot_mask; while (!probe(slot));
     }
   }
-  // 3. hits behind the carried ones, in position order
+  // 2. hits behind the carried ones, in position order
   const uint64_t hb = __ballot(hit);
   const uint32_t hidx = R.hc + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32),
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0));
@@ -133,7 +156,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   const uint32_t nh = R.hc + (uint32_t)__popcll(hb);
   R.hits_run += (uint32_t)__popcll(__ballot(hit && p >= a));
   wave_sync();
-  // 4. words [E, F): lane j = hit j
+  // 3. words [E, F): lane j = hit j
   uint32_t cnt = 0, lo = 0;
   if ((uint32_t)lane < nh) {
     const uint32_t pj = S.p[lane];
@@ -190,7 +213,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
     }
   }
   R.rows_run += tot;
-  // 5. hits that may cover words >= F move to the front
+  // 4. hits that may cover words >= F move to the front
   const bool keep = (uint32_t)lane < nh && S.p[lane] + N > F;
   const uint64_t kb = __ballot(keep);
   const uint32_t first_keep = kb ? (uint32_t)(__ffsll((unsigned long long)kb) - 1) : nh;
@@ -234,6 +257,12 @@ struct RowSync {
   uint32_t epoch;            // >= 1
   uint32_t n_blocks;
   uint32_t spin_limit;       // polls of one batch of granules before the wait gives up
+  // the other finish (searches overlapped on several lanes: a waiting workgroup would hold
+  // its CU): per-range and per-workgroup counts go to memory and k_compact, the next
+  // kernel, puts the records into place
+  uint4* rinfo;              // nullptr: finish inside the launch
+  uint4* csum;
+  uint32_t* cmax;
 };
 
 struct RowFinal {
@@ -258,6 +287,25 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const uint32_t L = blockIdx.x;
   const uint32_t staged = my_rows < out.caprow ? my_rows : out.caprow;
+  if (sy.rinfo) {                      // k_compact finishes
+    if (lane == 0) {
+      sy.rinfo[range_id] = make_uint4(my_rows, hits, pairs, cands);
+      s_cnt[4 * wave] = my_rows; s_cnt[4 * wave + 1] = hits; s_cnt[4 * wave + 2] = pairs;
+      s_cnt[4 * wave + 3] = cands;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint4 t = make_uint4(0, 0, 0, 0);
+      uint32_t mx = 0;
+      for (uint32_t i = 0; i < n_waves; ++i) {
+        t.x += s_cnt[4 * i]; t.y += s_cnt[4 * i + 1]; t.z += s_cnt[4 * i + 2]; t.w += s_cnt[4 * i + 3];
+        mx = s_cnt[4 * i] > mx ? s_cnt[4 * i] : mx;
+      }
+      sy.csum[L] = t;
+      sy.cmax[L] = mx;
+    }
+    return;
+  }
   if (lane == 0) {
     s_cnt[wave] = staged;
     s_cnt[n_waves + 2 + 4 * wave] = hits; s_cnt[n_waves + 3 + 4 * wave] = pairs;

@@ -415,11 +415,13 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
 // the other waves of the SIMD keep scanning meanwhile (flushes fall at data-dependent
 // times, so the waves drift apart instead of queueing at the end of the kernel).
 constexpr uint32_t kRecQueue = 128;   // queued records per wave (a sub-tile adds at most 64)
-constexpr uint32_t kRecFlush = 40;    // flush threshold
+constexpr uint32_t kRecFlush = 34;    // flush threshold: about 1.35 candidates per record, so
+                                      // that queue + halo mostly fit one round
 
 struct alignas(16) FusedLds {         // per wave
   fsdev::RangeLds R;
-  uint32_t rec[kRecQueue];
+  uint32_t rec[kRecQueue];            // {(position - range start) / 8 << 8 | flag byte}
+  uint16_t rk[kRecQueue];             // candidates (halo included) in front of the record's
 };
 
 template <int N, bool NT, bool LW14>
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_cnt[5 * 16 + 2];
+  __shared__ uint8_t s_kth[256 * 8];            // [flag byte][k] -> position of its k-th set bit
   uint32_t* s_filter = s_dyn;
   FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << g.log2_words));
   const int lane = threadIdx.x & 63;
@@ -439,6 +442,13 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
   copy_filter_to_lds(g.filter, s_filter, g.log2_words);
+  for (uint32_t e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
+    uint32_t f = e >> 3, pos = 0;
+    for (uint32_t k = e & 7; f; f &= f - 1) {
+      if (k-- == 0) { pos = (uint32_t)__ffs(f) - 1; break; }
+    }
+    s_kth[e] = (uint8_t)pos;
+  }
   __syncthreads();
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   const uint32_t n_ranges = gridDim.x * n_waves;
@@ -514,57 +524,56 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       rec_cnt += (uint32_t)__popcll(has);
       cacc += __popc(flags);
       const bool last_sub = j + 1 == s1;
-      if ((diag & 2) && !last_sub) { if (rec_cnt >= kRecFlush) rec_cnt = 0; continue; }
-      if (rec_cnt >= kRecFlush || (last_sub && (rec_cnt | halo_n | R.hc))) {      // wave-uniform
+      const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
+      if ((diag & 2) && !last_sub) { if (rec_cnt >= flush_at) rec_cnt = 0; continue; }
+      if (rec_cnt >= flush_at || (last_sub && (rec_cnt | halo_n | R.hc))) {      // wave-uniform
         wave_sync();
-        // ranks of the queued candidates: lane t holds records t and t + 64
+        // candidates in front of every queued record (lane t: records t and t + 64)
         const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
         const uint32_t rb = (uint32_t)lane + 64 < rec_cnt ? W.rec[lane + 64] : 0u;
         const uint32_t ca = __popc(ra & 0xFFu), cb = __popc(rb & 0xFFu);
         const uint32_t ia = wave_incl_scan_dpp(ca);
         const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
-        uint32_t ib = 0, tb = 0;
+        uint32_t tb = 0;
+        // (0xFFFF behind the last record: the search below needs no bound)
+        W.rk[lane] = (uint32_t)lane < rec_cnt ? (uint16_t)(halo_n + ia - ca) : (uint16_t)0xFFFFu;
+        uint16_t rkb = 0xFFFFu;
         if (rec_cnt > 64) {
-          ib = wave_incl_scan_dpp(cb);
+          const uint32_t ib = wave_incl_scan_dpp(cb);
           tb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+          if ((uint32_t)lane + 64 < rec_cnt) rkb = (uint16_t)(halo_n + ta + ib - cb);
         }
+        W.rk[lane + 64] = rkb;
+        wave_sync();
         const uint32_t total = halo_n + ta + tb;
         const uint32_t F_end = last_sub ? bnd : base + SUB;
         uint32_t r0 = 0;
         do {
-          const uint32_t left = total - r0;
-          const uint32_t m = left < RS ? left : RS;
-          S.cand[lane] = FS_NONE;
-          wave_sync();
-          if ((uint32_t)lane < halo_n && (uint32_t)lane >= r0 && (uint32_t)lane - r0 <= RS)
-            S.cand[lane - r0] = a - halo_n + lane;
-          {
-            uint32_t fl = ra & 0xFFu, li = halo_n + ia - ca;
-            const uint32_t q0 = a + ((ra >> 8) << 3);
-            while (fl) {
-              const int bb = __ffs(fl) - 1;
-              fl &= fl - 1;
-              if (li >= r0 && li - r0 <= RS) S.cand[li - r0] = q0 + (uint32_t)bb;
-              ++li;
+          // candidate r0 + lane: a halo window, or bit k of the last record with at most
+          // that many candidates in front of it (lane RS: the next round's first)
+          const uint32_t ci = r0 + lane;
+          uint32_t p = FS_NONE;
+          if (ci < total) {
+            if (ci < halo_n) {
+              p = a - halo_n + ci;
+            } else {
+              uint32_t t = 0;
+#pragma unroll
+              for (uint32_t step = kRecQueue / 2; step > 0; step >>= 1) {
+                const uint32_t v = W.rk[t + step];
+                t = v <= ci ? t + step : t;
+              }
+              const uint32_t rec = W.rec[t];
+              p = a + ((rec >> 8) << 3) + s_kth[((rec & 0xFFu) << 3) + (ci - W.rk[t])];
             }
           }
-          if (rec_cnt > 64) {
-            uint32_t fl = rb & 0xFFu, li = halo_n + ta + ib - cb;
-            const uint32_t q0 = a + ((rb >> 8) << 3);
-            while (fl) {
-              const int bb = __ffs(fl) - 1;
-              fl &= fl - 1;
-              if (li >= r0 && li - r0 <= RS) S.cand[li - r0] = q0 + (uint32_t)bb;
-              ++li;
-            }
-          }
-          wave_sync();
           uint32_t F = F_end;
           if (r0 + RS < total) {
-            const uint32_t nx = S.cand[RS];
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)p, RS);
             if (nx < F) F = nx;
           }
-          if (!(diag & 1)) range_round<N>(c, g, sbest, S, m, F, a, range_id, out, R);
+          if (!(diag & 1))
+            range_round<N>(c, g, sbest, S, (uint32_t)lane < RS ? p : FS_NONE, F, a, range_id, out, R);
           r0 += RS;
         } while (r0 < total);
         rec_cnt = 0;
@@ -870,5 +879,8 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rca
     case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
     default: fs_set_error("k_scan_rows covers n = 2..8"); return FS_E_UNSUPPORTED;
   }
+  if (sy.rinfo)
+    return fs_launch_compact_after_scan_rows(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st,
+                                             s, count_out);
   return FS_OK;
 }

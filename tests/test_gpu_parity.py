@@ -523,15 +523,17 @@ def test_dense_chunks_span_several_verify_tiles(synth_base, monkeypatch):
 
 
 @pytest.mark.parametrize("n", [2, 4, 5, 6, 7, 8])
-def test_range_kernel_and_chain_agree(synth_base, monkeypatch, n):
-    """k_scan_rows (scan + records in one kernel, the default), k_scan8 + k_ranges
-    (FS_SCAN_ROWS=0: scan records -> output records per wave range, fs_ranges.hip), the
-    chain they replace (FS_POST_RANGES=0: k_verify_direct, k_hitrows, k_rows) and
-    the oracle: same bytes and statistics in all three record formats, also when
-    the staging area starts far too small (FS_RANGES_CAPROW=2), with works that quote
-    long stretches of the script (several rounds of candidates per wave, hits carried
-    from round to round), hits at range and work boundaries, ragged and empty works.
-    n = 7, 8 need a table the exact-n-gram proof accepts: 256 one-hot vectors."""
+def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
+    """k_scan_rows (tokens -> records in one kernel, the default) against the chain it
+    replaces (FS_SCAN_ROWS=0: k_scan8, k_verify_direct, k_hitrows, k_rows) and the oracle:
+    same bytes and statistics in all three record formats, also when the staging area
+    starts far too small (FS_RANGES_CAPROW=2), with both ways of putting the records into
+    place (inside the launch, or k_compact: FS_ROWS_FINISH=2), when the in-launch wait
+    gives up at once (FS_WAIT_SPINS=0: the search is flagged and repeated through the
+    chained kernels), with works that quote long stretches of the script (several rounds
+    of candidates per flush, hits carried from round to round), hits at range and work
+    boundaries, ragged and empty works.  n = 7, 8 need a table the exact-n-gram proof
+    accepts: 256 one-hot vectors."""
     import torch
     from fandom_search_amd.engine import ScriptIndex
     from fandom_search_amd.vocab import pack_strings
@@ -559,12 +561,10 @@ def test_range_kernel_and_chain_agree(synth_base, monkeypatch, n):
     normals = synth.lsh_normals(n)
     cfg = abi.make_config(window_size=n)
     results = []
-    # FS_WAIT_SPINS=0: the in-launch wait for the workgroups in front gives up at once, the
-    # search is flagged and repeated through the chained kernels
-    for env in ({}, {"FS_SCAN_ROWS": "0"}, {"FS_SCAN_ROWS": "0", "FS_POST_RANGES": "0"},
-                {"FS_RANGES_CAPROW": "2"}, {"FS_SCAN_ROWS": "0", "FS_RANGES_CAPROW": "2"},
-                {"FS_WAIT_SPINS": "0"}, {"FS_SCAN_ROWS": "0", "FS_WAIT_SPINS": "0"}):
-        for k in ("FS_SCAN_ROWS", "FS_POST_RANGES", "FS_RANGES_CAPROW", "FS_WAIT_SPINS"):
+    envs = ({}, {"FS_SCAN_ROWS": "0"}, {"FS_RANGES_CAPROW": "2"}, {"FS_WAIT_SPINS": "0"},
+            {"FS_ROWS_FINISH": "2"}, {"FS_ROWS_FINISH": "2", "FS_RANGES_CAPROW": "2"})
+    for env in envs:
+        for k in ("FS_SCAN_ROWS", "FS_RANGES_CAPROW", "FS_WAIT_SPINS", "FS_ROWS_FINISH"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

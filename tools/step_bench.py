@@ -2,7 +2,7 @@
 """A/B timing of whole search steps under different FS_* switches, one process.
 
   python tools/step_bench.py [--workload c2] [--steps 300] [--rounds 3] \
-      "FS_SCAN_ROWS=1" "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=0 FS_POST_RANGES=0"
+      "FS_SCAN_ROWS=1" "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=1 FS_LANES=4"
 
 Each variant gets its own index (the switches are read at fs_index_create) over the
 same resident corpus; the variants are timed in interleaved rounds (two searches in
@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("variants", nargs="*", default=["FS_SCAN_ROWS=1", "FS_SCAN_ROWS=0",
-                                                    "FS_SCAN_ROWS=0 FS_POST_RANGES=0"])
+                                                    "FS_SCAN_ROWS=1 FS_LANES=4"])
     ap.add_argument("--workload", default="c2")
     ap.add_argument("--works", type=int, default=0)
     ap.add_argument("--window", type=int, default=6)
