@@ -40,6 +40,7 @@ extern "C" const char* fs_strerror(int code) {
 GramIndexDev fs_index::gram_dev() const {
   GramIndexDev g;
   g.stok = d_stok.p; g.filter = d_filter.p; g.table = d_table.p; g.gpos = d_gpos.p;
+  g.sfilter = d_sfilter.p;
   g.gcnt = d_gcnt.p; g.selfdist = d_selfdist.p; g.schars = d_schars.p; g.soff = d_soff.p;
   g.log2_words = log2_words; g.log2_slots = log2_slots;
   g.tstride = (int)((2 + cfg.window_size + 3) & ~3u);
@@ -90,6 +91,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->scan_capw = num("FS_SCAN_CAPW");
   sw->post_fused = getenv("FS_POST_FUSED") != nullptr;
   if (const char* e = getenv("FS_SCAN_ROWS")) sw->scan_rows = e[0] != '0';
+  if (const char* e = getenv("FS_SCAN_SUB")) sw->scan_sub = e[0] != '0';
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
   sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
@@ -195,6 +197,16 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
   }
   FS_TRY(ix->d_disp.upload(disp.data(), disp.size(), ix->stream));
   FS_TRY(ix->d_filter.upload(filter.data(), filter.size(), ix->stream));
+  // sub-shingle filter (fs_hash.h): one bit per script K-gram, same size as the Bloom filter
+  if (const int K = fs_sub_k((int)n)) {
+    std::vector<uint32_t> sub(1u << lw, 0u);
+    for (uint64_t i = 0; i + K <= ix->n_script; ++i) {
+      const uint32_t h = fs_gram_hash(stok + i, K);
+      sub[fs_bloom_word(h, lw)] |= 1u << (h & 31);
+    }
+    FS_TRY(ix->d_sfilter.upload(sub.data(), sub.size(), ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+  }
   FS_TRY(ix->d_table.upload(table.data(), table.size(), ix->stream));
   FS_TRY(ix->d_gpos.upload(gpos.data(), gpos.size(), ix->stream));
   FS_TRY(ix->d_gcnt.upload(gcnt.data(), gcnt.size(), ix->stream));

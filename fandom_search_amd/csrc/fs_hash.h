@@ -67,6 +67,15 @@ FS_HD uint32_t fs_bloom_test(uint32_t word, uint32_t h) {
   return (word >> (h & 31)) & (word >> ((h >> 8) & 31)) & (word >> ((h >> 13) & 31)) & 1u;
 }
 
+// Sub-shingle filter of k_scan_rows: one bit per script K-gram (K = fs_sub_k(n) <= n),
+// word = top log2_words bits of the K-gram's hash, bit = its low five bits.  A fan window
+// of n ids can equal a script window only if all its n-K+1 K-grams are script K-grams,
+// so "n-K+1 consecutive set bits" is a sound candidate test (no false negatives) that
+// costs one LDS word, one shift and one funnel shift per token instead of the three-bit
+// test of the full n-gram; every candidate is still compared id for id afterwards.
+// K = 4 for n >= 6 (n-3 tests per window), 3 for n = 4, 5; n <= 3 keeps the Bloom test.
+constexpr int fs_sub_k(int n) { return n >= 6 ? 4 : n >= 4 ? 3 : 0; }
+
 // Exact (verification) table, hash-and-displace: 2^log2_buckets buckets, each with a
 // displacement seed d; an n-gram with hash h lives in slot fs_table_slot_d(h, d).
 // The seed of a bucket is chosen at build time so that all its n-grams fall into

@@ -103,6 +103,7 @@ struct alignas(16) fs_best {
 struct GramIndexDev {
   const uint32_t* stok;      // [n_script] script vector ids
   const uint32_t* filter;    // [1 << log2_words] blocked Bloom filter
+  const uint32_t* sfilter;   // [1 << log2_words] one bit per script K-gram (fs_hash.h), or nullptr
   const uint32_t* table;     // [1 << log2_slots][tstride] {gram id + 1 (0 = empty), kept occurrences, the n vector ids, pad}
   const uint32_t* gpos;      // [n_grams][nn] first <= nn script positions, ascending
   const uint32_t* gcnt;      // [n_grams] min(occurrences, nn)
@@ -157,6 +158,7 @@ struct fs_switches {
   int scan_capw = 0;              // FS_SCAN_CAPW: records per wave range to start with (tests)
   bool post_fused = false;        // FS_POST_FUSED
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
+  bool scan_sub = true;           // FS_SCAN_SUB=0: k_scan_rows tests the full n-gram (Bloom) instead of K-gram runs
   int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
   int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
@@ -177,7 +179,7 @@ struct fs_index {
   int log2_words = 0, log2_slots = 0, log2_buckets = 0;
   int num_cu = 256;
 
-  DBuf<uint32_t> d_stok, d_filter, d_table, d_disp, d_gpos, d_gcnt, d_schars;
+  DBuf<uint32_t> d_stok, d_filter, d_sfilter, d_table, d_disp, d_gpos, d_gcnt, d_schars;
   DBuf<uint64_t> d_soff;
   DBuf<double> d_q, d_selfdist;
   DBuf<float> d_emb;

@@ -278,7 +278,7 @@ struct RowFinal {
 //   range_id   the wave's range (blockIdx.x * waves + wave)
 //   my_rows    (wave-uniform) records of the wave's range; stats of the wave: hits, pairs,
 //              candidates
-//   s_cnt      LDS, 5 * n_waves + 2 words
+//   s_cnt      LDS, 6 * n_waves + 2 words
 __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& fin,
                                             const RangeOut& out, uint32_t range_id,
                                             uint32_t my_rows, uint32_t hits, uint32_t pairs,
@@ -315,8 +315,8 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   bool gave_up = false;
+  uint32_t total = 0;
   if (wave == 0) {
-    uint32_t total = 0;
     uint4 bs = make_uint4(0, 0, 0, 0);
     for (uint32_t i = 0; i < n_waves; ++i) {
       total += s_cnt[i];
@@ -334,30 +334,35 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // statistics before the granule
       __hip_atomic_store(sy.gran + L, ((unsigned long long)sy.epoch << 32) | total, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
+      s_cnt[n_waves + 1] = total;
     }
-    // records of the workgroups in front: every granule, once it carries this launch's epoch
-    uint32_t pre = 0;
-    for (uint32_t i0 = 0; i0 < L; i0 += 64) {
-      const uint32_t i = i0 + lane;
-      unsigned long long v = 0;
-      bool ok = i >= L;
-      for (uint32_t spins = 0; !__all(ok); ++spins) {
-        if (!ok) {
-          v = __hip_atomic_load(sy.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = (uint32_t)(v >> 32) == sy.epoch;
-        }
-        if (spins > 16) __builtin_amdgcn_s_sleep(1);
-        if (spins >= sy.spin_limit) { gave_up = true; break; }   // default: about a second
-      }
-      pre += (i < L && ok) ? (uint32_t)v : 0u;
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) pre += (uint32_t)__shfl_xor((int)pre, d);
-    if (lane == 0) { s_cnt[n_waves] = pre; s_cnt[n_waves + 1] = total; }
   }
+  // records of the workgroups in front: every granule, once it carries this launch's
+  // epoch.  Wave w takes the granules [64 w, 64 w + 64), and so on in steps of the
+  // workgroup: all waves poll side by side, one round trip when everybody is done.
+  uint32_t pre = 0;
+  for (uint32_t i0 = wave * 64; i0 < L; i0 += n_waves * 64) {
+    const uint32_t i = i0 + lane;
+    unsigned long long v = 0;
+    bool ok = i >= L;
+    for (uint32_t spins = 0; !__all(ok); ++spins) {
+      if (!ok) {
+        v = __hip_atomic_load(sy.gran + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = (uint32_t)(v >> 32) == sy.epoch;
+      }
+      if (spins > 16) __builtin_amdgcn_s_sleep(1);
+      if (spins >= sy.spin_limit) { gave_up = true; break; }   // default: about a second
+    }
+    pre += (i < L && ok) ? (uint32_t)v : 0u;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) pre += (uint32_t)__shfl_xor((int)pre, d);
+  if (lane == 0) s_cnt[5 * n_waves + 2 + wave] = pre;
   __syncthreads();
   // this wave's records: from the staging area to their place
-  uint32_t first = s_cnt[n_waves];
+  uint32_t before = 0;                                   // records of the workgroups in front
+  for (uint32_t i = 0; i < n_waves; ++i) before += s_cnt[5 * n_waves + 2 + i];
+  uint32_t first = before;
   for (uint32_t i = 0; i < wave; ++i) first += s_cnt[i];
   const uint32_t rec_bytes = out.wire ? (uint32_t)out.wire : 32u;
   uint32_t n = staged;
@@ -387,7 +392,6 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
       if (two) dp[i + 64] = v1;
     }
   }
-  if (wave != 0) return;
   if (gave_up && lane == 0) {
     // whoever gives up flags the search, in a word of its own that nothing else writes
     __hip_atomic_store(reinterpret_cast<uint32_t*>(fin.host_st + 1), FS_WAIT_GAVE_UP, __ATOMIC_RELAXED,
@@ -395,7 +399,7 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   }
   // the last workgroup: every other one has published; their statistics were stored
   // write-through before their granules and are read past the caches
-  if (L + 1 == sy.n_blocks) {
+  if (L + 1 == sy.n_blocks && wave == 0) {
     uint32_t h = 0, pr = 0, cd = 0, mx = 0;
     for (uint32_t i = lane; i < sy.n_blocks; i += 64) {
       const uint32_t* b = reinterpret_cast<const uint32_t*>(sy.bstat + i);
@@ -416,7 +420,7 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
       fs_status o;
       if (fin.fresh) { o.max_recs = 0; o.lev_overflow = 0; o.bad_string = 0; }
       else o = *fin.st;
-      o.n_rows = s_cnt[n_waves] + s_cnt[n_waves + 1];
+      o.n_rows = before + s_cnt[n_waves + 1];
       o.n_hits = h; o.n_matches = pr; o.n_cands = cd;
       o.max_rows = mx > out.caprow ? mx : 0;
       *fin.st = o;

@@ -272,6 +272,45 @@ __device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint3
   return flags;
 }
 
+// The same for k_scan_rows' sub-shingle filter (fs_hash.h): the lane tests the K-grams at
+// its 8 + N - K positions (one bit each: filter word shifted by the hash's low five bits),
+// window w is a candidate when the K-grams w .. w + N - K are all script K-grams.
+// m[0 .. 8 + N - 1): premixed ids.  VALU per window: slide 3, word address 1, shift 1,
+// funnel shift 1 for each of (8 + N - K) / 8 positions, plus 2 (N - K) / 8 for the runs.
+template <int N, int K, bool TAIL, bool LW14>
+__device__ __forceinline__ uint32_t window_flags_sub(const uint32_t* m, const uint32_t* s_filter,
+                                                     int word_shift, uint32_t mask_fffc,
+                                                     uint32_t p0, uint32_t n_tok) {
+  constexpr int NB = 8 + N - K;                 // K-gram positions of the lane
+  uint32_t x = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) x ^= fs_rotl(m[k], fs_rot_of(K - 1 - k));
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j) x = (uint32_t)__builtin_amdgcn_bitop3_b32(fs_rotl(x, 7), fs_rotl(m[j - 1], fs_rot_of(K)),
+                                                      m[j - 1 + K], 0x96);   // three-way xor
+    uint32_t word;
+    if constexpr (LW14)
+      word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filter) +
+                                                fs_word_offset14(x, mask_fffc));
+    else
+      word = s_filter[x >> word_shift];
+    bits = __builtin_amdgcn_alignbit(word >> (x & 31), bits, 1);   // bit 0 enters at bit 31
+  }
+  bits >>= 32 - NB;                             // K-gram j at bit j
+  uint32_t flags = bits;
+#pragma unroll
+  for (int d = 1; d <= N - K; ++d) flags &= bits >> d;
+  flags &= 0xFFu;
+  if (TAIL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
+  }
+  return flags;
+}
+
 // Work assignment: the kernels that follow cut the sub-tiles into kNB chunks and need the
 // candidate count of every chunk.  Workgroup b takes the kChunksPerBlock consecutive
 // chunks [4b, 4b+4); inside a chunk each of four waves scans a contiguous quarter of the
@@ -424,7 +463,7 @@ struct alignas(16) FusedLds {         // per wave
   uint16_t rk[kRecQueue];             // candidates (halo included) in front of the record's
 };
 
-template <int N, bool NT, bool LW14>
+template <int N, int K, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     const fs_best* __restrict__ sbest,
                                                     uint32_t n_sub, fsdev::RangeOut out,
@@ -433,7 +472,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  __shared__ uint32_t s_cnt[5 * 16 + 2];
+  __shared__ uint32_t s_cnt[6 * 16 + 2];
   __shared__ uint8_t s_kth[256 * 8];            // [flag byte][k] -> position of its k-th set bit
   uint32_t* s_filter = s_dyn;
   FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << g.log2_words));
@@ -441,7 +480,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
-  copy_filter_to_lds(g.filter, s_filter, g.log2_words);
+  copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, g.log2_words);
   for (uint32_t e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
     uint32_t f = e >> 3, pos = 0;
     for (uint32_t k = e & 7; f; f &= f - 1) {
@@ -491,13 +530,14 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       r.h0 = hp[0]; r.h1 = hp[1];
       return r;
     };
+    // the next sub-tile's ids are requested before this one's work (and a flush) begins
     Tile ta = request(s0), tb = ta;
     if (s0 + 1 < s1) tb = request(s0 + 1);
     for (uint32_t j = s0; j < s1; ++j) {
       const uint32_t base = j * SUB;
       const uint4 v00 = ta.t0, v01 = ta.t1, v10 = ta.h0, v11 = ta.h1;
       ta = tb;
-      if (j + 2 < s1) tb = request(j + 2);     // in flight during the next two sub-tiles' work
+      if (j + 2 < s1) tb = request(j + 2);
       uint32_t aa[16];
       aa[0] = v00.x; aa[1] = v00.y; aa[2] = v00.z; aa[3] = v00.w;
       aa[4] = v01.x; aa[5] = v01.y; aa[6] = v01.z; aa[7] = v01.w;
@@ -513,10 +553,17 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       for (int k = 0; k < 8 + (int)HALO; ++k) aa[k] = fs_premix(aa[k]);
       const uint32_t p0 = base + 8 * lane;
       uint32_t flags;
-      if (base + SUB + HALO > n_tok)
-        flags = window_flags8<N, true, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
-      else
-        flags = window_flags8<N, false, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+      if constexpr (K != 0) {
+        if (base + SUB + HALO > n_tok)
+          flags = window_flags_sub<N, K, true, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+        else
+          flags = window_flags_sub<N, K, false, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+      } else {
+        if (base + SUB + HALO > n_tok)
+          flags = window_flags8<N, true, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+        else
+          flags = window_flags8<N, false, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+      }
       const uint64_t has = __ballot(flags != 0);
       const uint32_t slot = rec_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32),
                                           __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0));
@@ -826,8 +873,12 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   const char e = ix->sw.scan_flags;
   const bool nt = e == 'n' || (!e && big);
   const bool lw14 = ix->log2_words == 14;
-  auto kern = nt ? (lw14 ? k_scan_rows<N, true, true> : k_scan_rows<N, true, false>)
-                 : (lw14 ? k_scan_rows<N, false, true> : k_scan_rows<N, false, false>);
+  constexpr int K = fs_sub_k(N);
+  auto kern = nt ? (lw14 ? k_scan_rows<N, 0, true, true> : k_scan_rows<N, 0, true, false>)
+                 : (lw14 ? k_scan_rows<N, 0, false, true> : k_scan_rows<N, 0, false, false>);
+  if (K != 0 && ix->sw.scan_sub && ix->d_sfilter.p)
+    kern = nt ? (lw14 ? k_scan_rows<N, K, true, true> : k_scan_rows<N, K, true, false>)
+              : (lw14 ? k_scan_rows<N, K, false, true> : k_scan_rows<N, K, false, false>);
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(fs_scan_rows_blocks(ix)), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), (const fs_best*)c->d_sbest.p, n_sub, out,
@@ -839,7 +890,7 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
 }  // namespace
 
 // waves per workgroup of k_scan_rows: sixteen when filter + per-wave state fit the
-// 160 KB of LDS, eight with a 128 KB filter, 0: does not apply
+// 160 KB of LDS, four with a 128 KB filter, 0: does not apply
 uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c) {
   const uint32_t n = ix->cfg.window_size;
   if (!ix->sw.scan_rows || n < 2 || n > 8 || c->has_str || !c->d_sbest.p) return 0;
@@ -849,8 +900,9 @@ uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c) {
       sw.scan_capw)
     return 0;
   const size_t filter = (size_t)4 << ix->log2_words;
-  for (uint32_t w : {16u, 8u})
-    if (filter + w * sizeof(FusedLds) + 256 <= 160 * 1024) return w;
+  // (3 KB: the kernel's static LDS, s_kth and s_cnt)
+  for (uint32_t w : {16u, 8u, 4u})
+    if (filter + w * sizeof(FusedLds) + 3072 <= 160 * 1024) return w;
   return 0;
 }
 

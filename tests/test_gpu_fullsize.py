@@ -102,7 +102,7 @@ def test_c2_full_properties_and_pipeline_equality(c2, synth_base, monkeypatch):
     brows, bst = ix.search(corpus)
     monkeypatch.delenv("FS_SCAN_DIRECT")
     ix.reload_switches()
-    assert brows.tobytes() == rows.tobytes() and bst.candidates == st.candidates
+    assert brows.tobytes() == rows.tobytes() and bst.matches == st.matches
     # the 8-byte wire records of the whole batch expand to the same bytes
     import torch
     cap = len(rows) + 16
