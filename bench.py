@@ -1,22 +1,35 @@
 #!/usr/bin/env python3
 """fanworks/sec of the 6-gram search hot path on MI355X.
 
-A step = one pass of the search over one batch of synthetic fan works that is
-already resident in HBM (fs_search_corpus of include/fandom_search.h: scan
-kernel + verify + Levenshtein + per-word records, rows left in HBM).  At N=1
-the batch is BASELINE.json configs[1] ("c2": 10k works x 2k tokens vs a
-2k-line script, 6-gram); with N ranks every rank searches its own c2-sized
-shard of distinct works (weak scaling) and the match rows of all ranks are
-gathered to rank 0 over RCCL inside the step (double-buffered, so the gather
-of step i overlaps the scan of step i+1).
+A step = one pass of the search over one batch of synthetic fan works that is already
+resident in HBM (fs_search_corpus_begin/_end of include/fandom_search.h: scan, exact
+verification, Levenshtein records, per-word dedupe, records left in HBM).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus
-  roofline     scan kernel: algorithmic bytes (4 B per fan token)
-               / HIP-event duration of the kernel, against 8 TB/s HBM
-  cpu_baseline the plain-C oracle (the reference's LSH algorithm) on a bounded
-               sample of the same workload on the host cores (N=1 only), and as
-               `reference_shaped` the literal Python restatement on configs[0] in
-               a 4-process pool, the way search.py:381-385 runs the original
+  N = 1   BASELINE.json configs[1] ("c2": 10k works x 2k tokens vs a 2k-line script,
+          6-gram).  The timed steps rotate over four DISTINCT c2 batches (320 MB of
+          ids, more than the 256 MiB Infinity Cache), so every step reads its ids
+          from HBM; `--rotate 1` re-scans one resident batch (bound: infinity-cache).
+  N > 1   strong scaling on configs[2] ("c3": 100k works x 5k tokens split N ways; rank
+          r holds works [r W/N, (r+1) W/N)), the match records of all ranks gathered
+          to rank 0 over RCCL inside the step (fandom_search_amd.dist.RowGather: 8-byte
+          wire records, count and records in one collective, gather of step i beside
+          the search of step i+1).  `--scaling weak`: one c2-sized shard per rank.
+
+Prints ONE JSON line (rank 0): the driver's contract plus
+  roofline      the dominant kernel (k_scan_rows: tokens -> records in one launch):
+                algorithmic bytes per launch (4 B per fan token + 32 B per record,
+                SURVEY 8(d)) / its average duration over the timed steps, from HIP
+                events attached to its dispatch; `step` = the same bytes / ms_per_step;
+                `alone_ms` = its duration with nothing else on the GPU (measured after
+                the timed region), since several searches in flight share the machine
+  companions    (N = 1) the same search with what `value` leaves out: records copied
+                to the host, ids streamed from pinned host memory, a mixed-case fan
+                side (per-match Levenshtein on the GPU), and the LSH pipeline on a
+                table with near-synonyms (where the exact-n-gram proof fails)
+  cpu_baseline  the plain-C oracle (the reference's LSH algorithm) on a bounded sample
+                of the same workload on the host cores, and as `reference_shaped` the
+                literal Python restatement on configs[0] in a 4-process pool, the way
+                search.py:381-385 runs the original
 """
 
 import argparse
@@ -32,6 +45,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+MALL_BYTES = 256 << 20    # Infinity Cache
 
 
 def parse():
@@ -39,23 +53,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="c2",
-                    help="per-rank shard: c2 (default), c3shard, c3, c1")
-    ap.add_argument("--works", type=int, default=0, help="override works per rank")
+    ap.add_argument("--workload", default="",
+                    help="c2 (default at N=1), c3 (default at N>1, split over the ranks), c3shard, c1")
+    ap.add_argument("--scaling", default="strong", help="N > 1: strong (c3 split N ways) or weak")
+    ap.add_argument("--works", type=int, default=0, help="override works (per rank)")
     ap.add_argument("--window", type=int, default=6)
+    ap.add_argument("--rotate", type=int, default=0,
+                    help="distinct batches the timed steps rotate over (default: enough "
+                         "to exceed the Infinity Cache, at most 4)")
+    ap.add_argument("--lanes", type=int, default=4,
+                    help="streams the library spreads searches over (FS_LANES): searches in "
+                         "flight overlap on the GPU; 1 = one after the other")
+    ap.add_argument("--inflight", type=int, default=0, help="searches kept in flight (default: lanes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl",
-                    help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: every rank "
-                         "computes on GPU 0, rows gathered through host memory)")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--lanes", type=int, default=0,
-                    help="streams the library spreads searches over (FS_LANES; library "
-                         "default 1): 2 or 4 trade the scan kernel's own speed for step rate")
-    ap.add_argument("--wire", type=int, default=0, help="N > 1: force 16-byte wire records")
-    ap.add_argument("--inflight", type=int, default=2,
-                    help="searches kept in flight (the library overlaps them on its lanes)")
     ap.add_argument("--no-reference-shaped", action="store_true",
                     help="skip the Python reference-shaped leg of cpu_baseline")
+    ap.add_argument("--no-companions", action="store_true")
+    ap.add_argument("--backend", default="nccl",
+                    help="nccl (RCCL, one GPU per rank) or gloo (rehearsal: every rank "
+                         "computes on GPU 0, records gathered through host memory)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--wire", type=int, default=0, help="N > 1: force 16-byte wire records")
     return ap.parse_args()
 
 
@@ -155,10 +173,116 @@ def cpu_reference_shaped(window):
                                              -(-conf["n_works"] // 31))}
 
 
+def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb, window, n_works):
+    """What `value` leaves out, each on a bounded run of the same c2 batches (N = 1)."""
+    import torch
+    from fandom_search_amd import abi, synth, vocab
+    from fandom_search_amd.engine import PinnedBuffer, ScriptIndex, search_stream
+    out = {}
+    # (1) records copied to the host after every search (FS_ROWS_HOST, synchronous)
+    reps = 10
+    ix.search(corpora[0])
+    t0 = time.perf_counter()
+    for i in range(reps):
+        rows, st = ix.search(corpora[i % len(corpora)])
+    dt = time.perf_counter() - t0
+    out["rows_to_host"] = {"value": n_works * reps / dt, "unit": "fanworks/s",
+                           "ms_per_step": dt / reps * 1e3, "rows_per_step": int(len(rows)),
+                           "note": "synchronous fs_search_corpus with the 32-byte records "
+                                   "copied to host memory after every search"}
+    # (2) ids streamed from pinned host memory, upload of batch i+1 beside the search of
+    # batch i (configs[4] mechanics on c2 batches; PCIe-inclusive)
+    pins = []
+    for t in toks:
+        pb = PinnedBuffer(len(t), np.uint32)
+        pb.array[:] = t
+        pins.append(pb)
+    poffs = []
+    for o in offs:
+        po = PinnedBuffer(len(o), np.uint64)
+        po.array[:] = o
+        poffs.append(po)
+
+    def batches(k):
+        for i in range(k):
+            yield pins[i % len(pins)].array, poffs[i % len(poffs)].array
+
+    for _ in search_stream(ix, batches(2), chars, coff):
+        pass
+    k = 12
+    t0 = time.perf_counter()
+    n_rows = 0
+    for rows, st in search_stream(ix, batches(k), chars, coff):
+        n_rows += len(rows)
+    dt = time.perf_counter() - t0
+    out["streamed"] = {"value": n_works * k / dt, "unit": "fanworks/s", "ms_per_step": dt / k * 1e3,
+                       "ids_GBps": sum(len(toks[i % len(toks)]) for i in range(k)) * 4 / dt / 1e9,
+                       "note": "%d c2 batches from pinned host memory through two device "
+                               "corpora (fs_corpus_update_begin/_end), records copied back: "
+                               "H2D and D2H inside the time" % k}
+    for pb in pins + poffs:
+        pb.close()
+    # (3) mixed-case fan side: string ids differ from vector ids (the reference's fan side is
+    # case-sensitive, search.py:166), so every match takes its Levenshtein distance on the GPU
+    strings = list(words) + [w.capitalize() for w in words]
+    schars, scoff = vocab.pack_strings(strings)
+    rng = np.random.default_rng(11)
+    tok_str = toks[0].copy()
+    cap_sel = rng.random(len(tok_str)) < 0.08
+    tok_str[cap_sel] += np.uint32(len(words))
+    cs = ix.corpus(toks[0], offs[0], schars, scoff, tok_str=tok_str)
+    rows, st = ix.search(cs)
+    cap = len(rows) + 64
+    bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(3)]
+    reps, tickets = 30, []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(reps):
+        tickets.append(ix.search_begin(cs, bufs[i % 3].data_ptr(), cap, header=True))
+        if len(tickets) >= 2:
+            ix.search_end(tickets.pop(0))
+    while tickets:
+        ix.search_end(tickets.pop(0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["tok_str"] = {"value": n_works * reps / dt, "unit": "fanworks/s", "ms_per_step": dt / reps * 1e3,
+                      "rows_per_step": int(len(rows)), "kernel": ix.kernel_name(cs),
+                      "note": "8 % of the fan tokens capitalised: string ids next to vector "
+                              "ids, Levenshtein per (match, rank) inside the timed region "
+                              "(k_scan8 + k_verify_direct + k_matchlev + k_cbest + k_hitrows + k_rows)"}
+    cs.close()
+    # (4) the LSH pipeline on a table with near-synonyms (c_max ~ 1: the exact-n-gram proof
+    # fails, every real embedding table is of this kind)
+    emb_c, perm = synth.clustered_table()
+    n_l = 500
+    tk = synth.synonym_swaps(toks[0][:n_l * (len(toks[0]) // n_works)], perm)
+    of = offs[0][:n_l + 1]
+    t0 = time.perf_counter()
+    ixl = ScriptIndex(script, swords, emb_c, synth.lsh_normals(window),
+                      cfg=abi.make_config(window_size=window))
+    t_index = time.perf_counter() - t0
+    cl = ixl.corpus(tk, of, chars, coff)
+    rows, st = ixl.search(cl)
+    best = None
+    for _ in range(3):
+        rows, st = ixl.search(cl)
+        best = st.total_ms if best is None else min(best, st.total_ms)
+    out["lsh_clustered_table"] = {
+        "value": n_l / (best * 1e-3), "unit": "fanworks/s", "ms_per_step": best,
+        "windows_per_s": st.windows_processed / (best * 1e-3), "works": n_l,
+        "rows_per_step": int(len(rows)), "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()),
+        "c_max": ixl.info["c_max"], "path": "lsh", "index_s": round(t_index, 2),
+        "note": "synth.clustered_table (1024 groups of 8 near-synonyms), 10 % of the fan "
+                "tokens swapped for a synonym: k_lsh_scan + k_lsh_verify, device time of one search"}
+    cl.close()
+    ixl.close()
+    return out
+
+
 def main():
     args = parse()
-    if args.lanes:
-        os.environ["FS_LANES"] = str(args.lanes)
+    os.environ["FS_LANES"] = str(max(1, args.lanes))
+    inflight = args.inflight or max(1, args.lanes)
     ref_shaped = None
     if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline
             and not args.no_reference_shaped):
@@ -172,6 +296,7 @@ def main():
     import torch
     import torch.distributed as dist
     from fandom_search_amd import _lib, abi, synth, vocab
+    from fandom_search_amd.dist import HDR, RowGather
     from fandom_search_amd.engine import ScriptIndex
 
     rehearsal = args.backend == "gloo"
@@ -182,143 +307,98 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    cdev = "cpu" if rehearsal else "cuda"        # where collectives run
 
-    conf = dict(synth.CONFIGS[args.workload])
-    if args.works:
-        conf["n_works"] = args.works
-    n_works, tpw = conf["n_works"], conf["tokens_per_work"]
+    # ---- workload -------------------------------------------------------------------
+    strong = world > 1 and args.scaling == "strong"
+    wl = args.workload or ("c3" if strong else "c2")
+    conf = dict(synth.CONFIGS[wl])
+    tpw = conf["tokens_per_work"]
+    if strong:
+        total_works = args.works * world if args.works else conf["n_works"]
+        lo, hi = rank * total_works // world, (rank + 1) * total_works // world
+        n_works, first_work = hi - lo, lo
+    else:
+        n_works = args.works or conf["n_works"]
+        total_works = n_works * world
+        first_work = rank * n_works
+    shard_bytes = 4 * n_works * tpw
+    rotate = args.rotate or (min(4, -(-(MALL_BYTES + 1) // shard_bytes)) if world == 1 else 1)
+    rotate = max(1, rotate)
     words = synth.vocab_words()
     emb = synth.embedding()
     normals = synth.lsh_normals(args.window)
     script = synth.script_tokens(conf["script_tokens"])
     swords = [words[int(t)] for t in script]
     chars, coff = vocab.pack_strings(words)
-    tok, off = synth.corpus_tokens(n_works, tpw, script, first_work=rank * n_works)
+    toks, offs = [], []
+    for r in range(rotate):          # distinct works per batch (and per rank)
+        t, o = synth.corpus_tokens(n_works, tpw, script, first_work=first_work + r * total_works)
+        toks.append(t)
+        offs.append(o)
 
     cfg = abi.make_config(window_size=args.window, device=dev_index)
     ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
-    corpus = ix.corpus(tok, off, chars, coff)
+    corpora = [ix.corpus(t, o, chars, coff) for t, o in zip(toks, offs)]
+    n_tok = corpora[0].n_tok
 
-    # row buffers in HBM.  With more than one rank the exact pipeline emits wire
-    # records for the gather, which rank 0 expands again without loss: 8 bytes each
-    # (token position + packed script position / offset / Levenshtein; rank 0 needs the
-    # ranks' work offsets for them, gathered once below), or 16 bytes for scripts of
-    # 2^18 tokens and more.
+    # wire records of the gather: 8 bytes (exact pipeline, scripts below 2^18 tokens), else
+    # 16; fs_row when there is one rank
     packed = False
     if world > 1 and ix.info["path"] == abi.FS_MODE_EXACT:
         packed = 8 if len(script) < abi.PACKED8_MAX_SCRIPT and args.wire != 16 else 16
     rec_bytes = packed if packed else 32
-    # every row buffer starts with a 32-byte header whose first 8 bytes carry the
-    # row count of the step: count and records travel in ONE gather per step
-    HDR = 32
-    cap = max(4096, corpus.n_tok // 16)
+    cap = 4096
+    probe = torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
+    rows_per_corpus = []
+    for c in corpora:
+        while True:
+            try:
+                n, st0 = ix.search_device(c, probe.data_ptr() + HDR, cap, packed=packed)
+                rows_per_corpus.append(n)
+                break
+            except _lib.FsError as e:
+                if e.code != abi.FS_E_CAPACITY:
+                    raise
+                cap = int(e.required * 1.05) + 64
+                probe = torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
+    del probe
+    NB = inflight + 1
+    gather = RowGather(ix, cap, rec_bytes, n_buffers=NB, rehearsal=rehearsal)
+    cap = gather.cap
+    if packed == 8:
+        gather.set_offsets(offs[0])
 
-    def row_buffer():
-        return torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
-
-    while True:
-        bufs = [row_buffer() for _ in range(2)]
-        try:
-            n_rows, st = ix.search_device(corpus, bufs[0].data_ptr() + HDR, cap, packed=packed)
-            break
-        except _lib.FsError as e:
-            if e.code != abi.FS_E_CAPACITY:
-                raise
-            cap = int(e.required * 1.05) + 64
-    pad = cap
-    if world > 1:
-        t = torch.tensor([cap], dtype=torch.int64, device=cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        pad = int(t.item())
-        if pad != cap:
-            cap = pad
-            bufs = [row_buffer() for _ in range(2)]
-        gathered = full_rows = None
-        if rank == 0:
-            # one contiguous landing buffer per slot; rank r's header + records at
-            # [r * (HDR + cap * rec_bytes), ...)
-            gathered = [torch.zeros(world * (HDR + cap * rec_bytes), dtype=torch.uint8,
-                                    device=cdev) for _ in range(2)]
-            if packed:
-                full_rows = torch.empty(world * cap * 32, dtype=torch.uint8, device="cuda")
-        all_off = None
-        if packed == 8:
-            # the batch layout of every rank, once per corpus: (n_works + 1) offsets
-            mine_off = torch.from_numpy(off.astype(np.int64)).to(cdev)
-            all_off = torch.zeros(world * len(off), dtype=torch.int64, device=cdev)
-            dist.all_gather_into_tensor(all_off, mine_off)
-            all_off = all_off.cuda() if rank == 0 else None
-
-    # Software pipeline over NB row buffers: the search of step i is queued while
-    # the GPU still finishes step i-1 (fs_search_corpus_begin / _end), and with more
-    # than one rank the gather of step i-1 runs beside the search of step i.
-    NB = args.inflight + 1
-    while len(bufs) < NB:
-        bufs.append(row_buffer())
-    if world > 1 and rank == 0:
-        while len(gathered) < NB:
-            gathered.append(torch.zeros(world * (HDR + cap * rec_bytes), dtype=torch.uint8,
-                                        device=cdev))
-    pending = [None] * NB       # gathers in flight, per buffer
-    tickets = {}                # step -> (ticket, buffer)
+    # ---- the step: search of batch i queued while earlier ones run, gathers behind ----
+    tickets = {}
     scan_ms = []
-    total_ms = []
-    total_rows = 0
-    last_st = [None]
-    last_gathered = [0]
-
-    def finish(b):
-        """Buffer b is about to be reused: its gather must be complete.  Work.wait()
-        on RCCL only orders torch's current stream, so the host also waits for that
-        stream (the library writes the buffers from its own stream).  Rank 0 now
-        holds every rank's records of that step: 32-byte rows, or the lossless
-        16-byte wire records, which are expanded where they are consumed
-        (fs_rows_unpack; done once after the timed region for the verification)."""
-        if pending[b] is None:
-            return
-        for h in pending[b]:
-            h.wait()
-        pending[b] = None
-        if not rehearsal:
-            torch.cuda.current_stream().synchronize()
-        last_gathered[0] = b
-
-    # the scan kernel is timed (events attached to its dispatch) on every 4th step
-    # (a timed search carries extra event records, about 15 us: time few of them)
-    ix.set_scan_timing(4 if args.steps >= 8 else 2 if args.steps >= 4 else 1)
+    last = {"st": None, "rows": 0, "buf": 0}
 
     def complete(i):
-        """Finish the search of step i and hand its rows to the gather."""
-        nonlocal total_rows
         t, b = tickets.pop(i)
         n, st = ix.search_end(t)
         if st.scan_ms > 0:
             scan_ms.append(st.scan_ms)
-            total_ms.append(st.total_ms)
-        total_rows = n
-        last_st[0] = st
-        if world > 1:
-            send = bufs[b].cpu() if rehearsal else bufs[b]
-            h = dist.gather(send, list(gathered[b].chunk(world)) if rank == 0 else None, dst=0,
-                            async_op=True)
-            pending[b] = (h,)
+        last["st"], last["rows"] = st, n
+        gather.start(b)
+        last["buf"] = b
 
     def step(i):
         b = i % NB
-        finish(b)
-        # the library writes the step's row count into the buffer's header itself
-        tickets[i] = (ix.search_begin(corpus, bufs[b].data_ptr(), cap, packed=packed,
-                                      header=True), b)
-        if i - (args.inflight - 1) in tickets:
-            complete(i - (args.inflight - 1))
+        gather.wait(b)
+        tickets[i] = (ix.search_begin(corpora[i % rotate], gather.bufs[b].data_ptr(), cap,
+                                      packed=packed, header=True), b)
+        if i - (inflight - 1) in tickets:
+            complete(i - (inflight - 1))
 
     def drain():
         for i in sorted(tickets):
             complete(i)
         for b in range(NB):
-            finish(b)
+            gather.wait(b)
 
+    # the dominant kernel carries timing events on every search of a short run (the driver
+    # passes --steps 20), on every 4th of a long one (an event record costs stream time)
+    ix.set_scan_timing(1 if args.steps <= 64 else 4)
     for i in range(args.warmup):
         step(i)
     drain()
@@ -326,86 +406,76 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     scan_ms.clear()
-    total_ms.clear()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     drain()
-    st = last_st[0]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        t = torch.tensor([dt], dtype=torch.float64, device=gather.cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    st = last["st"]
 
-    # outside the timed region: what rank 0 holds after the last gather must be
-    # every rank's own records (CRC of the 32-byte rows)
+    # outside the timed region: what rank 0 holds after the last gather must be every
+    # rank's own records of that step (CRC of the 32-byte rows)
     gather_verified = None
     if world > 1:
         import zlib
-        own, _ = ix.search(corpus)
-        crc = torch.tensor([zlib.crc32(own.tobytes()), len(own)], dtype=torch.int64, device=cdev)
-        crcs = torch.zeros(2 * world, dtype=torch.int64, device=cdev)
+        last_corpus = corpora[(args.warmup + args.steps - 1) % rotate]
+        own, _ = ix.search(last_corpus)
+        crc = torch.tensor([zlib.crc32(own.tobytes()), len(own)], dtype=torch.int64, device=gather.cdev)
+        crcs = torch.zeros(2 * world, dtype=torch.int64, device=gather.cdev)
         dist.all_gather_into_tensor(crcs, crc)
         if rank == 0:
-            last = last_gathered[0]
+            parts, cnts = gather.rows(last["buf"])
             crcs = crcs.cpu().tolist()
-            stride = HDR + cap * rec_bytes
-            src = gathered[last].cuda() if rehearsal else gathered[last]
-            cnts = src.view(world, stride)[:, :8].contiguous().view(torch.int64).flatten().cpu().tolist()
-            if packed:
-                for r in range(world):
-                    if packed == 8:
-                        ix.unpack8_device(src.data_ptr() + r * stride + HDR, min(cnts[r], cap),
-                                          all_off.data_ptr() + r * len(off) * 8, len(off) - 1,
-                                          full_rows.data_ptr() + r * cap * 32)
-                    else:
-                        ix.unpack_device(src.data_ptr() + r * stride + HDR, min(cnts[r], cap),
-                                         full_rows.data_ptr() + r * cap * 32)
-                landed = full_rows.cpu().numpy()
-            else:
-                landed = src.view(world, stride)[:, HDR:].contiguous().cpu().numpy().reshape(-1)
-            gather_verified = True
-            for r in range(world):
-                chunk = landed[r * cap * 32:(r * cap + cnts[r]) * 32]
-                if cnts[r] != crcs[2 * r + 1] or zlib.crc32(chunk.tobytes()) != crcs[2 * r]:
-                    gather_verified = False
+            gather_verified = all(cnts[r] == crcs[2 * r + 1] and
+                                  zlib.crc32(parts[r].tobytes()) == crcs[2 * r] for r in range(world))
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = world * n_works * args.steps / dt
+        value = total_works * args.steps / dt
         if not scan_ms:                       # no timed launch fell into the region
             ix.set_scan_timing(1)
-            scan_ms.append(ix.search_end(ix.search_begin(corpus, bufs[0].data_ptr(), cap,
+            scan_ms.append(ix.search_end(ix.search_begin(corpora[0], gather.bufs[0].data_ptr(), cap,
                                                          packed=packed, header=True))[1].scan_ms)
-        scan_avg_ms = float(np.mean(scan_ms))
+        kernel_ms = float(np.mean(scan_ms))
+        # the same kernel with nothing else on the GPU: one search at a time
+        ix.set_scan_timing(1)
+        alone = []
+        for i in range(12):
+            alone.append(ix.search_end(ix.search_begin(corpora[i % rotate], gather.bufs[0].data_ptr(), cap,
+                                                       packed=packed, header=True))[1].scan_ms)
+        alone_ms = float(np.mean(alone[2:]))
+        kernel = ix.kernel_name(corpora[0])
+        rows_step = float(np.mean(rows_per_corpus))
         exact = st.path == abi.FS_MODE_EXACT
+        fused = kernel.startswith("k_scan_rows")
         if exact:
-            # fs_scan_tpl: eight tokens per lane (byte bitmap) while the ids fit 256 MiB
-            if corpus.n_tok * 4 <= (256 << 20) and 2 <= args.window <= 8:
-                kernel = "k_scan8<%d>" % args.window
-            else:
-                kernel = "k_scan<%d,4,shuffle,nt>" % args.window
-            algo_bytes = 4.0 * corpus.n_tok       # 4 B per fan token
-            note = "4 B per fan token"
+            # 4 B per fan token read + 32 B per emitted record.  k_scan_rows
+            # is the whole search (ids in, records out); the k_scan8 chain's first kernel
+            # only reads the ids.
+            algo_bytes = 4.0 * n_tok + (32.0 * rows_step if fused else 0.0)
+            note = "4 B per fan token" + (" + 32 B per record" if fused else "")
         else:
-            # LSH pipeline: per window n rows of H*B float64 projections are gathered
-            # (L2 / Infinity Cache resident table, so 'hbm' is nominal here)
             kernel = "k_lsh_scan"
             algo_bytes = float(st.windows_processed) * args.window * 212 * 4
             note = "n rows of 212 float32 projections (848 B) per window (cache-served gather)"
-        achieved = algo_bytes / (scan_avg_ms * 1e-3) / 1e9
-        traffic = None
+        step_bytes = 4.0 * n_tok + 32.0 * rows_step
+        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        resident = rotate * shard_bytes <= MALL_BYTES
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                if rec.get("workload") == args.workload and rec.get("window") == args.window \
-                        and rec.get("n_tok") == corpus.n_tok:
+                if rec.get("kernel") == kernel and rec.get("n_tok") == n_tok and rec.get("rotate") == rotate:
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/scan_traffic.json: " + rec.get("source", "rocprofv3 --pmc")
             except Exception:
                 traffic = None
         out = {
@@ -417,31 +487,49 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d works x %d tokens per GPU vs %d-token script, "
-                                   "%d-gram" % (args.workload, n_works, tpw,
-                                                conf["script_tokens"], args.window),
+            "config": {"workload": ("%s: %d works x %d tokens split over %d GPU(s) (%d works, %.0f MB of ids "
+                                    "per GPU) vs %d-token script, %d-gram"
+                                    % (wl, total_works, tpw, world, n_works, shard_bytes / 1e6,
+                                       conf["script_tokens"], args.window)) if strong else
+                                   ("%s: %d works x %d tokens per GPU vs %d-token script, %d-gram"
+                                    % (wl, n_works, tpw, conf["script_tokens"], args.window)),
                        "works_per_gpu": n_works, "tokens_per_work": tpw,
                        "script_tokens": conf["script_tokens"], "window": args.window,
-                       "rows_per_gpu_step": int(total_rows),
+                       "distinct_batches": rotate,
+                       "ids_bytes_rotated": rotate * shard_bytes,
+                       "rows_per_gpu_step": int(round(rows_step)),
                        "wire_record_bytes": rec_bytes if world > 1 else None,
                        "gather_verified": gather_verified,
-                       "pipeline": "%d searches in flight (fs_search_corpus_begin/_end, %d row "
+                       "pipeline": "%d searches in flight (fs_search_corpus_begin/_end, %d record "
                                    "buffers) on %s lane(s) = stream(s) of the library"
-                                   % (args.inflight, NB, os.environ.get("FS_LANES", "1")),
+                                   % (inflight, NB, os.environ.get("FS_LANES", "1")),
                        "gather": ("%s gather to rank 0, overlapped" % ("gloo (rehearsal)" if rehearsal
                                                                         else "rccl")) if world > 1 else "none",
-                       "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh"},
-            "roofline": {"bound": "hbm", "kernel": kernel, "bytes_model": note,
+                       "path": ("exact-ngram-scan (synthetic table only: the exact-n-gram proof holds, "
+                                "c_max %.3f); tables with near-synonyms take the LSH pipeline, see "
+                                "companions.lsh_clustered_table" % ix.info["c_max"]) if exact else "lsh"},
+            "roofline": {"bound": "infinity-cache" if resident else "hbm",
+                         "kernel": kernel, "bytes_model": note,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "avg_launch_ms": scan_avg_ms, "timed_launches": len(scan_ms)},
-            "device_total_ms": float(np.mean(total_ms)) if total_ms and np.mean(total_ms) > 0 else None,
+                         "avg_launch_ms": kernel_ms, "timed_launches": len(scan_ms),
+                         "launch_ms_alone": alone_ms,
+                         "frac_alone": algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "step_bytes": step_bytes,
+                         "note": "%d searches in flight share the GPU: avg_launch_ms is the kernel's "
+                                 "dispatch-to-completion time inside the timed region, launch_ms_alone "
+                                 "the same kernel with nothing else running; step = (4 B x tokens + "
+                                 "32 B x records) / ms_per_step" % inflight},
         }
+        if world == 1 and not args.no_companions:
+            out["companions"] = companions(ix, corpora, toks, offs, chars, coff, words, script,
+                                           swords, emb, args.window, n_works)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, script, swords, words, emb, normals, tpw,
                                                chars, coff, args.cpu_seconds)

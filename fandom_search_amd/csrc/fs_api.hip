@@ -87,7 +87,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_SCAN_DIRECT")) sw->scan_direct = e[0] != '0';
   sw->scan_unroll = num("FS_SCAN_UNROLL");
   if (const char* e = getenv("FS_SCAN_HALO")) sw->scan_halo_loads = e[0] == 'l';
-  sw->no_stagger = getenv("FS_NO_STAGGER") != nullptr;
+  sw->stagger = getenv("FS_STAGGER") != nullptr;
   sw->scan_capw = num("FS_SCAN_CAPW");
   sw->post_fused = getenv("FS_POST_FUSED") != nullptr;
   if (const char* e = getenv("FS_SCAN_ROWS")) sw->scan_rows = e[0] != '0';
@@ -97,6 +97,8 @@ void fs_read_switches(fs_switches* sw) {
   sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
+  sw->rows_waves = num("FS_ROWS_WAVES");
+  sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
 
 static int ceil_log2(uint64_t x) {
@@ -395,6 +397,24 @@ extern "C" int fs_index_info_get(const fs_index* ix, fs_index_info* info) {
   return FS_OK;
 }
 
+extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
+  static thread_local char name[64];
+  if (!ix || !c || c->ix != ix) return "";
+  const int n = (int)ix->cfg.window_size;
+  const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
+  if (!exact) {
+    snprintf(name, sizeof name, "k_lsh_scan");
+  } else if (fs_scan_rows_waves(ix, c)) {
+    const int k = ix->sw.scan_sub && ix->d_sfilter.p ? fs_sub_k(n) : 0;
+    snprintf(name, sizeof name, "k_scan_rows<%d,%d>", n, k);
+  } else if (fs_scan_tpl(ix, c->n_tok) == 8) {
+    snprintf(name, sizeof name, "k_scan8<%d>", n);
+  } else {
+    snprintf(name, sizeof name, "k_scan<%d>", n);
+  }
+  return name;
+}
+
 // Diagnostics: the FS_* switches are read at fs_index_create; a test or sweep that
 // changes them on a live index calls this (never needed on the search path).
 extern "C" int fs_index_reload_switches(fs_index* ix) {
@@ -638,12 +658,11 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
-  // With two lanes the scans do not run side by side (two scans would only halve each
-  // other's bandwidth): a search's scan is ordered behind the scan of the search queued
-  // before it, and what overlaps is a scan with the other lane's chain.  With three or
-  // four lanes (FS_LANES, throughput over everything else) the order is left to the GPU:
-  // measured on C2, 47 us per step with four lanes against 58 us with the ordering.
-  const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && !ix->sw.no_stagger;
+  // FS_STAGGER (two lanes): a search's first kernel is ordered behind the first kernel of the
+  // search queued before it, so that what overlaps is a scan with the other lane's chain.
+  // Off by default: with k_scan_rows the GPU's own ordering measured faster (32 against
+  // 41 us per C2 step).
+  const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && ix->sw.stagger;
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact && sl.fused_waves) {
     FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,

@@ -154,7 +154,7 @@ struct fs_switches {
   bool scan_direct = true;        // FS_SCAN_DIRECT=0: bitmap + k_expand instead of candidate records
   int scan_unroll = 0;            // FS_SCAN_UNROLL
   bool scan_halo_loads = false;   // FS_SCAN_HALO=loads
-  bool no_stagger = false;        // FS_NO_STAGGER
+  bool stagger = false;           // FS_STAGGER: two lanes, scans ordered one behind the other
   int scan_capw = 0;              // FS_SCAN_CAPW: records per wave range to start with (tests)
   bool post_fused = false;        // FS_POST_FUSED
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
@@ -162,6 +162,8 @@ struct fs_switches {
   int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
   int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
+  int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
+  int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
   int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
   int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range of k_scan_rows to start with (tests)
 };

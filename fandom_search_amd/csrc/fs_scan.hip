@@ -901,12 +901,15 @@ uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c) {
     return 0;
   const size_t filter = (size_t)4 << ix->log2_words;
   // (3 KB: the kernel's static LDS, s_kth and s_cnt)
+  if (sw.rows_waves) return (uint32_t)sw.rows_waves;
   for (uint32_t w : {16u, 8u, 4u})
     if (filter + w * sizeof(FusedLds) + 3072 <= 160 * 1024) return w;
   return 0;
 }
 
-uint32_t fs_scan_rows_blocks(const fs_index* ix) { return (uint32_t)ix->num_cu; }
+uint32_t fs_scan_rows_blocks(const fs_index* ix) {
+  return (uint32_t)ix->num_cu * (uint32_t)std::max(1, ix->sw.rows_blocks_per_cu);
+}
 
 // tokens -> output records: one launch of fs_scan_rows_blocks() workgroups of `waves` wave ranges
 int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,

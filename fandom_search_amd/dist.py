@@ -98,6 +98,129 @@ def gather_rows(rows, group=None, dst=0):
     return np.concatenate(parts)
 
 
+HDR = 32      # bytes in front of the records of a device row buffer (FS_ROWS_HEADER)
+
+
+class RowGather(object):
+    """Gather of device-resident match records to rank 0, one collective per search.
+
+    Every rank owns `n_buffers` device buffers [32-byte header | cap records]; a search
+    (ScriptIndex.search_begin(..., header=True)) writes its record count into the
+    header and the records behind it, both on the GPU, and `start(b)` hands the whole
+    buffer to ONE padded torch.distributed.gather (RCCL over xGMI with the nccl
+    backend): count and records travel together, nothing visits the host in between.
+    Rank 0 receives rank r's buffer at landing[b][r].  With the exact pipeline the
+    records are 8-byte wire records {token position, orig_ix | k << 18 | lev << 22}
+    (a quarter of fs_row; 16-byte ones for scripts of 2^18 tokens and more), expanded
+    without loss by `unpack` from the ranks' work offsets, which are gathered once per
+    corpus.  `rehearsal`: gloo between ranks that all compute on GPU 0 (the buffers
+    go through host memory); used to rehearse the N > 1 path on a one-GPU box.
+
+    This is what stands where the reference concatenates the lists its pool workers
+    return (/root/reference/search.py:381-386)."""
+
+    def __init__(self, index, cap, rec_bytes, n_buffers=1, group=None, rehearsal=False):
+        import torch
+        import torch.distributed as dist
+        self.index, self.rec_bytes, self.group, self.rehearsal = index, int(rec_bytes), group, rehearsal
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.cdev = "cpu" if rehearsal else "cuda"
+        if self.world > 1:                     # one capacity for all ranks (padded gather)
+            t = torch.tensor([int(cap)], dtype=torch.int64, device=self.cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            cap = int(t.item())
+        self.cap = int(cap)
+        self.stride = HDR + self.cap * self.rec_bytes
+        self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device="cuda")
+                     for _ in range(n_buffers)]
+        self.landing = None
+        if self.world > 1 and self.rank == 0:
+            self.landing = [torch.zeros(self.world * self.stride, dtype=torch.uint8, device=self.cdev)
+                            for _ in range(n_buffers)]
+        self.pending = [None] * n_buffers
+        self.all_off = None
+        self.off_len = 0
+
+    def set_offsets(self, work_off):
+        """Work offsets of this rank's batch (all ranks: same number of works is not
+        required).  Needed by rank 0 to expand 8-byte records; one gather per corpus."""
+        import torch
+        import torch.distributed as dist
+        off = np.ascontiguousarray(work_off, dtype=np.int64)
+        self.off_len = len(off)
+        if self.world > 1:
+            n = torch.tensor([len(off)], dtype=torch.int64, device=self.cdev)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+            self.off_len = int(n.item())
+        # [offsets padded with the last one | number of works]
+        mine = torch.full((self.off_len + 1,), int(off[-1]) if len(off) else 0, dtype=torch.int64)
+        mine[:len(off)] = torch.from_numpy(off)
+        mine[self.off_len] = len(off) - 1
+        if self.world == 1:
+            self.all_off = mine.cuda()
+            return
+        mine = mine.to(self.cdev)
+        out = torch.zeros(self.world * (self.off_len + 1), dtype=torch.int64, device=self.cdev)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        self.all_off = out.cuda() if self.rank == 0 else None
+
+    def start(self, b):
+        """Queue the gather of buffer b (after the search that fills it has ended)."""
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        send = self.bufs[b].cpu() if self.rehearsal else self.bufs[b]
+        recv = list(self.landing[b].chunk(self.world)) if self.rank == 0 else None
+        self.pending[b] = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
+
+    def wait(self, b):
+        """Buffer b may be written again / read on rank 0 after this.  Work.wait() on
+        RCCL only orders torch's current stream, and the library writes the buffers
+        from its own streams, so the host also waits for that stream."""
+        import torch
+        if self.pending[b] is None:
+            return
+        self.pending[b].wait()
+        self.pending[b] = None
+        if not self.rehearsal:
+            torch.cuda.current_stream().synchronize()
+
+    def counts(self, b):
+        """Record count per rank of the last completed gather of buffer b (rank 0)."""
+        import torch
+        src = self.landing[b] if self.world > 1 else self.bufs[b]
+        return src.view(self.world, self.stride)[:, :8].contiguous().view(torch.int64) \
+            .flatten().cpu().tolist()
+
+    def rows(self, b):
+        """fs_row records of all ranks in rank order (numpy, rank 0): the 8- or 16-byte
+        wire records expanded on the GPU, work indices local to each rank's batch.
+        Returns (rows, per-rank counts)."""
+        import torch
+        cnts = self.counts(b)
+        src = self.landing[b] if self.world > 1 else self.bufs[b]
+        if self.rehearsal and self.world > 1:
+            src = src.cuda()
+        parts = []
+        for r in range(self.world):
+            n = min(int(cnts[r]), self.cap)
+            at = src.data_ptr() + r * self.stride + HDR
+            if self.rec_bytes == 32:
+                parts.append(src[r * self.stride + HDR:r * self.stride + HDR + n * 32]
+                             .cpu().numpy().view(abi.ROW_DTYPE).copy())
+                continue
+            full = torch.empty(max(1, n) * 32, dtype=torch.uint8, device="cuda")
+            if self.rec_bytes == 8:
+                base = self.all_off.data_ptr() + r * (self.off_len + 1) * 8
+                n_works = int(self.all_off[r * (self.off_len + 1) + self.off_len].item())
+                self.index.unpack8_device(at, n, base, n_works, full.data_ptr())
+            else:
+                self.index.unpack_device(at, n, full.data_ptr())
+            parts.append(full[:n * 32].cpu().numpy().view(abi.ROW_DTYPE).copy())
+        return parts, cnts
+
+
 def gather_strings(items, group=None, dst=0):
     """Gather a list of Python strings per rank to `dst` (rank order)."""
     import torch.distributed as dist

@@ -229,6 +229,10 @@ class ScriptIndex(object):
         _lib.check(_lib.load().fs_index_set_scan_timing(self._h, int(period)),
                    "fs_index_set_scan_timing")
 
+    def kernel_name(self, corpus):
+        """Diagnostics: the kernel that dominates a search of `corpus` (profile name)."""
+        return _lib.load().fs_search_kernel_name(self._h, corpus._h).decode()
+
     def reload_switches(self):
         """Diagnostics: re-read the FS_* environment switches (read at creation)."""
         _lib.check(_lib.load().fs_index_reload_switches(self._h), "fs_index_reload_switches")

@@ -55,6 +55,36 @@ def embedding(size=VOCAB_SIZE, dim=EMB_DIM, seed=EMB_SEED):
     return np.ascontiguousarray(emb, dtype=np.float32)
 
 
+def clustered_table(seed=3, clusters=1024, per=8, dim=EMB_DIM, noise=0.25):
+    """A table shaped like a real word-embedding table as far as this search is
+    concerned: `clusters` groups of `per` near-synonyms (cosine 0.85-0.97 inside a
+    group), so approximate matches exist, c_max ~ 1 and the exact-n-gram proof fails
+    (the LSH pipeline runs).  Returns (emb[clusters*per][dim] float32, perm): row
+    perm[i] holds member i % per of group i // per (synonyms are not neighbours in id
+    space)."""
+    rng = np.random.default_rng(seed)
+    centers = rng.standard_normal((clusters, dim))
+    emb = np.repeat(centers, per, axis=0) + noise * rng.standard_normal((clusters * per, dim))
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    perm = rng.permutation(len(emb))
+    out = np.empty_like(emb)
+    out[perm] = emb
+    return np.ascontiguousarray(out, dtype=np.float32), perm
+
+
+def synonym_swaps(tok, perm, per=8, rate=0.1, seed=9):
+    """Replace `rate` of the tokens by a random member of their group of
+    `clustered_table` (genuine approximate matches)."""
+    rng = np.random.default_rng(seed)
+    inv = np.argsort(perm)
+    tok = np.array(tok, dtype=np.uint32, copy=True)
+    sel = np.nonzero(rng.random(len(tok)) < rate)[0]
+    orig = inv[tok[sel]]
+    syn = (orig // per) * per + rng.integers(0, per, size=len(sel))
+    tok[sel] = perm[syn].astype(np.uint32)
+    return tok
+
+
 def lsh_normals(window_size=6, number_of_hashes=15, hash_dimensions=14,
                 dim=EMB_DIM, seed=NORMALS_SEED):
     rng = np.random.default_rng(seed)

@@ -249,6 +249,11 @@ int fs_reuse_histogram_rows(fs_index* ix, const fs_row* d_rows, uint64_t n_rows,
  * microseconds of stream time per launch, which matters for sub-100 us searches. */
 int fs_index_set_scan_timing(fs_index* ix, uint32_t period);
 
+/* Diagnostics: name of the kernel that dominates a search of `c` on `ix` as things stand
+ * (pipeline, window size, corpus size, switches), e.g. "k_scan_rows<6,4>": what a profile
+ * of the search lists first.  Static storage, valid until the next call on this thread. */
+const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c);
+
 /* Diagnostics: the FS_* environment switches (kernel variants, forced capacities) are
  * read once at fs_index_create; a test or sweep that changes them on a live index
  * calls this to have them read again.  Not part of the search path. */

@@ -23,15 +23,6 @@ from fandom_search_amd import abi, synth, vocab  # noqa: E402
 from fandom_search_amd.engine import ScriptIndex  # noqa: E402
 
 
-def clustered_table(seed=3, clusters=1024, per=8, dim=300, noise=0.25):
-    rng = np.random.default_rng(seed)
-    centers = rng.standard_normal((clusters, dim))
-    emb = np.repeat(centers, per, axis=0) + noise * rng.standard_normal((clusters * per, dim))
-    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
-    perm = rng.permutation(len(emb))            # synonyms are not neighbours in id space
-    return emb[perm].astype(np.float32), perm
-
-
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--table", default="clustered")
@@ -45,19 +36,14 @@ def main():
     words = synth.vocab_words()
     words += ["zz%x" % i for i in range(len(words), a.rows)]
     if a.table == "clustered":
-        emb, perm = clustered_table(clusters=a.rows // 8)
-        inv = np.argsort(perm)
+        emb, perm = synth.clustered_table(clusters=a.rows // 8)
     else:
         emb = synth.embedding()
     script = synth.script_tokens(a.script_tokens)
     tok, off = synth.corpus_tokens(a.works, a.tokens, script)
     if a.table == "clustered":
         # swap 10 % of the planted/ordinary tokens for a synonym: genuine approximate matches
-        rng = np.random.default_rng(9)
-        sel = np.nonzero(rng.random(len(tok)) < 0.1)[0]
-        orig = inv[tok[sel]]                      # position in the clustered order
-        syn = (orig // 8) * 8 + rng.integers(0, 8, size=len(sel))
-        tok[sel] = perm[syn].astype(np.uint32)
+        tok = synth.synonym_swaps(tok, perm)
     chars, coff = vocab.pack_strings(words)
     cfg = abi.make_config(window_size=a.window, mode=abi.FS_MODE_GENERAL)
     t0 = time.time()
