@@ -30,11 +30,23 @@ def test_levenshtein_of_verbatim_ngram_is_n_plus_1():
     assert sr.lev_distance("kitten", "sitting") == 3
     assert sr.lev_distance("", "abc") == 3
     assert sr.lev_distance("flaw", "lawn") == 2
+    # the two examples in python-Levenshtein's own docstring of distance()
+    assert sr.lev_distance("Hello world!", "Holly grail!") == 7
+    assert sr.lev_distance("Brian", "Jesus") == 5
+    # textbook pairs: insertion/deletion/substitution mixes, code points not bytes
+    assert sr.lev_distance("Saturday", "Sunday") == 3
+    assert sr.lev_distance("intention", "execution") == 5
+    assert sr.lev_distance("gumbo", "gambol") == 2
+    assert sr.lev_distance("\u00e9t\u00e9", "ete") == 2
 
 
 def test_spacy_string_hash_known_values():
+    """Values printed in spaCy's documentation ("Vocab, hashes and lexemes": the rows of
+    "I love coffee"; StringStore: nlp.vocab.strings["apple"])."""
     assert vocab.hash_string("coffee") == 3197928453018144401
     assert vocab.hash_string("apple") == 8566208034543834098
+    assert vocab.hash_string("I") == 4690420944186131903
+    assert vocab.hash_string("love") == 3702023516439754181
 
 
 def test_unique_filter_keeps_first_insertion_order():
