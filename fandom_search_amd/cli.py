@@ -34,6 +34,13 @@ def build_parser():
                                help='n-gram size (reference: fixed at 6)')
     search_parser.add_argument('--device', default=0, type=int,
                                help='HIP device ordinal')
+    search_parser.add_argument('--vectors', default=None,
+                               help="vector table, .npz with 'words' and 'vectors' (what the "
+                                    "reference takes from spaCy's en_core_web_md); also "
+                                    "FANDOM_SEARCH_VECTORS")
+    search_parser.add_argument('--synthetic-vocab', action='store_true',
+                               help='use the synthetic benchmark vocabulary (8192 pseudo-words '
+                                    'with random vectors: no semantic similarity)')
     search_parser.set_defaults(func=_search)
 
     data_parser = subparsers.add_parser(
@@ -67,7 +74,12 @@ def _validate(args):
 
 
 def _search(args):
+    import os
     from . import search
+    if getattr(args, 'vectors', None):
+        os.environ['FANDOM_SEARCH_VECTORS'] = args.vectors
+    if getattr(args, 'synthetic_vocab', False):
+        os.environ['FANDOM_SEARCH_SYNTHETIC_VOCAB'] = '1'
     return search.analyze(args)
 
 

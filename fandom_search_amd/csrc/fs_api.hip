@@ -465,6 +465,14 @@ extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
     if (len >= n) windows += len - n + 1;
   }
   FS_ENTER(ix->device);
+  // a search of this corpus still in flight would race with the copies queued below (and a
+  // repeat of it would run with the old batch's geometry)
+  for (int i = 0; i < FS_SEARCH_SLOTS; ++i)
+    if (ix->slots[i].busy && ix->slots[i].c == c) {
+      fs_set_error("a search of this corpus is still in flight: finish it (fs_search_corpus_end) "
+                   "before the corpus is updated");
+      return FS_E_INVALID;
+    }
   if (c->pending) FS_HIP(hipEventSynchronize(c->ev_ready));
   hipStream_t cs = c->copy_stream;
   c->n_tok = T; c->n_works = n_works; c->windows = windows;

@@ -6,10 +6,12 @@ works of a batch whose results are concatenated in input order
 (/root/reference/search.py:381-386).  Here the works of a batch are split into
 contiguous ranges, rank r searches range r on its own GPU against a replicated
 script index (built from the same inputs on every rank: no broadcast), and the
-variable-length row buffers are gathered to rank 0 -- an all_gather of one
-count per rank, then a padded gather of `count_r x 32 B` (RCCL has no gatherv).
+variable-length record buffers are gathered to rank 0 by RowGather: the records stay
+in HBM from the search kernel to the collective (8-byte wire records of the exact
+pipeline, count in a header in front of them, one padded gather: RCCL has no gatherv).
 Rank 0 concatenates in rank order == work order, so the output bytes do not
-depend on the number of GPUs.
+depend on the number of GPUs.  `ao3.py search` under torch.distributed.run
+(search.analyze -> search_sharded) and bench.py --gpus N use the same class.
 
 Backend: "nccl" (= RCCL over xGMI) when a GPU is present, "gloo" otherwise
 (CPU tests).
@@ -36,13 +38,24 @@ def init_from_env(backend=None):
         import torch.distributed as dist
         if not dist.is_initialized():
             if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+                # FANDOM_SEARCH_DIST_BACKEND=gloo with GPUs: rehearsal, every rank on GPU 0
+                backend = os.environ.get("FANDOM_SEARCH_DIST_BACKEND") or \
+                    ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
                 torch.cuda.set_device(local_rank)
                 dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
             else:
                 dist.init_process_group(backend)
     return rank, local_rank, world
+
+
+def finalize():
+    """Leave together: a rank that exits while others still use the group takes the
+    collective backend's threads down mid-flight."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def split_contiguous(weights, parts):
@@ -63,39 +76,6 @@ def split_contiguous(weights, parts):
         bounds.append(cut)
     bounds.append(n)
     return bounds
-
-
-def gather_rows(rows, group=None, dst=0):
-    """Gather fs_row arrays (numpy, abi.ROW_DTYPE) of all ranks to `dst`, in
-    rank order.  Returns the concatenated array on dst, None elsewhere."""
-    import torch
-    import torch.distributed as dist
-
-    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return rows
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    on_gpu = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-
-    counts = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.tensor([len(rows)], dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(counts, mine, group=group)
-    counts = counts.cpu().tolist()
-    pad = max(counts)
-    if pad == 0:
-        return np.zeros(0, dtype=abi.ROW_DTYPE) if rank == dst else None
-    send = torch.zeros(pad * abi.ROW_DTYPE.itemsize, dtype=torch.uint8)
-    send[:rows.nbytes] = torch.from_numpy(rows.view(np.uint8).reshape(-1))
-    send = send.to(dev)
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    parts = [recv[r][:counts[r] * abi.ROW_DTYPE.itemsize].cpu().numpy().view(abi.ROW_DTYPE)
-             for r in range(world)]
-    return np.concatenate(parts)
 
 
 HDR = 32      # bytes in front of the records of a device row buffer (FS_ROWS_HEADER)
@@ -125,14 +105,15 @@ class RowGather(object):
         self.index, self.rec_bytes, self.group, self.rehearsal = index, int(rec_bytes), group, rehearsal
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.cdev = "cpu" if rehearsal else "cuda"
+        self.dev = "cuda" if torch.cuda.is_available() else "cpu"     # where the searches write
+        self.cdev = "cpu" if rehearsal or self.dev == "cpu" else "cuda"   # where collectives run
         if self.world > 1:                     # one capacity for all ranks (padded gather)
             t = torch.tensor([int(cap)], dtype=torch.int64, device=self.cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             cap = int(t.item())
         self.cap = int(cap)
         self.stride = HDR + self.cap * self.rec_bytes
-        self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device="cuda")
+        self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device=self.dev)
                      for _ in range(n_buffers)]
         self.landing = None
         if self.world > 1 and self.rank == 0:
@@ -158,19 +139,19 @@ class RowGather(object):
         mine[:len(off)] = torch.from_numpy(off)
         mine[self.off_len] = len(off) - 1
         if self.world == 1:
-            self.all_off = mine.cuda()
+            self.all_off = mine.to(self.dev)
             return
         mine = mine.to(self.cdev)
         out = torch.zeros(self.world * (self.off_len + 1), dtype=torch.int64, device=self.cdev)
         dist.all_gather_into_tensor(out, mine, group=self.group)
-        self.all_off = out.cuda() if self.rank == 0 else None
+        self.all_off = out.to(self.dev) if self.rank == 0 else None
 
     def start(self, b):
         """Queue the gather of buffer b (after the search that fills it has ended)."""
         import torch.distributed as dist
         if self.world == 1:
             return
-        send = self.bufs[b].cpu() if self.rehearsal else self.bufs[b]
+        send = self.bufs[b].to(self.cdev)           # no copy unless the collective runs elsewhere
         recv = list(self.landing[b].chunk(self.world)) if self.rank == 0 else None
         self.pending[b] = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
 
@@ -183,7 +164,7 @@ class RowGather(object):
             return
         self.pending[b].wait()
         self.pending[b] = None
-        if not self.rehearsal:
+        if self.cdev == "cuda":
             torch.cuda.current_stream().synchronize()
 
     def counts(self, b):
@@ -200,8 +181,8 @@ class RowGather(object):
         import torch
         cnts = self.counts(b)
         src = self.landing[b] if self.world > 1 else self.bufs[b]
-        if self.rehearsal and self.world > 1:
-            src = src.cuda()
+        if self.rec_bytes != 32 and src.device.type != "cuda":
+            src = src.cuda()                        # the expansion kernels need the records in HBM
         parts = []
         for r in range(self.world):
             n = min(int(cnts[r]), self.cap)
@@ -221,35 +202,96 @@ class RowGather(object):
         return parts, cnts
 
 
-def gather_strings(items, group=None, dst=0):
-    """Gather a list of Python strings per rank to `dst` (rank order)."""
+def gather_bytes(payload, group=None, dst=0):
+    """Gather one byte string per rank to `dst` (rank order) with tensor collectives:
+    sizes by all_gather, then one padded gather of uint8."""
+    import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return list(items)
-    world = dist.get_world_size(group)
-    out = [None] * world if dist.get_rank(group) == dst else None
-    dist.gather_object(list(items), out, dst=dst, group=group)
-    if out is None:
+        return [bytes(payload)]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([len(payload)], dtype=torch.int64, device=dev),
+                                group=group)
+    sizes = sizes.cpu().tolist()
+    pad = max(1, max(sizes))
+    send = torch.zeros(pad, dtype=torch.uint8)
+    if payload:
+        send[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    send = send.to(dev)
+    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+    dist.gather(send, recv, dst=dst, group=group)
+    if rank != dst:
         return None
-    return [s for part in out for s in part]
+    return [recv[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
 
 
-def search_sharded(filenames, weights, search_rows, group=None):
+class Shard(object):
+    """What one rank's search of its share of a batch leaves behind.
+      buf        torch uint8 [32-byte header | records]: the count in the header's first
+                 eight bytes, records of `rec_bytes` (32: fs_row, 16 / 8: wire records)
+      work_off   token offsets of the shard's works (numpy uint64; for 8-byte records)
+      words      fan word text per record, in record order
+    """
+
+    def __init__(self, buf, rec_bytes, n_rows, work_off, words):
+        self.buf, self.rec_bytes, self.n_rows = buf, int(rec_bytes), int(n_rows)
+        self.work_off, self.words = work_off, words
+
+
+def shard_from_rows(rows, words, n_works):
+    """A Shard of host fs_row records (searchers without a device path)."""
+    import torch
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    buf = torch.zeros(HDR + max(1, len(rows)) * 32, dtype=torch.uint8)
+    buf[:8] = torch.from_numpy(np.array([len(rows)], dtype=np.uint64).view(np.uint8))
+    if len(rows):
+        buf[HDR:HDR + rows.nbytes] = torch.from_numpy(rows.view(np.uint8).reshape(-1).copy())
+    return Shard(buf, 32, len(rows), np.zeros(n_works + 1, dtype=np.uint64), list(words))
+
+
+def search_sharded(filenames, weights, searcher, group=None):
     """Search one batch of works across all ranks.
 
-    search_rows(sub_filenames) -> (rows with work indices local to the sub
-    list, fan word text per row).  Returns on rank 0 (rows with work indices
-    into `filenames`, fan words), elsewhere (None, None)."""
+    `searcher.search_shard(sub_filenames) -> Shard` (AnnIndexSearch: records left in HBM)
+    or, without it, `searcher.search_rows(sub_filenames) -> (rows, words)`.  The shards
+    travel to rank 0 through RowGather (one padded gather of [count | records]) and the
+    fan words as one byte string per rank.  Returns on rank 0 (fs_row records with work
+    indices into `filenames`, fan words), elsewhere (None, None)."""
+    import torch
     import torch.distributed as dist
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     bounds = split_contiguous(weights, world)
     lo, hi = bounds[rank], bounds[rank + 1]
-    rows, words = search_rows(filenames[lo:hi])
-    rows = np.array(rows, dtype=abi.ROW_DTYPE, copy=True)
-    rows["work"] += np.uint32(lo)
-    all_rows = gather_rows(rows, group=group)
-    all_words = gather_strings(words, group=group)
+    sub = filenames[lo:hi]
+    if hasattr(searcher, "search_shard"):
+        shard = searcher.search_shard(sub)
+    else:
+        rows, words = searcher.search_rows(sub)
+        shard = shard_from_rows(rows, words, len(sub))
+    rehearsal = dist.is_initialized() and dist.get_backend(group) != "nccl" and torch.cuda.is_available()
+    g = RowGather(getattr(searcher, "engine", None), shard.n_rows, shard.rec_bytes, n_buffers=1,
+                  group=group, rehearsal=rehearsal)
+    n = min(shard.buf.numel(), g.stride)
+    g.bufs[0][:n] = shard.buf[:n].to(g.bufs[0].device)
+    if shard.rec_bytes == 8:
+        g.set_offsets(shard.work_off)
+    g.start(0)
+    blobs = gather_bytes("\n".join(shard.words).encode("utf-8"), group=group)
+    g.wait(0)
     if rank != 0:
         return None, None
+    parts, cnts = g.rows(0)
+    for r, part in enumerate(parts):
+        part["work"] += np.uint32(bounds[r])
+    all_rows = np.concatenate(parts) if parts else np.zeros(0, dtype=abi.ROW_DTYPE)
+    all_words = []
+    for r, blob in enumerate(blobs):
+        if cnts[r]:
+            all_words += blob.decode("utf-8").split("\n")
+    if len(all_words) != len(all_rows):
+        raise RuntimeError("gathered %d fan words for %d records" % (len(all_words), len(all_rows)))
     return all_rows, all_words

@@ -59,9 +59,11 @@ SHUFFLE_SEED = 4815162342        # search.py:354
 
 def get_vocab():
     """The process-wide vocabulary (stands where get_spacy_model stands,
-    search.py:40-45).  FANDOM_SEARCH_VECTORS=<file.npz with 'words' and
-    'vectors'> selects a real table; the default is the synthetic vocabulary of
-    SURVEY.md 8(d)."""
+    search.py:40-45).  FANDOM_SEARCH_VECTORS=<file.npz with 'words' and 'vectors'>
+    selects the vector table (e.g. an export of en_core_web_md).  The synthetic
+    vocabulary of SURVEY.md 8(d) (8192 pseudo-words, random vectors: no semantic
+    similarity) must be asked for: FANDOM_SEARCH_SYNTHETIC_VOCAB=1 or `ao3.py search
+    --synthetic-vocab`; there is no silent default."""
     global _VOCAB
     if _VOCAB is None:
         path = os.environ.get("FANDOM_SEARCH_VECTORS")
@@ -69,8 +71,15 @@ def get_vocab():
             data = np.load(path, allow_pickle=False)
             _VOCAB = vocab_mod.Vocab([str(w) for w in data["words"]],
                                      data["vectors"])
-        else:
+        elif os.environ.get("FANDOM_SEARCH_SYNTHETIC_VOCAB", "") not in ("", "0"):
             _VOCAB = vocab_mod.Vocab(synth.vocab_words(), synth.embedding())
+        else:
+            raise RuntimeError(
+                "no vector table: set FANDOM_SEARCH_VECTORS=<file.npz with 'words' and "
+                "'vectors'> (the reference uses spaCy's en_core_web_md), or ask for the "
+                "synthetic benchmark vocabulary with --synthetic-vocab / "
+                "FANDOM_SEARCH_SYNTHETIC_VOCAB=1 (random vectors: results carry no "
+                "semantic similarity)")
     return _VOCAB
 
 
@@ -113,9 +122,11 @@ def load_markup_script(filename):
             if m:
                 scene_tags += 1
                 digits = ''.join(ch for ch in m.group('scene') if ch.isdigit())
-                if digits:
+                try:
+                    # (isdigit() also accepts characters int() refuses, e.g. superscripts:
+                    # the reference catches the ValueError, search.py:309-314)
                     scene = int(digits)
-                else:
+                except ValueError:
                     count_scenes = True
                     print("Error in Scene markup: {}".format(text))
                 if count_scenes:
@@ -232,6 +243,7 @@ class AnnIndexSearch(object):
         self.engine = ScriptIndex(script_vec, self.word_lowercase,
                                   self.vocab.vectors, normals, cfg=cfg)
         self.last_stats = None
+        self.last_oov_rate = None
         self.reset_stats()
 
     def reset_stats(self):
@@ -258,7 +270,8 @@ class AnnIndexSearch(object):
         texts = [read_work_tokens(f) for f in filenames]
         return self.search_tokens(texts)
 
-    def search_tokens(self, texts):
+    def _corpus_of(self, texts):
+        """(string ids, vector ids, work offsets, device corpus) of tokenised works."""
         v = self.vocab
         sid_parts, vid_parts = [], []
         off = np.zeros(len(texts) + 1, dtype=np.uint64)
@@ -272,9 +285,16 @@ class AnnIndexSearch(object):
         tok_vec = np.concatenate(vid_parts) if vid_parts else \
             np.zeros(0, np.uint32)
         chars, coff = v.string_table()
+        self.last_oov_rate = float((tok_vec & np.uint32(abi.FS_OOV_FLAG)).astype(bool).mean()) \
+            if len(tok_vec) else 0.0
         same = bool(np.array_equal(tok_str, tok_vec))
         corpus = self.engine.corpus(tok_vec, off, chars, coff,
                                     tok_str=None if same else tok_str)
+        return tok_str, tok_vec, off, corpus
+
+    def search_tokens(self, texts):
+        v = self.vocab
+        tok_str, tok_vec, off, corpus = self._corpus_of(texts)
         try:
             rows, st = self.engine.search(corpus)
         finally:
@@ -284,6 +304,48 @@ class AnnIndexSearch(object):
         pos = off[rows['work']].astype(np.int64) + rows['fan_ix'].astype(np.int64)
         words = [v.strings[s] for s in tok_str[pos].tolist()]
         return rows, words
+
+    def search_shard(self, filenames):
+        """This rank's share of a batch for fandom_search_amd.dist.search_sharded: the
+        records stay in HBM (wire records of the exact pipeline: 8 bytes, 16 for scripts of
+        2^18 tokens and more; fs_row from the LSH pipeline) behind a 32-byte header that
+        the search itself fills with their number; the fan words are looked up from the
+        token positions of a host copy taken beside the gather."""
+        import torch
+        from . import _lib
+        from .dist import HDR, Shard
+        texts = [read_work_tokens(f) for f in filenames]
+        tok_str, tok_vec, off, corpus = self._corpus_of(texts)
+        exact = self.engine.info["path"] == abi.FS_MODE_EXACT and \
+            not bool((tok_vec & np.uint32(abi.FS_OOV_FLAG)).any())
+        packed = False
+        if exact:
+            packed = 8 if len(self.word_lowercase) < abi.PACKED8_MAX_SCRIPT else 16
+        rec = packed if packed else 32
+        cap = max(1024, len(tok_vec) // 16)
+        try:
+            while True:
+                buf = torch.zeros(HDR + cap * rec, dtype=torch.uint8, device="cuda")
+                try:
+                    n, st = self.engine.search_end(self.engine.search_begin(
+                        corpus, buf.data_ptr(), cap, packed=packed, header=True))
+                    break
+                except _lib.FsError as e:
+                    if e.code != abi.FS_E_CAPACITY:
+                        raise
+                    cap = int(e.required) + 16
+        finally:
+            corpus.close()
+        self.last_stats = st
+        self._windows_processed += int(st.windows_processed)
+        host = buf[HDR:HDR + n * rec].cpu().numpy()
+        if rec == 8:
+            pos = host.view(np.uint32)[0::2].astype(np.int64)         # token position
+        else:
+            r = host.view(np.uint32).reshape(n, rec // 4)
+            pos = off[r[:, 0]].astype(np.int64) + r[:, 1].astype(np.int64)
+        words = [self.vocab.strings[s] for s in tok_str[pos].tolist()]
+        return Shard(buf, rec, n, off, words)
 
     def records(self, filenames, rows, words):
         """Join the numeric rows with file name, fan word / orth id and the
@@ -357,7 +419,8 @@ def analyze(args,
     window_size = getattr(args, 'window_size', None) or window_size
     device = getattr(args, 'device', 0) or 0
     if world > 1:
-        device = local_rank
+        import torch.distributed as tdist
+        device = local_rank if tdist.get_backend() == "nccl" else 0   # gloo: rehearsal on GPU 0
 
     fan_clusters = [fan_works[i:i + chunk_size]
                     for i in range(0, len(fan_works), chunk_size)]
@@ -380,10 +443,17 @@ def analyze(args,
                                                          chunk_size * (i + 1)))
         if world > 1:
             weights = [os.path.getsize(f) for f in fan_cluster]
-            rows, words = dist.search_sharded(fan_cluster, weights,
-                                              ann_index.search_rows)
+            rows, words = dist.search_sharded(fan_cluster, weights, ann_index)
         else:
             rows, words = ann_index.search_rows(fan_cluster)
+        st = getattr(ann_index, 'last_stats', None)
+        oov = getattr(ann_index, 'last_oov_rate', None)
+        if oov is not None and oov > 0.2:
+            import sys
+            print('warning: {:.0%} of the fan tokens of this batch have no row in the vector '
+                  'table (out-of-vocabulary 3-hot vectors, search.py:79-83); check '
+                  'FANDOM_SEARCH_VECTORS'.format(oov), file=sys.stderr)
+        del st
         if rank != 0:
             continue
         records = join_records(fan_cluster, rows, words,
@@ -392,8 +462,10 @@ def analyze(args,
         write_records(records, batch_filename.format(i))
         accumulated_records.extend(records)
 
-    if rank != 0:
-        return None
-    name = unused_result_name(filename_base)
-    write_records(accumulated_records, name)
+    name = None
+    if rank == 0:
+        name = unused_result_name(filename_base)
+        write_records(accumulated_records, name)
+    if world > 1:
+        dist.finalize()
     return name

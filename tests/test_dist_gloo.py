@@ -1,6 +1,9 @@
-"""The N>1 path on CPU: world_size-2 gloo processes run analyze() with an
-oracle-backed searcher; the CSVs must be byte-identical to a single-process
-run.  Also the range splitter and the variable-length row gather."""
+"""The N>1 path on CPU: gloo processes (world sizes 2 and 4) run analyze() with an
+oracle-backed searcher through the product's gather (dist.search_sharded ->
+RowGather: header + records in one padded gather, fan words as bytes); the CSVs must
+be byte-identical to a single-process run.  Also the range splitter.  With a GPU
+(-m gpu): two ranks with the real AnnIndexSearch, 8-byte wire records left in HBM by
+the search and expanded on rank 0."""
 
 import os
 import subprocess
@@ -28,11 +31,18 @@ def test_split_contiguous():
         assert len(b) == parts + 1 and b[0] == 0 and b[-1] == 37 and b == sorted(b)
 
 
-def test_gather_rows_single_process_is_identity():
+def test_search_sharded_single_process_is_identity():
+    """One rank: the shard goes through RowGather and comes back unchanged."""
     rows = np.zeros(3, dtype=abi.ROW_DTYPE)
     rows["work"] = [0, 1, 2]
-    out = dist.gather_rows(rows)
-    assert out.tobytes() == rows.tobytes()
+    rows["fan_ix"] = [5, 6, 7]
+
+    class One(object):
+        def search_rows(self, filenames):
+            return rows, ["a", "b c", "d"]
+
+    out, words = dist.search_sharded(["x", "y", "z"], [1, 1, 1], One())
+    assert out.tobytes() == rows.tobytes() and words == ["a", "b c", "d"]
 
 
 WORKER = textwrap.dedent('''
@@ -91,7 +101,7 @@ def _run(tmp_path, outdir, fandir, script, world):
 
 
 @pytest.mark.timeout(900)
-def test_two_rank_gloo_run_writes_identical_csvs(tmp_path):
+def test_gloo_runs_write_identical_csvs(tmp_path):
     from fandom_search_amd import synth
     words = synth.vocab_words()
     script = synth.script_tokens(1500)
@@ -107,8 +117,62 @@ def test_two_rank_gloo_run_writes_identical_csvs(tmp_path):
     with open(spath, "w") as fh:
         fh.write(synth.script_markup(script, words))
     one = _run(tmp_path, str(tmp_path / "out1"), fandir, spath, 1)
-    two = _run(tmp_path, str(tmp_path / "out2"), fandir, spath, 2)
-    assert list(one) == list(two) and len(one) == 4          # 3 batch files + dated file
-    for name in one:
-        assert one[name] == two[name], name
-    assert sum(len(v) for v in one.values()) > 1000
+    assert len(one) == 4 and sum(len(v) for v in one.values()) > 1000   # 3 batch files + dated file
+    for world in (2, 4):
+        many = _run(tmp_path, str(tmp_path / ("out%d" % world)), fandir, spath, world)
+        assert list(one) == list(many)
+        for name in one:
+            assert one[name] == many[name], (world, name)
+
+
+GPU_WORKER = textwrap.dedent('''
+    import os, sys, types
+    sys.path.insert(0, %(root)r)
+    from fandom_search_amd import search
+    os.chdir(sys.argv[1])
+    args = types.SimpleNamespace(fan_works=sys.argv[2], script=sys.argv[3],
+                                 skip_works=0, num_works=-1)
+    search.analyze(args, chunk_size=9)
+''')
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_two_ranks_with_the_hip_searcher(tmp_path):
+    """`ao3.py search` under torch.distributed.run with the real AnnIndexSearch: every
+    rank searches its share on the GPU, the 8-byte wire records go from HBM into the
+    gather and are expanded on rank 0.  (One GPU here, so the ranks share it and the
+    collective is gloo: FANDOM_SEARCH_DIST_BACKEND; with one GPU per rank the same code
+    runs over RCCL.)  Byte-identical to the single-process run."""
+    from fandom_search_amd import synth
+    words = synth.vocab_words()
+    script = synth.script_tokens(1500)
+    fandir = str(tmp_path / "fan")
+    lens = [300, 0, 120, 4, 260, 310, 90, 200, 150, 333, 70, 128, 256, 64, 180, 222, 199, 6, 5]
+    os.makedirs(fandir)
+    for i, n in enumerate(lens):
+        tok = synth.fanwork_tokens(i, n, script) if n else []
+        with open(os.path.join(fandir, synth.work_name(i)), "w") as fh:
+            fh.write(" ".join(words[int(t)] for t in tok))
+    spath = str(tmp_path / "script.txt")
+    with open(spath, "w") as fh:
+        fh.write(synth.script_markup(script, words))
+    worker = tmp_path / "gpu_worker.py"
+    worker.write_text(GPU_WORKER % dict(root=ROOT))
+    outs = {}
+    for world in (1, 2):
+        outdir = str(tmp_path / ("gout%d" % world))
+        os.makedirs(outdir)
+        env = dict(os.environ, FANDOM_SEARCH_DIST_BACKEND="gloo", FANDOM_SEARCH_SYNTHETIC_VOCAB="1")
+        if world == 1:
+            cmd = [sys.executable, str(worker), outdir, fandir, spath]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                   "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                   "--master-port", "29534", str(worker), outdir, fandir, spath]
+        subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
+        outs[world] = {f: open(os.path.join(outdir, f), "rb").read() for f in sorted(os.listdir(outdir))}
+    assert list(outs[1]) == list(outs[2]) and len(outs[1]) == 4
+    for name in outs[1]:
+        assert outs[1][name] == outs[2][name], name
+    assert sum(len(v) for v in outs[1].values()) > 1000

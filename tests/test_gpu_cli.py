@@ -25,7 +25,12 @@ def test_ao3_search_c1(tmp_path, monkeypatch, synth_base, capsys):
     (tmp_path / "script.txt").write_text(synth.script_markup(script, words))
     monkeypatch.chdir(tmp_path)
     search.set_vocab(None)
-    assert main(["search", str(fandir), str(tmp_path / "script.txt")]) == 0
+    monkeypatch.delenv("FANDOM_SEARCH_VECTORS", raising=False)
+    monkeypatch.delenv("FANDOM_SEARCH_SYNTHETIC_VOCAB", raising=False)
+    # no vector table named: refuse instead of silently searching with random vectors
+    with pytest.raises(RuntimeError, match="no vector table"):
+        main(["search", str(fandir), str(tmp_path / "script.txt")])
+    assert main(["search", str(fandir), str(tmp_path / "script.txt"), "--synthetic-vocab"]) == 0
     assert "Processing cluster 0 (0-500)" in capsys.readouterr().out
     today = '{:%Y%m%d}'.format(datetime.date.today())
     final = (tmp_path / ("match-6gram-%s.csv" % today)).read_bytes()

@@ -80,3 +80,34 @@ def test_device_side_validation(synth_base):
     # a good corpus still works afterwards
     rows, _ = ix.search(ix.corpus(tok, off, synth_base["chars"], synth_base["off"]))
     assert len(rows) == 0
+
+
+def test_update_of_a_corpus_with_a_search_in_flight_is_refused(synth_base):
+    """fs_corpus_update_begin while a search of the same corpus has been queued and not
+    finished would race with its kernels: FS_E_INVALID until fs_search_corpus_end."""
+    import torch
+    from fandom_search_amd import _lib
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(2000)
+    tok, off = util.ragged_corpus([600] * 10, script)
+    tok2, off2 = util.ragged_corpus([500] * 8, script, first_work=50)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                     cfg=abi.make_config())
+    c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    want, _ = ix.search(c)
+    buf = torch.zeros(32 + (len(want) + 8) * 32, dtype=torch.uint8, device="cuda")
+    t = ix.search_begin(c, buf.data_ptr(), len(want) + 8, header=True)
+    with pytest.raises(_lib.FsError) as e:
+        c.update_begin(tok2, off2)
+    assert e.value.code == abi.FS_E_INVALID
+    n, _ = ix.search_end(t)
+    assert n == len(want)
+    assert buf[32:32 + n * 32].cpu().numpy().tobytes() == want.tobytes()
+    c.update_begin(tok2, off2)            # fine now
+    c.update_end()
+    got2, _ = ix.search(c)
+    oi = util.oracle_index(abi.make_config(), script, words, emb, synth.lsh_normals(6))
+    want2, _ = oi.search(tok2, off2, synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(got2, want2)
+    ix.close()

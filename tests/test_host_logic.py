@@ -60,6 +60,31 @@ def test_load_markup_script_rows(tmp_path):
     assert [r[3] for r in body] == ["REY"] * 5 + ["FINN"] * 2
 
 
+def test_scene_label_that_isdigit_accepts_and_int_refuses(tmp_path):
+    """'\u00b2' passes str.isdigit() but int() raises ValueError: the reference catches
+    it and switches to the running scene count for the rest of the file
+    (search.py:309-317)."""
+    p = tmp_path / "s.txt"
+    p.write_text("SCENE_NUMBER<<7>>\nLINE<<one>>\nSCENE_NUMBER<<\u00b2>>\nLINE<<two>>\n"
+                 "SCENE_NUMBER<<90>>\nLINE<<three>>\n", encoding="utf-8")
+    body = search.load_markup_script(str(p))[1:]
+    assert [r[2] for r in body] == [7, 2, 3]
+
+
+def test_vocabulary_must_be_named(monkeypatch):
+    """No silent fall-back to the synthetic vocabulary (random vectors)."""
+    monkeypatch.delenv("FANDOM_SEARCH_VECTORS", raising=False)
+    monkeypatch.delenv("FANDOM_SEARCH_SYNTHETIC_VOCAB", raising=False)
+    search.set_vocab(None)
+    with pytest.raises(RuntimeError, match="no vector table"):
+        search.get_vocab()
+    monkeypatch.setenv("FANDOM_SEARCH_SYNTHETIC_VOCAB", "1")
+    try:
+        assert search.get_vocab().dim == synth.EMB_DIM
+    finally:
+        search.set_vocab(None)
+
+
 def test_synthetic_script_round_trip(tmp_path):
     words = synth.vocab_words()
     script = synth.script_tokens(1234)

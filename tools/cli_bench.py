@@ -39,7 +39,7 @@ def main():
             fh.write(synth.script_markup(script, words))
         t_write = time.time() - t0
         t0 = time.time()
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "ao3.py"), "search", fan, spath],
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "ao3.py"), "search", fan, spath, "--synthetic-vocab"],
                              cwd=tmp, capture_output=True, text=True)
         dt = time.time() - t0
         csvs = [f for f in os.listdir(tmp) if f.startswith("match-")]
