@@ -97,6 +97,12 @@ void fs_read_switches(fs_switches* sw) {
   sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
+  if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);
+  if (const char* e = getenv("FS_LSH_F32")) sw->lsh_f32 = e[0] != '0';
+  sw->lsh_diag = num("FS_LSH_DIAG");
+  sw->lsh_no_gtab = getenv("FS_LSH_NO_GTAB") != nullptr;
+  sw->lsh_serial = getenv("FS_LSH_SERIAL") != nullptr;
+  if (const char* e = getenv("FS_LSH_PREFILTER")) sw->lsh_prefilter = e[0] != '0';
   sw->rows_waves = num("FS_ROWS_WAVES");
   sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
@@ -239,7 +245,7 @@ static int prove_exact(fs_index* ix, const uint32_t* stok) {
     std::vector<uint8_t> seen(V, 0);
     for (uint64_t i = 0; i < ix->n_script; ++i) {
       const uint32_t id = stok[i];
-      if (id & FS_OOV_FLAG) { script_oov = true; continue; }   // 3-hot vectors: no proof
+      if (id & FS_OOV_FLAG) { script_oov = true; ix->script_oov = true; continue; }   // 3-hot vectors: no proof
       if (!seen[id]) { seen[id] = 1; rows_u.push_back(id); }
     }
   }
@@ -403,7 +409,7 @@ extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   const int n = (int)ix->cfg.window_size;
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   if (!exact) {
-    snprintf(name, sizeof name, "k_lsh_scan");
+    snprintf(name, sizeof name, fs_lsh_prefilter_ok(ix, c) ? "k_scan_near<%d>" : "k_lsh_scan", n);
   } else if (fs_scan_rows_waves(ix, c)) {
     const int k = ix->sw.scan_sub && ix->d_sfilter.p ? fs_sub_k(n) : 0;
     snprintf(name, sizeof name, "k_scan_rows<%d,%d>", n, k);
@@ -684,7 +690,12 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
   } else {
-    FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+    // tables whose proof fails by one slot only: the integer prefilter flags the windows
+    // that can have a neighbour at all, the LSH work runs on those
+    if (fs_lsh_prefilter_ok(ix, c))
+      FS_TRY(fs_launch_scan_near(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+    else
+      FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));

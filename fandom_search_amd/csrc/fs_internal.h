@@ -162,6 +162,12 @@ struct fs_switches {
   int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
   int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
+  double lsh_f32_slack = 1.0;     // FS_LSH_F32_SLACK: factor on the float32 key bound (tests force the fallback)
+  bool lsh_f32 = true;            // FS_LSH_F32=0: float64 keys only
+  int lsh_diag = 0;               // FS_LSH_DIAG
+  bool lsh_no_gtab = false;       // FS_LSH_NO_GTAB
+  bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
+  bool lsh_prefilter = true;      // FS_LSH_PREFILTER=0: always the full key scan
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
   int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
@@ -195,6 +201,9 @@ struct fs_index {
   DBuf<uint32_t> d_boff, d_bids;
   bool lsh_ready = false;
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors
+  bool script_oov = false;   // the script holds out-of-vocabulary (3-hot) vectors
+  int lsh_m_min = 0;         // fewer id-identical slots than this cannot reach the threshold
+  DBuf<uint32_t> d_sfilter3; // one bit per script 3-gram: the <= 1 mismatch prefilter (fs_scan.hip)
 
   // Lanes: a stream with its own workspaces (grown on demand) and status block.
   // Searches are spread over n_lanes of them (FS_LANES in the environment, default
@@ -321,6 +330,10 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
                        uint32_t n_sub, hipStream_t s, hipEvent_t e0 = nullptr,
                        hipEvent_t e1 = nullptr);
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
+// fs_scan.hip: the integer prefilter of the LSH pipeline ("all but one slot identical")
+bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c);
+int fs_launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                        uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
                            uint32_t* check, hipStream_t s);
 int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_row* d_rows,

@@ -65,6 +65,7 @@ struct LshDev {
   int m_min;               // fewer id-identical slots than this cannot reach the threshold
   int diag;                // diagnostics: 1 = skip candidate walk, 2 = skip key computation,
                            // 3 = walk the buckets but skip the distances
+  int serial_neighbours;   // FS_LSH_SERIAL=1: k_lsh_verify walks the buckets on one lane (cross-check)
   const double* gtab;      // [n_srow][V] g(script row, table row), or nullptr
   const int32_t* sidx;     // [V] row of gtab for a table id, -1 if not a script word
   uint32_t V, W;
@@ -236,6 +237,90 @@ __device__ int lsh_neighbours(const LshDev& L, const uint32_t* keys, const uint3
     }
   }
   return cnt;
+}
+
+// The same neighbour list computed by a whole wave (all 64 lanes call it with the same
+// arguments; `keys`, `f`, `top_s`, `top_d`, `s_pre`, `s_e0` in LDS, private to the wave).
+// Lane h reads the bucket range of table h; the bucket entries of table 0, 1, ... are
+// numbered in order and dealt to the lanes, 64 - nn at a time, behind the <= nn entries
+// kept so far: every lane fetches its script window and computes its distance (the
+// dependent loads of all candidates in flight together), UniqueFilter = not equal to a
+// kept entry or to an earlier lane of the round (an entry dropped earlier has the same
+// distance and would be dropped again), NearestFilter = rank in the stable order
+// (distance, then arrival) below nn.  Equal to lsh_neighbours<false> entry for entry.
+__device__ int lsh_neighbours_wave(const LshDev& L, const uint32_t* keys, const uint32_t* f,
+                                   uint32_t* top_s, double* top_d, uint32_t* s_pre,
+                                   uint32_t* s_e0) {
+  const int lane = threadIdx.x & 63;
+  double ff = 0.0;
+  for (int k = 0; k < L.n; ++k) ff = __dadd_rn(ff, q_of(L, f[k]));
+  const double rff = __dsqrt_rn(ff);
+  const uint32_t nb1 = (1u << L.B) + 1;
+  uint32_t e0 = 0, cnt_h = 0;
+  if (lane < L.H) {
+    const uint32_t* o = L.boff + (size_t)lane * nb1 + keys[lane];
+    e0 = o[0];
+    cnt_h = o[1] - e0;
+  }
+  const uint32_t incl = wave_incl_scan_dpp(cnt_h);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  s_pre[lane] = incl - cnt_h;                  // lanes >= H: = total
+  s_e0[lane] = e0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const uint32_t nn = (uint32_t)L.nn;
+  const uint32_t R = 64 - nn;                  // new candidates per round
+  uint32_t kcnt = 0;
+  for (uint32_t r0 = 0; r0 < total; r0 += R) {
+    const uint32_t m = total - r0 < R ? total - r0 : R;
+    uint32_t s = FS_NONE;
+    double d = 0.0;
+    bool valid = false;
+    if ((uint32_t)lane < kcnt) {               // kept so far, in rank order
+      s = top_s[lane]; d = top_d[lane]; valid = true;
+    } else if ((uint32_t)lane - kcnt < m) {
+      const uint32_t j = r0 + ((uint32_t)lane - kcnt);
+      uint32_t h = 0;                          // last table with s_pre[h] <= j
+#pragma unroll
+      for (uint32_t step = 32; step > 0; step >>= 1)
+        if (h + step < (uint32_t)L.H && s_pre[h + step] <= j) h += step;
+      s = L.bids[(size_t)h * L.W + s_e0[h] + (j - s_pre[h])];
+      if (L.diag != 3) valid = window_distance(L, s, f, ff, rff, &d) && d < L.thr;
+    }
+    if (L.unique) {
+      // not the window of a kept entry or of an earlier lane of this round
+      uint64_t live = __ballot(s != FS_NONE);
+      bool dup = false;
+      while (live) {
+        const int l = __ffsll((unsigned long long)live) - 1;
+        live &= live - 1;
+        const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)s, l);
+        dup = dup || (l < lane && sl == s);
+      }
+      if ((uint32_t)lane >= kcnt) valid = valid && !dup;
+    }
+    // rank in the stable order: smaller distance first, earlier arrival first
+    uint64_t vm = __ballot(valid);
+    const uint32_t nvalid = (uint32_t)__popcll(vm);
+    uint32_t rank = 0;
+    const uint32_t dlo = (uint32_t)__double_as_longlong(d), dhi = (uint32_t)(__double_as_longlong(d) >> 32);
+    while (vm) {
+      const int l = __ffsll((unsigned long long)vm) - 1;
+      vm &= vm - 1;
+      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)dlo, l);
+      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)dhi, l);
+      const double dl = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+      rank += (dl < d || (dl == d && l < lane)) ? 1u : 0u;
+    }
+    __builtin_amdgcn_wave_barrier();           // every lane has read its kept entry
+    if (valid && rank < nn) { top_s[rank] = s; top_d[rank] = d; }
+    kcnt = nvalid < nn ? nvalid : nn;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  return (int)kcnt;
 }
 
 // ---- build kernels -----------------------------------------------------------
@@ -523,7 +608,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
 }
 
 // one wave per flagged window
-__global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
+__global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
                                                     const uint32_t* __restrict__ cpos, NSrc nc,
                                                     uint32_t* __restrict__ cg,
                                                     uint32_t* __restrict__ cw,
@@ -539,6 +624,7 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
   __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];
   __shared__ int s_n[4];
   __shared__ uint32_t s_w32[4];
+  __shared__ uint32_t s_pre[4][64], s_e0[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = nc.get();
   const int NW = (L.C + 63) >> 6;
@@ -561,10 +647,65 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
       s_fs[wave][lane] = c.str ? c.str[p + lane] : c.tok[p + lane];
     }
     __builtin_amdgcn_wave_barrier();
-    for (int ch = 0; ch < NW; ++ch) {
+    // keys.  Fast path as in k_lsh_scan: lane l holds projection columns 4l .. 4l+3, one
+    // 16-byte load per lane and slot fetches the float32 row, all slots requested together;
+    // the float32 sums decide the signs when every column is farther from zero than the
+    // worst-case distance to the canonical float64 sum, else (and with an OOV token) the
+    // window is redone in float64.
+    bool keys_done = false;
+    if (L.atab32 && L.C <= 256 && !(L.diag & 8)) {
+      float am = 0.0f;
+      bool oov = false;
+      if (lane < L.n) {
+        const uint32_t id = s_f[wave][lane];
+        oov = (id & FS_OOV_FLAG) != 0;
+        if (!oov) am = L.amax[(size_t)lane * L.V + id];
+      }
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) am += __shfl_xor(am, d);      // n <= 16 lanes hold a value
+      am = __shfl(am, 0);
+      if (!__any(oov)) {
+        const float bnd = L.bound_scale * am;
+        const int col = 4 * lane;
+        const int left = L.C - col;
+        const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
+        const int colc = left > 0 ? col : 0;
+        // (eight rows in flight at a time; summed in slot order like k_lsh_scan)
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int k0 = 0; k0 < L.n; k0 += 8) {
+          float4 r[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k0 + k < L.n)
+              r[k] = *reinterpret_cast<const float4*>(
+                  L.atab32 + ((size_t)(k0 + k) * L.V + s_f[wave][k0 + k]) * L.Cp + colc);
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+            if (k0 + k < L.n) {
+              if (k0 + k == 0) { acc = r[0]; continue; }
+              acc.x = __fadd_rn(acc.x, r[k].x); acc.y = __fadd_rn(acc.y, r[k].y);
+              acc.z = __fadd_rn(acc.z, r[k].z); acc.w = __fadd_rn(acc.w, r[k].w);
+            }
+        }
+        const uint32_t sure = (fabsf(acc.x) > bnd ? 1u : 0u) | (fabsf(acc.y) > bnd ? 2u : 0u) |
+                              (fabsf(acc.z) > bnd ? 4u : 0u) | (fabsf(acc.w) > bnd ? 8u : 0u);
+        if (!__any((~sure & cmask) != 0u)) {
+          uint32_t x = ((acc.x > 0.0f ? 1u : 0u) | (acc.y > 0.0f ? 2u : 0u) |
+                        (acc.z > 0.0f ? 4u : 0u) | (acc.w > 0.0f ? 8u : 0u)) & cmask;
+          // eight lanes -> one 32-bit piece of the column bit string
+          x |= (uint32_t)__shfl_down((int)x, 1) << 4;
+          x |= (uint32_t)__shfl_down((int)x, 2) << 8;
+          x |= (uint32_t)__shfl_down((int)x, 4) << 16;
+          uint32_t* pieces = reinterpret_cast<uint32_t*>(s_bal[wave]);
+          if ((lane & 7) == 0 && (lane >> 3) < 2 * NW) pieces[lane >> 3] = x;
+          keys_done = true;
+        }
+      }
+    }
+    for (int ch = 0; ch < NW && !keys_done; ++ch) {
       const int col = ch * 64 + lane;
       bool bit = false;
-      if (col < L.C) {
+      if (col < L.C && !(L.diag & 8)) {
         double acc = a_value(L, 0, s_f[wave][0], col);
         for (int k = 1; k < L.n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_f[wave][k], col));
         bit = acc > 0.0;
@@ -576,10 +717,18 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
     __builtin_amdgcn_wave_barrier();
     if (lane < L.H) s_key[wave][lane] = assemble_key(s_bal[wave], lane, L.B);
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0)
-      s_n[wave] = lsh_neighbours<false>(L, s_key[wave], s_f[wave], s_top_s[wave], s_top_d[wave]);
-    __builtin_amdgcn_wave_barrier();
-    const int cnt = s_n[wave];
+    int cnt;
+    if (L.diag & 32) {
+      cnt = 0;
+    } else if (L.nn <= 48 && L.H <= 64 && !L.serial_neighbours) {
+      cnt = lsh_neighbours_wave(L, s_key[wave], s_f[wave], s_top_s[wave], s_top_d[wave], s_pre[wave],
+                                s_e0[wave]);
+    } else {                                    // NearestFilter(N > 48): one lane walks the buckets
+      if (lane == 0)
+        s_n[wave] = lsh_neighbours<false>(L, s_key[wave], s_f[wave], s_top_s[wave], s_top_d[wave]);
+      __builtin_amdgcn_wave_barrier();
+      cnt = s_n[wave];
+    }
     if (cnt == 0) {
       if (lane == 0) cg[i] = FS_NONE;
       continue;
@@ -587,7 +736,8 @@ __global__ __launch_bounds__(256) void k_lsh_verify(CorpusDev c, LshDev L, GramI
     // Levenshtein of every kept match (search.py:189-190), the wave working on one
     // match at a time
     for (int r = 0; r < cnt; ++r) {
-      const uint32_t lv = lev_wave(g, s_top_s[wave][r], s_fs[wave], c.chars, c.coff, c.n_str, st,
+      const uint32_t lv = (L.diag & 16) ? 1u :
+                          lev_wave(g, s_top_s[wave][r], s_fs[wave], c.chars, c.coff, c.n_str, st,
                                    s_la[wave], s_lb[wave]);
       if (lane == 0) s_lev[wave][r] = lv;
       __builtin_amdgcn_wave_barrier();
@@ -632,29 +782,47 @@ static LshDev lsh_dev(const fs_index* ix) {
   {
     // n * 2^-22; FS_LSH_F32_SLACK multiplies it (tests force the float64 fallback),
     // FS_LSH_F32=0 disables the float32 path
-    double scale = (double)ix->cfg.window_size * ldexp(1.0, -22);
-    if (const char* e = getenv("FS_LSH_F32_SLACK")) scale *= atof(e);
-    L.bound_scale = (float)scale;
-    if (const char* e = getenv("FS_LSH_F32")) if (e[0] == '0') L.atab32 = nullptr;
-    // smallest number of identical slots that can reach cos >= 1 - thr - 1e-6
-    L.m_min = 0;
-    const double qmin = ix->info.norm_min * ix->info.norm_min, qmax = ix->info.norm_max * ix->info.norm_max;
-    if (qmin > 0.0 && ix->lsh_cmax < 1.0) {
-      const double lim = (1.0 - L.thr - 1e-6) * L.n * qmin * (1.0 - 1e-9);
-      int m = 0;
-      while (m <= L.n && (m + (L.n - m) * ix->lsh_cmax) * qmax < lim) ++m;
-      L.m_min = m;          // n + 1 would mean "nothing can match": exact windows still do
-      if (L.m_min > L.n) L.m_min = L.n;
-    }
-    L.diag = 0;
-    if (const char* e = getenv("FS_LSH_DIAG")) L.diag = atoi(e);
+    L.bound_scale = (float)((double)ix->cfg.window_size * ldexp(1.0, -22) * ix->sw.lsh_f32_slack);
+    if (!ix->sw.lsh_f32) L.atab32 = nullptr;
+    L.m_min = ix->lsh_m_min;
+    L.diag = ix->sw.lsh_diag;
+    L.serial_neighbours = ix->sw.lsh_serial ? 1 : 0;
   }
   return L;
 }
 
 // Engine.store_vector for every script window (search.py:122-123)
+// smallest number of id-identical slots with which a window pair can reach
+// cos >= 1 - thr - 1e-6 (n: only identical windows)
+static int lsh_m_min(const fs_index* ix) {
+  const int n = (int)ix->cfg.window_size;
+  const double qmin = ix->info.norm_min * ix->info.norm_min, qmax = ix->info.norm_max * ix->info.norm_max;
+  if (!(qmin > 0.0) || !(ix->lsh_cmax < 1.0)) return 0;
+  const double lim = (1.0 - ix->cfg.distance_threshold - 1e-6) * n * qmin * (1.0 - 1e-9);
+  int m = 0;
+  while (m <= n && (m + (n - m) * ix->lsh_cmax) * qmax < lim) ++m;
+  return m > n ? n : m;          // n + 1 would mean "nothing can match": exact windows still do
+}
+
 int fs_lsh_build(fs_index* ix) {
   if (ix->lsh_ready) return FS_OK;
+  ix->lsh_m_min = lsh_m_min(ix);
+  if ((int)ix->cfg.window_size - ix->lsh_m_min == 1 && !ix->script_oov && ix->cfg.window_size >= 4 &&
+      ix->n_vec <= FS_MAX_EXACT_ID) {
+    // a neighbour differs from the window in at most one slot: one bit per script 3-gram
+    // for the integer prefilter (k_scan_near, fs_scan.hip)
+    std::vector<uint32_t> st(ix->n_script);
+    FS_HIP(hipMemcpyAsync(st.data(), ix->d_stok.p, ix->n_script * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    std::vector<uint32_t> sub(1u << ix->log2_words, 0u);
+    for (uint64_t i = 0; i + 3 <= ix->n_script; ++i) {
+      const uint32_t h = fs_gram_hash(st.data() + i, 3);
+      sub[fs_bloom_word(h, ix->log2_words)] |= 1u << (h & 31);
+    }
+    FS_TRY(ix->d_sfilter3.upload(sub.data(), sub.size(), ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+  }
   if (!ix->d_normals.p) { fs_set_error("normals are required for the LSH pipeline"); return FS_E_INVALID; }
   hipStream_t s = ix->stream;
   const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
@@ -686,7 +854,7 @@ int fs_lsh_build(fs_index* ix) {
       if (!(id & FS_OOV_FLAG) && sidx[id] < 0) { sidx[id] = (int32_t)srow.size(); srow.push_back(id); }
     FS_TRY(ix->d_sidx.upload(sidx.data(), sidx.size(), s));
     const uint64_t bytes = (uint64_t)srow.size() * V * sizeof(double);
-    if (!srow.empty() && V && bytes <= (64ull << 30) && !getenv("FS_LSH_NO_GTAB")) {
+    if (!srow.empty() && V && bytes <= (64ull << 30) && !ix->sw.lsh_no_gtab) {
       DBuf<uint32_t> d_srow;
       DBuf<float> embT;
       FS_TRY(d_srow.upload(srow.data(), srow.size(), s));

@@ -215,6 +215,114 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok,
   }
 }
 
+// ---- integer prefilter of the LSH pipeline -------------------------------------------
+// Vector tables whose exact-n-gram proof fails by one slot only (n = 8, 10 on
+// the synthetic table): a fan window can have a neighbour within the threshold only if it
+// equals a script window in at least n-1 slots (lsh_m_min, from the table's c_max).  Such a
+// window keeps every 3-gram that does not contain the odd slot, so among its n-2 3-gram
+// tests (one bit per script 3-gram, as in window_flags_sub) all failures lie within three
+// consecutive positions.  Sound (no window with a neighbour is lost), integer only, at
+// scan rate; the LSH keys, buckets and distances are then computed for the flagged
+// windows alone (k_lsh_verify), instead of 5 KB of projection rows for every window.
+// Same bitmap as k_scan / k_lsh_scan: four ballot words + one count per 256 tokens.
+template <int N, bool TAIL>
+__device__ __forceinline__ void window_ballots_near(const uint32_t* m, const uint32_t* s_filter,
+                                                    int word_shift, uint32_t p0, uint32_t n_tok,
+                                                    uint64_t* b) {
+  constexpr int K = 3, T = N - K + 1;           // 3-gram tests per window
+  constexpr int NB = kTokPerLane + N - K;       // 3-gram positions of the lane
+  uint32_t x = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) x ^= fs_rotl(m[k], fs_rot_of(K - 1 - k));
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    if (j) x = (uint32_t)__builtin_amdgcn_bitop3_b32(fs_rotl(x, 7), fs_rotl(m[j - 1], fs_rot_of(K)),
+                                                      m[j - 1 + K], 0x96);
+    const uint32_t word = s_filter[x >> word_shift];
+    bits = __builtin_amdgcn_alignbit(word >> (x & 31), bits, 1);
+  }
+  bits >>= 32 - NB;                             // 3-gram j at bit j
+  uint32_t flags = 0;
+#pragma unroll
+  for (int j = 0; j < kTokPerLane; ++j) {
+    const uint32_t z = ~(bits >> j) & ((1u << T) - 1);       // failed tests of window j
+    // none, or all within three consecutive positions
+    const bool hit = z == 0 || (31 - __clz((int)z)) - (__ffs((int)z) - 1) < K;
+    flags |= (hit ? 1u : 0u) << j;
+  }
+  if (TAIL) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
+  }
+  b[0] = __ballot(flags & 1u); b[1] = __ballot(flags & 2u);
+  b[2] = __ballot(flags & 4u); b[3] = __ballot(flags & 8u);
+}
+
+template <int N, bool NT>
+__global__ __launch_bounds__(1024) void k_scan_near(const uint32_t* __restrict__ tok, uint32_t n_tok,
+                                                    const uint32_t* __restrict__ filter,
+                                                    int log2_words, uint64_t* __restrict__ qbm,
+                                                    uint32_t* __restrict__ qcnt,
+                                                    uint32_t n_bm_words, uint32_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
+  copy_filter_to_lds(filter, s_filter, log2_words);
+  __syncthreads();
+  constexpr int U = 2;
+  constexpr int HALO = N - 1;
+  constexpr int NV = (HALO + 3) / 4;            // neighbour vectors needed
+  const int word_shift = 32 - log2_words;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
+    const uint32_t base = tile * (uint32_t)(kSubTile * U);
+    uint32_t a[U][4 + 4 * NV];
+    uint4 v[U + 1];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint4* src = reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
+      if constexpr (NT) {
+        v[u].x = __builtin_nontemporal_load(&src->x); v[u].y = __builtin_nontemporal_load(&src->y);
+        v[u].z = __builtin_nontemporal_load(&src->z); v[u].w = __builtin_nontemporal_load(&src->w);
+      } else {
+        v[u] = *src;
+      }
+    }
+    // first vectors of the next tile, in lanes 0..3 (the buffer is padded)
+    v[U] = *reinterpret_cast<const uint4*>(tok + base + U * kSubTile + 4 * (lane & 3));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u][0] = v[u].x; a[u][1] = v[u].y; a[u][2] = v[u].z; a[u][3] = v[u].w;
+#pragma unroll
+      for (int d = 1; d <= NV; ++d) {
+        const bool wrap = lane + d > 63;        // past lane 63: a vector of the next sub-tile
+        const int srcl = (lane + d) & 63;
+        const int need = (HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4;
+        // lanes 0 .. d-1 publish the next sub-tile's vector instead of their own
+        const bool pub = lane < d;
+        (void)wrap;
+        a[u][4 * d + 0] = __shfl(pub ? v[u + 1].x : v[u].x, srcl);
+        if (need > 1) a[u][4 * d + 1] = __shfl(pub ? v[u + 1].y : v[u].y, srcl);
+        if (need > 2) a[u][4 * d + 2] = __shfl(pub ? v[u + 1].z : v[u].z, srcl);
+        if (need > 3) a[u][4 * d + 3] = __shfl(pub ? v[u + 1].w : v[u].w, srcl);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int i = 0; i < 4 + HALO; ++i) a[u][i] = fs_premix(a[u][i]);
+      const uint32_t p0 = base + u * kSubTile + 4 * lane;
+      uint64_t b[4];
+      const bool tail = base + (uint32_t)(kSubTile * U) + HALO > n_tok;   // wave-uniform
+      if (tail) window_ballots_near<N, true>(a[u], s_filter, word_shift, p0, n_tok, b);
+      else window_ballots_near<N, false>(a[u], s_filter, word_shift, p0, n_tok, b);
+      store_ballots(b, lane, tile * U + u, n_bm_words, qbm, qcnt);
+    }
+  }
+}
+
 // ---- eight tokens per lane ---------------------------------------------------
 // The same scan with lane L owning tokens [8L, 8L+8) of a 512-token sub-tile: the
 // n-1 halo tokens are shuffled in once per 8 windows instead of once per 4, 13
@@ -938,4 +1046,44 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rca
     return fs_launch_compact_after_scan_rows(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st,
                                              s, count_out);
   return FS_OK;
+}
+
+// ---- k_scan_near (integer prefilter of the LSH pipeline) --------------------------------
+bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c) {
+  const int n = (int)ix->cfg.window_size;
+  if (!ix->sw.lsh_prefilter || !ix->d_sfilter3.p || c->has_oov || ix->script_oov) return false;
+  if (n - ix->lsh_m_min != 1) return false;
+  return n == 7 || n == 8 || n == 9 || n == 10 || n == 12;
+}
+
+namespace {
+template <int N>
+int launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                     uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  const uint32_t tile_tok = kSubTile * 2;
+  const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
+  if (n_tiles == 0) return FS_OK;
+  const size_t lds = (size_t)4 << ix->log2_words;
+  const uint32_t max_blocks = ix->num_cu * (lds <= 64 * 1024 ? 2 : 1);
+  const uint32_t blocks = std::min<uint32_t>((n_tiles + 15) / 16, max_blocks);
+  const bool nt = (uint64_t)c.n_tok * 4 > (256ull << 20);
+  auto kern = nt ? k_scan_near<N, true> : k_scan_near<N, false>;
+  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
+  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok, c.n_tok,
+                        (const uint32_t*)ix->d_sfilter3.p, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+}  // namespace
+
+int fs_launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+                        uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  switch (ix->cfg.window_size) {
+    case 7: return launch_scan_near<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 8: return launch_scan_near<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 9: return launch_scan_near<9>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 10: return launch_scan_near<10>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 12: return launch_scan_near<12>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
+    default: fs_set_error("k_scan_near covers n = 7..10, 12"); return FS_E_UNSUPPORTED;
+  }
 }

@@ -41,6 +41,51 @@ def test_window_sizes_without_proof(synth_base, n):
     assert len(got) > 0
 
 
+@pytest.mark.parametrize("n", [8, 9, 10, 12])
+def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
+    """Where the proof fails by one slot only, k_scan_near flags the windows that equal a
+    script window in all but one slot (failed 3-gram tests confined to three consecutive
+    positions) and the LSH work runs on those; FS_LSH_PREFILTER=0 computes keys and
+    buckets for every window.  Same bytes, equal to the oracle, with planted spans whose
+    odd token sits at every slot of a window (records with a distance well above 0)."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(4000)
+    tok, off = util.ragged_corpus([800] * 14 + [0, n - 1, n, 1700], script)
+    tok = tok.copy()
+    # one substituted token at slot j, replaced by the table vector closest to it (cosine
+    # 0.25-0.30 on this table: (n-1+c)/n stays above 0.9, a genuine inexact neighbour);
+    # a random substitute (cosine ~0) only produces a window the prefilter must let through
+    cos = emb[script[:600]] @ emb.T
+    cos[np.arange(600), script[:600]] = -1.0
+    best = cos.argmax(axis=1)
+    for j in range(n):
+        src = 300 + 20 * j
+        at = int(off[j % 14]) + 100 + 40 * j
+        tok[at:at + n] = script[src:src + n]
+        tok[at + j] = best[src + j] if j % 2 == 0 else (int(tok[at + j]) + 17) % len(words)
+    for j in range(3):                                   # two substituted tokens: no match
+        at = int(off[10 + j]) + 600
+        tok[at:at + n] = script[900 + 30 * j:900 + 30 * j + n]
+        tok[at + 1] = (int(tok[at + 1]) + 5) % len(words)
+        tok[at + n - 2] = (int(tok[at + n - 2]) + 9) % len(words)
+    cfg = abi.make_config(window_size=n)
+    normals = synth.lsh_normals(n)
+    swords = [words[int(t)] for t in script]
+    ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
+                       synth_base["chars"], synth_base["off"])
+    assert st.path == abi.FS_MODE_GENERAL
+    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near<%d>" % n
+    assert int((got["dist"] > 0.01).sum()) > 0           # inexact neighbours are records
+    monkeypatch.setenv("FS_LSH_PREFILTER", "0")
+    full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    assert full.kernel_name(c) == "k_lsh_scan"
+    got2, st2 = full.search(c)
+    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+    full.close()
+
+
 def test_general_mode_equals_exact_mode(synth_base):
     """Forcing the LSH pipeline where the proof holds must not change a byte."""
     from fandom_search_amd.engine import ScriptIndex
