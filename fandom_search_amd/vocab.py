@@ -19,9 +19,12 @@ here, so the host layer carries its own:
                 vector is id OOV_FLAG | ((a*D + b)*D + c) with a <= b <= c the
                 sorted hot positions, so two tokens carry the same id exactly
                 when they carry the same vector.
-* tokenizer     whitespace / punctuation splitter.  It is NOT spaCy's rule
-                set; on the synthetic corpora (single-space separated
-                alphabetic words) both give the same tokens.
+* tokenizer     fandom_search_amd.tokenizer: spaCy 2.x's tokenizer algorithm with
+                its English prefix / suffix / infix rules and tokenizer
+                exceptions restated (contractions, abbreviations, URLs ...).
+                FANDOM_SEARCH_TOKENIZER=spacy uses an installed spaCy instead,
+                =simple the old `\\w+|[^\\w\\s]` splitter.  On the synthetic corpora
+                (single-space separated alphabetic words) all three agree.
 """
 
 import re
@@ -64,12 +67,24 @@ def default_oov_hash(text):
 
 
 _TOKEN_RE = re.compile(r"\w+|[^\w\s]", re.UNICODE)
+_SPACY_NLP = None
 
 
 def tokenize(text):
     """Token texts of `text`, whitespace dropped (search.py:166 drops
-    is_space tokens)."""
-    return _TOKEN_RE.findall(text)
+    is_space tokens).  Default: the restated spaCy rules (tokenizer.py)."""
+    import os
+    kind = os.environ.get("FANDOM_SEARCH_TOKENIZER", "rules")
+    if kind == "simple":
+        return _TOKEN_RE.findall(text)
+    if kind == "spacy":
+        global _SPACY_NLP
+        if _SPACY_NLP is None:
+            import spacy                       # fails loudly when it is not installed
+            _SPACY_NLP = spacy.blank("en")
+        return [t.text for t in _SPACY_NLP(text) if not t.is_space]
+    from . import tokenizer
+    return tokenizer.tokenize(text)
 
 
 def chunk_text(txt, size=100000):
