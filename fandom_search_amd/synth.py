@@ -36,6 +36,7 @@ LINES_PER_SCENE = 50
 CHARACTERS = ("ALDER", "BRISA", "CORMAC", "DELPHINE",
               "EAMON", "FREYA", "GARETH", "HESTER")
 
+_NOT_ONE_TOKEN = ("weve",)
 _CONS = "bcdfghjklmnprstvwxyz"   # 20
 _VOWS = "aeiou"                  # 5  -> 100 syllables, 10000 two-syllable words
 
@@ -45,7 +46,13 @@ def vocab_words(size=VOCAB_SIZE):
     syl = [c + v for c in _CONS for v in _VOWS]
     if size > len(syl) ** 2:
         raise ValueError("vocabulary too large for two syllables")
-    return [syl[i // len(syl)] + syl[i % len(syl)] for i in range(size)]
+    words = [syl[i // len(syl)] + syl[i % len(syl)] for i in range(size)]
+    # "weve" is a tokenizer exception of spaCy's English rules (we + ve): one token under
+    # any tokenizer means it has to go; its slot takes a pseudo-word beyond the 8192
+    for i, w in enumerate(words):
+        if w in _NOT_ONE_TOKEN:
+            words[i] = syl[-1] + syl[-1 - _NOT_ONE_TOKEN.index(w)]
+    return words
 
 
 def embedding(size=VOCAB_SIZE, dim=EMB_DIM, seed=EMB_SEED):
