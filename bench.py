@@ -461,8 +461,12 @@ def main():
             # only reads the ids.
             algo_bytes = 4.0 * n_tok + (32.0 * rows_step if fused else 0.0)
             note = "4 B per fan token" + (" + 32 B per record" if fused else "")
+        elif kernel.startswith("k_scan_near"):
+            # the integer prefilter of the LSH pipeline is the kernel the events bracket; the
+            # LSH work proper (keys, buckets, distances of the flagged windows) is k_lsh_verify
+            algo_bytes = 4.0 * n_tok
+            note = "4 B per fan token (prefilter only; the step is dominated by k_lsh_verify)"
         else:
-            kernel = "k_lsh_scan"
             algo_bytes = float(st.windows_processed) * args.window * 212 * 4
             note = "n rows of 212 float32 projections (848 B) per window (cache-served gather)"
         step_bytes = 4.0 * n_tok + 32.0 * rows_step
