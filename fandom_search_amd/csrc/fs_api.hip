@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <new>
 #include <numeric>
 
@@ -42,9 +43,10 @@ GramIndexDev fs_index::gram_dev() const {
   g.stok = d_stok.p; g.filter = d_filter.p; g.table = d_table.p; g.gpos = d_gpos.p;
   g.sfilter = d_sfilter.p;
   g.gcnt = d_gcnt.p; g.selfdist = d_selfdist.p; g.schars = d_schars.p; g.soff = d_soff.p;
-  g.log2_words = log2_words; g.log2_slots = log2_slots;
+  g.log2_words = log2_words; g.log2_swords = log2_swords; g.log2_slots = log2_slots;
   g.tstride = (int)((2 + cfg.window_size + 3) & ~3u);
   g.disp = d_disp.p; g.log2_buckets = log2_buckets;
+  g.disp8 = reinterpret_cast<const uint8_t*>(d_disp8.p);
   g.n = (int)cfg.window_size; g.nn = (int)cfg.nearest_n; g.n_grams = n_grams;
   return g;
 }
@@ -53,6 +55,8 @@ CorpusDev fs_corpus::dev() const {
   CorpusDev c;
   c.tok = d_tok.p; c.str = has_str ? d_str.p : nullptr; c.work_off = d_work_off.p;
   c.blk_work = reinterpret_cast<const uint2*>(d_blk_work.p);
+  c.blk4 = reinterpret_cast<const uint4*>(d_blk4.p);
+  c.ctab = reinterpret_cast<const uint4*>(d_ctab.p);
   c.chars = d_chars.p; c.coff = d_coff.p;
   c.n_tok = (uint32_t)n_tok; c.n_works = (uint32_t)n_works; c.n_str = (uint32_t)n_str;
   return c;
@@ -205,12 +209,38 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
   }
   FS_TRY(ix->d_disp.upload(disp.data(), disp.size(), ix->stream));
   FS_TRY(ix->d_filter.upload(filter.data(), filter.size(), ix->stream));
-  // sub-shingle filter (fs_hash.h): one bit per script K-gram, same size as the Bloom filter
+  // batch table of k_scan_rows (fs_hash.h): same placement, 64-byte entries whose best
+  // records k_ctab fills in per batch; seeds as bytes
+  ix->ctab_ok = false;
+  if (n <= FS_CTAB_MAX_N) {
+    std::vector<uint32_t> proto((size_t)FS_CTAB_WORDS << ix->log2_slots, 0u);
+    for (size_t sl = 0; sl <= slot_mask; ++sl) {
+      const uint32_t* e = &table[ts * sl];
+      if (e[0]) memcpy(&proto[sl * FS_CTAB_WORDS], e, (2 + n) * sizeof(uint32_t));   // {gram + 1, kept, ids}
+    }
+    std::vector<uint32_t> disp8((n_buckets + 3) / 4 + 4, 0u);
+    for (uint32_t b = 0; b < n_buckets; ++b) {
+      const uint32_t d = disp[b] < FS_DISP8_WIDE ? disp[b] : FS_DISP8_WIDE;
+      disp8[b >> 2] |= d << (8 * (b & 3));
+    }
+    FS_TRY(ix->d_cproto.upload(proto.data(), proto.size(), ix->stream));
+    FS_TRY(ix->d_disp8.upload(disp8.data(), disp8.size(), ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    ix->ctab_ok = true;
+  }
+  // sub-shingle filter (fs_hash.h): one bit per script K-gram.  A window passes by
+  // chance with probability (bit density)^(n-K+1); sized for about 5e-4 (a few hundred
+  // extra candidates per million windows, against two workgroups per CU fitting in LDS)
   if (const int K = fs_sub_k((int)n)) {
-    std::vector<uint32_t> sub(1u << lw, 0u);
+    const double dens = std::pow(5e-4, 1.0 / (double)(n - K + 1));
+    int ls = ceil_log2((uint64_t)((double)std::max<uint64_t>(1, ix->n_script) / (32.0 * dens)) + 1);
+    if (const char* e = getenv("FS_SFILTER_LOG2_WORDS")) ls = atoi(e);
+    ls = std::min(15, std::max(10, ls));
+    ix->log2_swords = ls;
+    std::vector<uint32_t> sub(1u << ls, 0u);
     for (uint64_t i = 0; i + K <= ix->n_script; ++i) {
       const uint32_t h = fs_gram_hash(stok + i, K);
-      sub[fs_bloom_word(h, lw)] |= 1u << (h & 31);
+      sub[fs_bloom_word(h, ls)] |= 1u << (h & 31);
     }
     FS_TRY(ix->d_sfilter.upload(sub.data(), sub.size(), ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
@@ -410,7 +440,7 @@ extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   if (!exact) {
     snprintf(name, sizeof name, fs_lsh_prefilter_ok(ix, c) ? "k_scan_near<%d>" : "k_lsh_scan", n);
-  } else if (fs_scan_rows_waves(ix, c)) {
+  } else if (uint32_t blocks = 0; fs_scan_rows_shape(ix, c, &blocks)) {
     const int k = ix->sw.scan_sub && ix->d_sfilter.p ? fs_sub_k(n) : 0;
     snprintf(name, sizeof name, "k_scan_rows<%d,%d>", n, k);
   } else if (fs_scan_tpl(ix, c->n_tok) == 8) {
@@ -495,8 +525,10 @@ extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
   FS_TRY(c->d_work_off.upload(work_off, n_works + 1, cs));
   const uint32_t n_blocks = (uint32_t)((T + 255) / 256);
   FS_TRY(c->d_blk_work.reserve(2 * (size_t)n_blocks));
+  FS_TRY(c->d_blk4.reserve(4 * (size_t)n_blocks));
   FS_TRY(fs_launch_blk_work(c->d_work_off.p, (uint32_t)n_works, n_blocks,
-                            reinterpret_cast<uint2*>(c->d_blk_work.p), cs));
+                            reinterpret_cast<uint2*>(c->d_blk_work.p),
+                            reinterpret_cast<uint4*>(c->d_blk4.p), cs));
   FS_TRY(c->d_check.reserve(4));
   FS_HIP(hipMemsetAsync(c->d_check.p, 0, 4 * sizeof(uint32_t), cs));
   FS_TRY(fs_launch_corpus_check(c->d_tok.p, tok_str ? c->d_str.p : nullptr, (uint32_t)T,
@@ -541,7 +573,7 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
     ix->cur = &ix->lanes[0];
     FS_HIP(hipMemsetAsync(ix->cur->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
-    FS_TRY(fs_launch_sbest(ix, c, ix->stream));
+    FS_TRY(fs_launch_ctab(ix, c, ix->stream));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->cur->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     if (ix->h_status->bad_string) { fs_set_error("script vector id without a string"); return FS_E_INVALID; }
@@ -679,7 +711,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && ix->sw.stagger;
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact && sl.fused_waves) {
-    FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,
+    FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, sl.fused_blocks, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,
                                e0, e1, count_out));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
   } else if (sl.exact) {
@@ -767,9 +799,9 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   // k_scan_rows (tokens -> records in one kernel): staged records per wave range, more once
   // a search has asked for it
   sl.caprow = 0;
-  sl.fused_waves = sl.exact ? fs_scan_rows_waves(ix, c) : 0;
+  sl.fused_waves = sl.exact ? fs_scan_rows_shape(ix, c, &sl.fused_blocks) : 0;
   if (sl.fused_waves) {
-    const uint32_t ranges = fs_scan_rows_blocks(ix) * sl.fused_waves;
+    const uint32_t ranges = sl.fused_blocks * sl.fused_waves;
     // staged records per wave range: a sixteenth of its tokens (C2: 305, 72 used on average)
     const uint32_t dflt = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(128, T / ranges / 16), 1u << 20);
     sl.caprow = std::max<uint32_t>(dflt, ln.caprow_hint);

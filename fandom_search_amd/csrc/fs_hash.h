@@ -90,3 +90,11 @@ FS_HD uint32_t fs_table_bucket(uint32_t h, int log2_buckets) {
 FS_HD uint32_t fs_table_slot_d(uint32_t h, uint32_t d, int log2_slots) {
   return ((h ^ (d * 0x9E3779B9u)) * 0xC2B2AE35u) >> (32 - log2_slots);
 }
+
+// Batch table of k_scan_rows: the exact table's placement (slot of an n-gram as above)
+// with 64-byte entries that hold the n-gram's ids together with its best record for one
+// fan batch, so a lookup is one cache line; the displacement seeds travel as bytes
+// (FS_DISP8_WIDE: look the seed up in the 32-bit array) and live in LDS during the scan.
+#define FS_CTAB_WORDS 16
+#define FS_CTAB_MAX_N 8
+#define FS_DISP8_WIDE 0xFFu

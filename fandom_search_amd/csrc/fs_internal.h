@@ -111,10 +111,12 @@ struct GramIndexDev {
   const uint32_t* schars;    // script word text
   const uint64_t* soff;      // [n_script + 1]
   int log2_words;
+  int log2_swords;           // of sfilter
   int log2_slots;
   int tstride;               // words per table entry: 2 + n rounded up to a multiple of 4
   const uint32_t* disp;      // [1 << log2_buckets] displacement seed per bucket (fs_hash.h)
   int log2_buckets;
+  const uint8_t* disp8;      // the seeds as bytes (FS_DISP8_WIDE: see disp), or nullptr
   int n;                     // window size
   int nn;                    // NearestFilter N
   uint32_t n_grams;
@@ -125,6 +127,8 @@ struct CorpusDev {
   const uint32_t* str;       // [n_tok] string ids or nullptr (== vector ids)
   const uint64_t* work_off;  // [n_works + 1]
   const uint2* blk_work;     // [ceil(n_tok / 256)] {work of token 256*i, end of that work}
+  const uint4* blk4;         // same blocks: {work w, start of w, end of w, end of w + 1}
+  const uint4* ctab;         // [1 << log2_slots][4] batch table of k_scan_rows (fs_hash.h), or nullptr
   const uint32_t* chars;     // fan-side string table
   const uint64_t* coff;      // [n_str + 1]
   uint32_t n_tok;
@@ -184,10 +188,11 @@ struct fs_index {
   fs_index_info info{};
   uint64_t n_script = 0, n_windows = 0, n_vec = 0;
   uint32_t n_grams = 0;
-  int log2_words = 0, log2_slots = 0, log2_buckets = 0;
+  int log2_words = 0, log2_slots = 0, log2_buckets = 0, log2_swords = 0;
+  bool ctab_ok = false;                // d_cproto / d_disp8 built (window sizes k_scan_rows takes)
   int num_cu = 256;
 
-  DBuf<uint32_t> d_stok, d_filter, d_sfilter, d_table, d_disp, d_gpos, d_gcnt, d_schars;
+  DBuf<uint32_t> d_stok, d_filter, d_sfilter, d_table, d_disp, d_gpos, d_gcnt, d_schars, d_cproto, d_disp8;
   DBuf<uint64_t> d_soff;
   DBuf<double> d_q, d_selfdist;
   DBuf<float> d_emb;
@@ -254,6 +259,7 @@ struct fs_index {
     uint32_t capw = 0;                // direct path: record capacity per wave range (0: bitmap path)
     uint32_t caprow = 0;              // k_scan_rows: staged records per wave range
     uint32_t fused_waves = 0;         // k_scan_rows: waves per workgroup (0: separate kernels)
+    uint32_t fused_blocks = 0;        //              workgroups
   };
   Slot slots[FS_SEARCH_SLOTS];
   uint32_t next_slot = 0;
@@ -275,14 +281,14 @@ struct fs_corpus {
   uint64_t windows = 0;      // sum over works of max(0, len - n + 1)
   bool has_oov = false;
   bool has_str = false;
-  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab, d_blk_work, d_check;
+  DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab, d_blk_work, d_blk4, d_check;
   hipStream_t copy_stream = nullptr;   // uploads run here, beside the search stream
   hipEvent_t ev_ready = nullptr;
   uint32_t* h_check = nullptr;         // pinned: {max table id + 1, any OOV, max string id + 1}
   bool pending = false;                // an upload is queued and not yet waited for
   DBuf<uint64_t> d_work_off, d_coff;
   DBuf<fs_best> d_gbest;
-  DBuf<fs_best> d_sbest;               // d_gbest by table slot (k_ranges reads it beside the table entry)
+  DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
   CorpusDev dev() const;
   ~fs_corpus();
@@ -340,36 +346,22 @@ int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_r
                         uint64_t n_rows, uint64_t n_script, const double* d_thr, uint32_t n_thr,
                         uint32_t* d_counts, hipStream_t s);
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
-                       uint2* blk_work, hipStream_t s);
+                       uint2* blk_work, uint4* blk4, hipStream_t s);
 
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 
 // fs_ranges.hip: helpers of the records path of k_scan_rows
-int fs_launch_sbest(fs_index* ix, fs_corpus* c, hipStream_t s);
+int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s);
 // fs_scan.hip: scan + records in one kernel (k_scan_rows)
 namespace fsdev { struct RowSync; }
 int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
 int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
                                       int rec_bytes, uint32_t rcap, fs_row* d_rows,
                                       fs_status* host_st, hipStream_t s, uint64_t* count_out);
-uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c);   // 0: does not apply
-uint32_t fs_scan_rows_blocks(const fs_index* ix);
-int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
+uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* blocks);   // waves per workgroup, 0: does not apply
+int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blocks, uint32_t rcap, fs_row* d_rows,
                         int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
                         hipEvent_t e0, hipEvent_t e1, uint64_t* count_out);
-namespace fsdev { struct RowSync; }
-int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
-int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
-                                      int rec_bytes, uint32_t rcap, fs_row* d_rows,
-                                      fs_status* host_st, hipStream_t s, uint64_t* count_out);
-uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c);   // 0: does not apply
-uint32_t fs_scan_rows_blocks(const fs_index* ix);
-int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
-                        int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
-                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out);
-int fs_launch_ranges(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t rcap, fs_row* d_rows,
-                     int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
-                     const fs_scan_extra& scan, uint64_t* count_out = nullptr);
 
 int fs_launch_rownorms(const float* emb, uint64_t n_vec, int D, double* q, hipStream_t s);
 int fs_launch_selfdist(const uint32_t* stok, uint64_t n_windows, int n, int D,

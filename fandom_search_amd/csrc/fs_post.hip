@@ -675,7 +675,8 @@ __global__ void k_hist_cumulate(uint32_t* __restrict__ counts, uint64_t n_script
 // work of the first token of every 256-token block and where that work ends
 // (corpus build time)
 __global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_works,
-                           uint32_t n_blocks, uint2* __restrict__ blk_work) {
+                           uint32_t n_blocks, uint2* __restrict__ blk_work,
+                           uint4* __restrict__ blk4) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_blocks) return;
   const uint64_t p = (uint64_t)b * 256;
@@ -685,6 +686,8 @@ __global__ void k_blk_work(const uint64_t* __restrict__ work_off, uint32_t n_wor
     if (work_off[mid] <= p) lo = mid; else hi = mid;
   }
   blk_work[b] = make_uint2(lo, (uint32_t)work_off[lo + 1]);      // a batch holds < 2^32 tokens
+  blk4[b] = make_uint4(lo, (uint32_t)work_off[lo], (uint32_t)work_off[lo + 1],
+                       (uint32_t)work_off[lo + 2 < n_works ? lo + 2 : n_works]);
 }
 
 // validation of an uploaded batch: largest embedding row id + 1, "any OOV id",
@@ -750,10 +753,10 @@ int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_r
 }
 
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
-                       uint2* blk_work, hipStream_t s) {
+                       uint2* blk_work, uint4* blk4, hipStream_t s) {
   if (!n_blocks || !n_works) return FS_OK;
   hipLaunchKernelGGL(k_blk_work, dim3((n_blocks + 255) / 256), dim3(256), 0, s, work_off, n_works,
-                     n_blocks, blk_work);
+                     n_blocks, blk_work, blk4);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -12,10 +12,11 @@
 // follow from its own candidates plus the n-1 windows in front of it (the "halo",
 // verified unconditionally): no data crosses ranges.  Per round of at most 64-(n-1)
 // candidates (one per lane, position order) the wave
-//   1. verifies every candidate: ids -> hash -> displacement -> table entry, compared id
-//      for id, and the work boundary (three levels of loads, every load of a level
-//      requested before any is used); the per-corpus table `sbest` (indexed by table slot,
-//      so fetched beside the entry) carries the best rank's record of the matched n-gram
+//   1. verifies every candidate: ids -> hash -> displacement seed (a byte in LDS) -> the
+//      64-byte entry of the batch table (fs_hash.h), compared id for id, and the work
+//      boundary from the token block's entry (two levels of loads, every load of a level
+//      requested before any is used); the entry carries the best rank's record of the
+//      n-gram for this batch (k_ctab)
 //   2. compacts the hits behind the <= n-1 hits carried over from the last round
 //   3. emits the records of the words in [E, F): E = words done so far, F = the first
 //      position whose hit status is not known yet (the next round's first candidate, or
@@ -72,21 +73,22 @@ struct RangeOut {
 // scan masks windows that run past it; a halo window is in front of the range).
 template <int N>
 __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexDev& g,
-                                            const fs_best* __restrict__ sbest, RangeLds& S,
+                                            const uint8_t* s_disp, RangeLds& S,
                                             uint32_t p, uint32_t F, uint32_t a,
                                             uint32_t range_id, const RangeOut& out,
                                             RangeState& R) {
-  constexpr int TS = (2 + N + 3) & ~3;             // words per table entry
   const int lane = threadIdx.x & 63;
   if (F < R.E) F = R.E;
-  // 1. verification, one candidate per lane: every load of a level is requested before
-  // anything of that level is looked at (ids + block table | displacement | entry + best
-  // record + work start)
+  // 1. verification, one candidate per lane, two levels of loads: ids + work of the
+  // token block, then (seed from LDS) the 64-byte entry of the n-gram, which holds the
+  // ids and the batch's best record.  Every load of a level is requested before
+  // anything of that level is looked at.
   bool hit = false;
   uint32_t kept = 0, w = 0, wbase = 0, bs = 0, blev = 0;
   double comb = 0.0, bdist = 0.0;
   if (p != FS_NONE) {
     uint32_t f[8];
+    uint4 bw;
     {
       const uint4 q0 = *reinterpret_cast<const uint4*>(c.tok + p);   // unaligned 16-byte loads;
       f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w;            // the buffer is padded
@@ -96,53 +98,55 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       } else if constexpr (N > 4) {
         const uint2 q1 = *reinterpret_cast<const uint2*>(c.tok + p + 4);
         f[4] = q1.x; f[5] = q1.y; f[6] = 0; f[7] = 0;
+      } else {
+        f[4] = f[5] = f[6] = f[7] = 0;
       }
+      bw = c.blk4[p >> 8];
+      asm volatile("" : "+v"(bw.x), "+v"(bw.y), "+v"(bw.z), "+v"(bw.w), "+v"(f[0]));
     }
-    const uint2 bw = c.blk_work[p >> 8];
     uint32_t h = 0;
 #pragma unroll
     for (int k = 0; k < N; ++k) h ^= fs_rotl(fs_premix(f[k]), fs_rot_of(N - 1 - k));
-    const uint32_t d = g.disp[fs_table_bucket(h, g.log2_buckets)];
-    w = bw.x;
-    uint32_t we = bw.y;                               // a batch holds < 2^32 tokens
-    while (we <= p) { ++w; we = (uint32_t)c.work_off[w + 1]; }
-    const bool inside = p + N <= we;
-    uint32_t slot = fs_table_slot_d(h, d & FS_DISP_MASK, g.log2_slots);
-    // one probe decides unless the bucket holds n-grams with colliding 32-bit hashes
-    // (flagged: those continue by linear probing)
-    auto probe = [&](uint32_t sl) {
-      const uint4* e = reinterpret_cast<const uint4*>(g.table + (size_t)sl * TS);
-      uint32_t ew[TS];
-#pragma unroll
-      for (int qd = 0; qd < TS / 4; ++qd) {
-        const uint4 t = e[qd];
-        ew[4 * qd] = t.x; ew[4 * qd + 1] = t.y; ew[4 * qd + 2] = t.z; ew[4 * qd + 3] = t.w;
-      }
-      const uint4* sb = reinterpret_cast<const uint4*>(sbest + sl);       // beside the entry
-      uint4 b0 = sb[0];
-      uint2 b1 = *reinterpret_cast<const uint2*>(sb + 1);
-      uint32_t wb = reinterpret_cast<const uint32_t*>(c.work_off)[2 * (size_t)w];
-      // all of this level is in registers before any of it is looked at (left alone, the
-      // compiler requests the best record and the work start only behind the id compare)
-      asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y),
-                        "+v"(wb), "+v"(ew[0]), "+v"(ew[1]));
-      uint32_t diff = 0;
-#pragma unroll
-      for (int k = 0; k < N; ++k) diff |= ew[2 + k] ^ f[k];
+    const uint32_t bucket = fs_table_bucket(h, g.log2_buckets);
+    uint32_t d = s_disp ? s_disp[bucket] : g.disp8[bucket];
+    if (d == FS_DISP8_WIDE) d = g.disp[bucket];
+    // entry: {n-gram + 1, kept, id0, id1 | id2..id5 | id6, id7, s, lev | dist, comb}
+    uint4 q0, q1, q2, q3;
+    auto differ = [&]() {
+      uint32_t diff = (q0.z ^ f[0]) | (N > 1 ? q0.w ^ f[1] : 0u);
+      if constexpr (N > 2) diff |= q1.x ^ f[2];
+      if constexpr (N > 3) diff |= q1.y ^ f[3];
+      if constexpr (N > 4) diff |= q1.z ^ f[4];
+      if constexpr (N > 5) diff |= q1.w ^ f[5];
+      if constexpr (N > 6) diff |= q2.x ^ f[6];
+      if constexpr (N > 7) diff |= q2.y ^ f[7];
       asm volatile("" : "+v"(diff));       // one compare of the OR, not one compare per id
-      bs = b0.x; blev = b0.y;
-      bdist = __longlong_as_double((long long)(b0.z | ((uint64_t)b0.w << 32)));
-      comb = __longlong_as_double((long long)(b1.x | ((uint64_t)b1.y << 32)));
-      wbase = wb;
-      kept = ew[1];
-      const bool used = ew[0] != 0, same = used & (diff == 0);
-      hit = same & inside;
-      return same | !used;                             // decided
+      return diff;
     };
-    if (!probe(slot) && (d & FS_DISP_OVERFLOW)) {
-      const uint32_t slot_mask = (1u << g.log2_slots) - 1;
-      do slot = (slot + 1) & slot_mask; while (!probe(slot));
+    uint32_t slot = fs_table_slot_d(h, d & FS_DISP_MASK, g.log2_slots);
+    bool same = false;
+    for (;;) {
+      const uint4* e = c.ctab + 4 * (size_t)slot;
+      q0 = e[0]; q1 = e[1]; q2 = e[2]; q3 = e[3];
+      asm volatile("" : "+v"(q0.x), "+v"(q1.x), "+v"(q2.x), "+v"(q3.x));
+      same = (q0.x != 0) & (differ() == 0);
+      // one probe decides unless the bucket holds n-grams with colliding 32-bit hashes
+      // (flagged: those continue by linear probing)
+      if (same | (q0.x == 0) | !(d & FS_DISP_OVERFLOW)) break;
+      slot = (slot + 1) & ((1u << g.log2_slots) - 1);
     }
+    kept = q0.y; bs = q2.z; blev = q2.w;
+    const uint32_t d0 = q3.x, d1 = q3.y, c0 = q3.z, c1 = q3.w;
+    bdist = __longlong_as_double((long long)(d0 | ((uint64_t)d1 << 32)));
+    comb = __longlong_as_double((long long)(c0 | ((uint64_t)c1 << 32)));
+    // the work of p: the block's first work or the one behind it, else walk on
+    w = bw.x; wbase = bw.y;
+    uint32_t we = bw.z;                               // a batch holds < 2^32 tokens
+    if (we <= p) {
+      ++w; wbase = we; we = bw.w;
+      while (we <= p) { ++w; wbase = we; we = (uint32_t)c.work_off[w + 1]; }
+    }
+    hit = same & (p + N <= we);
   }
   // 2. hits behind the carried ones, in position order
   const uint64_t hb = __ballot(hit);

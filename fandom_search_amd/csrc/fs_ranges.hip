@@ -1,6 +1,6 @@
 // fs_ranges.hip -- host side and helper kernels of the records path of k_scan_rows
 // (fs_scan.hip; the per-round device code is fs_ranges.h):
-//   k_sbest     per corpus: the best record of every script n-gram, by table slot
+//   k_ctab      per batch: the table k_scan_rows verifies against (ids + best record per entry)
 //   k_compact   staged records -> their place in the output, totals and status, for
 //               indexes that overlap searches on several lanes (with one lane the
 //               workgroups of k_scan_rows do that themselves, finish_rows)
@@ -149,25 +149,33 @@ __global__ __launch_bounds__(kThreads) void k_compact(
 }
 
 // per-corpus copy of the best record of every script n-gram, indexed by table slot
-__global__ void k_sbest(GramIndexDev g, const fs_best* __restrict__ gbest, fs_best* __restrict__ sbest) {
-  const uint32_t slots = 1u << g.log2_slots;
+__global__ void k_ctab(const uint4* __restrict__ proto, uint32_t slots,
+                       const fs_best* __restrict__ gbest, uint4* __restrict__ ctab) {
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
-    const uint32_t e0 = g.table[(size_t)s * g.tstride];
-    fs_best b;
-    b.s = 0; b.lev = 0; b.dist = 0.0; b.comb = 0.0; b.pad = 0.0;
-    if (e0) b = gbest[e0 - 1];
-    sbest[s] = b;
+    const uint4 q0 = proto[4 * (size_t)s], q1 = proto[4 * (size_t)s + 1];
+    uint4 q2 = proto[4 * (size_t)s + 2], q3 = make_uint4(0, 0, 0, 0);
+    if (q0.x) {
+      const fs_best b = gbest[q0.x - 1];
+      const uint64_t db = (uint64_t)__double_as_longlong(b.dist), cb = (uint64_t)__double_as_longlong(b.comb);
+      q2.z = b.s; q2.w = b.lev;
+      q3 = make_uint4((uint32_t)db, (uint32_t)(db >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
+    }
+    uint4* e = ctab + 4 * (size_t)s;
+    e[0] = q0; e[1] = q1; e[2] = q2; e[3] = q3;
   }
 }
 
 }  // namespace
 
-int fs_launch_sbest(fs_index* ix, fs_corpus* c, hipStream_t s) {
+// the batch table of k_scan_rows: ids from the index, best records from d_gbest
+int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s) {
+  if (!ix->ctab_ok) return FS_OK;
   const size_t slots = (size_t)1 << ix->log2_slots;
-  FS_TRY(c->d_sbest.reserve(slots));
+  FS_TRY(c->d_ctab.reserve(slots * FS_CTAB_WORDS));
   const uint32_t blocks = (uint32_t)std::min<size_t>((slots + 255) / 256, 1024);
-  hipLaunchKernelGGL(k_sbest, dim3(blocks), dim3(256), 0, s, ix->gram_dev(), c->d_gbest.p,
-                     c->d_sbest.p);
+  hipLaunchKernelGGL(k_ctab, dim3(blocks), dim3(256), 0, s,
+                     reinterpret_cast<const uint4*>(ix->d_cproto.p), (uint32_t)slots, c->d_gbest.p,
+                     reinterpret_cast<uint4*>(c->d_ctab.p));
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -573,22 +573,27 @@ struct alignas(16) FusedLds {         // per wave
 
 template <int N, int K, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
-                                                    const fs_best* __restrict__ sbest,
                                                     uint32_t n_sub, fsdev::RangeOut out,
                                                     fsdev::RowSync sy, fsdev::RowFinal fin,
-                                                    uint32_t diag) {
+                                                    uint32_t disp_lds, uint32_t diag) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_cnt[6 * 16 + 2];
   __shared__ uint8_t s_kth[256 * 8];            // [flag byte][k] -> position of its k-th set bit
   uint32_t* s_filter = s_dyn;
-  FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << g.log2_words));
+  // displacement seeds of the exact table as bytes behind the filter (disp_lds bytes, a
+  // multiple of 16; 0: too many, read from memory)
+  const int lw = K ? g.log2_swords : g.log2_words;
+  const uint8_t* s_disp = disp_lds ? reinterpret_cast<const uint8_t*>(s_dyn + (1u << lw)) : nullptr;
+  FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << lw) + disp_lds / 4);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
-  copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, g.log2_words);
+  for (uint32_t e = threadIdx.x; e < disp_lds / 4; e += blockDim.x)
+    s_dyn[(1u << lw) + e] = reinterpret_cast<const uint32_t*>(g.disp8)[e];
+  copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
   for (uint32_t e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
     uint32_t f = e >> 3, pos = 0;
     for (uint32_t k = e & 7; f; f &= f - 1) {
@@ -606,7 +611,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
 
   constexpr uint32_t HALO = N - 1, RS = 64 - HALO;
   constexpr uint32_t SUB = 512;
-  const int word_shift = 32 - g.log2_words;
+  const int word_shift = 32 - lw;
   const int src_lane = (lane + 1) & 63;
   uint32_t mask_fffc = 0xFFFCu;
   asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
@@ -622,30 +627,34 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     uint32_t rec_cnt = 0, halo_n = a ? HALO : 0;
     // two sub-tiles in flight: own eight ids (t*) and the first eight of the sub-tile
     // behind (h*: lane 63's halo)
-    struct Tile { uint4 t0, t1, h0, h1; };
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    struct Tile { v4u t0, t1, h0, h1; };
     auto request = [&](uint32_t sub) {
       Tile r;
-      const uint4* p = reinterpret_cast<const uint4*>(tok + sub * SUB + 8 * lane);
+      const v4u* p = reinterpret_cast<const v4u*>(tok + sub * SUB + 8 * lane);
       if constexpr (NT) {
-        r.t0.x = __builtin_nontemporal_load(&p[0].x); r.t0.y = __builtin_nontemporal_load(&p[0].y);
-        r.t0.z = __builtin_nontemporal_load(&p[0].z); r.t0.w = __builtin_nontemporal_load(&p[0].w);
-        r.t1.x = __builtin_nontemporal_load(&p[1].x); r.t1.y = __builtin_nontemporal_load(&p[1].y);
-        r.t1.z = __builtin_nontemporal_load(&p[1].z); r.t1.w = __builtin_nontemporal_load(&p[1].w);
+        r.t0 = __builtin_nontemporal_load(&p[0]);
+        r.t1 = __builtin_nontemporal_load(&p[1]);
       } else {
         r.t0 = p[0]; r.t1 = p[1];
       }
-      const uint4* hp = reinterpret_cast<const uint4*>(tok + sub * SUB + SUB);   // the buffer is padded
+      const v4u* hp = reinterpret_cast<const v4u*>(tok + sub * SUB + SUB);   // the buffer is padded
       r.h0 = hp[0]; r.h1 = hp[1];
       return r;
     };
-    // the next sub-tile's ids are requested before this one's work (and a flush) begins
-    Tile ta = request(s0), tb = ta;
-    if (s0 + 1 < s1) tb = request(s0 + 1);
-    for (uint32_t j = s0; j < s1; ++j) {
+    // the point where a sub-tile's ids are first needed: whole 16-byte registers, so the
+    // compiler neither copies single ids out of a request early (it waits for the data
+    // wherever it puts such a copy) nor waits before this point
+    auto arrive = [&](Tile v) {
+      asm volatile("" : "+v"(v.t0), "+v"(v.t1), "+v"(v.h0), "+v"(v.h1));
+      return v;
+    };
+    // Sub-tiles go in pairs, each with its own registers (ta, tb), so the ids of a sub-tile
+    // are requested two sub-tiles of work ahead: a wave waits for the older of its two
+    // requests only, never for the one it has just issued.
+    auto scan = [&](const Tile& v, uint32_t j) {
       const uint32_t base = j * SUB;
-      const uint4 v00 = ta.t0, v01 = ta.t1, v10 = ta.h0, v11 = ta.h1;
-      ta = tb;
-      if (j + 2 < s1) tb = request(j + 2);
+      const v4u v00 = v.t0, v01 = v.t1, v10 = v.h0, v11 = v.h1;
       uint32_t aa[16];
       aa[0] = v00.x; aa[1] = v00.y; aa[2] = v00.z; aa[3] = v00.w;
       aa[4] = v01.x; aa[5] = v01.y; aa[6] = v01.z; aa[7] = v01.w;
@@ -678,62 +687,81 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       if (flags != 0) W.rec[slot] = ((((base - a) >> 3) + (uint32_t)lane) << 8) | flags;
       rec_cnt += (uint32_t)__popcll(has);
       cacc += __popc(flags);
-      const bool last_sub = j + 1 == s1;
-      const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
-      if ((diag & 2) && !last_sub) { if (rec_cnt >= flush_at) rec_cnt = 0; continue; }
-      if (rec_cnt >= flush_at || (last_sub && (rec_cnt | halo_n | R.hc))) {      // wave-uniform
-        wave_sync();
-        // candidates in front of every queued record (lane t: records t and t + 64)
-        const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
-        const uint32_t rb = (uint32_t)lane + 64 < rec_cnt ? W.rec[lane + 64] : 0u;
-        const uint32_t ca = __popc(ra & 0xFFu), cb = __popc(rb & 0xFFu);
-        const uint32_t ia = wave_incl_scan_dpp(ca);
-        const uint32_t ta = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
-        uint32_t tb = 0;
-        // (0xFFFF behind the last record: the search below needs no bound)
-        W.rk[lane] = (uint32_t)lane < rec_cnt ? (uint16_t)(halo_n + ia - ca) : (uint16_t)0xFFFFu;
-        uint16_t rkb = 0xFFFFu;
-        if (rec_cnt > 64) {
-          const uint32_t ib = wave_incl_scan_dpp(cb);
-          tb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
-          if ((uint32_t)lane + 64 < rec_cnt) rkb = (uint16_t)(halo_n + ta + ib - cb);
-        }
-        W.rk[lane + 64] = rkb;
-        wave_sync();
-        const uint32_t total = halo_n + ta + tb;
-        const uint32_t F_end = last_sub ? bnd : base + SUB;
-        uint32_t r0 = 0;
-        do {
-          // candidate r0 + lane: a halo window, or bit k of the last record with at most
-          // that many candidates in front of it (lane RS: the next round's first)
-          const uint32_t ci = r0 + lane;
-          uint32_t p = FS_NONE;
-          if (ci < total) {
-            if (ci < halo_n) {
-              p = a - halo_n + ci;
-            } else {
-              uint32_t t = 0;
-#pragma unroll
-              for (uint32_t step = kRecQueue / 2; step > 0; step >>= 1) {
-                const uint32_t v = W.rk[t + step];
-                t = v <= ci ? t + step : t;
-              }
-              const uint32_t rec = W.rec[t];
-              p = a + ((rec >> 8) << 3) + s_kth[((rec & 0xFFu) << 3) + (ci - W.rk[t])];
-            }
-          }
-          uint32_t F = F_end;
-          if (r0 + RS < total) {
-            const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)p, RS);
-            if (nx < F) F = nx;
-          }
-          if (!(diag & 1))
-            range_round<N>(c, g, sbest, S, (uint32_t)lane < RS ? p : FS_NONE, F, a, range_id, out, R);
-          r0 += RS;
-        } while (r0 < total);
-        rec_cnt = 0;
-        halo_n = 0;
+    };
+    // records queued so far -> rounds of candidates; F_end = the scan front
+    auto flush = [&](uint32_t F_end) {
+      wave_sync();
+      // candidates in front of every queued record (lane t: records t and t + 64)
+      const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
+      const uint32_t rb = (uint32_t)lane + 64 < rec_cnt ? W.rec[lane + 64] : 0u;
+      const uint32_t ca = __popc(ra & 0xFFu), cb = __popc(rb & 0xFFu);
+      const uint32_t ia = wave_incl_scan_dpp(ca);
+      const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+      uint32_t nb = 0;
+      // (0xFFFF behind the last record: the search below needs no bound)
+      W.rk[lane] = (uint32_t)lane < rec_cnt ? (uint16_t)(halo_n + ia - ca) : (uint16_t)0xFFFFu;
+      uint16_t rkb = 0xFFFFu;
+      if (rec_cnt > 64) {
+        const uint32_t ib = wave_incl_scan_dpp(cb);
+        nb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+        if ((uint32_t)lane + 64 < rec_cnt) rkb = (uint16_t)(halo_n + na + ib - cb);
       }
+      W.rk[lane + 64] = rkb;
+      wave_sync();
+      const uint32_t total = halo_n + na + nb;
+      uint32_t r0 = 0;
+      do {
+        // candidate r0 + lane: a halo window, or bit k of the last record with at most
+        // that many candidates in front of it (lane RS: the next round's first)
+        const uint32_t ci = r0 + lane;
+        uint32_t p = FS_NONE;
+        if (ci < total) {
+          if (ci < halo_n) {
+            p = a - halo_n + ci;
+          } else {
+            uint32_t t = 0;
+#pragma unroll
+            for (uint32_t step = kRecQueue / 2; step > 0; step >>= 1) {
+              const uint32_t v = W.rk[t + step];
+              t = v <= ci ? t + step : t;
+            }
+            const uint32_t rec = W.rec[t];
+            p = a + ((rec >> 8) << 3) + s_kth[((rec & 0xFFu) << 3) + (ci - W.rk[t])];
+          }
+        }
+        uint32_t F = F_end;
+        if (r0 + RS < total) {
+          const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)p, RS);
+          if (nx < F) F = nx;
+        }
+        if (!(diag & 1))
+          range_round<N>(c, g, s_disp, S, (uint32_t)lane < RS ? p : FS_NONE, F, a, range_id, out, R);
+        r0 += RS;
+      } while (r0 < total);
+      rec_cnt = 0;
+      halo_n = 0;
+    };
+    const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
+    Tile ta = request(s0), tb = ta;
+    if (s0 + 1 < s1) tb = request(s0 + 1);
+    for (uint32_t j = s0; j < s1; j += 2) {
+      {
+        const Tile v = arrive(ta);
+        if (j + 2 < s1) ta = request(j + 2);
+        scan(v, j);
+      }
+      // (a queue of kRecQueue records: at most 64 more come from one sub-tile)
+      const bool odd_end = j + 1 == s1;
+      if (odd_end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt > kRecQueue - 64)
+        flush(odd_end ? bnd : j * SUB + SUB);
+      if (odd_end) break;
+      {
+        const Tile v = arrive(tb);
+        if (j + 3 < s1) tb = request(j + 3);
+        scan(v, j + 1);
+      }
+      const bool end = j + 2 == s1;
+      if (end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt >= flush_at) flush(end ? bnd : j * SUB + 2 * SUB);
     }
   }
 #pragma unroll
@@ -970,17 +998,33 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
 }
 
 // ---- k_scan_rows (scan + records) -----------------------------------------------------
+// bytes of LDS for the displacement seeds (one per bucket, rounded up to 16), 0 = the
+// kernel reads them from memory
+static uint32_t fs_scan_rows_disp_lds(const fs_index* ix) {
+  const uint32_t bytes = ((1u << ix->log2_buckets) + 15u) & ~15u;
+  return bytes <= 16 * 1024 ? bytes : 0;
+}
+
 namespace {
 
+// log2 words of the filter k_scan_rows holds in LDS: the sub-shingle filter's where it
+// applies (fs_hash.h), else the Bloom filter's
+static int rows_filter_log2(const fs_index* ix) {
+  return fs_sub_k((int)ix->cfg.window_size) && ix->sw.scan_sub && ix->d_sfilter.p ? ix->log2_swords
+                                                                                   : ix->log2_words;
+}
+
 template <int N>
-int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
+int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves, uint32_t blocks,
                      const fsdev::RangeOut& out, const fsdev::RowSync& sy,
                      const fsdev::RowFinal& fin, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  const size_t lds = ((size_t)4 << ix->log2_words) + waves * sizeof(FusedLds);
+  const uint32_t disp_lds = fs_scan_rows_disp_lds(ix);
+  const int lw = rows_filter_log2(ix);
+  const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds);
   const bool big = c->n_tok * 4 > (256ull << 20);
   const char e = ix->sw.scan_flags;
   const bool nt = e == 'n' || (!e && big);
-  const bool lw14 = ix->log2_words == 14;
+  const bool lw14 = lw == 14;
   constexpr int K = fs_sub_k(N);
   auto kern = nt ? (lw14 ? k_scan_rows<N, 0, true, true> : k_scan_rows<N, 0, true, false>)
                  : (lw14 ? k_scan_rows<N, 0, false, true> : k_scan_rows<N, 0, false, false>);
@@ -988,58 +1032,66 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
     kern = nt ? (lw14 ? k_scan_rows<N, K, true, true> : k_scan_rows<N, K, true, false>)
               : (lw14 ? k_scan_rows<N, K, false, true> : k_scan_rows<N, K, false, false>);
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
-  hipExtLaunchKernelGGL(kern, dim3(fs_scan_rows_blocks(ix)), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
-                        0u, c->dev(), ix->gram_dev(), (const fs_best*)c->d_sbest.p, n_sub, out,
-                        sy, fin, (uint32_t)ix->sw.diag);
+  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
+                        0u, c->dev(), ix->gram_dev(), n_sub, out,
+                        sy, fin, disp_lds, (uint32_t)ix->sw.diag);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 
 }  // namespace
 
-// waves per workgroup of k_scan_rows: sixteen when filter + per-wave state fit the
-// 160 KB of LDS, four with a 128 KB filter, 0: does not apply
-uint32_t fs_scan_rows_waves(const fs_index* ix, const fs_corpus* c) {
+// Shape of a k_scan_rows launch: waves per workgroup (0: the kernel does not apply) and
+// workgroups.  One workgroup of sixteen wave ranges per CU when searches run one at a
+// time; an index with several lanes overlaps searches on the GPU, and two workgroups of
+// eight per CU (when filter + seeds + per-wave state fit twice into the 160 KB of LDS)
+// let one search's scan fill the stalls of another's records and hand-off.
+uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* blocks) {
   const uint32_t n = ix->cfg.window_size;
-  if (!ix->sw.scan_rows || n < 2 || n > 8 || c->has_str || !c->d_sbest.p) return 0;
+  *blocks = 0;
+  if (!ix->sw.scan_rows || n < 2 || n > 8 || c->has_str || !c->d_ctab.p || !ix->ctab_ok) return 0;
   // a switch that asks for one of the other scan kernels or paths
   const fs_switches& sw = ix->sw;
   if (sw.scan_simple || sw.scan_tpl == 4 || sw.scan_unroll || sw.scan_halo_loads || !sw.scan_direct ||
       sw.scan_capw)
     return 0;
-  const size_t filter = (size_t)4 << ix->log2_words;
   // (3 KB: the kernel's static LDS, s_kth and s_cnt)
-  if (sw.rows_waves) return (uint32_t)sw.rows_waves;
+  const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 3072;
+  const size_t cu_lds = 160 * 1024;
+  if (sw.rows_waves) {
+    *blocks = (uint32_t)ix->num_cu * (uint32_t)std::max(1, sw.rows_blocks_per_cu);
+    return (uint32_t)sw.rows_waves;
+  }
+  if (sw.rows_blocks_per_cu != 1 && ix->n_lanes > 1 && 2 * (fixed + 8 * sizeof(FusedLds)) <= cu_lds) {
+    *blocks = 2u * (uint32_t)ix->num_cu;
+    return 8;
+  }
   for (uint32_t w : {16u, 8u, 4u})
-    if (filter + w * sizeof(FusedLds) + 3072 <= 160 * 1024) return w;
+    if (fixed + w * sizeof(FusedLds) <= cu_lds) { *blocks = (uint32_t)ix->num_cu; return w; }
   return 0;
 }
 
-uint32_t fs_scan_rows_blocks(const fs_index* ix) {
-  return (uint32_t)ix->num_cu * (uint32_t)std::max(1, ix->sw.rows_blocks_per_cu);
-}
-
 // tokens -> output records: one launch of fs_scan_rows_blocks() workgroups of `waves` wave ranges
-int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t rcap, fs_row* d_rows,
+int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blocks, uint32_t rcap, fs_row* d_rows,
                         int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
                         hipEvent_t e0, hipEvent_t e1, uint64_t* count_out) {
   fs_index::Lane& ln = *ix->cur;
-  const uint32_t n_ranges = fs_scan_rows_blocks(ix) * waves;
+  const uint32_t n_ranges = blocks * waves;
   const int rec_bytes = wire ? wire : 32;
   const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
   FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * rec_bytes));
   const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
   fsdev::RowSync sy;
-  FS_TRY(fs_row_sync(ix, fs_scan_rows_blocks(ix), &sy));
+  FS_TRY(fs_row_sync(ix, blocks, &sy));
   const fsdev::RowFinal fin{reinterpret_cast<uint8_t*>(d_rows), rcap, ln.d_status.p, host_st, count_out, true};
   switch (ix->cfg.window_size) {
-    case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
-    case 3: FS_TRY(launch_scan_rows<3>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
-    case 4: FS_TRY(launch_scan_rows<4>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
-    case 5: FS_TRY(launch_scan_rows<5>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
-    case 6: FS_TRY(launch_scan_rows<6>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
-    case 7: FS_TRY(launch_scan_rows<7>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
-    case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, out, sy, fin, s, e0, e1)); break;
+    case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
+    case 3: FS_TRY(launch_scan_rows<3>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
+    case 4: FS_TRY(launch_scan_rows<4>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
+    case 5: FS_TRY(launch_scan_rows<5>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
+    case 6: FS_TRY(launch_scan_rows<6>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
+    case 7: FS_TRY(launch_scan_rows<7>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
+    case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
     default: fs_set_error("k_scan_rows covers n = 2..8"); return FS_E_UNSUPPORTED;
   }
   if (sy.rinfo)

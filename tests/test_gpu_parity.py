@@ -80,7 +80,8 @@ def test_scan_simple_variant(synth_base):
 
 @pytest.mark.parametrize("lw", [10, 12, 15])
 def test_filter_sizes(synth_base, lw):
-    _case(synth_base, [2000] * 30, 8000, FS_FILTER_LOG2_WORDS=lw)
+    _case(synth_base, [2000] * 30, 8000, FS_FILTER_LOG2_WORDS=lw, FS_SFILTER_LOG2_WORDS=lw)
+    _case(synth_base, [2000] * 30, 8000, FS_FILTER_LOG2_WORDS=lw, FS_SFILTER_LOG2_WORDS=lw, FS_LANES=2)
 
 
 def test_window_size_4(synth_base):
@@ -535,7 +536,9 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
     place (inside the launch, or k_compact: FS_ROWS_FINISH=2), when the in-launch wait
     gives up at once (FS_WAIT_SPINS=0: the search is flagged and repeated through the
     chained kernels), with the Bloom test of the whole n-gram in place of the runs of
-    script K-grams (FS_SCAN_SUB=0), with works that quote long stretches of the script (several rounds
+    script K-grams (FS_SCAN_SUB=0), with the launch shape of an index that overlaps searches
+    (FS_LANES=4: two workgroups of eight wave ranges per CU), with a sub-shingle filter far
+    too small (many false candidates), with works that quote long stretches of the script (several rounds
     of candidates per flush, hits carried from round to round), hits at range and work
     boundaries, ragged and empty works.  n = 7, 8 need a table the exact-n-gram proof
     accepts: 256 one-hot vectors."""
@@ -568,9 +571,11 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
     results = []
     envs = ({}, {"FS_SCAN_ROWS": "0"}, {"FS_RANGES_CAPROW": "2"}, {"FS_WAIT_SPINS": "0"},
             {"FS_ROWS_FINISH": "2"}, {"FS_ROWS_FINISH": "2", "FS_RANGES_CAPROW": "2"},
-            {"FS_SCAN_SUB": "0"})
+            {"FS_SCAN_SUB": "0"}, {"FS_LANES": "4"}, {"FS_LANES": "4", "FS_RANGES_CAPROW": "2"},
+            {"FS_SFILTER_LOG2_WORDS": "10"})
     for env in envs:
-        for k in ("FS_SCAN_ROWS", "FS_RANGES_CAPROW", "FS_WAIT_SPINS", "FS_ROWS_FINISH", "FS_SCAN_SUB"):
+        for k in ("FS_SCAN_ROWS", "FS_RANGES_CAPROW", "FS_WAIT_SPINS", "FS_ROWS_FINISH", "FS_SCAN_SUB",
+                  "FS_LANES", "FS_SFILTER_LOG2_WORDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
