@@ -591,17 +591,6 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
-  for (uint32_t e = threadIdx.x; e < disp_lds / 4; e += blockDim.x)
-    s_dyn[(1u << lw) + e] = reinterpret_cast<const uint32_t*>(g.disp8)[e];
-  copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
-  for (uint32_t e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
-    uint32_t f = e >> 3, pos = 0;
-    for (uint32_t k = e & 7; f; f &= f - 1) {
-      if (k-- == 0) { pos = (uint32_t)__ffs(f) - 1; break; }
-    }
-    s_kth[e] = (uint8_t)pos;
-  }
-  __syncthreads();
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   const uint32_t n_ranges = gridDim.x * n_waves;
   // sub-tiles dealt out evenly: the first n_sub % n_ranges ranges take one more
@@ -618,6 +607,43 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t* __restrict__ tok = c.tok;
   const uint32_t n_tok = c.n_tok;
 
+  // Sub-tiles go in pairs: per lane its eight ids of sub-tile A (a*), of sub-tile B (b*)
+  // and the first eight ids behind B (h*: lane 63's halo in B; A's halo is lane 0's b*).
+  typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+  struct Pair { v4u a0, a1, b0, b1, h0, h1; };
+  auto request = [&](uint32_t sub) {
+    Pair r;
+    const v4u* p = reinterpret_cast<const v4u*>(tok + sub * SUB + 8 * lane);
+    if constexpr (NT) {
+      r.a0 = __builtin_nontemporal_load(&p[0]);
+      r.a1 = __builtin_nontemporal_load(&p[1]);
+      r.b0 = __builtin_nontemporal_load(&p[SUB / 4]);
+      r.b1 = __builtin_nontemporal_load(&p[SUB / 4 + 1]);
+    } else {
+      r.a0 = p[0]; r.a1 = p[1]; r.b0 = p[SUB / 4]; r.b1 = p[SUB / 4 + 1];
+    }
+    const v4u* hp = reinterpret_cast<const v4u*>(tok + sub * SUB + 2 * SUB);   // the buffer is padded
+    r.h0 = hp[0]; r.h1 = hp[1];
+    return r;
+  };
+  // the point where a pair's ids are needed: whole 16-byte registers, so the compiler
+  // does not copy single ids out of a request early (it waits for the data wherever it
+  // puts such a copy)
+  auto arrive = [&](Pair v) {
+    asm volatile("" : "+v"(v.a0), "+v"(v.a1), "+v"(v.b0), "+v"(v.b1), "+v"(v.h0), "+v"(v.h1));
+    return v;
+  };
+  for (uint32_t e = threadIdx.x; e < disp_lds / 4; e += blockDim.x)
+    s_dyn[(1u << lw) + e] = reinterpret_cast<const uint32_t*>(g.disp8)[e];
+  copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
+  for (uint32_t e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
+    uint32_t f = e >> 3, pos = 0;
+    for (uint32_t k = e & 7; f; f &= f - 1) {
+      if (k-- == 0) { pos = (uint32_t)__ffs(f) - 1; break; }
+    }
+    s_kth[e] = (uint8_t)pos;
+  }
+  __syncthreads();
   RangeState R;
   R.E = 0; R.hc = 0; R.rows_run = 0; R.hits_run = 0; R.match_acc = 0;
   uint32_t cacc = 0;                           // per lane: candidates seen
@@ -625,36 +651,11 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     const uint32_t a = s0 * SUB, bnd = s1 * SUB;
     R.E = a;
     uint32_t rec_cnt = 0, halo_n = a ? HALO : 0;
-    // two sub-tiles in flight: own eight ids (t*) and the first eight of the sub-tile
-    // behind (h*: lane 63's halo)
-    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-    struct Tile { v4u t0, t1, h0, h1; };
-    auto request = [&](uint32_t sub) {
-      Tile r;
-      const v4u* p = reinterpret_cast<const v4u*>(tok + sub * SUB + 8 * lane);
-      if constexpr (NT) {
-        r.t0 = __builtin_nontemporal_load(&p[0]);
-        r.t1 = __builtin_nontemporal_load(&p[1]);
-      } else {
-        r.t0 = p[0]; r.t1 = p[1];
-      }
-      const v4u* hp = reinterpret_cast<const v4u*>(tok + sub * SUB + SUB);   // the buffer is padded
-      r.h0 = hp[0]; r.h1 = hp[1];
-      return r;
-    };
-    // the point where a sub-tile's ids are first needed: whole 16-byte registers, so the
-    // compiler neither copies single ids out of a request early (it waits for the data
-    // wherever it puts such a copy) nor waits before this point
-    auto arrive = [&](Tile v) {
-      asm volatile("" : "+v"(v.t0), "+v"(v.t1), "+v"(v.h0), "+v"(v.h1));
-      return v;
-    };
-    // Sub-tiles go in pairs, each with its own registers (ta, tb), so the ids of a sub-tile
-    // are requested two sub-tiles of work ahead: a wave waits for the older of its two
-    // requests only, never for the one it has just issued.
-    auto scan = [&](const Tile& v, uint32_t j) {
+    // The next pair is requested as soon as this one has arrived, a whole pair of work
+    // (and its flushes) ahead; every step issues a request, the last one for the range's
+    // last sub-tiles again (a request under a condition would only complicate the waits).
+    auto scan = [&](const v4u& v00, const v4u& v01, const v4u& v10, const v4u& v11, uint32_t j) {
       const uint32_t base = j * SUB;
-      const v4u v00 = v.t0, v01 = v.t1, v10 = v.h0, v11 = v.h1;
       uint32_t aa[16];
       aa[0] = v00.x; aa[1] = v00.y; aa[2] = v00.z; aa[3] = v00.w;
       aa[4] = v01.x; aa[5] = v01.y; aa[6] = v01.z; aa[7] = v01.w;
@@ -742,24 +743,17 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       halo_n = 0;
     };
     const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
-    Tile ta = request(s0), tb = ta;
-    if (s0 + 1 < s1) tb = request(s0 + 1);
+    Pair nx = request(s0);
     for (uint32_t j = s0; j < s1; j += 2) {
-      {
-        const Tile v = arrive(ta);
-        if (j + 2 < s1) ta = request(j + 2);
-        scan(v, j);
-      }
+      const Pair v = arrive(nx);
+      nx = request(j + 2 < s1 ? j + 2 : j);
+      scan(v.a0, v.a1, v.b0, v.b1, j);
       // (a queue of kRecQueue records: at most 64 more come from one sub-tile)
       const bool odd_end = j + 1 == s1;
       if (odd_end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt > kRecQueue - 64)
         flush(odd_end ? bnd : j * SUB + SUB);
       if (odd_end) break;
-      {
-        const Tile v = arrive(tb);
-        if (j + 3 < s1) tb = request(j + 3);
-        scan(v, j + 1);
-      }
+      scan(v.b0, v.b1, v.h0, v.h1, j + 1);
       const bool end = j + 2 == s1;
       if (end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt >= flush_at) flush(end ? bnd : j * SUB + 2 * SUB);
     }
