@@ -39,6 +39,7 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+constexpr uint32_t FS_NO_LDS = 0xFFFFFFFFu;
 constexpr int kHitPad = 72;     // 64 hits + the n-1 <= 7 slots the first-minimum walk may look at
 
 struct alignas(16) RangeLds {
@@ -73,7 +74,7 @@ struct RangeOut {
 // scan masks windows that run past it; a halo window is in front of the range).
 template <int N>
 __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexDev& g,
-                                            const uint8_t* s_disp, RangeLds& S,
+                                            uint32_t disp_off, RangeLds& S,
                                             uint32_t p, uint32_t F, uint32_t a,
                                             uint32_t range_id, const RangeOut& out,
                                             RangeState& R) {
@@ -108,7 +109,17 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
 #pragma unroll
     for (int k = 0; k < N; ++k) h ^= fs_rotl(fs_premix(f[k]), fs_rot_of(N - 1 - k));
     const uint32_t bucket = fs_table_bucket(h, g.log2_buckets);
-    uint32_t d = s_disp ? s_disp[bucket] : g.disp8[bucket];
+    // the seed: a byte of the workgroup's dynamic LDS (offset disp_off; an LDS read, not
+    // a load through a generic pointer) or, with too many buckets for LDS, of memory
+    uint32_t d;
+    if (disp_off != FS_NO_LDS) {
+      extern __shared__ __attribute__((aligned(16))) uint8_t fs_dyn_lds_bytes[];
+      d = fs_dyn_lds_bytes[disp_off + bucket];
+    } else {
+      d = g.disp8[bucket];
+      asm volatile("" : "+v"(d));   // (keeps the two reads apart: merged, they become one
+                                    // load through a generic pointer, slower than either)
+    }
     if (d == FS_DISP8_WIDE) d = g.disp[bucket];
     // entry: {n-gram + 1, kept, id0, id1 | id2..id5 | id6, id7, s, lev | dist, comb}
     uint4 q0, q1, q2, q3;

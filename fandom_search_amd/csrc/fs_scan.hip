@@ -585,7 +585,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   // displacement seeds of the exact table as bytes behind the filter (disp_lds bytes, a
   // multiple of 16; 0: too many, read from memory)
   const int lw = K ? g.log2_swords : g.log2_words;
-  const uint8_t* s_disp = disp_lds ? reinterpret_cast<const uint8_t*>(s_dyn + (1u << lw)) : nullptr;
+  const uint32_t disp_off = disp_lds ? 4u << lw : FS_NO_LDS;
   FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << lw) + disp_lds / 4);
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
@@ -736,7 +736,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
           if (nx < F) F = nx;
         }
         if (!(diag & 1))
-          range_round<N>(c, g, s_disp, S, (uint32_t)lane < RS ? p : FS_NONE, F, a, range_id, out, R);
+          range_round<N>(c, g, disp_off, S, (uint32_t)lane < RS ? p : FS_NONE, F, a, range_id, out, R);
         r0 += RS;
       } while (r0 < total);
       rec_cnt = 0;
