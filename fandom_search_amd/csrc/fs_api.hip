@@ -107,6 +107,8 @@ void fs_read_switches(fs_switches* sw) {
   sw->lsh_no_gtab = getenv("FS_LSH_NO_GTAB") != nullptr;
   sw->lsh_serial = getenv("FS_LSH_SERIAL") != nullptr;
   if (const char* e = getenv("FS_LSH_PREFILTER")) sw->lsh_prefilter = e[0] != '0';
+  if (const char* e = getenv("FS_LSH_WILD")) sw->lsh_wild = e[0] != '0';
+  if (const char* e = getenv("FS_LSH_SELFLEV")) sw->lsh_selflev = e[0] != '0';
   sw->rows_waves = num("FS_ROWS_WAVES");
   sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
@@ -582,6 +584,13 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
       return FS_E_UNSUPPORTED;
     }
     c->levtab_ready = true;
+  }
+  if (!c->has_str && !c->has_oov && ix->info.path != FS_MODE_EXACT && !c->selflev_ready && ix->sw.lsh_selflev) {
+    // LSH pipeline, string id == vector id: the Levenshtein distance of a match with the
+    // same id in every slot, once per string table
+    FS_TRY(fs_launch_selflev(ix, c, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    c->selflev_ready = true;
   }
   return FS_OK;
 }

@@ -98,3 +98,20 @@ FS_HD uint32_t fs_table_slot_d(uint32_t h, uint32_t d, int log2_slots) {
 #define FS_CTAB_WORDS 16
 #define FS_CTAB_MAX_N 8
 #define FS_DISP8_WIDE 0xFFu
+
+// One-slot-wildcard keys (LSH pipeline, windows that may differ from a script window in
+// at most one slot): key j of a window is a hash of its ids with slot j left out, i.e.
+// the XOR-rotate fold of all n ids with slot j's term taken out again, mixed with j.  A
+// blocked Bloom filter (one 32-bit word, four bits) holds the n keys of every script
+// window; a fan window none of whose n keys is present differs from every script window
+// in two or more slots.
+FS_HD uint32_t fs_wild_key(uint32_t fold_all, uint32_t term_j, int j) {
+  uint32_t h = (fold_all ^ term_j) + 0x9E3779B9u * (uint32_t)(j + 1);
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+FS_HD uint32_t fs_wild_word(uint32_t h, int log2_words) { return h >> (32 - log2_words); }
+FS_HD uint32_t fs_wild_mask(uint32_t h) {
+  const uint32_t b = h * 0x9E3779B1u;
+  return (1u << (b >> 27)) | (1u << ((b >> 22) & 31)) | (1u << ((b >> 17) & 31)) | (1u << ((b >> 12) & 31));
+}

@@ -172,6 +172,8 @@ struct fs_switches {
   bool lsh_no_gtab = false;       // FS_LSH_NO_GTAB
   bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
   bool lsh_prefilter = true;      // FS_LSH_PREFILTER=0: always the full key scan
+  bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
+  bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
   int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
@@ -209,6 +211,8 @@ struct fs_index {
   bool script_oov = false;   // the script holds out-of-vocabulary (3-hot) vectors
   int lsh_m_min = 0;         // fewer id-identical slots than this cannot reach the threshold
   DBuf<uint32_t> d_sfilter3; // one bit per script 3-gram: the <= 1 mismatch prefilter (fs_scan.hip)
+  DBuf<uint32_t> d_wild;     // one-slot-wildcard keys of the script windows (fs_hash.h; k_lsh_verify)
+  int log2_wild = 0;
 
   // Lanes: a stream with its own workspaces (grown on demand) and status block.
   // Searches are spread over n_lanes of them (FS_LANES in the environment, default
@@ -290,6 +294,8 @@ struct fs_corpus {
   DBuf<fs_best> d_gbest;
   DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
+  DBuf<uint32_t> d_selflev;            // LSH pipeline, string id == vector id: Levenshtein of script window w
+  bool selflev_ready = false;          // against the strings of its own ids (k_selflev), FS_NONE: not known
   CorpusDev dev() const;
   ~fs_corpus();
 };
@@ -335,6 +341,7 @@ int fs_lsh_build(fs_index* ix);
 int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                        uint32_t n_sub, hipStream_t s, hipEvent_t e0 = nullptr,
                        hipEvent_t e1 = nullptr);
+int fs_launch_selflev(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 // fs_scan.hip: the integer prefilter of the LSH pipeline ("all but one slot identical")
 bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c);

@@ -68,6 +68,10 @@ struct LshDev {
   int serial_neighbours;   // FS_LSH_SERIAL=1: k_lsh_verify walks the buckets on one lane (cross-check)
   const double* gtab;      // [n_srow][V] g(script row, table row), or nullptr
   const int32_t* sidx;     // [V] row of gtab for a table id, -1 if not a script word
+  const uint32_t* selflev; // [W] Levenshtein of script window w against the strings of its own ids for
+                           // this batch's string table (FS_NONE: compute), or nullptr
+  const uint32_t* wild;    // one-slot-wildcard keys of the script windows (fs_hash.h), or nullptr
+  int log2_wild;
   uint32_t V, W;
   int n, H, B, D, C, Cp, nn, unique;
   double thr, cmax;
@@ -157,15 +161,26 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
   // no OOV vector involved, m identical slots bound the cosine by
   // (m q_max + (n-m) c_max q_max) / (n q_min); m_min is the smallest m for which that
   // reaches 1 - threshold (host side, lsh_dev).
+  int same = -1;
   if (L.m_min > 0) {
-    int same = 0;
+    // (the window's ids requested together: stok is padded by a window)
+    const uint4* sp = reinterpret_cast<const uint4*>(L.stok + s);
+    same = 0;
     uint32_t anyoov = 0;
-    for (int k = 0; k < L.n; ++k) {
-      const uint32_t u = L.stok[s + k];
-      same += u == f[k];
-      anyoov |= u | f[k];
+#pragma unroll
+    for (int q4 = 0; q4 < FS_MAX_WINDOW / 4; ++q4) {
+      if (4 * q4 >= L.n) break;
+      const uint4 t = sp[q4];
+      const uint32_t u4[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (4 * q4 + k < L.n) {
+          same += u4[k] == f[4 * q4 + k];
+          anyoov |= u4[k] | f[4 * q4 + k];
+        }
     }
-    if (same < L.m_min && !(anyoov & FS_OOV_FLAG)) return false;
+    if (anyoov & FS_OOV_FLAG) same = -1;
+    else if (same < L.m_min) return false;
   }
   // stage 1: the canonical sum SF slot by slot, leaving as soon as the slots still to
   // come cannot lift it to the threshold.  By Cauchy-Schwarz the remaining slots add
@@ -176,6 +191,14 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
   // costs one 32-byte record of the script window and one pair-table entry.
   const fs_swin sw = L.sw[s];
   const double norm = __dmul_rn(sw.rss, rff);
+  if (same == L.n) {
+    // identical ids in every slot: the canonical sum adds q(u_k) in slot order from 0.0,
+    // which is how k_ss computed sw.ss -- the same bits, no load
+    const double d = __dsub_rn(1.0, __ddiv_rn(sw.ss, norm));
+    if (d != d) return false;
+    *out = d;
+    return true;
+  }
   const double need = (1.0 - L.thr - 1e-6) * norm * (1.0 - 1e-9);
   double sf = 0.0, ssr = sw.ss, ffr = ff;
   for (int k = 0; k < L.n; ++k) {
@@ -432,6 +455,31 @@ __global__ __launch_bounds__(256) void k_keys(LshDev L, const uint32_t* __restri
   }
 }
 
+// string id == vector id: Levenshtein of every script window against the strings of its
+// own ids, one wave per window (FS_NONE where lev_wave reports a bad string or an
+// overflow: the search then computes that match itself and reports the same)
+__global__ __launch_bounds__(256) void k_selflev(GramIndexDev g, CorpusDev c, uint32_t W,
+                                                 uint32_t* __restrict__ selflev) {
+  __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];
+  __shared__ uint32_t s_ids[4][FS_MAX_WINDOW];
+  __shared__ fs_status s_st[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t w = blockIdx.x * 4 + wave; w < W; w += gridDim.x * 4) {
+    if (lane < g.n) s_ids[wave][lane] = g.stok[w + lane];
+    if (lane == 0) { s_st[wave].bad_string = 0; s_st[wave].lev_overflow = 0; }
+    __builtin_amdgcn_wave_barrier();
+    const bool oov = lane < g.n && (s_ids[wave][lane] & FS_OOV_FLAG);
+    uint32_t v = FS_NONE;
+    if (!__any(oov)) {
+      v = lev_wave(g, w, s_ids[wave], c.chars, c.coff, c.n_str, &s_st[wave], s_la[wave], s_lb[wave]);
+      __builtin_amdgcn_wave_barrier();
+      if (s_st[wave].bad_string | s_st[wave].lev_overflow) v = FS_NONE;
+    }
+    if (lane == 0) selflev[w] = v;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ---- search kernels ------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
@@ -629,7 +677,45 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
   const uint32_t total = nc.get();
   const int NW = (L.C + 63) >> 6;
   uint32_t matches = 0;
-  for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
+  // 64 candidates per wave and step, NWAVES apart (neighbouring candidates -- the windows
+  // of one quoted passage, all of them expensive -- go to neighbouring waves).  First one
+  // lane per candidate: with the wildcard filter (no OOV anywhere, at most one slot may
+  // differ) a window none of whose n keys is a script window's cannot have a neighbour
+  // within the threshold and is dropped here; then the wave takes the survivors one at a
+  // time.
+  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
+  for (uint32_t t0 = 0; (uint64_t)t0 * NWAVES < total; t0 += 64) {
+   const uint64_t il = (uint64_t)(t0 + lane) * NWAVES + gw;
+   bool live = il < total;
+   if (L.wild && live) {
+     const uint64_t p = cpos[il];
+     bool pass = true;
+     if (p + L.n <= c.n_tok) {
+       uint32_t term[FS_MAX_WINDOW];
+       uint32_t fold = 0;
+#pragma unroll
+       for (int k = 0; k < FS_MAX_WINDOW; ++k) {
+         term[k] = 0;
+         if (k < L.n) {
+           term[k] = fs_rotl(fs_premix(c.tok[p + k]), fs_rot_of(L.n - 1 - k));
+           fold ^= term[k];
+         }
+       }
+       pass = false;
+#pragma unroll
+       for (int k = 0; k < FS_MAX_WINDOW; ++k)
+         if (k < L.n) {
+           const uint32_t h = fs_wild_key(fold, term[k], k);
+           const uint32_t m = fs_wild_mask(h);
+           pass = pass || (L.wild[fs_wild_word(h, L.log2_wild)] & m) == m;
+         }
+     }
+     if (!pass) { cg[il] = FS_NONE; live = false; }
+   }
+   uint64_t todo = __ballot(live);
+   while (todo) {
+    const uint32_t i = (t0 + (uint32_t)(__ffsll((unsigned long long)todo) - 1)) * NWAVES + gw;
+    todo &= todo - 1;
     const uint64_t p = cpos[i];
     bool ok = p + L.n <= c.n_tok;
     uint32_t w = 0;
@@ -736,7 +822,16 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
     // Levenshtein of every kept match (search.py:189-190), the wave working on one
     // match at a time
     for (int r = 0; r < cnt; ++r) {
-      const uint32_t lv = (L.diag & 16) ? 1u :
+      uint32_t lv = FS_NONE;
+      if (L.selflev) {
+        // a match with the same id in every slot has the same strings as the script window's
+        // own ids: its distance was computed once per string table (k_selflev)
+        const uint32_t sr = s_top_s[wave][r];
+        const bool differs = lane < L.n && L.stok[sr + lane] != s_f[wave][lane];
+        if (!__any(differs)) lv = L.selflev[sr];
+      }
+      if (lv == FS_NONE)
+        lv = (L.diag & 16) ? 1u :
                           lev_wave(g, s_top_s[wave][r], s_fs[wave], c.chars, c.coff, c.n_str, st,
                                    s_la[wave], s_lb[wave]);
       if (lane == 0) s_lev[wave][r] = lv;
@@ -756,6 +851,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
       cw[i] = w;
       matches += (uint32_t)cnt;
     }
+   }
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
@@ -772,6 +868,7 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
+  L.wild = nullptr; L.log2_wild = 0; L.selflev = nullptr;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
   L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
@@ -821,6 +918,26 @@ int fs_lsh_build(fs_index* ix) {
       sub[fs_bloom_word(h, ix->log2_words)] |= 1u << (h & 31);
     }
     FS_TRY(ix->d_sfilter3.upload(sub.data(), sub.size(), ix->stream));
+    // ... and the n one-slot-wildcard keys of every script window, about 24 filter bits
+    // per key (k_lsh_verify drops a window none of whose keys is present)
+    const int n = (int)ix->cfg.window_size;
+    const uint64_t W = ix->n_windows;
+    int lwild = 12;
+    while (lwild < 24 && ((uint64_t)32 << lwild) < W * n * 24) ++lwild;
+    std::vector<uint32_t> wild((size_t)1 << lwild, 0u);
+    for (uint64_t w = 0; w < W; ++w) {
+      uint32_t term[FS_MAX_WINDOW], fold = 0;
+      for (int k = 0; k < n; ++k) {
+        term[k] = fs_rotl(fs_premix(st[w + k]), fs_rot_of(n - 1 - k));
+        fold ^= term[k];
+      }
+      for (int k = 0; k < n; ++k) {
+        const uint32_t h = fs_wild_key(fold, term[k], k);
+        wild[fs_wild_word(h, lwild)] |= fs_wild_mask(h);
+      }
+    }
+    FS_TRY(ix->d_wild.upload(wild.data(), wild.size(), ix->stream));
+    ix->log2_wild = lwild;
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
   if (!ix->d_normals.p) { fs_set_error("normals are required for the LSH pipeline"); return FS_E_INVALID; }
@@ -918,8 +1035,26 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   return FS_OK;
 }
 
+int fs_launch_selflev(fs_index* ix, fs_corpus* c, hipStream_t s) {
+  const uint32_t W = (uint32_t)ix->n_windows;
+  FS_TRY(c->d_selflev.reserve(W + 1));
+  if (W) {
+    hipLaunchKernelGGL(k_selflev, dim3(std::min<uint32_t>((W + 3) / 4, 4096)), dim3(256), 0, s,
+                       ix->gram_dev(), c->dev(), W, c->d_selflev.p);
+    FS_HIP(hipGetLastError());
+  }
+  return FS_OK;
+}
+
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s) {
-  const LshDev L = lsh_dev(ix);
+  LshDev L = lsh_dev(ix);
+  if (c->selflev_ready && !c->has_str) L.selflev = c->d_selflev.p;
+  // at most one slot may differ and no OOV id anywhere: the wildcard-key filter applies
+  if (ix->sw.lsh_wild && ix->d_wild.p && !c->has_oov && !ix->script_oov &&
+      (int)ix->cfg.window_size - ix->lsh_m_min == 1) {
+    L.wild = ix->d_wild.p;
+    L.log2_wild = ix->log2_wild;
+  }
   fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),

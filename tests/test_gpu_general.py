@@ -71,19 +71,28 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
         tok[at + n - 2] = (int(tok[at + n - 2]) + 9) % len(words)
     cfg = abi.make_config(window_size=n)
     normals = synth.lsh_normals(n)
-    swords = [words[int(t)] for t in script]
+    # (script words as written in the script, not always the table's spelling: the
+    # Levenshtein distance of an identical-id match is not a constant)
+    swords = [words[int(t)].upper() if i % 7 == 0 else words[int(t)] for i, t in enumerate(script)]
     ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
                        synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL
     assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near<%d>" % n
     assert int((got["dist"] > 0.01).sum()) > 0           # inexact neighbours are records
-    monkeypatch.setenv("FS_LSH_PREFILTER", "0")
-    full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
-    c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
-    assert full.kernel_name(c) == "k_lsh_scan"
-    got2, st2 = full.search(c)
-    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
-    full.close()
+    assert len(set(got["lev"].tolist())) > 1
+    # without the 3-gram prefilter (keys and buckets for every window), without the
+    # wildcard-key filter in front of k_lsh_verify, with every Levenshtein distance
+    # computed per match: the same bytes
+    for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near<%d>" % n),
+                        ("FS_LSH_SELFLEV", "k_scan_near<%d>" % n)):
+        monkeypatch.setenv(env, "0")
+        full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+        c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        assert full.kernel_name(c) == kernel
+        got2, st2 = full.search(c)
+        assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+        full.close()
+        monkeypatch.delenv(env)
 
 
 def test_general_mode_equals_exact_mode(synth_base):
