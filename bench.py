@@ -65,6 +65,9 @@ def parse():
                     help="streams the library spreads searches over (FS_LANES): searches in "
                          "flight overlap on the GPU; 1 = one after the other")
     ap.add_argument("--inflight", type=int, default=0, help="searches kept in flight (default: lanes)")
+    ap.add_argument("--scan-timing", type=int, default=0,
+                    help="HIP events around the dominant kernel of every Nth search (default: every "
+                         "search when steps <= 64, every 4th otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-shaped", action="store_true",
                     help="skip the Python reference-shaped leg of cpu_baseline")
@@ -373,9 +376,13 @@ def main():
     scan_ms = []
     last = {"st": None, "rows": 0, "buf": 0}
 
+    trace = [] if os.environ.get("BENCH_TRACE_HOST") else None
+
     def complete(i):
         t, b = tickets.pop(i)
         n, st = ix.search_end(t)
+        if trace is not None:
+            trace.append(("end", i, time.perf_counter(), st.scan_ms))
         if st.scan_ms > 0:
             scan_ms.append(st.scan_ms)
         last["st"], last["rows"] = st, n
@@ -387,6 +394,8 @@ def main():
         gather.wait(b)
         tickets[i] = (ix.search_begin(corpora[i % rotate], gather.bufs[b].data_ptr(), cap,
                                       packed=packed, header=True), b)
+        if trace is not None:
+            trace.append(("begin", i, time.perf_counter(), 0.0))
         if i - (inflight - 1) in tickets:
             complete(i - (inflight - 1))
 
@@ -398,7 +407,7 @@ def main():
 
     # the dominant kernel carries timing events on every search of a short run (the driver
     # passes --steps 20), on every 4th of a long one (an event record costs stream time)
-    ix.set_scan_timing(1 if args.steps <= 64 else 4)
+    ix.set_scan_timing(args.scan_timing or (1 if args.steps <= 64 else 4))
     for i in range(args.warmup):
         step(i)
     drain()
@@ -414,6 +423,11 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if trace is not None:
+        for kind, i, t, ms in trace:
+            if t >= t0:
+                sys.stderr.write("%-5s %3d %8.1f us  scan %.1f us\n" % (kind, i, (t - t0) * 1e6, ms * 1e3))
+        sys.stderr.write("total %.1f us\n" % (dt * 1e6))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=gather.cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -477,7 +491,8 @@ def main():
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                if rec.get("kernel") == kernel and rec.get("n_tok") == n_tok and rec.get("rotate") == rotate:
+                if (rec.get("kernel") == kernel and rec.get("n_tok") == n_tok and rec.get("rotate") == rotate
+                        and rec.get("lanes") in (None, int(os.environ.get("FS_LANES", "1")))):
                     traffic = rec.get("hbm_bytes_per_launch")
                     traffic_src = "profiles/scan_traffic.json: " + rec.get("source", "rocprofv3 --pmc")
             except Exception:
@@ -504,6 +519,7 @@ def main():
                        "works_per_gpu": n_works, "tokens_per_work": tpw,
                        "script_tokens": conf["script_tokens"], "window": args.window,
                        "distinct_batches": rotate,
+                       "lanes": int(os.environ.get("FS_LANES", "1")),
                        "ids_bytes_rotated": rotate * shard_bytes,
                        "rows_per_gpu_step": int(round(rows_step)),
                        "wire_record_bytes": rec_bytes if world > 1 else None,

@@ -231,10 +231,11 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
     ix->ctab_ok = true;
   }
   // sub-shingle filter (fs_hash.h): one bit per script K-gram.  A window passes by
-  // chance with probability (bit density)^(n-K+1); sized for about 5e-4 (a few hundred
-  // extra candidates per million windows, against two workgroups per CU fitting in LDS)
+  // chance with probability (bit density)^(n-K+1); sized for about 2e-3 (false candidates
+  // a few per cent of the true ones on the synthetic workloads) -- a small filter is what
+  // lets two workgroups share a CU's LDS
   if (const int K = fs_sub_k((int)n)) {
-    const double dens = std::pow(5e-4, 1.0 / (double)(n - K + 1));
+    const double dens = std::pow(2e-3, 1.0 / (double)(n - K + 1));
     int ls = ceil_log2((uint64_t)((double)std::max<uint64_t>(1, ix->n_script) / (32.0 * dens)) + 1);
     if (const char* e = getenv("FS_SFILTER_LOG2_WORDS")) ls = atoi(e);
     ls = std::min(15, std::max(10, ls));

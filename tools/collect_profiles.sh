@@ -36,8 +36,10 @@ if [ "$part" = part1 ]; then
   prof_stats r02_c2 --no-companions --no-cpu-baseline
   prof_stats r02_c2_lanes1 --lanes 1 --inflight 2 --no-companions --no-cpu-baseline
   echo "== PMC: HBM traffic of k_scan_rows (separate passes)"
-  pmc r02_c2 FETCH_SIZE --steps 8 --warmup 2 --lanes 1 --inflight 1 --no-companions --no-cpu-baseline
-  pmc r02_c2 WRITE_SIZE --steps 8 --warmup 2 --lanes 1 --inflight 1 --no-companions --no-cpu-baseline
+  pmc r02_c2 FETCH_SIZE --steps 8 --warmup 2 --inflight 1 --no-companions --no-cpu-baseline
+  pmc r02_c2 WRITE_SIZE --steps 8 --warmup 2 --inflight 1 --no-companions --no-cpu-baseline
+  python tools/pmc_to_traffic.py $OUT/r02_c2_pmc_FETCH_SIZE.csv $OUT/r02_c2_pmc_WRITE_SIZE.csv \
+      $OUT/r02_c2_bench_steps20.json --out $OUT/scan_traffic.json
   echo "== c3shard: one GPU's share of configs[2] (12.5k works x 5k tokens, 250 MB)"
   python bench.py --workload c3shard --steps 100 --no-companions --no-cpu-baseline > $OUT/r02_c3shard_bench.json 2>/dev/null
   prof_stats r02_c3shard --workload c3shard --steps 60 --no-companions --no-cpu-baseline
@@ -63,6 +65,11 @@ if [ "$part" = part2 ]; then
   python tools/cli_bench.py > $OUT/r02_cli_bench.json 2>$OUT/r02_cli_bench.err
   echo "== lanes / finish A/B in one process"
   python tools/step_bench.py --inflight 4 "FS_SCAN_ROWS=1" "FS_SCAN_ROWS=1 FS_LANES=2" "FS_SCAN_ROWS=1 FS_LANES=4" \
-      "FS_SCAN_ROWS=1 FS_LANES=4 FS_SCAN_SUB=0" "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=0 FS_LANES=4" > $OUT/r02_step_ab.log 2>/dev/null
+      "FS_SCAN_ROWS=1 FS_LANES=4 FS_ROWS_BLOCKS_PER_CU=1" "FS_SCAN_ROWS=1 FS_LANES=4 FS_SCAN_SUB=0" \
+      "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=0 FS_LANES=4" > $OUT/r02_step_ab.log 2>/dev/null
+  echo "== LSH pipeline filters A/B (n = 8)"
+  for e in FS_X=1 FS_LSH_WILD=0 FS_LSH_SELFLEV=0 FS_LSH_PREFILTER=0; do
+    echo "$e $(env $e python tools/lsh_bench.py --window 8 --table synthetic --works 10000 2>/dev/null | tail -1)"
+  done > $OUT/r02_lsh_n8_filters_ab.log
   ls -la $OUT
 fi
