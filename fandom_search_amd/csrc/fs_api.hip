@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <new>
 #include <numeric>
@@ -109,6 +110,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_LSH_PREFILTER")) sw->lsh_prefilter = e[0] != '0';
   if (const char* e = getenv("FS_LSH_WILD")) sw->lsh_wild = e[0] != '0';
   if (const char* e = getenv("FS_LSH_SELFLEV")) sw->lsh_selflev = e[0] != '0';
+  if (const char* e = getenv("FS_ROWS_DISP_LDS")) sw->rows_disp_lds = e[0] != '0';
   sw->rows_waves = num("FS_ROWS_WAVES");
   sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
@@ -388,6 +390,18 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     FS_TRY(ix->lanes[l].w_bsum64.reserve(2048));
   }
 
+  // FS_BUILD_TIMES=1: seconds per stage of the index build on stderr
+  const bool times = getenv("FS_BUILD_TIMES") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!times) return;
+    (void)hipStreamSynchronize(ix->stream);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "fs_index_create: %-28s %8.3f ms\n", what,
+            std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  tick("streams, lanes, workspaces");
   // script ids padded by n so that device code may read a full window anywhere
   std::vector<uint32_t> stok(n_script + FS_MAX_WINDOW + 1, 0u);
   if (n_script) memcpy(stok.data(), script_vec, n_script * sizeof(uint32_t));
@@ -411,9 +425,12 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   FS_TRY(fs_launch_rownorms(ix->d_emb.p, n_vec, (int)cfg->emb_dim, ix->d_q.p, ix->stream));
   FS_TRY(fs_launch_selfdist(ix->d_stok.p, ix->n_windows, (int)cfg->window_size, (int)cfg->emb_dim,
                             n_vec, ix->d_q.p, ix->d_selfdist.p, ix->stream));
+  tick("uploads, norms, self distances");
   FS_TRY(build_gram_index(ix, stok.data()));
+  tick("n-gram index");
   FS_TRY(prove_exact(ix, stok.data()));
   FS_HIP(hipStreamSynchronize(ix->stream));
+  tick("proof (c_max)");
 
   ix->info.n_script = n_script;
   ix->info.n_windows = ix->n_windows;
@@ -425,6 +442,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   }
   ix->info.path = exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
   if (!exact) FS_TRY(fs_lsh_build(ix));
+  tick("LSH structures");
   guard.p = nullptr;
   *out = ix;
   return FS_OK;

@@ -480,6 +480,104 @@ __global__ __launch_bounds__(256) void k_selflev(GramIndexDev g, CorpusDev c, ui
   }
 }
 
+// ---- CSR buckets on the device (Engine.store_vector for every script window) ----------
+// boff[h][k+1] counts the windows with key k in table h, a scan turns the counts into
+// offsets, a scatter fills bids in arrival order, and every bucket is then sorted by window
+// index: the reference's buckets list their windows in insertion (= ascending) order, and
+// the order decides UniqueFilter's and NearestFilter's ties.
+__global__ void k_bucket_count(const uint32_t* __restrict__ keys, uint32_t W, int H, uint32_t nb,
+                               uint32_t* __restrict__ boff) {
+  const uint64_t total = (uint64_t)W * H;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = (uint32_t)(i % H);
+    atomicAdd(&boff[(size_t)h * (nb + 1) + keys[i] + 1], 1u);
+  }
+}
+
+// one workgroup per table: counts -> offsets in place (boff[h][0] = 0), and a copy of the
+// bucket starts as the scatter's cursors
+__global__ __launch_bounds__(256) void k_bucket_offsets(uint32_t nb, uint32_t* __restrict__ boff,
+                                                        uint32_t* __restrict__ cursor) {
+  __shared__ uint32_t s_w32[4];
+  uint32_t* off = boff + (size_t)blockIdx.x * (nb + 1);
+  uint32_t* cur = cursor + (size_t)blockIdx.x * nb;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t v = b < nb ? off[b + 1] : 0u;
+    uint32_t tot;
+    const uint32_t excl = block_excl_scan(v, s_w32, &tot);
+    if (b < nb) {
+      off[b + 1] = carry + excl + v;
+      cur[b] = carry + excl;
+    }
+    carry += tot;
+    __syncthreads();
+  }
+}
+
+__global__ void k_bucket_fill(const uint32_t* __restrict__ keys, uint32_t W, int H, uint32_t nb,
+                              uint32_t* __restrict__ cursor, uint32_t* __restrict__ bids) {
+  const uint64_t total = (uint64_t)W * H;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = (uint32_t)(i % H), w = (uint32_t)(i / H);
+    const uint32_t at = atomicAdd(&cursor[(size_t)h * nb + keys[i]], 1u);
+    bids[(size_t)h * W + at] = w;
+  }
+}
+
+// ascending window index inside every bucket: a thread sorts a bucket of up to kSmallBucket
+// entries by insertion; larger ones are listed for k_bucket_sort_big
+constexpr uint32_t kSmallBucket = 48;
+__global__ void k_bucket_sort(uint32_t W, int H, uint32_t nb, const uint32_t* __restrict__ boff,
+                              uint32_t* __restrict__ bids, uint32_t* __restrict__ big,
+                              uint32_t* __restrict__ n_big) {
+  const uint64_t total = (uint64_t)nb * H;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = (uint32_t)(i / nb), b = (uint32_t)(i % nb);
+    const uint32_t* off = boff + (size_t)h * (nb + 1) + b;
+    const uint32_t e0 = off[0], m = off[1] - e0;
+    if (m < 2) continue;
+    if (m > kSmallBucket) { big[atomicAdd(n_big, 1u)] = (uint32_t)i; continue; }
+    uint32_t* v = bids + (size_t)h * W + e0;
+    for (uint32_t a = 1; a < m; ++a) {
+      const uint32_t x = v[a];
+      uint32_t c = a;
+      while (c > 0 && v[c - 1] > x) { v[c] = v[c - 1]; --c; }
+      v[c] = x;
+    }
+  }
+}
+
+// a large bucket (many script windows with one key: a repeated passage): one workgroup, every
+// entry's place is the number of smaller entries (window indices are distinct)
+__global__ __launch_bounds__(256) void k_bucket_sort_big(uint32_t W, uint32_t nb,
+                                                         const uint32_t* __restrict__ boff,
+                                                         uint32_t* __restrict__ bids,
+                                                         const uint32_t* __restrict__ big,
+                                                         const uint32_t* __restrict__ n_big,
+                                                         uint32_t* __restrict__ tmp) {
+  for (uint32_t j = blockIdx.x; j < *n_big; j += gridDim.x) {
+    const uint32_t i = big[j], h = i / nb, b = i % nb;
+    const uint32_t* off = boff + (size_t)h * (nb + 1) + b;
+    const uint32_t e0 = off[0], m = off[1] - e0;
+    uint32_t* v = bids + (size_t)h * W + e0;
+    uint32_t* t = tmp + (size_t)h * W + e0;
+    for (uint32_t a = threadIdx.x; a < m; a += blockDim.x) {
+      const uint32_t x = v[a];
+      uint32_t r = 0;
+      for (uint32_t c = 0; c < m; ++c) r += v[c] < x;
+      t[r] = x;
+    }
+    __syncthreads();
+    for (uint32_t a = threadIdx.x; a < m; a += blockDim.x) v[a] = t[a];
+    __syncthreads();
+  }
+}
+
 // ---- search kernels ------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
@@ -990,29 +1088,37 @@ int fs_lsh_build(fs_index* ix) {
     }
   }
   const uint32_t nb = 1u << B;
-  std::vector<uint32_t> boff((size_t)H * (nb + 1), 0u), bids((size_t)H * std::max<uint64_t>(W, 1), 0u);
+  FS_TRY(ix->d_boff.reserve((size_t)H * (nb + 1)));
+  FS_TRY(ix->d_bids.reserve((size_t)H * std::max<uint64_t>(W, 1)));
+  FS_HIP(hipMemsetAsync(ix->d_boff.p, 0, (size_t)H * (nb + 1) * sizeof(uint32_t), s));
   if (W) {
     LshDev L = lsh_dev(ix);
     hipLaunchKernelGGL(k_ss, dim3((uint32_t)((W + 255) / 256)), dim3(256), 0, s, ix->d_stok.p,
                        (uint32_t)W, L, ix->d_ss.p, ix->d_sw.p);
-    DBuf<uint32_t> d_keys;
+    // script window keys and their CSR buckets, all on the device
+    DBuf<uint32_t> d_keys, d_cursor, d_big, d_tmp;
     FS_TRY(d_keys.reserve(W * H));
+    FS_TRY(d_cursor.reserve((size_t)H * nb));
+    FS_TRY(d_big.reserve((size_t)H * nb / kSmallBucket + (size_t)H * W / kSmallBucket + 2));
+    FS_TRY(d_tmp.reserve((size_t)H * W));
     hipLaunchKernelGGL(k_keys, dim3((uint32_t)std::min<uint64_t>((W + 3) / 4, 4096)), dim3(256), 0,
                        s, L, ix->d_stok.p, (uint32_t)W, d_keys.p);
+    const uint32_t gb = (uint32_t)std::min<uint64_t>((W * H + 255) / 256, 4096);
+    uint32_t* n_big = d_big.p;                 // [0] = count, list behind it
+    FS_HIP(hipMemsetAsync(n_big, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_bucket_count, dim3(gb), dim3(256), 0, s, d_keys.p, (uint32_t)W, H, nb,
+                       ix->d_boff.p);
+    hipLaunchKernelGGL(k_bucket_offsets, dim3((uint32_t)H), dim3(256), 0, s, nb, ix->d_boff.p,
+                       d_cursor.p);
+    hipLaunchKernelGGL(k_bucket_fill, dim3(gb), dim3(256), 0, s, d_keys.p, (uint32_t)W, H, nb,
+                       d_cursor.p, ix->d_bids.p);
+    hipLaunchKernelGGL(k_bucket_sort, dim3((uint32_t)std::min<uint64_t>(((uint64_t)nb * H + 255) / 256, 4096)),
+                       dim3(256), 0, s, (uint32_t)W, H, nb, ix->d_boff.p, ix->d_bids.p, d_big.p + 1, n_big);
+    hipLaunchKernelGGL(k_bucket_sort_big, dim3(256), dim3(256), 0, s, (uint32_t)W, nb, ix->d_boff.p,
+                       ix->d_bids.p, d_big.p + 1, n_big, d_tmp.p);
     FS_HIP(hipGetLastError());
-    std::vector<uint32_t> keys(W * H);
-    FS_HIP(hipMemcpyAsync(keys.data(), d_keys.p, keys.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    FS_HIP(hipStreamSynchronize(s));
-    for (int h = 0; h < H; ++h) {            // counting sort: ascending window index per bucket
-      uint32_t* off = boff.data() + (size_t)h * (nb + 1);
-      for (uint64_t w = 0; w < W; ++w) off[keys[w * H + h] + 1]++;
-      for (uint32_t b = 0; b < nb; ++b) off[b + 1] += off[b];
-      std::vector<uint32_t> cur(off, off + nb);
-      for (uint64_t w = 0; w < W; ++w) bids[(size_t)h * W + cur[keys[w * H + h]]++] = (uint32_t)w;
-    }
+    FS_HIP(hipStreamSynchronize(s));           // the scratch buffers die with this scope
   }
-  FS_TRY(ix->d_boff.upload(boff.data(), boff.size(), s));
-  FS_TRY(ix->d_bids.upload(bids.data(), bids.size(), s));
   FS_HIP(hipStreamSynchronize(s));
   ix->lsh_ready = true;
   return FS_OK;

@@ -996,7 +996,7 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
 // kernel reads them from memory
 static uint32_t fs_scan_rows_disp_lds(const fs_index* ix) {
   const uint32_t bytes = ((1u << ix->log2_buckets) + 15u) & ~15u;
-  return bytes <= 16 * 1024 ? bytes : 0;
+  return bytes <= 16 * 1024 && ix->sw.rows_disp_lds ? bytes : 0;
 }
 
 namespace {

@@ -273,3 +273,28 @@ def test_synonym_rich_table_benchmark_shape(synth_base):
                        synth.lsh_normals(6), tok, off, synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL and ix.info["c_max"] > 0.9
     assert len(got) > 0
+
+
+@pytest.mark.parametrize("unique", [1, 0])
+def test_crowded_buckets_keep_insertion_order(synth_base, unique):
+    """A passage that the script repeats 150 times puts 150 windows under one key in every
+    table: the CSR buckets (built on the device: count, scan, scatter, sort by window index,
+    large buckets by a workgroup) must list them in ascending order, as the reference's
+    store_vector does, because NearestFilter keeps the first N of equal distance."""
+    words, emb = synth_base["words"], synth_base["emb"]
+    rng = np.random.default_rng(99)
+    passage = synth.script_tokens(14)
+    filler = synth.script_tokens(3000)
+    parts = []
+    for r in range(150):
+        parts.append(passage)
+        parts.append(filler[20 * r:20 * r + int(rng.integers(3, 9))])
+    script = np.concatenate(parts).astype(np.uint32)
+    tok, off = util.ragged_corpus([600] * 6 + [0, 40], script)
+    tok = tok.copy()
+    tok[int(off[1]) + 50:int(off[1]) + 64] = passage
+    tok[int(off[4]) + 300:int(off[4]) + 310] = passage[2:12]
+    cfg = abi.make_config(window_size=6, mode=abi.FS_MODE_GENERAL, unique_filter=unique)
+    ix, got, st = _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
+                       tok, off, synth_base["chars"], synth_base["off"])
+    assert st.path == abi.FS_MODE_GENERAL and len(got) > 20

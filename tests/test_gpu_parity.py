@@ -538,7 +538,8 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
     chained kernels), with the Bloom test of the whole n-gram in place of the runs of
     script K-grams (FS_SCAN_SUB=0), with the launch shape of an index that overlaps searches
     (FS_LANES=4: two workgroups of eight wave ranges per CU), with a sub-shingle filter far
-    too small (many false candidates), with works that quote long stretches of the script (several rounds
+    too small (many false candidates), with the displacement seeds read from memory instead
+    of LDS (as for scripts with more than 16 K buckets), with works that quote long stretches of the script (several rounds
     of candidates per flush, hits carried from round to round), hits at range and work
     boundaries, ragged and empty works.  n = 7, 8 need a table the exact-n-gram proof
     accepts: 256 one-hot vectors."""
@@ -572,10 +573,10 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
     envs = ({}, {"FS_SCAN_ROWS": "0"}, {"FS_RANGES_CAPROW": "2"}, {"FS_WAIT_SPINS": "0"},
             {"FS_ROWS_FINISH": "2"}, {"FS_ROWS_FINISH": "2", "FS_RANGES_CAPROW": "2"},
             {"FS_SCAN_SUB": "0"}, {"FS_LANES": "4"}, {"FS_LANES": "4", "FS_RANGES_CAPROW": "2"},
-            {"FS_SFILTER_LOG2_WORDS": "10"})
+            {"FS_SFILTER_LOG2_WORDS": "10"}, {"FS_ROWS_DISP_LDS": "0"})
     for env in envs:
         for k in ("FS_SCAN_ROWS", "FS_RANGES_CAPROW", "FS_WAIT_SPINS", "FS_ROWS_FINISH", "FS_SCAN_SUB",
-                  "FS_LANES", "FS_SFILTER_LOG2_WORDS"):
+                  "FS_LANES", "FS_SFILTER_LOG2_WORDS", "FS_ROWS_DISP_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
