@@ -1015,9 +1015,9 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   const uint32_t disp_lds = fs_scan_rows_disp_lds(ix);
   const int lw = rows_filter_log2(ix);
   const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds);
-  const bool big = c->n_tok * 4 > (256ull << 20);
-  const char e = ix->sw.scan_flags;
-  const bool nt = e == 'n' || (!e && big);
+  // (non-temporal id loads only on request, FS_SCAN_FLAGS=n: they measured slower at every
+  // batch size, 0.50 against 0.61 of peak on a 1 GB batch)
+  const bool nt = ix->sw.scan_flags == 'n';
   const bool lw14 = lw == 14;
   constexpr int K = fs_sub_k(N);
   auto kern = nt ? (lw14 ? k_scan_rows<N, 0, true, true> : k_scan_rows<N, 0, true, false>)

@@ -43,6 +43,9 @@ if [ "$part" = part1 ]; then
   echo "== c3shard: one GPU's share of configs[2] (12.5k works x 5k tokens, 250 MB)"
   python bench.py --workload c3shard --steps 100 --no-companions --no-cpu-baseline > $OUT/r02_c3shard_bench.json 2>/dev/null
   prof_stats r02_c3shard --workload c3shard --steps 60 --no-companions --no-cpu-baseline
+  echo "== larger batches: the N = 4 and N = 2 shares of configs[2] (500 MB / 1 GB of ids per batch)"
+  python bench.py --workload c3 --works 25000 --steps 40 --warmup 4 --no-companions --no-cpu-baseline > $OUT/r02_c3_quarter_bench.json 2>/dev/null
+  python bench.py --workload c3 --works 50000 --steps 40 --warmup 4 --no-companions --no-cpu-baseline > $OUT/r02_c3_half_bench.json 2>/dev/null
   ls -la $OUT
 fi
 
