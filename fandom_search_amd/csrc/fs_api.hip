@@ -725,8 +725,9 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   // timing events only on timed searches: every event record is a barrier packet
   // in the queue (about 1.5 us of bubble each)
   sl.timed = ix->scan_timing_period <= 1 || (ix->searches++ % ix->scan_timing_period) == 0;
-  // the whole-search time only when every search is timed (the synchronous use)
-  const bool whole = sl.timed && ix->scan_timing_period <= 1;
+  // the whole-search time (fs_stats.total_ms) only for the synchronous call: one more
+  // event record, about 4 us of host time per search
+  const bool whole = sl.timed && ix->scan_timing_period <= 1 && ix->sync_call;
   if (whole) FS_HIP(hipEventRecord(sl.ev_begin, s));
   sl.whole_timed = whole;
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
@@ -786,6 +787,8 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
                  "FS_ROWS_DEVICE_PACKED8");
     return FS_E_INVALID;
   }
+  static const bool trace_begin = getenv("FS_TRACE_BEGIN") != nullptr;
+  const auto tb0 = std::chrono::steady_clock::now();
   FS_ENTER(ix->device);
   FS_TRY(fs_corpus_update_end(c));          // no-op unless an upload is in flight
   const uint32_t id = ix->next_slot % FS_SEARCH_SLOTS;
@@ -841,7 +844,14 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   sl.rcap = rows_mode != FS_ROWS_HOST
                 ? cap
                 : std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ln.w_rows.n);
+  const auto tb1 = std::chrono::steady_clock::now();
   FS_TRY(search_enqueue(ix, sl));
+  if (trace_begin) {
+    const auto tb2 = std::chrono::steady_clock::now();
+    fprintf(stderr, "fs_search_corpus_begin: set-up %.1f us, enqueue %.1f us\n",
+            std::chrono::duration<double, std::micro>(tb1 - tb0).count(),
+            std::chrono::duration<double, std::micro>(tb2 - tb1).count());
+  }
   sl.busy = true;
   *ticket = id;
   ++ix->next_slot;
@@ -934,7 +944,11 @@ extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64
                                 int rows_on_device, uint64_t* n_rows, fs_stats* st) {
   if (!n_rows) { fs_set_error("null argument"); return FS_E_INVALID; }
   uint32_t ticket = 0;
-  FS_TRY(fs_search_corpus_begin(ix, c, rows, cap, rows_on_device, &ticket));
+  if (!ix) { fs_set_error("null argument"); return FS_E_INVALID; }
+  ix->sync_call = true;
+  const int rc = fs_search_corpus_begin(ix, c, rows, cap, rows_on_device, &ticket);
+  ix->sync_call = false;
+  if (rc != FS_OK) return rc;
   return fs_search_corpus_end(ix, ticket, n_rows, st);
 }
 

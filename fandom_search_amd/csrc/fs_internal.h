@@ -267,6 +267,7 @@ struct fs_index {
     uint32_t fused_blocks = 0;        //              workgroups
   };
   Slot slots[FS_SEARCH_SLOTS];
+  bool sync_call = false;              // inside fs_search_corpus (begin + end in one call)
   uint32_t next_slot = 0;
   uint32_t scan_timing_period = 1;    // attach timing events to every k-th scan
   uint64_t searches = 0;

@@ -95,7 +95,8 @@ typedef struct fs_stats {
   uint64_t matches;            /* (window, script window) pairs kept          */
   uint64_t rows;               /* records after per-word dedupe               */
   double   scan_ms;            /* dominant kernel, HIP-event time; 0 if untimed */
-  double   total_ms;           /* all device work of the call, HIP events (0 on
+  double   total_ms;           /* all device work of the call, HIP events; fs_search_corpus
+                                  and fs_search only (0 for _begin/_end pairs and on
                                   searches without timing, fs_index_set_scan_timing) */
   uint32_t path;               /* FS_MODE_GENERAL or FS_MODE_EXACT            */
   uint32_t scan_launches;      /* launches of the dominant kernel in the call */
