@@ -111,6 +111,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_LSH_WILD")) sw->lsh_wild = e[0] != '0';
   if (const char* e = getenv("FS_LSH_SELFLEV")) sw->lsh_selflev = e[0] != '0';
   if (const char* e = getenv("FS_ROWS_DISP_LDS")) sw->rows_disp_lds = e[0] != '0';
+  if (const char* e = getenv("FS_STR_LEVTAB")) sw->str_levtab = e[0] != '0';
   sw->rows_waves = num("FS_ROWS_WAVES");
   sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
@@ -589,12 +590,15 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
   // out-of-vocabulary vectors are outside the exact n-gram proof: such a batch
   // goes through the LSH pipeline (built now if the index did not need it before)
   if (c->has_oov && ix->info.path == FS_MODE_EXACT) FS_TRY(fs_lsh_build(ix));
-  if (!c->has_str && !c->has_oov && ix->info.path == FS_MODE_EXACT && !c->levtab_ready) {
-    // string id == vector id: Levenshtein per (n-gram, rank), once per string table
+  if (!c->has_oov && ix->info.path == FS_MODE_EXACT && !c->levtab_ready) {
+    // Levenshtein per (n-gram, rank) against the strings whose ids are the n-gram's vector
+    // ids, once per string table: every hit's distance when string id == vector id, and
+    // with string ids of their own the distance of the hits whose tokens all carry string
+    // id == vector id (entries FS_NONE where such a string does not exist)
     ix->cur = &ix->lanes[0];
     FS_HIP(hipMemsetAsync(ix->cur->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
-    FS_TRY(fs_launch_ctab(ix, c, ix->stream));
+    if (!c->has_str) FS_TRY(fs_launch_ctab(ix, c, ix->stream));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->cur->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     if (ix->h_status->bad_string) { fs_set_error("script vector id without a string"); return FS_E_INVALID; }

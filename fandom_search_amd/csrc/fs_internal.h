@@ -173,6 +173,7 @@ struct fs_switches {
   bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
   bool lsh_prefilter = true;      // FS_LSH_PREFILTER=0: always the full key scan
   bool rows_disp_lds = true;      // FS_ROWS_DISP_LDS=0: k_scan_rows reads the displacement seeds from memory (as with > 16 K buckets)
+  bool str_levtab = true;         // FS_STR_LEVTAB=0: batches with string ids compute every Levenshtein distance per match
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)

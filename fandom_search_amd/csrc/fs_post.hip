@@ -388,11 +388,17 @@ __global__ __launch_bounds__(kThreads, 8) void k_verify_direct(CorpusDev c, Gram
   if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
 }
 
-// Per (gram, rank) Levenshtein table for corpora whose string id == vector id:
-// the fan text of a hit is then a function of the gram alone.  One wave per entry.
+// Per (gram, rank) Levenshtein table: the distance of script window gpos[gram][rank]
+// against the strings whose ids are the gram's vector ids.  For corpora whose string id ==
+// vector id the fan text of a hit is a function of the gram alone; corpora with string ids
+// of their own use the table for the hits whose tokens all carry string id == vector id
+// (k_matchlev).  One wave per entry.  `tolerant` (string ids of their own): an id without
+// a string or an over-long text gives FS_NONE instead of an error.
 __global__ __launch_bounds__(256) void k_levtab(GramIndexDev g, CorpusDev c,
-                                                uint32_t* __restrict__ levtab, fs_status* st) {
+                                                uint32_t* __restrict__ levtab, fs_status* st,
+                                                bool tolerant) {
   __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
+  __shared__ fs_status s_st[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = g.n_grams * (uint32_t)g.nn;
   for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
@@ -400,30 +406,63 @@ __global__ __launch_bounds__(256) void k_levtab(GramIndexDev g, CorpusDev c,
     uint32_t v = 0;
     if (r < g.gcnt[gram]) {                              // wave-uniform
       const uint32_t first = g.gpos[(size_t)gram * g.nn];
-      v = lev_wave(g, g.gpos[i], g.stok + first, c.chars, c.coff, c.n_str, st, s_a[wave], s_b[wave]);
+      if (tolerant) {
+        if (lane == 0) { s_st[wave].bad_string = 0; s_st[wave].lev_overflow = 0; }
+        __builtin_amdgcn_wave_barrier();
+        v = lev_wave(g, g.gpos[i], g.stok + first, c.chars, c.coff, c.n_str, &s_st[wave], s_a[wave],
+                     s_b[wave]);
+        __builtin_amdgcn_wave_barrier();
+        if (s_st[wave].bad_string | s_st[wave].lev_overflow) v = FS_NONE;
+      } else {
+        v = lev_wave(g, g.gpos[i], g.stok + first, c.chars, c.coff, c.n_str, st, s_a[wave], s_b[wave]);
+      }
     }
     if (lane == 0) levtab[i] = v;
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-// Per (candidate, rank) Levenshtein when fan tokens carry their own string ids.
+// Per (candidate, rank) Levenshtein when fan tokens carry their own string ids.  64 items
+// per wave and step, NWAVES apart; first one lane per item: not a hit or no such rank ->
+// nothing; every token of the window with string id == vector id -> the table's value;
+// the rest one at a time by the whole wave.
 __global__ __launch_bounds__(256) void k_matchlev(GramIndexDev g, CorpusDev c,
                                                   const uint32_t* __restrict__ cpos,
                                                   const uint32_t* __restrict__ cg, NSrc nc_nn,
+                                                  const uint32_t* __restrict__ levtab,
                                                   uint32_t* __restrict__ mlev, fs_status* st) {
   __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t total = nc_nn.get();
-  for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
-    const uint32_t cand = i / g.nn, r = i % g.nn;
-    const uint32_t gram = cg[cand];
-    if (gram == FS_NONE || r >= g.gcnt[gram]) continue;  // wave-uniform
-    const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
-    const uint32_t v = lev_wave(g, s, c.str + cpos[cand], c.chars, c.coff, c.n_str, st, s_a[wave],
-                                s_b[wave]);
-    if (lane == 0) mlev[i] = v;
-    __builtin_amdgcn_wave_barrier();
+  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
+  for (uint32_t t0 = 0; (uint64_t)t0 * NWAVES < total; t0 += 64) {
+    const uint64_t il = (uint64_t)(t0 + lane) * NWAVES + gw;
+    bool live = false;
+    if (il < total) {
+      const uint32_t cand = (uint32_t)(il / g.nn), r = (uint32_t)(il % g.nn);
+      const uint32_t gram = cg[cand];
+      live = gram != FS_NONE && r < g.gcnt[gram];
+      if (live && levtab) {
+        const uint32_t p = cpos[cand];
+        bool same = true;
+        for (int k = 0; k < g.n; ++k) same = same && c.str[p + k] == c.tok[p + k];
+        if (same) {
+          const uint32_t v = levtab[(size_t)gram * g.nn + r];
+          if (v != FS_NONE) { mlev[il] = v; live = false; }
+        }
+      }
+    }
+    uint64_t todo = __ballot(live);
+    while (todo) {
+      const uint32_t i = (t0 + (uint32_t)(__ffsll((unsigned long long)todo) - 1)) * NWAVES + gw;
+      todo &= todo - 1;
+      const uint32_t cand = i / g.nn, r = i % g.nn;
+      const uint32_t s = g.gpos[(size_t)cg[cand] * g.nn + r];
+      const uint32_t v = lev_wave(g, s, c.str + cpos[cand], c.chars, c.coff, c.n_str, st, s_a[wave],
+                                  s_b[wave]);
+      if (lane == 0) mlev[i] = v;
+      __builtin_amdgcn_wave_barrier();
+    }
   }
 }
 
@@ -768,7 +807,7 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   if (total) {
     const uint32_t blocks = (uint32_t)((total + 3) / 4);
     hipLaunchKernelGGL(k_levtab, dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, s,
-                       ix->gram_dev(), c->dev(), c->d_levtab.p, ix->cur->d_status.p);
+                       ix->gram_dev(), c->dev(), c->d_levtab.p, ix->cur->d_status.p, c->has_str);
     const uint32_t gb = (ix->n_grams + 255) / 256;
     hipLaunchKernelGGL(k_gbest, dim3(gb > 1024 ? 1024 : gb), dim3(256), 0, s, ix->gram_dev(),
                        c->d_levtab.p, c->d_gbest.p);
@@ -871,7 +910,9 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   if (per_cand) {
     const NSrc nc_nn{&st->n_cands, nn, ccap, 0};
     hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->cur->w_cpos.p,
-                       ix->cur->w_cg.p, nc_nn, ix->cur->w_mlev.p, st);
+                       ix->cur->w_cg.p, nc_nn,
+                       c->levtab_ready && ix->sw.str_levtab ? (const uint32_t*)c->d_levtab.p : nullptr,
+                       ix->cur->w_mlev.p, st);
     hipLaunchKernelGGL(k_cbest, dim3(kNB), dim3(kThreads), 0, s, g, ix->cur->w_cg.p, ix->cur->w_mlev.p, nc,
                        ix->cur->w_cbest.p);
   }

@@ -94,11 +94,14 @@ def test_c2_slice(synth_base):
     assert st.scan_ms > 0
 
 
-def test_separate_string_ids(synth_base):
+@pytest.mark.parametrize("plain", [0.34, 0.85])
+def test_separate_string_ids(synth_base, monkeypatch, plain):
     """Fan tokens whose text differs from the text of their vector row (the
     reference's fan side is case-sensitive, the script side lower-cased:
     search.py:151 vs :166): string ids travel next to vector ids and the
-    Levenshtein distance is computed per match."""
+    Levenshtein distance is computed per match -- except for the matches whose tokens
+    all carry string id == vector id, which take it from the per-gram table
+    (FS_STR_LEVTAB=0: none do; same bytes).  `plain`: share of such tokens."""
     from fandom_search_amd.engine import ScriptIndex
     from fandom_search_amd.vocab import pack_strings
     words, emb = synth_base["words"], synth_base["emb"]
@@ -109,7 +112,8 @@ def test_separate_string_ids(synth_base):
     rng = np.random.default_rng(5)
     # string table: lower-case words, then Capitalised, then UPPER + '!!'
     strings = list(words) + [w.capitalize() for w in words] + [w.upper() + "!!" for w in words]
-    variant = rng.integers(0, 3, size=len(tok)).astype(np.uint32)
+    rest = (1.0 - plain) / 2
+    variant = rng.choice(3, size=len(tok), p=[plain, rest, rest]).astype(np.uint32)
     tok_str = (tok + variant * len(words)).astype(np.uint32)
     chars, coff = pack_strings(strings)
     cfg = abi.make_config(window_size=n)
@@ -120,6 +124,11 @@ def test_separate_string_ids(synth_base):
     util.assert_rows_equal(got, want)
     assert len(set(got["lev"].tolist())) > 3      # text variants change the distance
     assert st.matches == ost.matches
+    monkeypatch.setenv("FS_STR_LEVTAB", "0")
+    ix2 = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=cfg)
+    got2, st2 = ix2.search(ix2.corpus(tok, off, chars, coff, tok_str=tok_str))
+    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+    ix2.close()
 
 
 def test_packed_wire_rows_round_trip(synth_base):
