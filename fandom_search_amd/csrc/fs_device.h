@@ -192,35 +192,62 @@ __device__ inline uint32_t lev_wave(const GramIndexDev& g, uint32_t s, const uin
                                     const uint32_t* chars, const uint64_t* coff, uint32_t n_str,
                                     fs_status* st, uint32_t* s_a, uint32_t* s_b) {
   const int lane = threadIdx.x & 63;
-  // lengths (uniform)
-  uint32_t la = g.n - 1, lb = 2 + 2 * (g.n - 1);
+  const int n = g.n;
+  // lane k < n: where word k of either side starts and how long it is (all offsets
+  // requested together; the n <= 16 words of a window)
+  uint64_t a0 = 0, b0 = 0;
+  uint32_t wla = 0, wlb = 0;
   bool bad = false;
-  for (int k = 0; k < g.n; ++k) {
-    la += (uint32_t)(g.soff[s + k + 1] - g.soff[s + k]);
-    const uint32_t sid = fan_sid[k];
-    if (sid >= n_str) { bad = true; break; }
-    lb += (uint32_t)(coff[sid + 1] - coff[sid]);
-  }
-  if (bad) { if (lane == 0) st->bad_string = 1; return 0; }
-  if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { if (lane == 0) st->lev_overflow = 1; return 0; }
-  // operands into LDS: a = script words joined by ' ', b = '[' + ', '.join(fan) + ']'
-  uint32_t pa = 0, pb = 0;
-  if (lane == 0) s_b[0] = '[';
-  pb = 1;
-  for (int k = 0; k < g.n; ++k) {
-    if (k) {
-      if (lane == 0) { s_a[pa] = ' '; s_b[pb] = ','; s_b[pb + 1] = ' '; }
-      pa += 1; pb += 2;
+  if (lane < n) {
+    a0 = g.soff[s + lane];
+    const uint64_t a1 = g.soff[s + lane + 1];
+    const uint32_t sid = fan_sid[lane];
+    bad = sid >= n_str;
+    if (!bad) {
+      b0 = coff[sid];
+      wlb = (uint32_t)(coff[sid + 1] - b0);
     }
-    const uint64_t a0 = g.soff[s + k], a1 = g.soff[s + k + 1];
-    for (uint64_t c = a0 + lane; c < a1; c += 64) s_a[pa + (uint32_t)(c - a0)] = g.schars[c];
-    pa += (uint32_t)(a1 - a0);
-    const uint32_t sid = fan_sid[k];
-    const uint64_t b0 = coff[sid], b1 = coff[sid + 1];
-    for (uint64_t c = b0 + lane; c < b1; c += 64) s_b[pb + (uint32_t)(c - b0)] = chars[c];
-    pb += (uint32_t)(b1 - b0);
+    wla = (uint32_t)(a1 - a0);
   }
-  if (lane == 0) s_b[pb] = ']';
+  if (__any(bad)) { if (lane == 0) st->bad_string = 1; return 0; }
+  const uint32_t ia = wave_incl_scan_dpp(wla), ib = wave_incl_scan_dpp(wlb);
+  const uint32_t la = (uint32_t)(n - 1) + (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
+  const uint32_t lb = 2u + 2u * (uint32_t)(n - 1) + (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
+  if (la > FS_LEV_MAX || lb > FS_LEV_MAX) { if (lane == 0) st->lev_overflow = 1; return 0; }
+  // operands into LDS: a = script words joined by ' ', b = '[' + ', '.join(fan) + ']';
+  // lane j takes code points j, j + 64, ... of each operand (one load per code point, all
+  // of a lane's requests independent of each other)
+  const uint32_t pa = (uint32_t)lane + (ia - wla);            // first position of word `lane` in a
+  const uint32_t pb = 1u + 2u * (uint32_t)lane + (ib - wlb);  //                              in b
+  const uint32_t a0lo = (uint32_t)a0, a0hi = (uint32_t)(a0 >> 32);
+  const uint32_t b0lo = (uint32_t)b0, b0hi = (uint32_t)(b0 >> 32);
+  for (uint32_t j = lane; j < la; j += 64) {
+    uint64_t at = 0;
+    bool in_word = false;
+    for (int k = 0; k < n; ++k) {
+      const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)pa, k);
+      const uint32_t len_k = (uint32_t)__builtin_amdgcn_readlane((int)wla, k);
+      const uint64_t src = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)a0lo, k) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)a0hi, k) << 32);
+      if (j - st_k < len_k) { at = src + (j - st_k); in_word = true; }
+    }
+    s_a[j] = in_word ? g.schars[at] : (uint32_t)' ';
+  }
+  for (uint32_t j = lane; j < lb; j += 64) {
+    uint32_t ch = j == 0 ? '[' : ']';
+    uint64_t at = 0;
+    bool in_word = false;
+    for (int k = 0; k < n; ++k) {
+      const uint32_t st_k = (uint32_t)__builtin_amdgcn_readlane((int)pb, k);
+      const uint32_t len_k = (uint32_t)__builtin_amdgcn_readlane((int)wlb, k);
+      const uint64_t src = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b0lo, k) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)b0hi, k) << 32);
+      if (j - st_k < len_k) { at = src + (j - st_k); in_word = true; }
+      else if (k + 1 < n && j == st_k + len_k) ch = ',';
+      else if (k + 1 < n && j == st_k + len_k + 1) ch = ' ';
+    }
+    s_b[j] = in_word ? chars[at] : ch;
+  }
   __builtin_amdgcn_wave_barrier();
   const uint32_t* pat = la <= lb ? s_a : s_b;
   const uint32_t* txt = la <= lb ? s_b : s_a;
