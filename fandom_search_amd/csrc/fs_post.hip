@@ -422,46 +422,51 @@ __global__ __launch_bounds__(256) void k_levtab(GramIndexDev g, CorpusDev c,
   }
 }
 
-// Per (candidate, rank) Levenshtein when fan tokens carry their own string ids.  64 items
-// per wave and step, NWAVES apart; first one lane per item: not a hit or no such rank ->
-// nothing; every token of the window with string id == vector id -> the table's value;
-// the rest one at a time by the whole wave.
+// Per (candidate, rank) Levenshtein when fan tokens carry their own string ids.  64
+// candidates per wave and step, NWAVES apart; first one lane per candidate: not a hit ->
+// nothing; every token of the window with string id == vector id -> the table's values for
+// all its ranks; the rest one (candidate, rank) at a time by the whole wave.
 __global__ __launch_bounds__(256) void k_matchlev(GramIndexDev g, CorpusDev c,
                                                   const uint32_t* __restrict__ cpos,
-                                                  const uint32_t* __restrict__ cg, NSrc nc_nn,
+                                                  const uint32_t* __restrict__ cg, NSrc nc,
                                                   const uint32_t* __restrict__ levtab,
                                                   uint32_t* __restrict__ mlev, fs_status* st) {
   __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t total = nc_nn.get();
+  const uint32_t total = nc.get();
   const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
   for (uint32_t t0 = 0; (uint64_t)t0 * NWAVES < total; t0 += 64) {
-    const uint64_t il = (uint64_t)(t0 + lane) * NWAVES + gw;
+    const uint64_t cl = (uint64_t)(t0 + lane) * NWAVES + gw;
     bool live = false;
-    if (il < total) {
-      const uint32_t cand = (uint32_t)(il / g.nn), r = (uint32_t)(il % g.nn);
-      const uint32_t gram = cg[cand];
-      live = gram != FS_NONE && r < g.gcnt[gram];
+    if (cl < total) {
+      const uint32_t gram = cg[cl];
+      live = gram != FS_NONE;
       if (live && levtab) {
-        const uint32_t p = cpos[cand];
+        const uint32_t p = cpos[cl];
         bool same = true;
         for (int k = 0; k < g.n; ++k) same = same && c.str[p + k] == c.tok[p + k];
         if (same) {
-          const uint32_t v = levtab[(size_t)gram * g.nn + r];
-          if (v != FS_NONE) { mlev[il] = v; live = false; }
+          const uint32_t m = g.gcnt[gram];
+          bool all = true;
+          for (uint32_t r = 0; r < m; ++r) all = all && levtab[(size_t)gram * g.nn + r] != FS_NONE;
+          if (all) {
+            for (uint32_t r = 0; r < m; ++r) mlev[cl * g.nn + r] = levtab[(size_t)gram * g.nn + r];
+            live = false;
+          }
         }
       }
     }
     uint64_t todo = __ballot(live);
     while (todo) {
-      const uint32_t i = (t0 + (uint32_t)(__ffsll((unsigned long long)todo) - 1)) * NWAVES + gw;
+      const uint32_t cand = (t0 + (uint32_t)(__ffsll((unsigned long long)todo) - 1)) * NWAVES + gw;
       todo &= todo - 1;
-      const uint32_t cand = i / g.nn, r = i % g.nn;
-      const uint32_t s = g.gpos[(size_t)cg[cand] * g.nn + r];
-      const uint32_t v = lev_wave(g, s, c.str + cpos[cand], c.chars, c.coff, c.n_str, st, s_a[wave],
-                                  s_b[wave]);
-      if (lane == 0) mlev[i] = v;
-      __builtin_amdgcn_wave_barrier();
+      const uint32_t gram = cg[cand], m = g.gcnt[gram], p = cpos[cand];
+      for (uint32_t r = 0; r < m; ++r) {                 // wave-uniform
+        const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
+        const uint32_t v = lev_wave(g, s, c.str + p, c.chars, c.coff, c.n_str, st, s_a[wave], s_b[wave]);
+        if (lane == 0) mlev[(size_t)cand * g.nn + r] = v;
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
 }
@@ -889,7 +894,6 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
   const CorpusDev cd = c->dev();
   fs_status* st = ix->cur->d_status.p;
   uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
-  const uint32_t nn = ix->cfg.nearest_n;
   const bool per_cand = c->has_str;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
   if (scan.direct) {
@@ -908,9 +912,8 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
                          ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
   }
   if (per_cand) {
-    const NSrc nc_nn{&st->n_cands, nn, ccap, 0};
     hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->cur->w_cpos.p,
-                       ix->cur->w_cg.p, nc_nn,
+                       ix->cur->w_cg.p, nc,
                        c->levtab_ready && ix->sw.str_levtab ? (const uint32_t*)c->d_levtab.p : nullptr,
                        ix->cur->w_mlev.p, st);
     hipLaunchKernelGGL(k_cbest, dim3(kNB), dim3(kThreads), 0, s, g, ix->cur->w_cg.p, ix->cur->w_mlev.p, nc,
