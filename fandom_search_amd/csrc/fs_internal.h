@@ -86,7 +86,7 @@ struct fs_status {
   uint32_t max_recs;     // direct path: largest record count of a wave range beyond its capacity
   uint32_t lev_overflow; // a Levenshtein operand exceeded FS_LEV_MAX
   uint32_t bad_string;   // string id outside the string table
-  uint32_t max_rows;     // k_ranges: largest record count of a wave range beyond its staging capacity
+  uint32_t max_rows;     // k_scan_rows: largest record count of a wave range beyond its staging capacity
 };
 
 // what one hit offers to the fan words of its window (first-minimum rank)
@@ -228,7 +228,7 @@ struct fs_index {
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
-    DBuf<uint8_t> w_stage;         // k_ranges / k_scan_rows: staged records, caprow per wave range
+    DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range
     uint32_t caprow_hint = 0;      //   staged records per wave range the last searches needed
     DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup
     DBuf<uint4> w_bstat;           //   {hits, pairs, candidates, max records of a range} per workgroup

@@ -252,7 +252,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
 }
 
 // ---- records into place inside the launch ------------------------------------------
-// Workgroup b of k_ranges / k_scan_rows holds the wave ranges [b * waves, (b + 1) * waves).
+// Workgroup b of k_scan_rows holds the wave ranges [b * waves, (b + 1) * waves).
 // When its waves are done it stores its statistics (write-through), then publishes its
 // record count as one 8-byte granule {epoch, count} (the data is the flag; epoch = launch
 // number of the lane, so nothing is cleared between launches), sums the granules of the

@@ -1,30 +1,29 @@
-// fs_scan.hip -- the n-gram scan kernel (the HBM-bound hot loop).
+// fs_scan.hip -- the kernels that read the fan token ids (the HBM-bound hot loop).
 //
 // Replaces, for corpora whose vector table admits the exact-n-gram proof
 // (DESIGN.md), the per-window engine.neighbours() call of the reference
 // (/root/reference/search.py:176-178): every fan window's n vector ids are
-// hashed and tested against the script's n-gram set.
+// tested against the script's n-gram set.
 //
-// Two kernels.  k_scan8 (n <= 8, ids up to 256 MiB: the benchmark's case), per wave and
-// 512-token sub-tile:
-//   * two coalesced global_load_dwordx4 per lane: tokens [8L, 8L+8)
-//   * the n-1 halo tokens come from lane L+1 by ds_bpermute (no second global read);
-//     the wrap into the next sub-tile is folded into the same permute by letting
-//     lane 0 publish the next sub-tile's first tokens
-//   * per window: sliding fold of premixed ids, one ds_read_b32 of the LDS-resident
-//     blocked Bloom filter, three-bit test; a lane's eight answers are one byte
-//   * direct path: a lane whose byte is not zero appends one 8-byte record to the
-//     list of its wave range (see the comment at k_scan8); the workgroup writes the
-//     candidate counts of its four chunks.  Bitmap path (FS_SCAN_DIRECT=0): the 64
-//     bytes of a sub-tile go out in natural order with the sub-tile's count.
-// k_scan (other n, larger corpora): four tokens per lane, 256-token sub-tiles, four
-// __ballot words per sub-tile (bit L of word j <-> window 256 i + 4 L + j) and the
-// sub-tile's popcount; counting and expansion are left to k_reduce / k_expand.
-// No global atomics, no inter-workgroup traffic, the output position is a function of
-// the token position, so the result is deterministic; exact verification happens
-// downstream on the (rare) flagged windows.  Algorithmic HBM traffic: 4 B read per
-// token; written: 8 B per lane with candidates (direct), 68 B per 512 tokens or 36 B
-// per 256 tokens (bitmap forms).
+// k_scan_rows (n = 2..8, string id == vector id: the benchmark's case) is the whole
+// search in one kernel, token ids in, output records out; the comment in front of it and
+// fs_ranges.h describe it.  Per wave and 512-token sub-tile its scan does
+//   * two coalesced global_load_dwordx4 per lane: tokens [8L, 8L+8), requested a pair of
+//     sub-tiles ahead
+//   * the n-1 halo tokens from lane L+1 by ds_bpermute (no second global read)
+//   * per token one ds_read_b32 of the LDS-resident filter of script K-grams; a window is
+//     a candidate when its n-K+1 K-grams are all script K-grams (n <= 3: the three-bit
+//     Bloom test of the whole n-gram); a lane's eight answers are one byte
+// and candidates are verified, turned into records and put into place by the same wave.
+//
+// The kernels of round 1 remain for batches with string ids, n >= 9 and as the fallback:
+// k_scan8 (same loop, Bloom test, candidate records or byte bitmap out), k_scan (four
+// tokens per lane, four __ballot words per 256 tokens), k_scan_simple (any n, cross-check);
+// counting, expansion and verification are then left to fs_post.hip.  k_scan_near is the
+// integer prefilter of the LSH pipeline (script 3-grams, at most one differing slot).
+// No global atomics on the data path; a record's bytes and place are functions of token
+// positions, so the result is deterministic.  Algorithmic HBM traffic: 4 B read per
+// token + 32 B per record written.
 #include "fs_internal.h"
 #include "fs_device.h"
 #include "fs_ranges.h"
