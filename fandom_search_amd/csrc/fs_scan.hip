@@ -579,7 +579,6 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_cnt[6 * 16 + 2];
-  __shared__ uint8_t s_kth[256 * 8];            // [flag byte][k] -> position of its k-th set bit
   uint32_t* s_filter = s_dyn;
   // displacement seeds of the exact table as bytes behind the filter (disp_lds bytes, a
   // multiple of 16; 0: too many, read from memory)
@@ -632,16 +631,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     asm volatile("" : "+v"(v.a0), "+v"(v.a1), "+v"(v.b0), "+v"(v.b1), "+v"(v.h0), "+v"(v.h1));
     return v;
   };
-  for (uint32_t e = threadIdx.x; e < disp_lds / 4; e += blockDim.x)
-    s_dyn[(1u << lw) + e] = reinterpret_cast<const uint32_t*>(g.disp8)[e];
+  for (uint32_t e = threadIdx.x; e < disp_lds / 16; e += blockDim.x)     // (a multiple of 16 bytes)
+    reinterpret_cast<uint4*>(s_dyn + (1u << lw))[e] = reinterpret_cast<const uint4*>(g.disp8)[e];
   copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
-  for (uint32_t e = threadIdx.x; e < 256 * 8; e += blockDim.x) {
-    uint32_t f = e >> 3, pos = 0;
-    for (uint32_t k = e & 7; f; f &= f - 1) {
-      if (k-- == 0) { pos = (uint32_t)__ffs(f) - 1; break; }
-    }
-    s_kth[e] = (uint8_t)pos;
-  }
   __syncthreads();
   RangeState R;
   R.E = 0; R.hc = 0; R.rows_run = 0; R.hits_run = 0; R.match_acc = 0;
@@ -726,7 +718,10 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
               t = v <= ci ? t + step : t;
             }
             const uint32_t rec = W.rec[t];
-            p = a + ((rec >> 8) << 3) + s_kth[((rec & 0xFFu) << 3) + (ci - W.rk[t])];
+            // its k-th candidate: the k-th set bit of the flag byte (mostly the first)
+            uint32_t fb = rec & 0xFFu;
+            for (uint32_t k = ci - W.rk[t]; k > 0; --k) fb &= fb - 1;
+            p = a + ((rec >> 8) << 3) + ((uint32_t)__ffs(fb) - 1u);
           }
         }
         uint32_t F = F_end;
@@ -1048,8 +1043,8 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
   if (sw.scan_simple || sw.scan_tpl == 4 || sw.scan_unroll || sw.scan_halo_loads || !sw.scan_direct ||
       sw.scan_capw)
     return 0;
-  // (3 KB: the kernel's static LDS, s_kth and s_cnt)
-  const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 3072;
+  // (1 KB: the kernel's static LDS, s_cnt)
+  const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 1024;
   const size_t cu_lds = 160 * 1024;
   if (sw.rows_waves) {
     *blocks = (uint32_t)ix->num_cu * (uint32_t)std::max(1, sw.rows_blocks_per_cu);
