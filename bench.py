@@ -325,7 +325,8 @@ def main():
         total_works = n_works * world
         first_work = rank * n_works
     shard_bytes = 4 * n_works * tpw
-    rotate = args.rotate or (min(4, -(-(MALL_BYTES + 1) // shard_bytes)) if world == 1 else 1)
+    # distinct batches in rotation: as many as it takes to exceed the Infinity Cache (at most 4)
+    rotate = args.rotate or min(4, -(-(MALL_BYTES + 1) // shard_bytes))
     rotate = max(1, rotate)
     words = synth.vocab_words()
     emb = synth.embedding()
