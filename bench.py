@@ -511,6 +511,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
+            # works differ in length between the workloads (c2: 2000 tokens, c3: 5000), so the
+            # rate in tokens is what compares an N = 1 line (c2) with an N > 1 line (c3)
+            "tokens_per_s": total_works * tpw * args.steps / dt,
             "config": {"workload": ("%s: %d works x %d tokens split over %d GPU(s) (%d works, %.0f MB of ids "
                                     "per GPU) vs %d-token script, %d-gram"
                                     % (wl, total_works, tpw, world, n_works, shard_bytes / 1e6,
