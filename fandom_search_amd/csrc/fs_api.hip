@@ -741,11 +741,13 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   // search queued before it, so that what overlaps is a scan with the other lane's chain.
   // Off by default: with k_scan_rows the GPU's own ordering measured faster (32 against
   // 41 us per C2 step).
+  bool end_attached = false;           // sl.ev_end rides on the last dispatch (no marker of its own)
   const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && ix->sw.stagger;
   if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact && sl.fused_waves) {
+    // (the whole-search timing of the synchronous call keeps its own end marker)
     FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, sl.fused_blocks, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,
-                               e0, e1, count_out));
+                               e0, e1, count_out, whole ? nullptr : sl.ev_end, &end_attached));
     if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
   } else if (sl.exact) {
     fs_scan_extra ex;
@@ -768,7 +770,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   }
   ++sl.launches;
   if (ix->n_lanes == 2) ix->last_scan_ev = sl.ev_scan_done;
-  FS_HIP(hipEventRecord(sl.ev_end, s));
+  if (!end_attached) FS_HIP(hipEventRecord(sl.ev_end, s));
   ix->cur = &ix->lanes[0];
   return FS_OK;
 }

@@ -367,11 +367,13 @@ namespace fsdev { struct RowSync; }
 int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
 int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
                                       int rec_bytes, uint32_t rcap, fs_row* d_rows,
-                                      fs_status* host_st, hipStream_t s, uint64_t* count_out);
+                                      fs_status* host_st, hipStream_t s, uint64_t* count_out,
+                                      hipEvent_t done);
 uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* blocks);   // waves per workgroup, 0: does not apply
 int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blocks, uint32_t rcap, fs_row* d_rows,
                         int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
-                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out);
+                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out, hipEvent_t done = nullptr,
+                        bool* done_attached = nullptr);
 
 int fs_launch_rownorms(const float* emb, uint64_t n_vec, int D, double* q, hipStream_t s);
 int fs_launch_selfdist(const uint32_t* stok, uint64_t n_windows, int n, int D,

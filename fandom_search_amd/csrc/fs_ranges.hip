@@ -7,6 +7,8 @@
 //   fs_row_sync the lane's hand-off words of one launch
 #include "fs_ranges.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 
 namespace {
@@ -184,14 +186,15 @@ int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 // (the finish of a search on an index with several lanes)
 static int launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, uint32_t caprow,
                           int rec_bytes, uint32_t rcap, fs_row* d_rows, fs_status* host_st,
-                          hipStream_t s, uint64_t* count_out, bool fresh) {
+                          hipStream_t s, uint64_t* count_out, bool fresh, hipEvent_t done = nullptr) {
   fs_index::Lane& ln = *ix->cur;
   if (n_ranges % kCompactRanges || kCompactRanges % csum_per) {
     fs_set_error("k_compact: %u ranges, %u per block sum", n_ranges, csum_per);
     return FS_E_INVALID;
   }
-  hipLaunchKernelGGL(k_compact, dim3(n_ranges / kCompactRanges + 1), dim3(kThreads), 0, s,
-                     ln.w_rinfo.p, ln.w_csum.p,
+  // (`done`: the search's completion event rides on this dispatch instead of a marker of its own)
+  hipExtLaunchKernelGGL(k_compact, dim3(n_ranges / kCompactRanges + 1), dim3(kThreads), 0, s,
+                     nullptr, done, 0u, ln.w_rinfo.p, ln.w_csum.p,
                      reinterpret_cast<const uint32_t*>(ln.w_csum.p + n_ranges / csum_per), csum_per,
                      n_ranges, (const uint32_t*)nullptr, 0u, fresh, ln.w_stage.p, caprow, rec_bytes,
                      rcap, reinterpret_cast<uint8_t*>(d_rows), ln.d_status.p, host_st, count_out);
@@ -232,6 +235,8 @@ int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy) {
 
 int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
                                       int rec_bytes, uint32_t rcap, fs_row* d_rows,
-                                      fs_status* host_st, hipStream_t s, uint64_t* count_out) {
-  return launch_compact(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st, s, count_out, true);
+                                      fs_status* host_st, hipStream_t s, uint64_t* count_out,
+                                      hipEvent_t done) {
+  return launch_compact(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st, s, count_out, true,
+                        done);
 }

@@ -1062,7 +1062,8 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
 // tokens -> output records: one launch of fs_scan_rows_blocks() workgroups of `waves` wave ranges
 int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blocks, uint32_t rcap, fs_row* d_rows,
                         int wire, uint32_t caprow, fs_status* host_st, hipStream_t s,
-                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out) {
+                        hipEvent_t e0, hipEvent_t e1, uint64_t* count_out, hipEvent_t done,
+                        bool* done_attached) {
   fs_index::Lane& ln = *ix->cur;
   const uint32_t n_ranges = blocks * waves;
   const int rec_bytes = wire ? wire : 32;
@@ -1071,6 +1072,10 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
   const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
   fsdev::RowSync sy;
   FS_TRY(fs_row_sync(ix, blocks, &sy));
+  // `done` (the search's completion event) rides on the search's last dispatch when that
+  // dispatch has a free stop-event slot: k_compact, or this kernel when it is not timed
+  if (done_attached) *done_attached = false;
+  if (done && !sy.rinfo && !e1) { e1 = done; if (done_attached) *done_attached = true; }
   const fsdev::RowFinal fin{reinterpret_cast<uint8_t*>(d_rows), rcap, ln.d_status.p, host_st, count_out, true};
   switch (ix->cfg.window_size) {
     case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
@@ -1082,9 +1087,11 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
     case 8: FS_TRY(launch_scan_rows<8>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
     default: fs_set_error("k_scan_rows covers n = 2..8"); return FS_E_UNSUPPORTED;
   }
-  if (sy.rinfo)
+  if (sy.rinfo) {
+    if (done_attached) *done_attached = done != nullptr;
     return fs_launch_compact_after_scan_rows(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st,
-                                             s, count_out);
+                                             s, count_out, done);
+  }
   return FS_OK;
 }
 
