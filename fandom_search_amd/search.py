@@ -273,17 +273,13 @@ class AnnIndexSearch(object):
     def _corpus_of(self, texts):
         """(string ids, vector ids, work offsets, device corpus) of tokenised works."""
         v = self.vocab
-        sid_parts, vid_parts = [], []
         off = np.zeros(len(texts) + 1, dtype=np.uint64)
-        for i, toks in enumerate(texts):
-            sids, vids = v.encode(toks)
-            sid_parts.append(sids)
-            vid_parts.append(vids)
-            off[i + 1] = off[i] + np.uint64(len(toks))
-        tok_str = np.concatenate(sid_parts) if sid_parts else \
-            np.zeros(0, np.uint32)
-        tok_vec = np.concatenate(vid_parts) if vid_parts else \
-            np.zeros(0, np.uint32)
+        if texts:
+            off[1:] = np.cumsum([len(toks) for toks in texts], dtype=np.uint64)
+        # one pass over the whole batch: the vocabulary is consulted once per distinct
+        # string of the batch, not once per work
+        flat = [t for toks in texts for t in toks]
+        tok_str, tok_vec = v.encode(flat)
         chars, coff = v.string_table()
         self.last_oov_rate = float((tok_vec & np.uint32(abi.FS_OOV_FLAG)).astype(bool).mean()) \
             if len(tok_vec) else 0.0
