@@ -6,6 +6,7 @@ import of anything that needs it fails with a clear error.
 
 import ctypes as C
 import os
+import sys
 import subprocess
 
 from . import abi
@@ -31,6 +32,9 @@ class FsError(RuntimeError):
         if detail:
             msg += " (%s)" % detail
         RuntimeError.__init__(self, msg)
+
+
+PRELOAD_TORCH = True    # see load()
 
 
 def lib_path():
@@ -64,10 +68,13 @@ def load():
     # DT_NEEDED libamdhip64.so.7 as well; loaded second, it would come in as a second
     # runtime next to /opt/rocm's (two sets of queues and contexts, and torch can then
     # fail with "No HIP GPUs are available" late in a long process).
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    # PRELOAD_TORCH = False (the single-process command line, which never imports torch:
+    # its start-up costs a second) loads the library against /opt/rocm's runtime alone.
+    if PRELOAD_TORCH or "torch" in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(path)
     u32p, u64p = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
     L.fs_version.restype = C.c_int

@@ -52,6 +52,9 @@ def init_from_env(backend=None):
 def finalize():
     """Leave together: a rank that exits while others still use the group takes the
     collective backend's threads down mid-flight."""
+    import sys
+    if "torch.distributed" not in sys.modules:     # never initialised in this process
+        return
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
