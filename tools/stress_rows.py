@@ -21,6 +21,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=60)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--strings", action="store_true",
+                    help="batches with string ids of their own (a random share of the tokens capitalised): "
+                         "the per-gram Levenshtein table of k_matchlev against FS_STR_LEVTAB=0")
     a = ap.parse_args()
     import torch
     from fandom_search_amd import abi, synth
@@ -57,18 +60,27 @@ def main():
         tok = np.concatenate(parts).astype(np.uint32) if n_works else np.zeros(0, np.uint32)
         lanes = int(rng.choice([1, 4]))
         caprow = int(rng.choice([0, 0, 2, 16]))
+        tok_str = None
+        if a.strings:
+            strings = list(words) + [w.capitalize() for w in words]
+            chars, coff = pack_strings(strings)
+            share = float(rng.choice([0.0, 0.02, 0.2, 0.9]))
+            tok_str = tok.copy()
+            tok_str[rng.random(len(tok)) < share] += np.uint32(len(words))
         cfg = abi.make_config(window_size=n)
         normals = synth.lsh_normals(n)
         results = []
         for rows_kernel in (1, 0):
             os.environ["FS_SCAN_ROWS"] = str(rows_kernel)
+            if a.strings:
+                os.environ["FS_STR_LEVTAB"] = str(rows_kernel)
             os.environ["FS_LANES"] = str(lanes)
             if caprow and rows_kernel:
                 os.environ["FS_RANGES_CAPROW"] = str(caprow)
             else:
                 os.environ.pop("FS_RANGES_CAPROW", None)
             ix = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=cfg)
-            c = ix.corpus(tok, off, chars, coff)
+            c = ix.corpus(tok, off, chars, coff, tok_str=tok_str)
             rows, st = ix.search(c)
             name = ix.kernel_name(c)
             results.append((rows.tobytes(), int(st.matches), int(st.windows_processed), name))
