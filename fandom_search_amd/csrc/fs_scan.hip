@@ -596,7 +596,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t s0 = range_id * per + (range_id < rem ? range_id : rem);
   const uint32_t s1 = s0 + per + (range_id < rem ? 1u : 0u);
 
-  constexpr uint32_t HALO = N - 1, RS = 64 - HALO;
+  constexpr uint32_t HALO = N - 1;
   constexpr uint32_t SUB = 512;
   const int word_shift = 32 - lw;
   const int src_lane = (lane + 1) & 63;
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       uint32_t r0 = 0;
       do {
         // candidate r0 + lane: a halo window, or bit k of the last record with at most
-        // that many candidates in front of it (lane RS: the next round's first)
+        // that many candidates in front of it (the lane behind the round's last: the next round's first)
         const uint32_t ci = r0 + lane;
         uint32_t p = FS_NONE;
         if (ci < total) {
@@ -724,14 +724,17 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
             p = a + ((rec >> 8) << 3) + ((uint32_t)__ffs(fb) - 1u);
           }
         }
+        // this round takes as many candidates as there are hit slots behind the carried
+        // hits (64 in all, one per lane), at most 63: the lane behind them looks ahead
+        const uint32_t take = R.hc ? 64u - R.hc : 63u;
         uint32_t F = F_end;
-        if (r0 + RS < total) {
-          const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)p, RS);
+        if (r0 + take < total) {
+          const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)take);
           if (nx < F) F = nx;
         }
         if (!(diag & 1))
-          range_round<N>(c, g, disp_off, S, (uint32_t)lane < RS ? p : FS_NONE, F, a, range_id, out, R);
-        r0 += RS;
+          range_round<N>(c, g, disp_off, S, (uint32_t)lane < take ? p : FS_NONE, F, a, range_id, out, R);
+        r0 += take;
       } while (r0 < total);
       rec_cnt = 0;
       halo_n = 0;
