@@ -586,7 +586,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t disp_off = disp_lds ? 4u << lw : FS_NO_LDS;
   FusedLds* s_wave = reinterpret_cast<FusedLds*>(s_dyn + (1u << lw) + disp_lds / 4);
   const int lane = threadIdx.x & 63;
-  const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  // (the wave index as a scalar: what follows from it -- range, sub-tile numbers, the halo address --
+  // then lives in scalar registers and is loaded by scalar loads)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
   const uint32_t range_id = blockIdx.x * n_waves + wave;
