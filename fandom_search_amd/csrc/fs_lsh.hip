@@ -434,7 +434,7 @@ __global__ void k_ss(const uint32_t* __restrict__ stok, uint32_t W, LshDev L,
 __global__ __launch_bounds__(256) void k_keys(LshDev L, const uint32_t* __restrict__ tok,
                                               uint32_t n_windows, uint32_t* __restrict__ keys) {
   __shared__ uint64_t s_bal[4][32];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int NW = (L.C + 63) >> 6;
   for (uint32_t w = blockIdx.x * 4 + wave; w < n_windows; w += gridDim.x * 4) {
     for (int ch = 0; ch < NW; ++ch) {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void k_selflev(GramIndexDev g, CorpusDev c, ui
   __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];
   __shared__ uint32_t s_ids[4][FS_MAX_WINDOW];
   __shared__ fs_status s_st[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   for (uint32_t w = blockIdx.x * 4 + wave; w < W; w += gridDim.x * 4) {
     if (lane < g.n) s_ids[wave][lane] = g.stok[w + lane];
     if (lane == 0) { s_st[wave].bad_string = 0; s_st[wave].lev_overflow = 0; }
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
   __shared__ uint32_t s_flag[256];
   __shared__ uint32_t s_cnt[4];
   __shared__ float s_bound[256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int n = L.n;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
     const uint64_t p0 = (uint64_t)sub * 256;
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
   __shared__ int s_n[4];
   __shared__ uint32_t s_w32[4];
   __shared__ uint32_t s_pre[4][64], s_e0[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t total = nc.get();
   const int NW = (L.C + 63) >> 6;
   uint32_t matches = 0;

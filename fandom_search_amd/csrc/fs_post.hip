@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void k_levtab(GramIndexDev g, CorpusDev c,
                                                 bool tolerant) {
   __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
   __shared__ fs_status s_st[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t total = g.n_grams * (uint32_t)g.nn;
   for (uint32_t i = blockIdx.x * 4 + wave; i < total; i += gridDim.x * 4) {
     const uint32_t gram = i / g.nn, r = i % g.nn;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_matchlev(GramIndexDev g, CorpusDev c,
                                                   const uint32_t* __restrict__ levtab,
                                                   uint32_t* __restrict__ mlev, fs_status* st) {
   __shared__ uint32_t s_a[4][FS_LEV_MAX + 2], s_b[4][FS_LEV_MAX + 2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t total = nc.get();
   const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
   for (uint32_t t0 = 0; (uint64_t)t0 * NWAVES < total; t0 += 64) {
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void k_corpus_check(const uint32_t* __restrict
     oov |= __shfl_xor(oov, d);
   }
   __shared__ uint32_t s_m[3][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (lane == 0) { s_m[0][wave] = max_row; s_m[1][wave] = oov; s_m[2][wave] = max_str; }
   __syncthreads();
   if (threadIdx.x == 0) {
