@@ -585,20 +585,23 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
                                                   uint32_t* __restrict__ qcnt, uint32_t n_sub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const int NW = (L.C + 63) >> 6;                    // ballot words per window
-  uint64_t* s_bal = reinterpret_cast<uint64_t*>(s_raw);                 // [256][NW + 1]
-  uint32_t* s_key = reinterpret_cast<uint32_t*>(s_bal + 256 * (NW + 1));   // [256][H]
+  // (LDS is what bounds this kernel's occupancy: 40 KB per workgroup, four per CU.  The
+  // ballot words are dead once the keys are assembled and then hold the phase-2 arrays
+  // s_ff and s_flag; s_bound, phase 1 only, lies where phase 2 keeps its pair offsets.)
+  uint64_t* s_bal = reinterpret_cast<uint64_t*>(s_raw);                 // [256][NW]
+  const int bal_words = 256 * NW > 384 ? 256 * NW : 384;                // (room for s_ff + s_flag)
+  uint32_t* s_key = reinterpret_cast<uint32_t*>(s_bal + bal_words);     // [256][H]
   uint32_t* s_tok = s_key + 256 * L.H;                                  // [256 + 16]
   uint32_t* s_pref = s_tok + 256 + 16;                                  // [256 * H + 1] pair offsets
-  double* s_ff = reinterpret_cast<double*>(s_pref + ((256 * L.H + 2) & ~1));   // [256]
-  __shared__ uint32_t s_flag[256];
+  double* s_ff = reinterpret_cast<double*>(s_bal);                      // [256]  (phase 2)
+  uint32_t* s_flag = reinterpret_cast<uint32_t*>(s_bal + 256);          // [256]  (phase 2)
+  float* s_bound = reinterpret_cast<float*>(s_pref);                    // [256]  (phase 1)
   __shared__ uint32_t s_cnt[4];
-  __shared__ float s_bound[256];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int n = L.n;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
     const uint64_t p0 = (uint64_t)sub * 256;
     for (int i = threadIdx.x; i < 256 + n - 1; i += 256) s_tok[i] = c.tok[p0 + i];
-    for (int i = threadIdx.x; i < 256; i += 256) s_bal[i * (NW + 1) + NW] = 0;
     __syncthreads();
     {
       // per window: the float32 decision bound, or -1 when the window needs float64
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
     // of the n table entries to float32 plus n-1 float32 additions; the float64
     // additions contribute 2^-53 terms).  A window with any column inside twice
     // that distance, or with an out-of-vocabulary token, is redone in float64.
-    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bal);           // [256][2 (NW + 1)]
+    uint32_t* s_bits = reinterpret_cast<uint32_t*>(s_bal);           // [256][2 NW]
     for (int c0 = 0; c0 < L.C && L.diag != 2; c0 += 256) {
       const int col = c0 + 4 * lane;
       const int left = L.C - col;                                    // columns this lane owns
@@ -680,14 +683,14 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
           x |= (uint32_t)__shfl_down((int)x, 1) << 4;
           x |= (uint32_t)__shfl_down((int)x, 2) << 8;
           x |= (uint32_t)__shfl_down((int)x, 4) << 16;
-          if (store) s_bits[(size_t)(w0 + u) * 2 * (NW + 1) + (c0 >> 5) + (lane >> 3)] = x;
+          if (store) s_bits[(size_t)(w0 + u) * 2 * NW + (c0 >> 5) + (lane >> 3)] = x;
         }
       }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256 * L.H; i += 256) {
       const int w = i / L.H, h = i - w * L.H;
-      s_key[i] = assemble_key(s_bal + w * (NW + 1), h, L.B);
+      s_key[i] = assemble_key(s_bal + w * NW, h, L.B);
     }
     __syncthreads();
     // phase 2: "is any bucket candidate of the window within the threshold?"  The 256 x H
@@ -1129,11 +1132,11 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   if (!n_sub) return FS_OK;
   const LshDev L = lsh_dev(ix);
   const int NW = (L.C + 63) >> 6;
-  const size_t lds = (size_t)256 * (NW + 1) * 8 + (size_t)256 * L.H * 4 + (256 + 16) * 4 +
-                     ((size_t)256 * L.H + 2) * 4 + 256 * 8;
+  const size_t lds = std::max<size_t>((size_t)256 * NW, 384) * 8 + (size_t)256 * L.H * 4 +
+                     (256 + 16) * 4 + ((size_t)256 * L.H + 2) * 4;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsh_scan),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+  const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 64)));
   const uint32_t blocks = std::min<uint32_t>(n_sub, ix->num_cu * per_cu);
   hipExtLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), (uint32_t)lds, s, e0, e1, 0u, c, L, qbm,
                         qcnt, n_sub);
