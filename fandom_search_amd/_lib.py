@@ -22,7 +22,7 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_host_alloc", "fs_host_free", "fs_rows_unpack", "fs_rows_unpack8",
            "fs_reuse_histogram", "fs_reuse_histogram_rows",
            "fs_search_corpus_begin", "fs_search_corpus_end", "fs_index_set_scan_timing",
-           "fs_index_reload_switches", "fs_search_kernel_name")
+           "fs_index_reload_switches", "fs_search_kernel_name", "fs_debug_stamps")
 
 
 class FsError(RuntimeError):
@@ -134,6 +134,8 @@ def load():
     L.fs_search_kernel_name.argtypes = [C.c_void_p, C.c_void_p]
     L.fs_index_reload_switches.restype = C.c_int
     L.fs_index_reload_switches.argtypes = [C.c_void_p]
+    L.fs_debug_stamps.restype = C.c_int
+    L.fs_debug_stamps.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_uint64, u64p]
     L.fs_scan_benchmark.restype = C.c_int
     L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.POINTER(C.c_double)]

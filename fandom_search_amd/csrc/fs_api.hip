@@ -969,6 +969,19 @@ extern "C" int fs_search(fs_index* ix, const uint32_t* tok_vec, const uint32_t* 
   return rc;
 }
 
+// Diagnostics (FS_DIAG & 2): the timeline stamps the last k_scan_rows launch of lane
+// `lane` left behind, eight words per wave range (fs_scan.hip).
+extern "C" int fs_debug_stamps(fs_index* ix, uint32_t lane, uint64_t* out, uint64_t cap, uint64_t* n) {
+  if (!ix || !n || lane >= FS_LANES) return FS_E_INVALID;
+  FS_ENTER(ix->device);
+  fs_index::Lane& ln = ix->lanes[lane];
+  FS_HIP(hipStreamSynchronize(ln.stream));
+  *n = ln.dbg_words;
+  if (!out || cap < ln.dbg_words || !ln.dbg_words) return ln.dbg_words && out ? FS_E_CAPACITY : FS_OK;
+  FS_HIP(hipMemcpy(out, ln.w_dbg.p, ln.dbg_words * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return FS_OK;
+}
+
 extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms) {
   if (!ix || !c || c->ix != ix || !avg_ms || reps == 0) return FS_E_INVALID;
   FS_ENTER(ix->device);

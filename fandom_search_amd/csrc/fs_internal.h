@@ -238,6 +238,8 @@ struct fs_index {
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
     DBuf<fs_row> w_rows;
     DBuf<fs_status> d_status;
+    DBuf<unsigned long long> w_dbg;    // FS_DIAG & 2: timeline stamps of the last k_scan_rows launch
+    size_t dbg_words = 0;
   };
   Lane lanes[FS_LANES];
   Lane* cur = &lanes[0];

@@ -574,9 +574,15 @@ template <int N, int K, bool NT, bool LW14>
 __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     uint32_t n_sub, fsdev::RangeOut out,
                                                     fsdev::RowSync sy, fsdev::RowFinal fin,
-                                                    uint32_t disp_lds, uint32_t diag) {
+                                                    uint32_t disp_lds, uint32_t diag,
+                                                    unsigned long long* __restrict__ dbg) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
+  // FS_DIAG & 2: eight words per wave range {entry, filter in LDS, scan done, rounds done,
+  // finished, rounds, flushes, -} in ticks of the 100 MHz constant clock (tools/scan_timeline.py)
+  unsigned long long t_entry = 0, t_ready = 0, t_scan = 0, t_rounds = 0;
+  uint32_t n_rounds = 0, n_flushes = 0;
+  if (dbg) t_entry = __builtin_amdgcn_s_memrealtime();
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   __shared__ uint32_t s_cnt[6 * 16 + 2];
   uint32_t* s_filter = s_dyn;
@@ -637,6 +643,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     reinterpret_cast<uint4*>(s_dyn + (1u << lw))[e] = reinterpret_cast<const uint4*>(g.disp8)[e];
   copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
   __syncthreads();
+  if (dbg) t_ready = __builtin_amdgcn_s_memrealtime();
   RangeState R;
   R.E = 0; R.hc = 0; R.rows_run = 0; R.hits_run = 0; R.match_acc = 0;
   uint32_t cacc = 0;                           // per lane: candidates seen
@@ -684,6 +691,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     };
     // records queued so far -> rounds of candidates; F_end = the scan front
     auto flush = [&](uint32_t F_end) {
+      if (diag & 4) __builtin_amdgcn_s_setprio(0);
       wave_sync();
       // candidates in front of every queued record (lane t: records t and t + 64)
       const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
@@ -737,23 +745,40 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
         if (!(diag & 1))
           range_round<N>(c, g, disp_off, S, (uint32_t)lane < take ? p : FS_NONE, F, a, range_id, out, R);
         r0 += take;
+        ++n_rounds;
       } while (r0 < total);
       rec_cnt = 0;
       halo_n = 0;
+      ++n_flushes;
+      if (diag & 4) __builtin_amdgcn_s_setprio(2);
     };
     const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
     Pair nx = request(s0);
+    if (diag & 4) __builtin_amdgcn_s_setprio(2);     // scanning waves go first, rounds fill the gaps
     for (uint32_t j = s0; j < s1; j += 2) {
+      if (diag & 8) {
+        // the four waves of a SIMD (wave slots w, w + 4, w + 8, w + 12 in age order) take turns at
+        // the top priority, one pair of sub-tiles each: left alone, the SIMD serves the oldest
+        // wave first and the youngest takes 60 % longer over the same number of sub-tiles
+        switch ((((j - s0) >> 1) + (wave >> 2)) & 3u) {
+          case 0: __builtin_amdgcn_s_setprio(3); break;
+          case 1: __builtin_amdgcn_s_setprio(2); break;
+          case 2: __builtin_amdgcn_s_setprio(1); break;
+          default: __builtin_amdgcn_s_setprio(0); break;
+        }
+      }
       const Pair v = arrive(nx);
       nx = request(j + 2 < s1 ? j + 2 : j);
       scan(v.a0, v.a1, v.b0, v.b1, j);
       // (a queue of kRecQueue records: at most 64 more come from one sub-tile)
       const bool odd_end = j + 1 == s1;
+      if (dbg && odd_end) t_scan = __builtin_amdgcn_s_memrealtime();
       if (odd_end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt > kRecQueue - 64)
         flush(odd_end ? bnd : j * SUB + SUB);
       if (odd_end) break;
       scan(v.b0, v.b1, v.h0, v.h1, j + 1);
       const bool end = j + 2 == s1;
+      if (dbg && end) t_scan = __builtin_amdgcn_s_memrealtime();
       if (end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt >= flush_at) flush(end ? bnd : j * SUB + 2 * SUB);
     }
   }
@@ -762,7 +787,14 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     R.match_acc += (uint32_t)__shfl_xor((int)R.match_acc, d);
     cacc += (uint32_t)__shfl_xor((int)cacc, d);
   }
+  if (diag & 4) __builtin_amdgcn_s_setprio(0);
+  if (dbg) t_rounds = __builtin_amdgcn_s_memrealtime();
   finish_rows(sy, fin, out, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt);
+  if (dbg && lane == 0) {
+    unsigned long long* d = dbg + 8 * (size_t)range_id;
+    d[0] = t_entry; d[1] = t_ready; d[2] = t_scan; d[3] = t_rounds;
+    d[4] = __builtin_amdgcn_s_memrealtime(); d[5] = n_rounds; d[6] = n_flushes; d[7] = R.rows_run;
+  }
 }
 
 // Simple variant for any n <= FS_MAX_WINDOW: every lane reads its ids straight
@@ -1011,6 +1043,12 @@ template <int N>
 int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves, uint32_t blocks,
                      const fsdev::RangeOut& out, const fsdev::RowSync& sy,
                      const fsdev::RowFinal& fin, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  unsigned long long* dbg = nullptr;
+  if (ix->sw.diag & 2) {               // timeline stamps, read back by fs_debug_stamps
+    FS_TRY(ix->cur->w_dbg.reserve((size_t)blocks * waves * 8));
+    dbg = ix->cur->w_dbg.p;
+    ix->cur->dbg_words = (size_t)blocks * waves * 8;
+  }
   const uint32_t disp_lds = fs_scan_rows_disp_lds(ix);
   const int lw = rows_filter_log2(ix);
   const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds);
@@ -1027,7 +1065,7 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), n_sub, out,
-                        sy, fin, disp_lds, (uint32_t)ix->sw.diag);
+                        sy, fin, disp_lds, (uint32_t)ix->sw.diag, dbg);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

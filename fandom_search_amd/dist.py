@@ -6,12 +6,15 @@ works of a batch whose results are concatenated in input order
 (/root/reference/search.py:381-386).  Here the works of a batch are split into
 contiguous ranges, rank r searches range r on its own GPU against a replicated
 script index (built from the same inputs on every rank: no broadcast), and the
-variable-length record buffers are gathered to rank 0 by RowGather: the records stay
-in HBM from the search kernel to the collective (8-byte wire records of the exact
-pipeline, count in a header in front of them, one padded gather: RCCL has no gatherv).
-Rank 0 concatenates in rank order == work order, so the output bytes do not
-depend on the number of GPUs.  `ao3.py search` under torch.distributed.run
-(search.analyze -> search_sharded) and bench.py --gpus N use the same class.
+variable-length record buffers are gathered to rank 0: the records stay in HBM from
+the search kernel to the collective (8-byte wire records of the exact pipeline, one
+padded gather: RCCL has no gatherv).  Rank 0 concatenates in rank order == work
+order, so the output bytes do not depend on the number of GPUs.
+  * `ao3.py search` under torch.distributed.run: search.analyze -> search_sharded,
+    one self-describing payload per rank and batch (records + work offsets + fan
+    words), an 8-byte size/failure agreement and one gather.
+  * bench.py --gpus N: RowGather, fixed device buffers [count header | records]
+    filled by the search kernel itself, one gather per step, overlapped.
 
 Backend: "nccl" (= RCCL over xGMI) when a GPU is present, "gloo" otherwise
 (CPU tests).
@@ -205,30 +208,68 @@ class RowGather(object):
         return parts, cnts
 
 
-def gather_bytes(payload, group=None, dst=0):
-    """Gather one byte string per rank to `dst` (rank order) with tensor collectives:
-    sizes by all_gather, then one padded gather of uint8."""
+SHARD_MAGIC = 0x46535348          # "FSSH"
+SHARD_HDR = 64                    # eight int64: magic, rec_bytes, n_rows, n_works, word bytes, 0, 0, 0
+
+
+def pack_shard(shard, device):
+    """One rank's share of a batch as ONE self-describing byte tensor on `device`:
+    [64-byte header | work offsets (n_works + 1 uint64) | records | fan words joined by
+    '\n' (UTF-8)].  The record format travels in the header, so ranks need not agree on
+    it (a shard with an out-of-vocabulary token carries fs_row records, its neighbour
+    8-byte wire records, an empty one nothing).  The records are sliced out of the
+    search's own buffer: on a GPU they go from the kernel to the collective without
+    visiting the host."""
     import torch
-    import torch.distributed as dist
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return [bytes(payload)]
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    on_gpu = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(sizes, torch.tensor([len(payload)], dtype=torch.int64, device=dev),
-                                group=group)
-    sizes = sizes.cpu().tolist()
-    pad = max(1, max(sizes))
-    send = torch.zeros(pad, dtype=torch.uint8)
-    if payload:
-        send[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
-    send = send.to(dev)
-    recv = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
-    dist.gather(send, recv, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return [recv[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)]
+    words = "\n".join(shard.words).encode("utf-8")
+    off = np.ascontiguousarray(shard.work_off, dtype=np.uint64)
+    hdr = np.zeros(SHARD_HDR // 8, dtype=np.int64)
+    hdr[:5] = (SHARD_MAGIC, shard.rec_bytes, shard.n_rows, len(off) - 1, len(words))
+    head = np.concatenate([hdr.view(np.uint8), off.view(np.uint8),
+                           np.zeros((-off.nbytes) % 16, dtype=np.uint8)])   # records 16-byte aligned
+    n = shard.n_rows * shard.rec_bytes
+    parts = [torch.from_numpy(head).to(device), shard.buf[HDR:HDR + n].to(device)]
+    if words:
+        parts.append(torch.frombuffer(bytearray(words), dtype=torch.uint8).to(device))
+    pad = (-sum(int(p.numel()) for p in parts)) % 16      # (the next rank's slot stays 16-byte aligned)
+    if pad:
+        parts.append(torch.zeros(pad, dtype=torch.uint8, device=device))
+    return torch.cat(parts)
+
+
+def unpack_shard(blob, index):
+    """(fs_row records, fan words) of one rank's payload (rank 0).  Wire records are
+    expanded by the library on the GPU (fs_rows_unpack8 / fs_rows_unpack)."""
+    import torch
+    hdr = blob[:SHARD_HDR].cpu().numpy().view(np.int64)
+    if int(hdr[0]) != SHARD_MAGIC:
+        raise RuntimeError("shard payload without its header (magic %#x)" % int(hdr[0]))
+    rec, n, n_works, wbytes = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4])
+    at_off = SHARD_HDR
+    at_rec = at_off + ((8 * (n_works + 1) + 15) & ~15)
+    at_words = at_rec + n * rec
+    if n == 0:
+        rows = np.zeros(0, dtype=abi.ROW_DTYPE)
+    elif rec == 32:
+        rows = blob[at_rec:at_words].cpu().numpy().view(abi.ROW_DTYPE).copy()
+    elif rec in (8, 16):
+        if index is None:
+            raise RuntimeError("wire records need the script index to be expanded")
+        dev = blob if blob.device.type == "cuda" else blob[:at_words].cuda()
+        full = torch.empty(max(1, n) * 32, dtype=torch.uint8, device="cuda")
+        if rec == 8:
+            # (uint64 offsets: an 8-byte aligned copy of their own)
+            offs = dev[at_off:at_off + 8 * (n_works + 1)].clone()
+            index.unpack8_device(dev.data_ptr() + at_rec, n, offs.data_ptr(), n_works, full.data_ptr())
+        else:
+            index.unpack_device(dev.data_ptr() + at_rec, n, full.data_ptr())
+        rows = full[:n * 32].cpu().numpy().view(abi.ROW_DTYPE).copy()
+    else:
+        raise RuntimeError("shard payload with %d-byte records" % rec)
+    words = bytes(blob[at_words:at_words + wbytes].cpu().numpy()).decode("utf-8").split("\n") if n else []
+    if len(words) != len(rows):
+        raise RuntimeError("gathered %d fan words for %d records" % (len(words), len(rows)))
+    return rows, words
 
 
 class Shard(object):
@@ -255,46 +296,69 @@ def shard_from_rows(rows, words, n_works):
     return Shard(buf, 32, len(rows), np.zeros(n_works + 1, dtype=np.uint64), list(words))
 
 
+class RankFailed(RuntimeError):
+    """Another rank failed in its share of a batch; this rank stops too."""
+
+
 def search_sharded(filenames, weights, searcher, group=None):
     """Search one batch of works across all ranks.
 
     `searcher.search_shard(sub_filenames) -> Shard` (AnnIndexSearch: records left in HBM)
-    or, without it, `searcher.search_rows(sub_filenames) -> (rows, words)`.  The shards
-    travel to rank 0 through RowGather (one padded gather of [count | records]) and the
-    fan words as one byte string per rank.  Returns on rank 0 (fs_row records with work
-    indices into `filenames`, fan words), elsewhere (None, None)."""
+    or, without it, `searcher.search_rows(sub_filenames) -> (rows, words)`.  Every rank
+    packs its shard into one self-describing payload (pack_shard); the exchange is
+    TWO collectives per batch: an 8-byte all_reduce(MAX) of {payload size, failure flag}
+    -- RCCL has no gatherv, so the ranks must agree on the padded size, and the same
+    word tells every rank when one of them failed, so that nobody waits in a gather for
+    a rank that has raised -- and ONE padded gather of the payloads to rank 0.  Returns
+    on rank 0 (fs_row records with work indices into `filenames`, fan words), elsewhere
+    (None, None)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    live = dist.is_initialized()
+    world = dist.get_world_size(group) if live else 1
+    rank = dist.get_rank(group) if live else 0
     bounds = split_contiguous(weights, world)
     lo, hi = bounds[rank], bounds[rank + 1]
     sub = filenames[lo:hi]
-    if hasattr(searcher, "search_shard"):
-        shard = searcher.search_shard(sub)
+    on_gpu = live and dist.get_backend(group) == "nccl"
+    cdev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    payload, failure = None, None
+    try:
+        if hasattr(searcher, "search_shard"):
+            shard = searcher.search_shard(sub)
+        else:
+            rows, words = searcher.search_rows(sub)
+            shard = shard_from_rows(rows, words, len(sub))
+        payload = pack_shard(shard, cdev)
+    except Exception as e:                      # told to the other ranks below, then raised
+        failure = e
+    if world > 1:
+        agree = torch.tensor([0 if payload is None else int(payload.numel()), 1 if failure else 0],
+                             dtype=torch.int64, device=cdev)
+        dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=group)
+        size, failed = (int(v) for v in agree.cpu().tolist())
     else:
-        rows, words = searcher.search_rows(sub)
-        shard = shard_from_rows(rows, words, len(sub))
-    rehearsal = dist.is_initialized() and dist.get_backend(group) != "nccl" and torch.cuda.is_available()
-    g = RowGather(getattr(searcher, "engine", None), shard.n_rows, shard.rec_bytes, n_buffers=1,
-                  group=group, rehearsal=rehearsal)
-    n = min(shard.buf.numel(), g.stride)
-    g.bufs[0][:n] = shard.buf[:n].to(g.bufs[0].device)
-    if shard.rec_bytes == 8:
-        g.set_offsets(shard.work_off)
-    g.start(0)
-    blobs = gather_bytes("\n".join(shard.words).encode("utf-8"), group=group)
-    g.wait(0)
+        size, failed = (0 if payload is None else int(payload.numel())), (1 if failure else 0)
+    if failure is not None:
+        raise failure
+    if failed:
+        raise RankFailed("another rank failed in its share of this batch")
+    if world == 1:
+        blobs = [payload]
+    else:
+        send = torch.zeros(size, dtype=torch.uint8, device=cdev)
+        send[:payload.numel()] = payload
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
+        dist.gather(send, recv, dst=0, group=group)
+        blobs = recv
     if rank != 0:
         return None, None
-    parts, cnts = g.rows(0)
-    for r, part in enumerate(parts):
-        part["work"] += np.uint32(bounds[r])
-    all_rows = np.concatenate(parts) if parts else np.zeros(0, dtype=abi.ROW_DTYPE)
-    all_words = []
+    engine = getattr(searcher, "engine", None)
+    all_rows, all_words = [], []
     for r, blob in enumerate(blobs):
-        if cnts[r]:
-            all_words += blob.decode("utf-8").split("\n")
-    if len(all_words) != len(all_rows):
-        raise RuntimeError("gathered %d fan words for %d records" % (len(all_words), len(all_rows)))
-    return all_rows, all_words
+        part, words = unpack_shard(blob, engine)
+        part["work"] += np.uint32(bounds[r])
+        all_rows.append(part)
+        all_words += words
+    rows = np.concatenate(all_rows) if all_rows else np.zeros(0, dtype=abi.ROW_DTYPE)
+    return rows, all_words

@@ -442,14 +442,13 @@ def analyze(args,
             rows, words = dist.search_sharded(fan_cluster, weights, ann_index)
         else:
             rows, words = ann_index.search_rows(fan_cluster)
-        st = getattr(ann_index, 'last_stats', None)
         oov = getattr(ann_index, 'last_oov_rate', None)
         if oov is not None and oov > 0.2:
             import sys
-            print('warning: {:.0%} of the fan tokens of this batch have no row in the vector '
+            print('warning: {}{:.0%} of the fan tokens of this batch have no row in the vector '
                   'table (out-of-vocabulary 3-hot vectors, search.py:79-83); check '
-                  'FANDOM_SEARCH_VECTORS'.format(oov), file=sys.stderr)
-        del st
+                  'FANDOM_SEARCH_VECTORS'.format('rank {}: '.format(rank) if world > 1 else '', oov),
+                  file=sys.stderr)
         if rank != 0:
             continue
         records = join_records(fan_cluster, rows, words,

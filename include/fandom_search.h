@@ -266,6 +266,12 @@ int fs_index_reload_switches(fs_index* ix);
  * overhead.  Not part of the search path. */
 int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms);
 
+/* Diagnostics (FS_DIAG=2 in the environment at fs_index_create): per wave range of the
+ * last k_scan_rows launch on stream `lane`, eight uint64 {entry, filter staged, scan done,
+ * rounds done, finished (ticks of the 100 MHz constant clock), rounds, flushes, records}.
+ * *n = words available; FS_E_CAPACITY when cap is smaller.  tools/scan_timeline.py. */
+int fs_debug_stamps(fs_index* ix, uint32_t lane, uint64_t* out, uint64_t cap, uint64_t* n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,7 +1,9 @@
 """The N>1 path on CPU: gloo processes (world sizes 2 and 4) run analyze() with an
-oracle-backed searcher through the product's gather (dist.search_sharded ->
-RowGather: header + records in one padded gather, fan words as bytes); the CSVs must
-be byte-identical to a single-process run.  Also the range splitter.  With a GPU
+oracle-backed searcher through the product's gather (dist.search_sharded: one
+self-describing payload per rank -- records, work offsets, fan words -- a size/failure
+agreement and one padded gather); the CSVs must be byte-identical to a single-process
+run.  Ranks whose shards differ in record format or are empty, and a rank that fails,
+are covered too.  Also the range splitter.  With a GPU
 (-m gpu): two ranks with the real AnnIndexSearch, 8-byte wire records left in HBM by
 the search and expanded on rank 0."""
 
@@ -32,7 +34,7 @@ def test_split_contiguous():
 
 
 def test_search_sharded_single_process_is_identity():
-    """One rank: the shard goes through RowGather and comes back unchanged."""
+    """One rank: the shard goes through pack_shard / unpack_shard and comes back unchanged."""
     rows = np.zeros(3, dtype=abi.ROW_DTYPE)
     rows["work"] = [0, 1, 2]
     rows["fan_ix"] = [5, 6, 7]
@@ -123,6 +125,92 @@ def test_gloo_runs_write_identical_csvs(tmp_path):
         assert list(one) == list(many)
         for name in one:
             assert one[name] == many[name], (world, name)
+
+
+MIXED_WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch
+    import torch.distributed as tdist
+    from fandom_search_amd import abi, dist
+
+    rank, _, world = dist.init_from_env("gloo")
+    mode = sys.argv[1]
+
+    class Searcher(object):
+        """Rank 0: fs_row records (as from a shard with an out-of-vocabulary token);
+        the last rank: an EMPTY shard that announces 8-byte wire records; `fail`: the
+        last rank raises instead."""
+        engine = None
+        def search_shard(self, sub):
+            if rank == world - 1:
+                if mode == "fail":
+                    raise ValueError("boom on rank %%d" %% rank)
+                return dist.Shard(torch.zeros(dist.HDR + 8, dtype=torch.uint8), 8, 0,
+                                  np.zeros(len(sub) + 1, np.uint64), [])
+            rows = np.zeros(len(sub), dtype=abi.ROW_DTYPE)
+            rows["work"] = np.arange(len(sub))
+            rows["fan_ix"] = 7 + rank
+            rows["comb"] = 0.5
+            return dist.shard_from_rows(rows, ["w%%d_%%d" %% (rank, i) for i in range(len(sub))], len(sub))
+
+    files = ["f%%d" %% i for i in range(9)]
+    try:
+        rows, words = dist.search_sharded(files, [1] * 9, Searcher())
+    except dist.RankFailed:
+        assert mode == "fail" and rank != world - 1
+        sys.exit(3)
+    except ValueError as e:
+        assert mode == "fail" and rank == world - 1
+        print("raised:", e, flush=True)
+        sys.exit(4)
+    assert mode == "mixed"
+    if rank == 0:
+        b = dist.split_contiguous([1] * 9, world)
+        n = b[world - 1]
+        assert len(rows) == n and rows["work"].tolist() == list(range(n)), rows["work"]
+        assert words[0] == "w0_0" and len(words) == n
+        print("MIXED_OK", n, flush=True)
+    else:
+        assert rows is None and words is None
+    dist.finalize()
+''')
+
+
+def _torchrun(worker, world, port, *argv):
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                           "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                           "--master-port", str(port), str(worker)] + list(argv),
+                          env=dict(os.environ, OMP_NUM_THREADS="1"), timeout=300, cwd=ROOT,
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+
+
+@pytest.mark.timeout(600)
+def test_ranks_with_different_record_formats_and_an_empty_shard(tmp_path):
+    """ADVICE r2 (high): one rank holds fs_row records, another an empty shard of 8-byte
+    wire records.  The payloads describe themselves, so the gather neither hangs nor
+    decodes one rank's records with another's format."""
+    worker = tmp_path / "mixed.py"
+    worker.write_text(MIXED_WORKER % dict(root=ROOT))
+    for world in (2, 3):
+        r = _torchrun(worker, world, 29541 + world, "mixed")
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert "MIXED_OK" in r.stdout
+
+
+@pytest.mark.timeout(600)
+def test_a_failing_rank_stops_every_rank(tmp_path):
+    """A rank that raises in its share tells the others through the size agreement:
+    nobody is left waiting in the gather (the run ends at once, non-zero)."""
+    import time
+    worker = tmp_path / "mixed.py"
+    worker.write_text(MIXED_WORKER % dict(root=ROOT))
+    t0 = time.time()
+    r = _torchrun(worker, 2, 29547, "fail")
+    assert r.returncode != 0
+    assert time.time() - t0 < 120, "the surviving rank waited for the failed one"
+    assert "boom on rank 1" in r.stdout
 
 
 GPU_WORKER = textwrap.dedent('''

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Where a k_scan_rows launch spends its time: in-kernel stamps (FS_DIAG=2) per wave range.
+
+  python tools/scan_timeline.py [--workload c2] [--rotate 4] [--extra "FS_X=1 FS_Y=2"]
+
+Runs a few searches (one at a time, ids from HBM when --rotate batches exceed the Infinity
+Cache), reads the stamps of the last one through fs_debug_stamps and prints, in
+microseconds from the first wave's entry, the percentiles of: entry, filter staged, scan
+done (before the range's last flush), rounds done, finished; and the rounds / flushes per
+range.  Diagnostic build paths only: the stamps cost a few scalar instructions.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c2")
+    ap.add_argument("--window", type=int, default=6)
+    ap.add_argument("--rotate", type=int, default=4)
+    ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--extra", default="")
+    ap.add_argument("--dump", default="", help="write the raw stamps (.npy) here")
+    a = ap.parse_args()
+    os.environ["FS_DIAG"] = str(2 | int(os.environ.get("FS_DIAG", "0")))
+    os.environ.setdefault("FS_LANES", "1")
+    for kv in a.extra.split():
+        k, v = kv.split("=", 1)
+        os.environ[k] = v
+    import torch
+    from fandom_search_amd import _lib, abi, synth, vocab
+    from fandom_search_amd.engine import ScriptIndex
+    conf = synth.CONFIGS[a.workload]
+    words, emb = synth.vocab_words(), synth.embedding()
+    script = synth.script_tokens(conf["script_tokens"])
+    swords = [words[int(t)] for t in script]
+    chars, coff = vocab.pack_strings(words)
+    ix = ScriptIndex(script, swords, emb, synth.lsh_normals(a.window), cfg=abi.make_config(window_size=a.window))
+    corpora = []
+    for r in range(a.rotate):
+        t, o = synth.corpus_tokens(conf["n_works"], conf["tokens_per_work"], script,
+                                   first_work=r * conf["n_works"])
+        corpora.append(ix.corpus(t, o, chars, coff))
+    rows, st = ix.search(corpora[0])
+    cap = len(rows) * 2 + 64
+    buf = torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda")
+    ix.set_scan_timing(1)
+    ms = []
+    for i in range(a.reps * a.rotate):
+        n, st = ix.search_end(ix.search_begin(corpora[i % a.rotate], buf.data_ptr(), cap, header=True))
+        ms.append(st.scan_ms)
+    L = _lib.load()
+    n = C.c_uint64(0)
+    _lib.check(L.fs_debug_stamps(ix._h, 0, None, 0, C.byref(n)), "fs_debug_stamps")
+    out = np.zeros(n.value, dtype=np.uint64)
+    _lib.check(L.fs_debug_stamps(ix._h, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)),
+               "fs_debug_stamps")
+    d = out.reshape(-1, 8).astype(np.int64)
+    if a.dump:
+        np.save(a.dump, d)
+    t0 = d[:, 0].min()
+    us = (d[:, :5] - t0) / 100.0
+    names = ["entry", "ready", "scan_done", "rounds_done", "finished"]
+    res = {"kernel": ix.kernel_name(corpora[0]), "kernel_us_events": round(float(np.mean(ms[a.rotate:])) * 1e3, 2),
+           "ranges": int(len(d)), "extra": a.extra}
+    pct = [0, 10, 50, 90, 100]
+    for k, nm in enumerate(names):
+        res[nm] = [round(float(x), 2) for x in np.percentile(us[:, k], pct)]
+    res["scan_dur"] = [round(float(x), 2) for x in np.percentile(us[:, 2] - us[:, 1], pct)]
+    res["rounds_dur"] = [round(float(x), 2) for x in np.percentile(us[:, 3] - us[:, 2], pct)]
+    res["finish_dur"] = [round(float(x), 2) for x in np.percentile(us[:, 4] - us[:, 3], pct)]
+    res["rounds_per_range"] = {int(k): int(v) for k, v in zip(*np.unique(d[:, 5], return_counts=True))}
+    res["flushes_per_range"] = {int(k): int(v) for k, v in zip(*np.unique(d[:, 6], return_counts=True))}
+    res["records_per_range"] = [int(x) for x in np.percentile(d[:, 7], [0, 50, 100])]
+    print(json.dumps(res), flush=True)
+
+
+if __name__ == "__main__":
+    main()
