@@ -9,11 +9,19 @@ verification, Levenshtein records, per-word dedupe, records left in HBM).
           6-gram).  The timed steps rotate over four DISTINCT c2 batches (320 MB of
           ids, more than the 256 MiB Infinity Cache), so every step reads its ids
           from HBM; `--rotate 1` re-scans one resident batch (bound: infinity-cache).
-  N > 1   strong scaling on configs[2] ("c3": 100k works x 5k tokens split N ways; rank
-          r holds works [r W/N, (r+1) W/N)), the match records of all ranks gathered
-          to rank 0 over RCCL inside the step (fandom_search_amd.dist.RowGather: 8-byte
-          wire records, count and records in one collective, gather of step i beside
-          the search of step i+1).  `--scaling weak`: one c2-sized shard per rank.
+  N > 1   weak scaling: every rank (one GPU each) holds its own c2 batches, the match
+          records of all ranks gathered to rank 0 over RCCL inside the step
+          (fandom_search_amd.dist.RowGather: 8-byte wire records, count and records in
+          one collective, gather of step i beside the search of step i+1).
+          `--scaling strong`: configs[2] ("c3": 100k works x 5k tokens) split N ways,
+          rank r holding works [r W/N, (r+1) W/N).
+          `python bench.py --gpus N` typed as is starts the N ranks itself
+          (torch.distributed.run as a child process); under a launcher (WORLD_SIZE set)
+          it is one of the ranks.
+
+The timed region is `--steps` steps between barrier + synchronize on both sides; when
+steps <= 64 it is repeated (7 regions, each primed by the warm-up) and the median region
+is reported, with every sample in `samples_ms` (a 0.6 ms region is a fragile basis).
 
 Prints ONE JSON line (rank 0): the driver's contract plus
   roofline      the dominant kernel (k_scan_rows: tokens -> records in one launch):
@@ -48,14 +56,19 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 MALL_BYTES = 256 << 20    # Infinity Cache
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="",
                     help="c2 (default at N=1), c3 (default at N>1, split over the ranks), c3shard, c1")
-    ap.add_argument("--scaling", default="strong", help="N > 1: strong (c3 split N ways) or weak")
+    ap.add_argument("--scaling", default="weak",
+                    help="N > 1: weak (one c2-sized shard per rank) or strong (c3 split N ways)")
+    ap.add_argument("--reps", type=int, default=0,
+                    help="timed regions of --steps steps (default: 7 when steps <= 64, else 3); "
+                         "the median is reported")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (default: a free one)")
     ap.add_argument("--works", type=int, default=0, help="override works (per rank)")
     ap.add_argument("--window", type=int, default=6)
     ap.add_argument("--rotate", type=int, default=0,
@@ -77,7 +90,25 @@ def parse():
                          "computes on GPU 0, records gathered through host memory)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--wire", type=int, default=0, help="N > 1: force 16-byte wire records")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def launcher_command(args, argv, env, port=None):
+    """`python bench.py --gpus N` typed without a launcher: the command that starts the N
+    ranks (None when this process is a rank already, or N == 1).  The parent never touches
+    the GPU; the ranks run as a child process whose exit code it returns."""
+    if args.gpus <= 1 or "WORLD_SIZE" in env:
+        return None
+    if port is None:
+        port = args.master_port
+    if not port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+            "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
 def host_cores():
@@ -284,6 +315,11 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
 
 def main():
     args = parse()
+    cmd = launcher_command(args, sys.argv[1:], os.environ)
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
     os.environ["FS_LANES"] = str(max(1, args.lanes))
     inflight = args.inflight or max(1, args.lanes)
     ref_shaped = None
@@ -294,7 +330,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d under a launcher of %d ranks" % (args.gpus, world))
 
     import torch
     import torch.distributed as dist
@@ -375,7 +411,7 @@ def main():
     # ---- the step: search of batch i queued while earlier ones run, gathers behind ----
     tickets = {}
     scan_ms = []
-    last = {"st": None, "rows": 0, "buf": 0}
+    last = {"st": None, "rows": 0, "buf": 0, "timing": False}
 
     trace = [] if os.environ.get("BENCH_TRACE_HOST") else None
 
@@ -384,7 +420,7 @@ def main():
         n, st = ix.search_end(t)
         if trace is not None:
             trace.append(("end", i, time.perf_counter(), st.scan_ms))
-        if st.scan_ms > 0:
+        if st.scan_ms > 0 and last["timing"]:
             scan_ms.append(st.scan_ms)
         last["st"], last["rows"] = st, n
         gather.start(b)
@@ -409,30 +445,39 @@ def main():
     # the dominant kernel carries timing events on every search of a short run (the driver
     # passes --steps 20), on every 4th of a long one (an event record costs stream time)
     ix.set_scan_timing(args.scan_timing or (1 if args.steps <= 64 else 4))
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    scan_ms.clear()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    drain()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    reps = args.reps or (7 if args.steps <= 64 else 3)
+    samples = []
+    it = 0
+    for rep in range(reps):
+        for i in range(args.warmup):              # every region starts from a primed pipeline
+            step(it)
+            it += 1
+        drain()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        last["timing"] = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(it)
+            it += 1
+        drain()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        samples.append(time.perf_counter() - t0)
+        last["timing"] = False
+    if world > 1:                                 # per region: the slowest rank
+        t = torch.tensor(samples, dtype=torch.float64, device=gather.cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        samples = [float(x) for x in t.cpu().tolist()]
+    dt = float(np.median(samples))
+    last_step = it - 1
     if trace is not None:
         for kind, i, t, ms in trace:
             if t >= t0:
                 sys.stderr.write("%-5s %3d %8.1f us  scan %.1f us\n" % (kind, i, (t - t0) * 1e6, ms * 1e3))
         sys.stderr.write("total %.1f us\n" % (dt * 1e6))
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=gather.cdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     st = last["st"]
 
     # outside the timed region: what rank 0 holds after the last gather must be every
@@ -440,7 +485,7 @@ def main():
     gather_verified = None
     if world > 1:
         import zlib
-        last_corpus = corpora[(args.warmup + args.steps - 1) % rotate]
+        last_corpus = corpora[last_step % rotate]
         own, _ = ix.search(last_corpus)
         crc = torch.tensor([zlib.crc32(own.tobytes()), len(own)], dtype=torch.int64, device=gather.cdev)
         crcs = torch.zeros(2 * world, dtype=torch.int64, device=gather.cdev)
@@ -488,14 +533,21 @@ def main():
         achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
         resident = rotate * shard_bytes <= MALL_BYTES
         traffic, traffic_src = None, None
+        build = _lib.source_hash()
         tpath = os.path.join(ROOT, "profiles", "scan_traffic.json")
         if os.path.exists(tpath):
             try:
                 rec = json.load(open(tpath))
-                if (rec.get("kernel") == kernel and rec.get("n_tok") == n_tok and rec.get("rotate") == rotate
+                # the PMC passes are separate runs (gpurun refuses counters next to a trace): the
+                # figure is taken only when it was measured on these very sources and this workload
+                if (rec.get("build") == build and rec.get("kernel") == kernel and rec.get("n_tok") == n_tok
+                        and rec.get("rotate") == rotate
                         and rec.get("lanes") in (None, int(os.environ.get("FS_LANES", "1")))):
                     traffic = rec.get("hbm_bytes_per_launch")
-                    traffic_src = "profiles/scan_traffic.json: " + rec.get("source", "rocprofv3 --pmc")
+                    traffic_src = "profiles/scan_traffic.json (build %s): %s" % (build, rec.get("source", "rocprofv3 --pmc"))
+                else:
+                    traffic_src = ("profiles/scan_traffic.json does not apply (its build %s, this build %s)"
+                                   % (rec.get("build"), build))
             except Exception:
                 traffic = None
         out = {
@@ -506,6 +558,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "ms_per_step_min": min(samples) / args.steps * 1e3,
+            "ms_per_step_max": max(samples) / args.steps * 1e3,
+            "samples_ms": [round(x * 1e3, 5) for x in samples],
+            "timed_regions": "%d regions of %d steps, each behind %d warm-up steps; median region reported"
+                             % (len(samples), args.steps, args.warmup),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
@@ -540,7 +597,7 @@ def main():
                          "kernel": kernel, "bytes_model": note,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_launch": algo_bytes, "build": build,
                          "avg_launch_ms": kernel_ms, "timed_launches": len(scan_ms),
                          "launch_ms_alone": alone_ms,
                          "frac_alone": algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

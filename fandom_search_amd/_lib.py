@@ -43,6 +43,25 @@ def lib_path():
     return os.path.join(_PKG, os.path.basename(os.environ.get("FS_LIB_FILE", LIB_NAME)))
 
 
+def source_hash():
+    """Identifies the kernels a measurement belongs to: SHA-256 (first 16 hex digits) over
+    the library's sources (csrc/*.hip, csrc/*.h, include/fandom_search.h), which travel
+    with the built .so.  Artifacts under profiles/ carry it, and bench.py refuses a
+    traffic figure whose stamp differs from the sources it runs (git is not available
+    where the measurements are made)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_PKG, "csrc")
+    files = sorted(f for f in os.listdir(src) if f.endswith((".hip", ".h")))
+    paths = [os.path.join(src, f) for f in files]
+    paths.append(os.path.join(os.path.dirname(_PKG), "include", "fandom_search.h"))
+    for path in paths:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles
     without a GPU)."""
@@ -134,8 +153,9 @@ def load():
     L.fs_search_kernel_name.argtypes = [C.c_void_p, C.c_void_p]
     L.fs_index_reload_switches.restype = C.c_int
     L.fs_index_reload_switches.argtypes = [C.c_void_p]
-    L.fs_debug_stamps.restype = C.c_int
-    L.fs_debug_stamps.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_uint64, u64p]
+    if hasattr(L, "fs_debug_stamps"):      # (absent from older builds loaded through FS_LIB_FILE)
+        L.fs_debug_stamps.restype = C.c_int
+        L.fs_debug_stamps.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_uint64, u64p]
     L.fs_scan_benchmark.restype = C.c_int
     L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.POINTER(C.c_double)]

@@ -163,7 +163,8 @@ struct fs_switches {
   bool post_fused = false;        // FS_POST_FUSED
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
   bool scan_sub = true;           // FS_SCAN_SUB=0: k_scan_rows tests the full n-gram (Bloom) instead of K-gram runs
-  int diag = 0;                   // FS_DIAG: timing experiments (results invalid)
+  int diag = 0;                   // FS_DIAG bits: 1 k_scan_rows without its rounds (results invalid), 2 in-kernel
+                                  // timeline stamps (fs_debug_stamps), 16 equal shares per wave, bits 8..: flush threshold
   int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
   double lsh_f32_slack = 1.0;     // FS_LSH_F32_SLACK: factor on the float32 key bound (tests force the fallback)
@@ -230,8 +231,7 @@ struct fs_index {
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range
     uint32_t caprow_hint = 0;      //   staged records per wave range the last searches needed
-    DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup
-    DBuf<uint4> w_bstat;           //   {hits, pairs, candidates, max records of a range} per workgroup
+    DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup, then four statistics granules each
     DBuf<uint4> w_rinfo, w_csum;   // k_compact: {records, hits, pairs, candidates} per range / per workgroup
     uint32_t sync_epoch = 0;
     DBuf<fs_best> w_cbest;
@@ -368,7 +368,7 @@ int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s);
 namespace fsdev { struct RowSync; }
 int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
 int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
-                                      int rec_bytes, uint32_t rcap, fs_row* d_rows,
+                                      int wire, uint32_t rcap, fs_row* d_rows,
                                       fs_status* host_st, hipStream_t s, uint64_t* count_out,
                                       hipEvent_t done);
 uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* blocks);   // waves per workgroup, 0: does not apply

@@ -44,7 +44,6 @@ constexpr int kHitPad = 72;     // 64 hits + the n-1 <= 7 slots the first-minimu
 
 struct alignas(16) RangeLds {
   double comb[kHitPad];       // hits: combined distance of the best rank
-  double dist[64];            //       its cosine distance
   uint32_t p[kHitPad];        //       window position
   uint32_t s[64];             //       script position of the best rank
   uint32_t lev[64];           //       its Levenshtein distance
@@ -65,7 +64,7 @@ struct RangeState {
 struct RangeOut {
   uint8_t* stage;      // caprow records per range
   uint32_t caprow;
-  int wire;            // 0: fs_row, 16 / 8: wire records
+  int wire;            // what the caller gets: 0 fs_row, 16 / 8 wire records (staged: 8 for 8, else 16)
 };
 
 // One round: lane i < 64 - (N-1) holds candidate window position `p` (ascending over the
@@ -86,7 +85,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   // anything of that level is looked at.
   bool hit = false;
   uint32_t kept = 0, w = 0, wbase = 0, bs = 0, blev = 0;
-  double comb = 0.0, bdist = 0.0;
+  double comb = 0.0;
   if (p != FS_NONE) {
     uint32_t f[8];
     uint4 bw;
@@ -147,9 +146,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       slot = (slot + 1) & ((1u << g.log2_slots) - 1);
     }
     kept = q0.y; bs = q2.z; blev = q2.w;
-    const uint32_t d0 = q3.x, d1 = q3.y, c0 = q3.z, c1 = q3.w;
-    bdist = __longlong_as_double((long long)(d0 | ((uint64_t)d1 << 32)));
-    comb = __longlong_as_double((long long)(c0 | ((uint64_t)c1 << 32)));
+    comb = __longlong_as_double((long long)(q3.z | ((uint64_t)q3.w << 32)));
     // the work of p: the block's first work or the one behind it, else walk on
     w = bw.x; wbase = bw.y;
     uint32_t we = bw.z;                               // a batch holds < 2^32 tokens
@@ -165,7 +162,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0));
   if (hit) {
     S.p[hidx] = p; S.s[hidx] = bs; S.lev[hidx] = blev; S.w[hidx] = w; S.wbase[hidx] = wbase;
-    S.comb[hidx] = comb; S.dist[hidx] = bdist;
+    S.comb[hidx] = comb;
     if (p >= a) R.match_acc += kept;                 // a halo hit belongs to the range before
   }
   const uint32_t nh = R.hc + (uint32_t)__popcll(hb);
@@ -213,18 +210,13 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
     const size_t at = (size_t)range_id * out.caprow + ridx;
     if (out.wire == 8) {
       reinterpret_cast<uint2*>(out.stage)[at] = make_uint2(x, orig | (koff << 18) | (lev << 22));
-    } else if (out.wire == 16) {
+    } else {
+      // 16-byte wire record, also when the caller wants fs_row: the distances of a record are
+      // functions of the matched script window (its distance to itself, times the Levenshtein
+      // distance) and are filled in where the record is put into place
       uint4 qv;
       qv.x = S.w[j]; qv.y = x - S.wbase[j]; qv.z = orig; qv.w = lev | (koff << 16);
       reinterpret_cast<uint4*>(out.stage)[at] = qv;
-    } else {
-      uint4 q0, q1;
-      q0.x = S.w[j]; q0.y = x - S.wbase[j]; q0.z = orig; q0.w = lev;
-      const uint64_t db = (uint64_t)__double_as_longlong(S.dist[bj]);
-      const uint64_t cb = (uint64_t)__double_as_longlong(best);
-      q1.x = (uint32_t)db; q1.y = (uint32_t)(db >> 32); q1.z = (uint32_t)cb; q1.w = (uint32_t)(cb >> 32);
-      uint4* dst = reinterpret_cast<uint4*>(out.stage) + 2 * at;
-      dst[0] = q0; dst[1] = q1;
     }
   }
   R.rows_run += tot;
@@ -234,16 +226,16 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   const uint32_t first_keep = kb ? (uint32_t)(__ffsll((unsigned long long)kb) - 1) : nh;
   if (kb) {                                                        // wave-uniform
     uint32_t tp = 0, ts = 0, tl = 0, tw = 0, tb = 0;
-    double tc = 0.0, td = 0.0;
+    double tc = 0.0;
     if (keep) {
       tp = S.p[lane]; ts = S.s[lane]; tl = S.lev[lane]; tw = S.w[lane]; tb = S.wbase[lane];
-      tc = S.comb[lane]; td = S.dist[lane];
+      tc = S.comb[lane];
     }
     wave_sync();
     if (keep) {
       const uint32_t dd = lane - first_keep;
       S.p[dd] = tp; S.s[dd] = ts; S.lev[dd] = tl; S.w[dd] = tw; S.wbase[dd] = tb;
-      S.comb[dd] = tc; S.dist[dd] = td;
+      S.comb[dd] = tc;
     }
   }
   R.hc = nh - first_keep;
@@ -251,13 +243,56 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   wave_sync();
 }
 
+// ---- records into place ------------------------------------------------------------
+// One staged record -> the caller's format.  The two halves are separate so that the
+// loads need not wait for the record's final index (the in-launch finish learns it last).
+struct StagedRec {
+  uint4 q;           // the staged record (8-byte ones in q.x, q.y)
+  double dist;
+  bool have;
+};
+
+__device__ __forceinline__ StagedRec fetch_staged(const uint8_t* __restrict__ stage, int wire,
+                                                  const double* __restrict__ selfdist, size_t at, bool have) {
+  StagedRec v;
+  v.have = have; v.dist = 0.0; v.q = make_uint4(0, 0, 0, 0);
+  if (!have) return v;
+  if (wire == 8) {
+    const uint2 t = reinterpret_cast<const uint2*>(stage)[at];
+    v.q.x = t.x; v.q.y = t.y;
+  } else {
+    v.q = reinterpret_cast<const uint4*>(stage)[at];
+    // fs_row: the distance is the matched script window's distance to itself, the
+    // combined distance its product with the Levenshtein distance (as fs_rows_unpack)
+    if (wire == 0) v.dist = selfdist[v.q.z - (v.q.w >> 16)];
+  }
+  return v;
+}
+
+__device__ __forceinline__ void store_staged(uint8_t* __restrict__ rows, int wire, const StagedRec& v, size_t dst) {
+  if (!v.have) return;
+  if (wire == 8) {
+    reinterpret_cast<uint2*>(rows)[dst] = make_uint2(v.q.x, v.q.y);
+  } else if (wire == 16) {
+    reinterpret_cast<uint4*>(rows)[dst] = v.q;
+  } else {
+    const uint32_t lev = v.q.w & 0xFFFFu;
+    const double comb = __dmul_rn(v.dist, (double)lev);
+    const uint64_t db = (uint64_t)__double_as_longlong(v.dist), cb = (uint64_t)__double_as_longlong(comb);
+    uint4* d4 = reinterpret_cast<uint4*>(rows) + 2 * dst;
+    d4[0] = make_uint4(v.q.x, v.q.y, v.q.z, lev);
+    d4[1] = make_uint4((uint32_t)db, (uint32_t)(db >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
+  }
+}
+
 // ---- records into place inside the launch ------------------------------------------
 // Workgroup b of k_scan_rows holds the wave ranges [b * waves, (b + 1) * waves).
-// When its waves are done it stores its statistics (write-through), then publishes its
-// record count as one 8-byte granule {epoch, count} (the data is the flag; epoch = launch
-// number of the lane, so nothing is cleared between launches), sums the granules of the
-// workgroups in front of it and copies its staged records to their final place.  The
-// last workgroup has then seen every other one and publishes totals and status.
+// When its waves are done it publishes its record count as one 8-byte granule
+// {epoch, count} (the data is the flag; epoch = launch number of the lane, so nothing is
+// cleared between launches) and its statistics as four more, sums the granules of the
+// workgroups in front of it and copies its staged records to their final place (every
+// lane has requested its first two records before it starts to wait).  The last
+// workgroup has then seen every other one and publishes totals and status.
 //
 // No atomic read-modify-write anywhere (one word serves about 88 of them per microsecond:
 // a ticket per workgroup or a counter update per wave would cost more than the whole
@@ -268,7 +303,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
 // through the chained kernels of fs_post.hip, which have no in-launch hand-off.
 struct RowSync {
   unsigned long long* gran;  // [n_blocks] {epoch << 32 | records of the workgroup}
-  uint4* bstat;              // [n_blocks] {hits, pairs, candidates, max records of a range}
+  unsigned long long* sgran; // [n_blocks][4] {epoch << 32 | hits, pairs, candidates, max records of a range}
   uint32_t epoch;            // >= 1
   uint32_t n_blocks;
   uint32_t spin_limit;       // polls of one batch of granules before the wait gives up
@@ -295,7 +330,8 @@ struct RowFinal {
 //              candidates
 //   s_cnt      LDS, 6 * n_waves + 2 words
 __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& fin,
-                                            const RangeOut& out, uint32_t range_id,
+                                            const RangeOut& out, const double* __restrict__ selfdist,
+                                            uint32_t range_id,
                                             uint32_t my_rows, uint32_t hits, uint32_t pairs,
                                             uint32_t cands, uint32_t* s_cnt) {
   const int lane = threadIdx.x & 63;
@@ -326,11 +362,16 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
     s_cnt[n_waves + 2 + 4 * wave] = hits; s_cnt[n_waves + 3 + 4 * wave] = pairs;
     s_cnt[n_waves + 4 + 4 * wave] = cands; s_cnt[n_waves + 5 + 4 * wave] = my_rows;
   }
-  // the staged records of this wave have reached memory before anything reads them back
+  // the staged records of this wave have reached memory before it reads them back
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // this lane's first two records: requested now, stored once their place is known
+  const size_t sbase = (size_t)range_id * out.caprow;
+  const StagedRec r0 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane, (uint32_t)lane < staged);
+  const StagedRec r1 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane + 64, (uint32_t)lane + 64 < staged);
   __syncthreads();
   bool gave_up = false;
   uint32_t total = 0;
+  const unsigned long long tag = (unsigned long long)sy.epoch << 32;
   if (wave == 0) {
     uint4 bs = make_uint4(0, 0, 0, 0);
     for (uint32_t i = 0; i < n_waves; ++i) {
@@ -340,16 +381,14 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
       const uint32_t r = s_cnt[n_waves + 5 + 4 * i];
       bs.w = r > bs.w ? r : bs.w;
     }
+    // five granules, no ordering between them: each carries the epoch
     if (lane == 0) {
-      uint32_t* b = reinterpret_cast<uint32_t*>(sy.bstat + L);
-      __hip_atomic_store(b + 0, bs.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(b + 1, bs.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(b + 2, bs.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(b + 3, bs.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // statistics before the granule
-      __hip_atomic_store(sy.gran + L, ((unsigned long long)sy.epoch << 32) | total, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sy.gran + L, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_cnt[n_waves + 1] = total;
+    }
+    if (lane < 4) {
+      const uint32_t v = lane == 0 ? bs.x : lane == 1 ? bs.y : lane == 2 ? bs.z : bs.w;
+      __hip_atomic_store(sy.sgran + 4 * (size_t)L + lane, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   // records of the workgroups in front: every granule, once it carries this launch's
@@ -379,50 +418,32 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   for (uint32_t i = 0; i < n_waves; ++i) before += s_cnt[5 * n_waves + 2 + i];
   uint32_t first = before;
   for (uint32_t i = 0; i < wave; ++i) first += s_cnt[i];
-  const uint32_t rec_bytes = out.wire ? (uint32_t)out.wire : 32u;
   uint32_t n = staged;
   if (first >= fin.rcap) n = 0;
   else if (first + n > fin.rcap) n = fin.rcap - first;
-  const uint8_t* src = out.stage + (size_t)range_id * out.caprow * rec_bytes;
-  uint8_t* dst = fin.rows + (size_t)first * rec_bytes;
-  if (rec_bytes == 8) {
-    const uint2* sp = reinterpret_cast<const uint2*>(src);
-    uint2* dp = reinterpret_cast<uint2*>(dst);
-    for (uint32_t i = lane; i < n; i += 128) {
-      const uint2 v0 = sp[i];
-      const bool two = i + 64 < n;
-      const uint2 v1 = two ? sp[i + 64] : v0;
-      dp[i] = v0;
-      if (two) dp[i + 64] = v1;
-    }
-  } else {
-    const uint32_t pieces = n * (rec_bytes >> 4);
-    const uint4* sp = reinterpret_cast<const uint4*>(src);
-    uint4* dp = reinterpret_cast<uint4*>(dst);
-    for (uint32_t i = lane; i < pieces; i += 128) {
-      const uint4 v0 = sp[i];
-      const bool two = i + 64 < pieces;
-      const uint4 v1 = two ? sp[i + 64] : v0;
-      dp[i] = v0;
-      if (two) dp[i + 64] = v1;
-    }
-  }
-  if (gave_up && lane == 0) {
-    // whoever gives up flags the search, in a word of its own that nothing else writes
-    __hip_atomic_store(reinterpret_cast<uint32_t*>(fin.host_st + 1), FS_WAIT_GAVE_UP, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // the last workgroup: every other one has published; their statistics were stored
-  // write-through before their granules and are read past the caches
+  if ((uint32_t)lane < n) store_staged(fin.rows, out.wire, r0, (size_t)first + lane);
+  if ((uint32_t)lane + 64 < n) store_staged(fin.rows, out.wire, r1, (size_t)first + lane + 64);
+  for (uint32_t i = lane + 128; i < n; i += 64)
+    store_staged(fin.rows, out.wire, fetch_staged(out.stage, out.wire, selfdist, sbase + i, true), (size_t)first + i);
+  // the last workgroup: every other one has published its count; their statistics are
+  // granules of their own, asked for together and again until every one is there
   if (L + 1 == sy.n_blocks && wave == 0) {
     uint32_t h = 0, pr = 0, cd = 0, mx = 0;
     for (uint32_t i = lane; i < sy.n_blocks; i += 64) {
-      const uint32_t* b = reinterpret_cast<const uint32_t*>(sy.bstat + i);
-      h += __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      pr += __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      cd += __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const uint32_t r = __hip_atomic_load(b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mx = r > mx ? r : mx;
+      const unsigned long long* sg = sy.sgran + 4 * (size_t)i;
+      unsigned long long a = 0, b = 0, c2 = 0, d2 = 0;
+      for (uint32_t spins = 0;; ++spins) {
+        a = __hip_atomic_load(sg + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = __hip_atomic_load(sg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c2 = __hip_atomic_load(sg + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        d2 = __hip_atomic_load(sg + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(a >> 32) == sy.epoch && (uint32_t)(b >> 32) == sy.epoch &&
+            (uint32_t)(c2 >> 32) == sy.epoch && (uint32_t)(d2 >> 32) == sy.epoch) break;
+        if (spins > 16) __builtin_amdgcn_s_sleep(1);
+        if (spins >= sy.spin_limit) { gave_up = true; break; }
+      }
+      h += (uint32_t)a; pr += (uint32_t)b; cd += (uint32_t)c2;
+      mx = (uint32_t)d2 > mx ? (uint32_t)d2 : mx;
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) {
@@ -442,6 +463,11 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
       *fin.host_st = o;
       if (fin.count_out) *fin.count_out = o.n_rows;
     }
+  }
+  if (__any(gave_up) && lane == 0) {
+    // whoever gives up flags the search, in a word of its own that nothing else writes
+    __hip_atomic_store(reinterpret_cast<uint32_t*>(fin.host_st + 1), FS_WAIT_GAVE_UP, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 

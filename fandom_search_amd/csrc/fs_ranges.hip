@@ -22,38 +22,37 @@ using namespace fsdev;
 // block publishes totals and status.
 constexpr int kCompactRanges = 16;
 
-template <class V>
+// record i of the block: its place in the staging area and in the output
 __device__ __forceinline__ void compact_copy(const uint8_t* __restrict__ stage,
                                              uint8_t* __restrict__ rows, uint32_t caprow,
-                                             uint32_t rec_bytes, uint32_t range0, uint32_t base,
-                                             const uint32_t* s_off, const uint32_t* s_poff) {
-  const uint32_t P = s_poff[kCompactRanges];
-  // piece i of the block: its place in the staging area and in the output
-  auto locate = [&](uint32_t i, const V** src, V** dst) {
-    uint32_t r = 0;                                        // last range with s_poff[r] <= i
+                                             int wire, const double* __restrict__ selfdist,
+                                             uint32_t range0, uint32_t base,
+                                             const uint32_t* s_off) {
+  const uint32_t P = s_off[kCompactRanges];
+  auto locate = [&](uint32_t i, size_t* src, size_t* dst) {
+    uint32_t r = 0;                                        // last range with s_off[r] <= i
 #pragma unroll
     for (int step = kCompactRanges / 2; step > 0; step >>= 1)
-      if (s_poff[r + step] <= i) r += step;
-    const uint32_t k = i - s_poff[r];
-    *src = reinterpret_cast<const V*>(stage + (size_t)(range0 + r) * caprow * rec_bytes) + k;
-    *dst = reinterpret_cast<V*>(rows + (size_t)(base + s_off[r]) * rec_bytes) + k;
+      if (s_off[r + step] <= i) r += step;
+    *src = (size_t)(range0 + r) * caprow + (i - s_off[r]);
+    *dst = (size_t)base + i;
   };
-  // four pieces per thread requested together (named registers: an array here is moved
+  // four records per thread requested together (named registers: an array here is moved
   // to LDS by the compiler, with a wait behind every load)
   uint32_t i = threadIdx.x;
   for (; i + 3 * kThreads < P; i += 4 * kThreads) {
-    const V *s0, *s1, *s2, *s3;
-    V *d0, *d1, *d2, *d3;
+    size_t s0, s1, s2, s3, d0, d1, d2, d3;
     locate(i, &s0, &d0); locate(i + kThreads, &s1, &d1);
     locate(i + 2 * kThreads, &s2, &d2); locate(i + 3 * kThreads, &s3, &d3);
-    const V v0 = *s0, v1 = *s1, v2 = *s2, v3 = *s3;
-    *d0 = v0; *d1 = v1; *d2 = v2; *d3 = v3;
+    const StagedRec v0 = fetch_staged(stage, wire, selfdist, s0, true), v1 = fetch_staged(stage, wire, selfdist, s1, true),
+                    v2 = fetch_staged(stage, wire, selfdist, s2, true), v3 = fetch_staged(stage, wire, selfdist, s3, true);
+    store_staged(rows, wire, v0, d0); store_staged(rows, wire, v1, d1);
+    store_staged(rows, wire, v2, d2); store_staged(rows, wire, v3, d3);
   }
   for (; i < P; i += kThreads) {
-    const V* s0;
-    V* d0;
+    size_t s0, d0;
     locate(i, &s0, &d0);
-    *d0 = *s0;
+    store_staged(rows, wire, fetch_staged(stage, wire, selfdist, s0, true), d0);
   }
 }
 
@@ -61,11 +60,11 @@ __global__ __launch_bounds__(kThreads) void k_compact(
     const uint4* __restrict__ rinfo, const uint4* __restrict__ csum,
     const uint32_t* __restrict__ cmax, uint32_t csum_per, uint32_t n_ranges,
     const uint32_t* __restrict__ cand_sums, uint32_t n_cand_sums, bool fresh,
-    const uint8_t* __restrict__ stage, uint32_t caprow, int rec_bytes, uint32_t rcap,
-    uint8_t* __restrict__ rows, fs_status* st, fs_status* host_st, uint64_t* count_out) {
+    const uint8_t* __restrict__ stage, uint32_t caprow, int wire, const double* __restrict__ selfdist,
+    uint32_t rcap, uint8_t* __restrict__ rows, fs_status* st, fs_status* host_st, uint64_t* count_out) {
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_w2[4];
-  __shared__ uint32_t s_n[kCompactRanges], s_off[kCompactRanges + 1], s_poff[kCompactRanges + 1];
+  __shared__ uint32_t s_n[kCompactRanges], s_off[kCompactRanges + 1];
   const uint32_t n_blocks = n_ranges / kCompactRanges;
   if (blockIdx.x == n_blocks) {
     // the extra block: totals over all block sums, largest range, status
@@ -130,24 +129,19 @@ __global__ __launch_bounds__(kThreads) void k_compact(
   }
   uint32_t base;
   block_excl_scan(pre, s_w, &base);
-  const uint32_t piece = rec_bytes == 8 ? 8 : 16;
   if (threadIdx.x == 0) {
-    uint32_t acc = 0, pacc = 0;
+    uint32_t acc = 0;
     for (int r = 0; r < kCompactRanges; ++r) {
-      s_off[r] = acc; s_poff[r] = pacc;
+      s_off[r] = acc;
       uint32_t n = s_n[r] < caprow ? s_n[r] : caprow;
       if (base + acc >= rcap) n = 0;                       // beyond the caller's buffer
       else if (base + acc + n > rcap) n = rcap - (base + acc);
       acc += n;
-      pacc += n * (rec_bytes / piece);
     }
-    s_off[kCompactRanges] = acc; s_poff[kCompactRanges] = pacc;
+    s_off[kCompactRanges] = acc;
   }
   __syncthreads();
-  if (piece == 16)
-    compact_copy<uint4>(stage, rows, caprow, rec_bytes, blockIdx.x * kCompactRanges, base, s_off, s_poff);
-  else
-    compact_copy<uint2>(stage, rows, caprow, rec_bytes, blockIdx.x * kCompactRanges, base, s_off, s_poff);
+  compact_copy(stage, rows, caprow, wire, selfdist, blockIdx.x * kCompactRanges, base, s_off);
 }
 
 // per-corpus copy of the best record of every script n-gram, indexed by table slot
@@ -185,7 +179,7 @@ int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 // staged records of `n_ranges` wave ranges -> the caller's buffer, totals, status
 // (the finish of a search on an index with several lanes)
 static int launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, uint32_t caprow,
-                          int rec_bytes, uint32_t rcap, fs_row* d_rows, fs_status* host_st,
+                          int wire, uint32_t rcap, fs_row* d_rows, fs_status* host_st,
                           hipStream_t s, uint64_t* count_out, bool fresh, hipEvent_t done = nullptr) {
   fs_index::Lane& ln = *ix->cur;
   if (n_ranges % kCompactRanges || kCompactRanges % csum_per) {
@@ -196,8 +190,9 @@ static int launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, ui
   hipExtLaunchKernelGGL(k_compact, dim3(n_ranges / kCompactRanges + 1), dim3(kThreads), 0, s,
                      nullptr, done, 0u, ln.w_rinfo.p, ln.w_csum.p,
                      reinterpret_cast<const uint32_t*>(ln.w_csum.p + n_ranges / csum_per), csum_per,
-                     n_ranges, (const uint32_t*)nullptr, 0u, fresh, ln.w_stage.p, caprow, rec_bytes,
-                     rcap, reinterpret_cast<uint8_t*>(d_rows), ln.d_status.p, host_st, count_out);
+                     n_ranges, (const uint32_t*)nullptr, 0u, fresh, ln.w_stage.p, caprow, wire,
+                     (const double*)ix->d_selfdist.p, rcap, reinterpret_cast<uint8_t*>(d_rows),
+                     ln.d_status.p, host_st, count_out);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -208,14 +203,13 @@ int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy) {
   fs_index::Lane& ln = *ix->cur;
   if (n_blocks > FS_SYNC_BLOCKS) { fs_set_error("%u workgroups in a records kernel", n_blocks); return FS_E_INVALID; }
   if (!ln.w_gran.p) {
-    FS_TRY(ln.w_gran.reserve(FS_SYNC_BLOCKS));
-    FS_TRY(ln.w_bstat.reserve(FS_SYNC_BLOCKS));
-    FS_HIP(hipMemsetAsync(ln.w_gran.p, 0, FS_SYNC_BLOCKS * sizeof(unsigned long long), ln.stream));
+    FS_TRY(ln.w_gran.reserve(5 * FS_SYNC_BLOCKS));
+    FS_HIP(hipMemsetAsync(ln.w_gran.p, 0, 5 * FS_SYNC_BLOCKS * sizeof(unsigned long long), ln.stream));
     ln.sync_epoch = 0;
   }
   if (++ln.sync_epoch == 0) ln.sync_epoch = 1;     // 0 is the tag of a granule never written
   sy->gran = ln.w_gran.p;
-  sy->bstat = ln.w_bstat.p;
+  sy->sgran = ln.w_gran.p + FS_SYNC_BLOCKS;
   sy->epoch = ln.sync_epoch;
   sy->n_blocks = n_blocks;
   sy->spin_limit = ix->sw.wait_spins >= 0 ? (uint32_t)ix->sw.wait_spins : (1u << 22);
@@ -234,9 +228,9 @@ int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy) {
 }
 
 int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
-                                      int rec_bytes, uint32_t rcap, fs_row* d_rows,
+                                      int wire, uint32_t rcap, fs_row* d_rows,
                                       fs_status* host_st, hipStream_t s, uint64_t* count_out,
                                       hipEvent_t done) {
-  return launch_compact(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st, s, count_out, true,
+  return launch_compact(ix, n_ranges, waves, caprow, wire, rcap, d_rows, host_st, s, count_out, true,
                         done);
 }

@@ -598,11 +598,27 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
   const uint32_t range_id = blockIdx.x * n_waves + wave;
-  const uint32_t n_ranges = gridDim.x * n_waves;
-  // sub-tiles dealt out evenly: the first n_sub % n_ranges ranges take one more
-  const uint32_t per = n_sub / n_ranges, rem = n_sub % n_ranges;
-  const uint32_t s0 = range_id * per + (range_id < rem ? range_id : rem);
-  const uint32_t s1 = s0 + per + (range_id < rem ? 1u : 0u);
+  // Sub-tiles dealt out evenly over the workgroups (the first n_sub % gridDim.x take one
+  // more), and inside a workgroup of sixteen waves by how fast its SIMD serves each wave: the
+  // four waves of a SIMD (slots w, w + 4, w + 8, w + 12) are served oldest first, and over
+  // equal shares the youngest takes 60 % longer than the oldest (in-kernel stamps,
+  // tools/scan_timeline.py: 10.3 / 11.0 / 12.2 / 16.5 us), so the shares are 29.8 / 26.8 /
+  // 24.5 / 18.9 % of a quarter each.  What comes out does not depend on the split.
+  uint32_t s0, s1;
+  {
+    const uint32_t per = n_sub / gridDim.x, rem = n_sub % gridDim.x;
+    const uint32_t b0 = blockIdx.x * per + (blockIdx.x < rem ? blockIdx.x : rem);
+    const uint32_t len = per + (blockIdx.x < rem ? 1u : 0u);
+    auto cut = [&](uint32_t w) -> uint32_t {             // first sub-tile of wave w (w <= n_waves)
+      if (n_waves != 16 || (diag & 16)) return (uint32_t)(((uint64_t)len * w) / n_waves);
+      const uint32_t g = w >> 2, r = w & 3;
+      const uint32_t share[5] = {0, 305, 579, 830, 1024};          // cumulative, in 1/1024 of a quarter
+      const uint32_t at = 4 * share[g] + r * (share[g + 1] - share[g]);
+      return (uint32_t)(((uint64_t)len * at) >> 12);
+    };
+    s0 = b0 + cut(wave);
+    s1 = b0 + cut(wave + 1);
+  }
 
   constexpr uint32_t HALO = N - 1;
   constexpr uint32_t SUB = 512;
@@ -691,7 +707,6 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     };
     // records queued so far -> rounds of candidates; F_end = the scan front
     auto flush = [&](uint32_t F_end) {
-      if (diag & 4) __builtin_amdgcn_s_setprio(0);
       wave_sync();
       // candidates in front of every queued record (lane t: records t and t + 64)
       const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
@@ -750,23 +765,10 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       rec_cnt = 0;
       halo_n = 0;
       ++n_flushes;
-      if (diag & 4) __builtin_amdgcn_s_setprio(2);
     };
     const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
     Pair nx = request(s0);
-    if (diag & 4) __builtin_amdgcn_s_setprio(2);     // scanning waves go first, rounds fill the gaps
     for (uint32_t j = s0; j < s1; j += 2) {
-      if (diag & 8) {
-        // the four waves of a SIMD (wave slots w, w + 4, w + 8, w + 12 in age order) take turns at
-        // the top priority, one pair of sub-tiles each: left alone, the SIMD serves the oldest
-        // wave first and the youngest takes 60 % longer over the same number of sub-tiles
-        switch ((((j - s0) >> 1) + (wave >> 2)) & 3u) {
-          case 0: __builtin_amdgcn_s_setprio(3); break;
-          case 1: __builtin_amdgcn_s_setprio(2); break;
-          case 2: __builtin_amdgcn_s_setprio(1); break;
-          default: __builtin_amdgcn_s_setprio(0); break;
-        }
-      }
       const Pair v = arrive(nx);
       nx = request(j + 2 < s1 ? j + 2 : j);
       scan(v.a0, v.a1, v.b0, v.b1, j);
@@ -787,9 +789,8 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     R.match_acc += (uint32_t)__shfl_xor((int)R.match_acc, d);
     cacc += (uint32_t)__shfl_xor((int)cacc, d);
   }
-  if (diag & 4) __builtin_amdgcn_s_setprio(0);
   if (dbg) t_rounds = __builtin_amdgcn_s_memrealtime();
-  finish_rows(sy, fin, out, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt);
+  finish_rows(sy, fin, out, g.selfdist, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt);
   if (dbg && lane == 0) {
     unsigned long long* d = dbg + 8 * (size_t)range_id;
     d[0] = t_entry; d[1] = t_ready; d[2] = t_scan; d[3] = t_rounds;
@@ -1109,9 +1110,9 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
                         bool* done_attached) {
   fs_index::Lane& ln = *ix->cur;
   const uint32_t n_ranges = blocks * waves;
-  const int rec_bytes = wire ? wire : 32;
+  const int stage_bytes = wire == 8 ? 8 : 16;          // (fs_row records are staged as 16-byte wire records)
   const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
-  FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * rec_bytes));
+  FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * stage_bytes));
   const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
   fsdev::RowSync sy;
   FS_TRY(fs_row_sync(ix, blocks, &sy));
@@ -1132,7 +1133,7 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
   }
   if (sy.rinfo) {
     if (done_attached) *done_attached = done != nullptr;
-    return fs_launch_compact_after_scan_rows(ix, n_ranges, waves, caprow, rec_bytes, rcap, d_rows, host_st,
+    return fs_launch_compact_after_scan_rows(ix, n_ranges, waves, caprow, wire, rcap, d_rows, host_st,
                                              s, count_out, done);
   }
   return FS_OK;

@@ -12,6 +12,10 @@ bench.py can tell whether the file applies to what it is measuring.
 import argparse
 import csv
 import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def mean_counter(path, kernel, counter):
@@ -46,6 +50,7 @@ def main():
         "rotate": bench["config"]["distinct_batches"],
         "lanes": bench["config"].get("lanes"),
         "kernel": bench["roofline"]["kernel"],
+        "build": __import__("fandom_search_amd._lib", fromlist=["source_hash"]).source_hash(),
         "FETCH_SIZE_KB": fetch,
         "WRITE_SIZE_KB": write,
         "dispatches": n,
