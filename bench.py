@@ -215,15 +215,16 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     out = {}
     # (1) records copied to the host after every search (FS_ROWS_HOST, synchronous)
     reps = 10
-    ix.search(corpora[0])
+    ix.search(corpora[0], reuse=True)
     t0 = time.perf_counter()
     for i in range(reps):
-        rows, st = ix.search(corpora[i % len(corpora)])
+        rows, st = ix.search(corpora[i % len(corpora)], reuse=True)
     dt = time.perf_counter() - t0
     out["rows_to_host"] = {"value": n_works * reps / dt, "unit": "fanworks/s",
                            "ms_per_step": dt / reps * 1e3, "rows_per_step": int(len(rows)),
-                           "note": "synchronous fs_search_corpus with the 32-byte records "
-                                   "copied to host memory after every search"}
+                           "note": "synchronous fs_search_corpus with host rows: 8-byte records over PCIe "
+                                   "into pinned memory, fs_row made on the host cores, into a row "
+                                   "buffer the caller reuses"}
     # (2) ids streamed from pinned host memory, upload of batch i+1 beside the search of
     # batch i (configs[4] mechanics on c2 batches; PCIe-inclusive)
     pins = []

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <new>
 #include <numeric>
@@ -67,6 +68,7 @@ fs_index::~fs_index() {
   if (ev_scan0) (void)hipEventDestroy(ev_scan0);
   if (ev_scan1) (void)hipEventDestroy(ev_scan1);
   if (h_status) (void)hipHostFree(h_status);
+  if (h_stage) (void)hipHostFree(h_stage);
   for (int l = 0; l < FS_LANES; ++l)
     if (lanes[l].stream) (void)hipStreamDestroy(lanes[l].stream);
   for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
@@ -426,6 +428,10 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
   FS_TRY(fs_launch_rownorms(ix->d_emb.p, n_vec, (int)cfg->emb_dim, ix->d_q.p, ix->stream));
   FS_TRY(fs_launch_selfdist(ix->d_stok.p, ix->n_windows, (int)cfg->window_size, (int)cfg->emb_dim,
                             n_vec, ix->d_q.p, ix->d_selfdist.p, ix->stream));
+  ix->h_selfdist.resize(ix->n_windows);
+  if (ix->n_windows)
+    FS_HIP(hipMemcpyAsync(ix->h_selfdist.data(), ix->d_selfdist.p, ix->n_windows * sizeof(double),
+                          hipMemcpyDeviceToHost, ix->stream));
   tick("uploads, norms, self distances");
   FS_TRY(build_gram_index(ix, stok.data()));
   tick("n-gram index");
@@ -545,6 +551,7 @@ extern "C" int fs_corpus_update_begin(fs_corpus* c, const uint32_t* tok_vec,
     if (T) FS_HIP(hipMemcpyAsync(c->d_str.p, tok_str, T * sizeof(uint32_t), hipMemcpyHostToDevice, cs));
   }
   FS_TRY(c->d_work_off.upload(work_off, n_works + 1, cs));
+  c->h_work_off.assign(work_off, work_off + n_works + 1);
   const uint32_t n_blocks = (uint32_t)((T + 255) / 256);
   FS_TRY(c->d_blk_work.reserve(2 * (size_t)n_blocks));
   FS_TRY(c->d_blk4.reserve(4 * (size_t)n_blocks));
@@ -721,8 +728,10 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     count_out = reinterpret_cast<uint64_t*>(sl.rows);
     d_rows = reinterpret_cast<fs_row*>(reinterpret_cast<char*>(sl.rows) + 32);
   }
-  if (sl.mode == FS_ROWS_HOST) { FS_TRY(ln.w_rows.reserve(sl.rcap)); d_rows = ln.w_rows.p; }
-  const int wire = sl.mode == FS_ROWS_DEVICE_PACKED ? 16 : sl.mode == FS_ROWS_DEVICE_PACKED8 ? 8 : 0;
+  // (host rows of the exact pipeline leave the device as 8-byte records: a quarter of the
+  // bytes over PCIe; w_rows is sized in fs_row either way)
+  if (sl.mode == FS_ROWS_HOST) { FS_TRY(ln.w_rows.reserve(sl.host_wire8 ? (sl.rcap + 3) / 4 : sl.rcap)); d_rows = ln.w_rows.p; }
+  const int wire = sl.mode == FS_ROWS_DEVICE_PACKED ? 16 : (sl.mode == FS_ROWS_DEVICE_PACKED8 || sl.host_wire8) ? 8 : 0;
 
   // the status block is cleared by the chain's first kernel (k_reduce) and its final
   // state is written to sl.h_status by the last one (k_rows)
@@ -815,6 +824,8 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   sl.lane = (int)(id % (uint32_t)ix->n_lanes);
   const fs_index::Lane& ln = ix->lanes[sl.lane];
   sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
+  static const bool host8 = !getenv("FS_HOST_WIRE8") || atoi(getenv("FS_HOST_WIRE8")) != 0;
+  sl.host_wire8 = rows_mode == FS_ROWS_HOST && sl.exact && ix->n_script < (1ull << 18) && host8;
   sl.tpl = sl.exact ? fs_scan_tpl(ix, T) : 4;
   sl.n_bm = (uint32_t)((T + 64 * sl.tpl - 1) / (64 * sl.tpl));
   if (rows_mode == FS_ROWS_DEVICE_PACKED8 && (!sl.exact || ix->n_script >= (1ull << 18))) {
@@ -862,6 +873,42 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   *ticket = id;
   ++ix->next_slot;
   return FS_OK;
+}
+
+// 8-byte wire records {token position, orig_ix | k << 18 | lev << 22} (ascending positions) ->
+// fs_row on the host, as fs_rows_unpack8 does on the device: the work of a record by a walk
+// along the work offsets, dist = the matched script window's distance to itself, comb =
+// dist * lev (one IEEE multiplication, as __dmul_rn).  A few threads, each over a slice.
+static void fs_expand_rows8_host(const uint32_t* rec, uint64_t n, const uint64_t* work_off, uint64_t n_works,
+                                 const double* selfdist, fs_row* rows) {
+  auto slice = [=](uint64_t lo, uint64_t hi) {
+    if (lo >= hi) return;
+    // the work of the slice's first record: last w with work_off[w] <= position
+    uint64_t a = 0, b = n_works;
+    const uint64_t x0 = rec[2 * lo];
+    while (b - a > 1) {
+      const uint64_t mid = a + ((b - a) >> 1);
+      if (work_off[mid] <= x0) a = mid; else b = mid;
+    }
+    uint64_t w = a;
+    for (uint64_t i = lo; i < hi; ++i) {
+      const uint32_t x = rec[2 * i], y = rec[2 * i + 1];
+      while (w + 1 < n_works && work_off[w + 1] <= x) ++w;
+      const uint32_t orig = y & 0x3FFFFu, k = (y >> 18) & 0xFu, lev = y >> 22;
+      fs_row r;
+      r.work = (uint32_t)w; r.fan_ix = (uint32_t)(x - work_off[w]); r.orig_ix = orig; r.lev = lev;
+      r.dist = selfdist[orig - k];
+      r.comb = r.dist * (double)lev;
+      rows[i] = r;
+    }
+  };
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const uint64_t nt = std::min<uint64_t>(std::min<uint64_t>(8, hw), n / 16384 + 1);
+  if (nt <= 1) { slice(0, n); return; }
+  std::vector<std::thread> th;
+  for (uint64_t t = 1; t < nt; ++t) th.emplace_back(slice, n * t / nt, n * (t + 1) / nt);
+  slice(0, n / nt);
+  for (std::thread& t : th) t.join();
 }
 
 extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_rows, fs_stats* st) {
@@ -939,9 +986,25 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
   if (hs.n_rows > sl.cap) return FS_E_CAPACITY;
   if (sl.mode == FS_ROWS_HOST && hs.n_rows) {
     fs_index::Lane& ln = ix->lanes[sl.lane];
-    FS_HIP(hipMemcpyAsync(sl.rows, ln.w_rows.p, (size_t)hs.n_rows * sizeof(fs_row),
-                          hipMemcpyDeviceToHost, ln.stream));
-    FS_HIP(hipStreamSynchronize(ln.stream));
+    if (sl.host_wire8) {
+      // 8-byte records into pinned memory (a quarter of fs_row over PCIe, and no pageable
+      // landing buffer in the copy's way), then fs_row on the host cores
+      const size_t bytes = (size_t)hs.n_rows * 8;
+      if (ix->h_stage_bytes < bytes) {
+        if (ix->h_stage) (void)hipHostFree(ix->h_stage);
+        ix->h_stage = nullptr; ix->h_stage_bytes = 0;
+        FS_HIP(hipHostMalloc(&ix->h_stage, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+        ix->h_stage_bytes = bytes + bytes / 4 + 4096;
+      }
+      FS_HIP(hipMemcpyAsync(ix->h_stage, ln.w_rows.p, bytes, hipMemcpyDeviceToHost, ln.stream));
+      FS_HIP(hipStreamSynchronize(ln.stream));
+      fs_expand_rows8_host(reinterpret_cast<const uint32_t*>(ix->h_stage), hs.n_rows, sl.c->h_work_off.data(),
+                           sl.c->n_works, ix->h_selfdist.data(), sl.rows);
+    } else {
+      FS_HIP(hipMemcpyAsync(sl.rows, ln.w_rows.p, (size_t)hs.n_rows * sizeof(fs_row),
+                            hipMemcpyDeviceToHost, ln.stream));
+      FS_HIP(hipStreamSynchronize(ln.stream));
+    }
   }
   return FS_OK;
 }

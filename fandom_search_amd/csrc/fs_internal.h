@@ -200,6 +200,9 @@ struct fs_index {
   DBuf<uint32_t> d_stok, d_filter, d_sfilter, d_table, d_disp, d_gpos, d_gcnt, d_schars, d_cproto, d_disp8;
   DBuf<uint64_t> d_soff;
   DBuf<double> d_q, d_selfdist;
+  std::vector<double> h_selfdist;   // host copy (host-row searches expand 8-byte records on the host)
+  void* h_stage = nullptr;          // pinned landing buffer of those records
+  size_t h_stage_bytes = 0;
   DBuf<float> d_emb;
   DBuf<double> d_normals;
 
@@ -258,6 +261,7 @@ struct fs_index {
     uint64_t cap = 0, ccap = 0, rcap = 0;
     int mode = 0;
     bool header = false;              // FS_ROWS_HEADER: rows = 32-byte header + records
+    bool host_wire8 = false;          // FS_ROWS_HOST: 8-byte records cross PCIe, fs_row made on the host
     bool exact = false;
     uint32_t n_bm = 0, launches = 0;
     bool timed = false;               // this search's scan carries timing events
@@ -288,6 +292,7 @@ struct fs_corpus {
   fs_index* ix = nullptr;
   uint64_t n_tok = 0, n_works = 0, n_str = 0;
   uint64_t windows = 0;      // sum over works of max(0, len - n + 1)
+  std::vector<uint64_t> h_work_off;   // host copy of the work offsets (host-row searches)
   bool has_oov = false;
   bool has_str = false;
   DBuf<uint32_t> d_tok, d_str, d_chars, d_levtab, d_blk_work, d_blk4, d_check;

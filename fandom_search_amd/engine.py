@@ -115,7 +115,8 @@ def search_stream(index, batches, str_chars, str_off):
     `batches` yields (tok_vec, work_off) pairs, or (tok_vec, work_off, tok_str).
     Two device corpora alternate: while batch i is searched, batch i+1 is copied
     to the GPU on the other corpus's copy stream.  Yields (rows, stats) per batch,
-    work indices local to the batch."""
+    work indices local to the batch; the rows are a view of a buffer that the next batch
+    overwrites (ScriptIndex.search(reuse=True))."""
     it = iter(batches)
     slots = [None, None]
     cur = None
@@ -139,7 +140,7 @@ def search_stream(index, batches, str_chars, str_off):
         if nxt_batch is not None:
             nxt = cur ^ 1
             stage(nxt, nxt_batch)            # queued; overlaps the search below
-        yield index.search(slots[cur])
+        yield index.search(slots[cur], reuse=True)
         cur = nxt
     for c in slots:
         if c is not None:
@@ -180,14 +181,23 @@ class ScriptIndex(object):
     def corpus(self, tok_vec, work_off, str_chars, str_off, tok_str=None):
         return Corpus(self, tok_vec, work_off, str_chars, str_off, tok_str)
 
-    def search(self, corpus, cap=None):
-        """Rows (numpy structured array, host) and stats of one batch."""
+    def search(self, corpus, cap=None, reuse=False):
+        """Rows (numpy structured array, host) and stats of one batch.  `reuse`: the rows
+        are a view of a buffer the index keeps and writes again on its next search with
+        `reuse` (a fresh 40 MB array per call costs more in page faults than the copy over
+        PCIe); take a copy of what must outlive that."""
         L = _lib.load()
         st = abi.FsStats()
         n = C.c_uint64(0)
         cap = int(cap) if cap else max(1024, corpus.n_tok // 16)
         while True:
-            rows = np.empty(cap, dtype=abi.ROW_DTYPE)
+            if reuse:
+                if getattr(self, "_rows_buf", None) is None or len(self._rows_buf) < cap:
+                    self._rows_buf = np.empty(cap, dtype=abi.ROW_DTYPE)
+                rows = self._rows_buf
+                cap = len(rows)
+            else:
+                rows = np.empty(cap, dtype=abi.ROW_DTYPE)
             rc = L.fs_search_corpus(self._h, corpus._h,
                                     rows.ctypes.data_as(C.c_void_p), cap, 0,
                                     C.byref(n), C.byref(st))

@@ -29,6 +29,7 @@ import datetime
 import os
 import random
 import re
+import shutil
 
 import numpy as np
 
@@ -213,6 +214,96 @@ def read_work_tokens(filename):
             for t in vocab_mod.tokenize(ch)]
 
 
+def _factorize(texts):
+    """(codes uint32, uniques list) of a list of strings, first-appearance order."""
+    if len(texts) == 0:
+        return np.zeros(0, np.uint32), []
+    try:
+        import pandas as pd
+        codes, uniques = pd.factorize(np.asarray(texts, dtype=object), sort=False)
+    except ImportError:
+        uniques, codes = np.unique(np.asarray(texts, dtype=object), return_inverse=True)
+    return np.asarray(codes, dtype=np.uint32), [str(u) for u in uniques]
+
+
+NEW_STRING = 1 << 31      # tokenize_files: codes from here on index the chunk's list of new strings
+
+
+def tokenize_files(filenames, vocab=None):
+    """What a pool worker does with a chunk of works (the reference's workers do the same at
+    search.py:164-166: read, chunked parse, whitespace tokens dropped): token counts per
+    work and the chunk's tokens as string ids of the vocabulary the worker inherited when
+    it was forked; a string that vocabulary did not hold yet travels back as text, once per
+    chunk, and its tokens carry NEW_STRING + its place in that list.  The compact form is
+    what makes the pool pay: 4 bytes per token instead of one Python string."""
+    lens = np.zeros(len(filenames), dtype=np.int64)
+    flat = []
+    for i, f in enumerate(filenames):
+        toks = read_work_tokens(f)
+        lens[i] = len(toks)
+        flat += toks
+    codes, uniques = _factorize(flat)
+    v = vocab if vocab is not None else _VOCAB
+    known = v._string_id if v is not None else {}
+    new = []
+    usid = np.zeros(len(uniques), dtype=np.uint32)
+    for k, t in enumerate(uniques):
+        sid = known.get(t)
+        if sid is None:
+            sid = NEW_STRING + len(new)
+            new.append(t)
+        usid[k] = sid
+    return lens, (usid[codes] if len(codes) else np.zeros(0, np.uint32)), new
+
+
+class TokenPool(object):
+    """Worker processes that read and tokenise fan works while the GPU searches and the
+    parent writes records (/root/reference/search.py:381-385 runs its whole search in such
+    a pool; here only the host text work is left for it).  Must be created BEFORE the
+    process touches the GPU: the workers are forked.  `start(filenames)` queues a list of
+    works in chunks of 31 (the reference's chunksize), `get(filenames)` returns
+    (lens, codes, uniques) of exactly that list, waiting for a queued job or doing the
+    work here when nothing was queued."""
+
+    CHUNK = 31
+
+    def __init__(self, processes):
+        import multiprocessing
+        self.processes = int(processes)
+        self.pool = multiprocessing.get_context("fork").Pool(self.processes) if self.processes > 1 else None
+        self.pending = {}
+
+    def start(self, filenames):
+        key = tuple(filenames)
+        if self.pool is None or not key or key in self.pending:
+            return
+        chunks = [list(key[i:i + self.CHUNK]) for i in range(0, len(key), self.CHUNK)]
+        self.pending[key] = self.pool.map_async(tokenize_files, chunks, chunksize=1)
+
+    def get(self, filenames):
+        job = self.pending.pop(tuple(filenames), None)
+        return job.get() if job is not None else [tokenize_files(list(filenames))]
+
+    def close(self):
+        if self.pool is not None:
+            self.pool.terminate()
+            self.pool.join()
+            self.pool = None
+
+
+def default_workers(world=1):
+    """Tokeniser processes per rank: FANDOM_SEARCH_WORKERS, else up to 8 of this rank's
+    share of the cores the process may use (0 or 1: tokenise in the parent)."""
+    env = os.environ.get("FANDOM_SEARCH_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(8, cores // max(1, world)))
+
+
 class AnnIndexSearch(object):
     def __init__(self, original_script_filename, window_size,
                  number_of_hashes, hash_dimensions, distance_threshold,
@@ -244,7 +335,40 @@ class AnnIndexSearch(object):
                                   self.vocab.vectors, normals, cfg=cfg)
         self.last_stats = None
         self.last_oov_rate = None
+        self.token_pool = None      # analyze() lends its TokenPool
         self.reset_stats()
+
+    def prefetch(self, filenames):
+        """Start reading and tokenising works that a later search_rows / search_shard call
+        will ask for (no-op without a pool)."""
+        if self.token_pool is not None:
+            self.token_pool.start(filenames)
+
+    def _encode_files(self, filenames):
+        """(string ids, vector ids, work offsets) of the works: tokenised by the pool (or
+        here) against the vocabulary as it was when the pool was forked; strings it has not
+        seen get their ids here, in work order (so the ids do not depend on the pool)."""
+        v = self.vocab
+        # (the workers hold the process-wide vocabulary; an index built on another one
+        # tokenises here)
+        parts = self.token_pool.get(filenames) if self.token_pool is not None and v is _VOCAB \
+            else [tokenize_files(list(filenames), v)]
+        lens = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
+        off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(lens, dtype=np.uint64)
+        strs = []
+        for _, sids, new in parts:
+            if new:
+                # (a worker's vocabulary is the parent's at fork time: what it calls new may
+                # have been added here since)
+                ids = np.fromiter((v.string_id(t) for t in new), dtype=np.uint32, count=len(new))
+                fresh = sids >= NEW_STRING
+                sids = sids.copy()
+                sids[fresh] = ids[sids[fresh] - NEW_STRING]
+            strs.append(sids)
+        tok_str = np.concatenate(strs) if strs else np.zeros(0, np.uint32)
+        tok_vec = v.vec_ids()[tok_str] if len(tok_str) else np.zeros(0, np.uint32)
+        return tok_str, tok_vec, off
 
     def reset_stats(self):
         self._windows_processed = 0
@@ -267,19 +391,11 @@ class AnnIndexSearch(object):
     def search_rows(self, filenames):
         """(fs_row array with work indices into `filenames`, fan word text per
         row) -- the form that travels between ranks (fandom_search_amd.dist)."""
-        texts = [read_work_tokens(f) for f in filenames]
-        return self.search_tokens(texts)
+        return self._search_encoded(*self._encode_files(filenames))
 
-    def _corpus_of(self, texts):
-        """(string ids, vector ids, work offsets, device corpus) of tokenised works."""
+    def _corpus_of_ids(self, tok_str, tok_vec, off):
+        """(string ids, vector ids, work offsets, device corpus) of encoded works."""
         v = self.vocab
-        off = np.zeros(len(texts) + 1, dtype=np.uint64)
-        if texts:
-            off[1:] = np.cumsum([len(toks) for toks in texts], dtype=np.uint64)
-        # one pass over the whole batch: the vocabulary is consulted once per distinct
-        # string of the batch, not once per work
-        flat = [t for toks in texts for t in toks]
-        tok_str, tok_vec = v.encode(flat)
         chars, coff = v.string_table()
         self.last_oov_rate = float((tok_vec & np.uint32(abi.FS_OOV_FLAG)).astype(bool).mean()) \
             if len(tok_vec) else 0.0
@@ -289,10 +405,21 @@ class AnnIndexSearch(object):
         return tok_str, tok_vec, off, corpus
 
     def search_tokens(self, texts):
+        """Records of works given as lists of token texts."""
+        off = np.zeros(len(texts) + 1, dtype=np.uint64)
+        if texts:
+            off[1:] = np.cumsum([len(toks) for toks in texts], dtype=np.uint64)
+        # one pass over the whole batch: the vocabulary is consulted once per distinct
+        # string of the batch, not once per work
+        tok_str, tok_vec = self.vocab.encode([t for toks in texts for t in toks])
+        return self._search_encoded(tok_str, tok_vec, off)
+
+    def _search_encoded(self, tok_str, tok_vec, off):
         v = self.vocab
-        tok_str, tok_vec, off, corpus = self._corpus_of(texts)
+        tok_str, tok_vec, off, corpus = self._corpus_of_ids(tok_str, tok_vec, off)
         try:
-            rows, st = self.engine.search(corpus)
+            rows, st = self.engine.search(corpus, reuse=True)
+            rows = rows.copy()                    # (the engine's buffer is written by the next batch)
         finally:
             corpus.close()
         self.last_stats = st
@@ -310,8 +437,7 @@ class AnnIndexSearch(object):
         import torch
         from . import _lib
         from .dist import HDR, Shard
-        texts = [read_work_tokens(f) for f in filenames]
-        tok_str, tok_vec, off, corpus = self._corpus_of(texts)
+        tok_str, tok_vec, off, corpus = self._corpus_of_ids(*self._encode_files(filenames))
         exact = self.engine.info["path"] == abi.FS_MODE_EXACT and \
             not bool((tok_vec & np.uint32(abi.FS_OOV_FLAG)).any())
         packed = False
@@ -410,6 +536,25 @@ def analyze(args,
     are the same for any number of GPUs.  `searcher` (tests) replaces the
     AnnIndexSearch instance; it needs search_rows() and the script columns."""
     from . import dist
+    # the tokeniser processes are forked before anything touches the GPU (the process group
+    # of a multi-GPU run does); they read and tokenise cluster i + 1 while the GPU searches
+    # cluster i and the parent writes its records (the reference's Pool(4) does its whole
+    # search in the workers, search.py:381-385)
+    pool = None
+    if searcher is None:
+        get_vocab()               # (host only) the workers inherit the string table
+        pool = TokenPool(default_workers(dist.env_world()[2]))
+    try:
+        return _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_threshold,
+                        chunk_size, searcher, pool)
+    finally:
+        if pool is not None:
+            pool.close()
+
+
+def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_threshold,
+             chunk_size, searcher, pool):
+    from . import dist
     rank, local_rank, world = dist.init_from_env()
     fan_works = list_fan_works(args.fan_works, args.skip_works, args.num_works)
     window_size = getattr(args, 'window_size', None) or window_size
@@ -424,7 +569,17 @@ def analyze(args,
     filename_base = 'match-{}gram{{}}'.format(window_size)
     batch_filename = filename_base.format('-batch-{}.csv')
 
-    accumulated_records = [new_record_structure['fields']]
+    n_batches = 0
+
+    def share(cluster):
+        """The works of `cluster` this rank reads (all of them without a launcher)."""
+        if world == 1:
+            return cluster
+        b = dist.split_contiguous([os.path.getsize(f) for f in cluster], world)
+        return cluster[b[rank]:b[rank + 1]]
+
+    if pool is not None and fan_clusters:
+        pool.start(share(fan_clusters[0]))          # beside the index build
     ann_index = searcher or AnnIndexSearch(args.script,
                                            window_size,
                                            number_of_hashes,
@@ -432,7 +587,22 @@ def analyze(args,
                                            distance_threshold,
                                            device=device)
 
+    if pool is not None:
+        ann_index.token_pool = pool
+    import time
+    timing = {} if os.environ.get("FANDOM_SEARCH_TIMING") else None
+    t_last = [time.perf_counter()]
+
+    def lap(what):
+        if timing is not None:
+            now = time.perf_counter()
+            timing[what] = timing.get(what, 0.0) + now - t_last[0]
+            t_last[0] = now
+
+    lap("index")
     for i, fan_cluster in enumerate(fan_clusters):
+        if pool is not None and i + 1 < len(fan_clusters):
+            pool.start(share(fan_clusters[i + 1]))
         if rank == 0:
             print('Processing cluster {} ({}-{})'.format(i,
                                                          chunk_size * i,
@@ -442,6 +612,7 @@ def analyze(args,
             rows, words = dist.search_sharded(fan_cluster, weights, ann_index)
         else:
             rows, words = ann_index.search_rows(fan_cluster)
+        lap("tokens + search")
         oov = getattr(ann_index, 'last_oov_rate', None)
         if oov is not None and oov > 0.2:
             import sys
@@ -454,13 +625,27 @@ def analyze(args,
         records = join_records(fan_cluster, rows, words,
                                ann_index.word_lowercase, ann_index.orth_id,
                                ann_index.character, ann_index.scene)
+        lap("join records")
         write_records(records, batch_filename.format(i))
-        accumulated_records.extend(records)
+        n_batches = i + 1
+        lap("write batch csv")
 
+    if pool is not None:
+        ann_index.token_pool = None
     name = None
     if rank == 0:
+        # the dated file = header row + the records of every batch file, in order
+        # (search.py:386-399 accumulates the same rows and writes them with the same writer)
         name = unused_result_name(filename_base)
-        write_records(accumulated_records, name)
+        write_records([new_record_structure['fields']], name)
+        with open(name, 'ab') as out:
+            for i in range(n_batches):
+                with open(batch_filename.format(i), 'rb') as part:
+                    shutil.copyfileobj(part, out)
+    lap("write dated csv")
+    if timing is not None:
+        import sys
+        print("analyze: " + ", ".join("%s %.3f s" % kv for kv in timing.items()), file=sys.stderr)
     if world > 1:
         dist.finalize()
     return name

@@ -56,9 +56,18 @@ def murmurhash64a(data, seed=1):
     return h
 
 
+_HASH_CACHE = {}
+
+
 def hash_string(text):
-    """spaCy StringStore key of `text`."""
-    return murmurhash64a(text.encode("utf8"), 1)
+    """spaCy StringStore key of `text` (remembered: the CSV writer asks once per record,
+    a corpus has far fewer distinct words than records)."""
+    h = _HASH_CACHE.get(text)
+    if h is None:
+        h = murmurhash64a(text.encode("utf8"), 1)
+        if len(_HASH_CACHE) < (1 << 20):
+            _HASH_CACHE[text] = h
+    return h
 
 
 def default_oov_hash(text):
@@ -147,6 +156,13 @@ class Vocab(object):
     def vec_id(self, sid):
         return self._vec_id[sid]
 
+    def vec_ids(self):
+        """Vector id per string id as one uint32 array (grown with the string table)."""
+        cached = getattr(self, "_vec_id_arr", None)
+        if cached is None or len(cached) != len(self._vec_id):
+            self._vec_id_arr = cached = np.array(self._vec_id, dtype=np.uint32)
+        return cached
+
     def orth(self, sid):
         return self._orth[sid]
 
@@ -166,10 +182,16 @@ class Vocab(object):
         distinct string, not once per token."""
         if len(texts) == 0:
             return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
-        try:
-            import pandas as pd
+        import sys
+        pd = sys.modules.get("pandas")
+        if pd is None and len(texts) > 200000:          # (pandas costs 0.3 s to import)
+            try:
+                import pandas as pd
+            except ImportError:
+                pd = None
+        if pd is not None:
             codes, uniques = pd.factorize(np.asarray(texts, dtype=object), sort=False)
-        except ImportError:
+        else:
             uniques, codes = np.unique(np.asarray(texts, dtype=object), return_inverse=True)
         usid = np.fromiter((self.string_id(t) for t in uniques), dtype=np.uint32,
                            count=len(uniques))

@@ -40,7 +40,7 @@ def main():
         t_write = time.time() - t0
         t0 = time.time()
         out = subprocess.run([sys.executable, os.path.join(ROOT, "ao3.py"), "search", fan, spath, "--synthetic-vocab"],
-                             cwd=tmp, capture_output=True, text=True)
+                             cwd=tmp, capture_output=True, text=True, env=dict(os.environ, FANDOM_SEARCH_TIMING="1"))
         dt = time.time() - t0
         csvs = [f for f in os.listdir(tmp) if f.startswith("match-")]
         rows = 0
@@ -51,7 +51,7 @@ def main():
         print(json.dumps({"works": a.works, "tokens_per_work": a.tokens, "write_inputs_s": round(t_write, 2),
                           "search_command_s": round(dt, 2), "works_per_s": round(a.works / dt, 1),
                           "rows": rows, "csv_files": len(csvs), "rc": out.returncode,
-                          "stderr_tail": out.stderr[-200:]}))
+                          "stderr_tail": out.stderr[-400:]}))
 
 
 if __name__ == "__main__":
