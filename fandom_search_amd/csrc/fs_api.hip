@@ -243,12 +243,12 @@ static int build_gram_index(fs_index* ix, const uint32_t* stok) {
     const double dens = std::pow(2e-3, 1.0 / (double)(n - K + 1));
     int ls = ceil_log2((uint64_t)((double)std::max<uint64_t>(1, ix->n_script) / (32.0 * dens)) + 1);
     if (const char* e = getenv("FS_SFILTER_LOG2_WORDS")) ls = atoi(e);
-    ls = std::min(15, std::max(10, ls));
+    ls = std::min(FS_SUB_MAX_LOG2_WORDS, std::max(10, ls));
     ix->log2_swords = ls;
     std::vector<uint32_t> sub(1u << ls, 0u);
     for (uint64_t i = 0; i + K <= ix->n_script; ++i) {
-      const uint32_t h = fs_gram_hash(stok + i, K);
-      sub[fs_bloom_word(h, ls)] |= 1u << (h & 31);
+      const uint32_t h = fs_sub_hash(stok + i, K);
+      sub[fs_sub_word(h, ls)] |= 1u << fs_sub_bit(h);
     }
     FS_TRY(ix->d_sfilter.upload(sub.data(), sub.size(), ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));

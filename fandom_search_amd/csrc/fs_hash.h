@@ -75,6 +75,23 @@ FS_HD uint32_t fs_bloom_test(uint32_t word, uint32_t h) {
 // test of the full n-gram; every candidate is still compared id for id afterwards.
 // K = 4 for n >= 6 (n-3 tests per window), 3 for n = 4, 5; n <= 3 keeps the Bloom test.
 constexpr int fs_sub_k(int n) { return n >= 6 ? 4 : n >= 4 ? 3 : 0; }
+// The K-gram hash is a polynomial in 2^S of the premixed ids, modulo 2^32, with K * S >= 32:
+//   P(w) = sum_k m(t[k]) << (S * (K - 1 - k))        S = 8 for K = 4, 11 for K = 3
+// so the oldest id has left the 32 bits when the hash slides on, and a step costs ONE
+// instruction: P(w + 1) = (P(w) << S) + m(t[K])  (v_lshl_add_u32; the XOR-rotate fold above
+// needs three).  Filter word = bits [18, 18 + log2_words) of the hash (log2_words <= 14: one
+// SDWA instruction turns bits 16.. into the word's byte offset), bit = bits 8..12 (an SDWA
+// byte select as shift amount).  A hash only selects candidates; every candidate is compared
+// id for id afterwards.
+constexpr int fs_sub_shift(int K) { return K >= 4 ? 8 : 11; }
+#define FS_SUB_MAX_LOG2_WORDS 14
+FS_HD uint32_t fs_sub_hash(const uint32_t* t, int K) {
+  uint32_t x = 0;
+  for (int k = 0; k < K; ++k) x = (x << fs_sub_shift(K)) + fs_premix(t[k]);
+  return x;
+}
+FS_HD uint32_t fs_sub_word(uint32_t h, int log2_words) { return (h >> 18) & ((1u << log2_words) - 1u); }
+FS_HD uint32_t fs_sub_bit(uint32_t h) { return (h >> 8) & 31u; }
 
 // Exact (verification) table, hash-and-displace: 2^log2_buckets buckets, each with a
 // displacement seed d; an n-gram with hash h lives in slot fs_table_slot_d(h, d).

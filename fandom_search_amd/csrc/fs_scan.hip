@@ -380,31 +380,47 @@ __device__ __forceinline__ uint32_t window_flags8(const uint32_t* m, const uint3
 }
 
 // The same for k_scan_rows' sub-shingle filter (fs_hash.h): the lane tests the K-grams at
-// its 8 + N - K positions (one bit each: filter word shifted by the hash's low five bits),
-// window w is a candidate when the K-grams w .. w + N - K are all script K-grams.
-// m[0 .. 8 + N - 1): premixed ids.  VALU per window: slide 3, word address 1, shift 1,
-// funnel shift 1 for each of (8 + N - K) / 8 positions, plus 2 (N - K) / 8 for the runs.
-template <int N, int K, bool TAIL, bool LW14>
+// its 8 + N - K positions (one bit each), window w is a candidate when the K-grams
+// w .. w + N - K are all script K-grams.  m[0 .. 8 + N - 1): premixed ids.  VALU per
+// position: slide 1 (shift-add: the polynomial hash), word address 1 (SDWA), shift by the
+// hash's byte 1 (SDWA) 1, funnel shift 1; plus 2 (N - K) / 8 per window for the runs.
+// mask_words: ((1 << log2_words) - 1) << 2, in a register.
+__device__ __forceinline__ uint32_t fs_sub_word_offset(uint32_t h, uint32_t mask_words) {
+  uint32_t r;     // byte offset of filter word (h >> 18) & (words - 1):  (h >> 16) & mask_words
+  asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+      : "=v"(r) : "v"(h), "v"(mask_words));
+  return r;
+}
+
+template <int N, int K, bool TAIL>
 __device__ __forceinline__ uint32_t window_flags_sub(const uint32_t* m, const uint32_t* s_filter,
-                                                     int word_shift, uint32_t mask_fffc,
-                                                     uint32_t p0, uint32_t n_tok) {
+                                                     uint32_t mask_words, uint32_t p0, uint32_t n_tok) {
   constexpr int NB = 8 + N - K;                 // K-gram positions of the lane
-  uint32_t x = 0;
+  constexpr int S = fs_sub_shift(K);
+  // three passes, so that the filter words are requested together and waited for once:
+  // hashes and word addresses, the LDS reads, the bits
+  uint32_t x[NB], w[NB];
+  x[0] = 0;
 #pragma unroll
-  for (int k = 0; k < K; ++k) x ^= fs_rotl(m[k], fs_rot_of(K - 1 - k));
+  for (int k = 0; k < K; ++k) x[0] = (x[0] << S) + m[k];
+#pragma unroll
+  for (int j = 1; j < NB; ++j) x[j] = (x[j - 1] << S) + m[j - 1 + K];   // the id K places back has left the 32 bits
+  // (the filter sits at LDS address 0 -- k_scan_rows has no static LDS, checked at launch --
+  // so a word's byte offset is its address: no add of a base the compiler cannot fold)
+  typedef const __attribute__((address_space(3))) uint32_t lds_word;
+  (void)s_filter;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = fs_sub_word_offset(x[j], mask_words);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = *reinterpret_cast<lds_word*>((uintptr_t)w[j]);
+  asm volatile("" : "+v"(w[0]), "+v"(w[NB - 1]));      // every read is out before the first is used
+  // (the shifts apart from the funnel chain: an SDWA result needs a wait state before its
+  // next use, which the other shifts fill)
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = fs_shr_by_byte1(w[j], x[j]);
   uint32_t bits = 0;
 #pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    if (j) x = (uint32_t)__builtin_amdgcn_bitop3_b32(fs_rotl(x, 7), fs_rotl(m[j - 1], fs_rot_of(K)),
-                                                      m[j - 1 + K], 0x96);   // three-way xor
-    uint32_t word;
-    if constexpr (LW14)
-      word = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(s_filter) +
-                                                fs_word_offset14(x, mask_fffc));
-    else
-      word = s_filter[x >> word_shift];
-    bits = __builtin_amdgcn_alignbit(word >> (x & 31), bits, 1);   // bit 0 enters at bit 31
-  }
+  for (int j = 0; j < NB; ++j) bits = __builtin_amdgcn_alignbit(w[j], bits, 1);   // bit 0 enters at bit 31
   bits >>= 32 - NB;                             // K-gram j at bit j
   uint32_t flags = bits;
 #pragma unroll
@@ -583,8 +599,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   unsigned long long t_entry = 0, t_ready = 0, t_scan = 0, t_rounds = 0;
   uint32_t n_rounds = 0, n_flushes = 0;
   if (dbg) t_entry = __builtin_amdgcn_s_memrealtime();
+  // all of the kernel's LDS is dynamic, the filter first: its word offsets are then LDS
+  // addresses (a static array in front of it costs an address add per filter read)
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-  __shared__ uint32_t s_cnt[6 * 16 + 2];
   uint32_t* s_filter = s_dyn;
   // displacement seeds of the exact table as bytes behind the filter (disp_lds bytes, a
   // multiple of 16; 0: too many, read from memory)
@@ -597,6 +614,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_wave + n_waves);   // 6 * n_waves + 2 words (finish_rows)
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   // Sub-tiles dealt out evenly over the workgroups (the first n_sub % gridDim.x take one
   // more), and inside a workgroup of sixteen waves by how fast its SIMD serves each wave: the
@@ -626,6 +644,8 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   const int src_lane = (lane + 1) & 63;
   uint32_t mask_fffc = 0xFFFCu;
   asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
+  uint32_t mask_words = ((1u << lw) - 1u) << 2;
+  asm volatile("" : "+v"(mask_words));
   const uint32_t* __restrict__ tok = c.tok;
   const uint32_t n_tok = c.n_tok;
 
@@ -689,9 +709,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       uint32_t flags;
       if constexpr (K != 0) {
         if (base + SUB + HALO > n_tok)
-          flags = window_flags_sub<N, K, true, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+          flags = window_flags_sub<N, K, true>(aa, s_filter, mask_words, p0, n_tok);
         else
-          flags = window_flags_sub<N, K, false, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
+          flags = window_flags_sub<N, K, false>(aa, s_filter, mask_words, p0, n_tok);
       } else {
         if (base + SUB + HALO > n_tok)
           flags = window_flags8<N, true, LW14>(aa, s_filter, word_shift, mask_fffc, p0, n_tok);
@@ -1052,7 +1072,7 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   }
   const uint32_t disp_lds = fs_scan_rows_disp_lds(ix);
   const int lw = rows_filter_log2(ix);
-  const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds);
+  const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds) + (6 * waves + 2) * sizeof(uint32_t);
   // (non-temporal id loads only on request, FS_SCAN_FLAGS=n: they measured slower at every
   // batch size, 0.50 against 0.61 of peak on a 1 GB batch)
   const bool nt = ix->sw.scan_flags == 'n';
@@ -1064,6 +1084,18 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
     kern = nt ? (lw14 ? k_scan_rows<N, K, true, true> : k_scan_rows<N, K, true, false>)
               : (lw14 ? k_scan_rows<N, K, false, true> : k_scan_rows<N, K, false, false>);
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
+  {
+    // the kernel addresses its filter from LDS address 0: it must not own static LDS
+    static std::vector<const void*> checked;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (std::find(checked.begin(), checked.end(), (const void*)kern) == checked.end()) {
+      hipFuncAttributes fa;
+      FS_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kern)));
+      if (fa.sharedSizeBytes != 0) { fs_set_error("k_scan_rows owns %zu bytes of static LDS", fa.sharedSizeBytes); return FS_E_DEVICE; }
+      checked.push_back((const void*)kern);
+    }
+  }
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), n_sub, out,
                         sy, fin, disp_lds, (uint32_t)ix->sw.diag, dbg);
