@@ -302,8 +302,17 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     for _ in range(3):
         rows, st = ixl.search(cl)
         best = st.total_ms if best is None else min(best, st.total_ms)
+    cp = (15 * 14 + 3) & ~3
+    lsh_bytes = float(st.windows_processed) * window * cp * 4
     out["lsh_clustered_table"] = {
         "value": n_l / (best * 1e-3), "unit": "fanworks/s", "ms_per_step": best,
+        "roofline": {"bound": "infinity-cache gather", "kernel": ixl.kernel_name(cl),
+                     "bytes_model": "n rows of %d float32 projections (%d B) per window, gathered from "
+                                    "a %d MB table" % (cp, 4 * cp, window * emb_c.shape[0] * cp * 4 // 1000000),
+                     "algorithmic_bytes_per_launch": lsh_bytes, "launch_ms": st.scan_ms,
+                     "achieved": lsh_bytes / (st.scan_ms * 1e-3) / 1e9 if st.scan_ms else None,
+                     "peak": 8600.0, "unit": "GB/s",
+                     "frac": lsh_bytes / (st.scan_ms * 1e-3) / 1e9 / 8600.0 if st.scan_ms else None},
         "windows_per_s": st.windows_processed / (best * 1e-3), "works": n_l,
         "rows_per_step": int(len(rows)), "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()),
         "c_max": ixl.info["c_max"], "path": "lsh", "index_s": round(t_index, 2),

@@ -77,7 +77,6 @@ fs_index::~fs_index() {
     if (sl.ev_scan0) (void)hipEventDestroy(sl.ev_scan0);
     if (sl.ev_scan1) (void)hipEventDestroy(sl.ev_scan1);
     if (sl.ev_end) (void)hipEventDestroy(sl.ev_end);
-    if (sl.ev_scan_done) (void)hipEventDestroy(sl.ev_scan_done);
     if (sl.h_status) (void)hipHostFree(sl.h_status);
   }
 }   // `stream` is lanes[0].stream
@@ -87,21 +86,15 @@ fs_index::~fs_index() {
 void fs_read_switches(fs_switches* sw) {
   *sw = fs_switches();
   auto num = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; };
-  sw->scan_blocks_per_cu = num("FS_SCAN_BLOCKS_PER_CU");
   if (const char* e = getenv("FS_SCAN_FLAGS")) sw->scan_flags = e[0] ? e[0] : '-';
   if (const char* e = getenv("FS_SCAN_VARIANT")) sw->scan_simple = e[0] == 's';
   sw->scan_tpl = num("FS_SCAN_TPL");
   if (const char* e = getenv("FS_SCAN_DIRECT")) sw->scan_direct = e[0] != '0';
-  sw->scan_unroll = num("FS_SCAN_UNROLL");
-  if (const char* e = getenv("FS_SCAN_HALO")) sw->scan_halo_loads = e[0] == 'l';
-  sw->stagger = getenv("FS_STAGGER") != nullptr;
   sw->scan_capw = num("FS_SCAN_CAPW");
-  sw->post_fused = getenv("FS_POST_FUSED") != nullptr;
   if (const char* e = getenv("FS_SCAN_ROWS")) sw->scan_rows = e[0] != '0';
   if (const char* e = getenv("FS_SCAN_SUB")) sw->scan_sub = e[0] != '0';
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
-  sw->scan_lds_pad = num("FS_SCAN_LDS_PAD");
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);
@@ -382,7 +375,6 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     FS_HIP(hipEventCreate(&sl.ev_scan0));
     FS_HIP(hipEventCreate(&sl.ev_scan1));
     FS_HIP(hipEventCreate(&sl.ev_end));
-    FS_HIP(hipEventCreateWithFlags(&sl.ev_scan_done, hipEventDisableTiming));
     // the status block and, behind it, the "a wait gave up" word of finish_rows
     FS_HIP(hipHostMalloc((void**)&sl.h_status, 2 * sizeof(fs_status), hipHostMallocDefault));
     memset(sl.h_status, 0, 2 * sizeof(fs_status));
@@ -605,7 +597,6 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
     ix->cur = &ix->lanes[0];
     FS_HIP(hipMemsetAsync(ix->cur->d_status.p, 0, sizeof(fs_status), ix->stream));
     FS_TRY(fs_launch_levtab(ix, c, ix->stream));
-    if (!c->has_str) FS_TRY(fs_launch_ctab(ix, c, ix->stream));
     FS_HIP(hipMemcpyAsync(ix->h_status, ix->cur->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     if (ix->h_status->bad_string) { fs_set_error("script vector id without a string"); return FS_E_INVALID; }
@@ -614,6 +605,15 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
       return FS_E_UNSUPPORTED;
     }
     c->levtab_ready = true;
+  }
+  // the batch table of k_scan_rows (ids + this string table's best records), on its own
+  // flag: a corpus that is reused (fs_corpus_update_begin) may see its first batch without
+  // string ids only after one with them
+  if (!c->has_oov && !c->has_str && ix->info.path == FS_MODE_EXACT && c->levtab_ready && !c->ctab_ready) {
+    ix->cur = &ix->lanes[0];
+    FS_TRY(fs_launch_ctab(ix, c, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    c->ctab_ready = true;
   }
   if (!c->has_str && !c->has_oov && ix->info.path != FS_MODE_EXACT && !c->selflev_ready && ix->sw.lsh_selflev) {
     // LSH pipeline, string id == vector id: the Levenshtein distance of a match with the
@@ -746,24 +746,16 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
-  // FS_STAGGER (two lanes): a search's first kernel is ordered behind the first kernel of the
-  // search queued before it, so that what overlaps is a scan with the other lane's chain.
-  // Off by default: with k_scan_rows the GPU's own ordering measured faster (32 against
-  // 41 us per C2 step).
   bool end_attached = false;           // sl.ev_end rides on the last dispatch (no marker of its own)
-  const bool stagger = ix->n_lanes == 2 && ix->last_scan_ev && ix->sw.stagger;
-  if (stagger) FS_HIP(hipStreamWaitEvent(s, ix->last_scan_ev, 0));
   if (sl.exact && sl.fused_waves) {
     // (the whole-search timing of the synchronous call keeps its own end marker)
     FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, sl.fused_blocks, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,
                                e0, e1, count_out, whole ? nullptr : sl.ev_end, &end_attached));
-    if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
   } else if (sl.exact) {
     fs_scan_extra ex;
     ex.bsum = ln.w_bsum.p; ex.zero = ln.d_status.p;
     if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
-    if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
   } else {
     // tables whose proof fails by one slot only: the integer prefilter flags the windows
@@ -772,13 +764,11 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
       FS_TRY(fs_launch_scan_near(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     else
       FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
-    if (ix->n_lanes == 2) FS_HIP(hipEventRecord(sl.ev_scan_done, s));
-    FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, false, s));
+    FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, s));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
     FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, 0, sl.h_status, s, count_out));
   }
   ++sl.launches;
-  if (ix->n_lanes == 2) ix->last_scan_ev = sl.ev_scan_done;
   if (!end_attached) FS_HIP(hipEventRecord(sl.ev_end, s));
   ix->cur = &ix->lanes[0];
   return FS_OK;

@@ -151,21 +151,15 @@ struct fs_corpus;
 // Diagnostic switches (FS_* environment variables), read once at fs_index_create and
 // again only on fs_index_reload_switches: nothing on the per-search path calls getenv.
 struct fs_switches {
-  int scan_blocks_per_cu = 0;     // FS_SCAN_BLOCKS_PER_CU (k_scan)
-  char scan_flags = 0;            // FS_SCAN_FLAGS: 'd' direct ballots, 'n' non-temporal loads, other: neither
+  char scan_flags = 0;            // FS_SCAN_FLAGS: 'n' non-temporal id loads, other: default policy
   bool scan_simple = false;       // FS_SCAN_VARIANT=simple
-  int scan_tpl = 0;               // FS_SCAN_TPL: tokens per lane (4 or 8)
+  int scan_tpl = 0;               // FS_SCAN_TPL=4: the chained kernels scan with k_scan_simple
   bool scan_direct = true;        // FS_SCAN_DIRECT=0: bitmap + k_expand instead of candidate records
-  int scan_unroll = 0;            // FS_SCAN_UNROLL
-  bool scan_halo_loads = false;   // FS_SCAN_HALO=loads
-  bool stagger = false;           // FS_STAGGER: two lanes, scans ordered one behind the other
   int scan_capw = 0;              // FS_SCAN_CAPW: records per wave range to start with (tests)
-  bool post_fused = false;        // FS_POST_FUSED
   bool scan_rows = true;          // FS_SCAN_ROWS=0: separate scan and post-scan kernels
   bool scan_sub = true;           // FS_SCAN_SUB=0: k_scan_rows tests the full n-gram (Bloom) instead of K-gram runs
   int diag = 0;                   // FS_DIAG bits: 1 k_scan_rows without its rounds (results invalid), 2 in-kernel
                                   // timeline stamps (fs_debug_stamps), 16 equal shares per wave, bits 8..: flush threshold
-  int scan_lds_pad = 0;           // FS_SCAN_LDS_PAD: extra dynamic LDS of k_scan8 (bytes)
   int wait_spins = -1;            // FS_WAIT_SPINS: polls before finish_rows gives up (tests: 0)
   double lsh_f32_slack = 1.0;     // FS_LSH_F32_SLACK: factor on the float32 key bound (tests force the fallback)
   bool lsh_f32 = true;            // FS_LSH_F32=0: float64 keys only
@@ -246,14 +240,12 @@ struct fs_index {
   };
   Lane lanes[FS_LANES];
   Lane* cur = &lanes[0];
-  hipEvent_t last_scan_ev = nullptr;   // scan of the most recently queued search
   int n_lanes = FS_LANES_DEFAULT;
   fs_status* h_status = nullptr;   // pinned
 
   // searches in flight (fs_search_corpus_begin / _end)
   struct Slot {
     hipEvent_t ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_end = nullptr;
-    hipEvent_t ev_scan_done = nullptr;   // no timing: orders the next search's scan behind this one's
     fs_status* h_status = nullptr;    // pinned
     bool busy = false;
     fs_corpus* c = nullptr;
@@ -304,6 +296,7 @@ struct fs_corpus {
   DBuf<fs_best> d_gbest;
   DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
+  bool ctab_ready = false;
   DBuf<uint32_t> d_selflev;            // LSH pipeline, string id == vector id: Levenshtein of script window w
   bool selflev_ready = false;          // against the strings of its own ids (k_selflev), FS_NONE: not known
   CorpusDev dev() const;
@@ -341,7 +334,7 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
                    const fs_scan_extra& scan, uint64_t* count_out = nullptr);
 int fs_launch_unpack(fs_index* ix, const void* packed, uint64_t n, fs_row* rows, hipStream_t s);
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
-                     bool verify, hipStream_t s, bool counted = false);
+                     hipStream_t s, bool counted = false);
 int fs_launch_rows(fs_index* ix, fs_corpus* c, const fs_best* best_tab, int best_per_cand,
                    uint32_t ccap, uint32_t rcap, fs_row* d_rows, int wire, fs_status* host_st,
                    hipStream_t s, uint64_t* count_out = nullptr);

@@ -176,21 +176,17 @@ __device__ __forceinline__ uint32_t verify_window(const CorpusDev& c, const Gram
 //          lane L + the set bits of the earlier words at lane L.
 //   TPL 8  eight words per sub-tile of 512 tokens in natural order, bit L of word j
 //          <-> window 512 i + 64 j + L.
-// One thread per word.
-// VERIFY (diagnostics, FS_POST_FUSED): the thread that finds a candidate also
-// verifies it; slower than the separate k_verify launch, see fs_launch_post.
-template <int TPL, bool VERIFY>
+// One thread per word.  (Verifying inside this kernel measured slower than the separate
+// k_verify launch, 110 against 84 us per C2 step in round 1: the thread that decodes a ballot
+// word then runs the dependent-load chain of each of its candidates one after the other.)
+template <int TPL>
 __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict__ qbm,
                                                      const uint32_t* __restrict__ qcnt,
                                                      uint32_t n_sub,
                                                      const uint32_t* __restrict__ bsum,
                                                      uint32_t* __restrict__ cpos, uint32_t ccap,
-                                                     fs_status* st, CorpusDev c, GramIndexDev g,
-                                                     uint32_t* __restrict__ cg,
-                                                     uint32_t* __restrict__ cw,
-                                                     uint32_t* __restrict__ bmatch) {
+                                                     fs_status* st) {
   constexpr int SUBS = kThreads / TPL;          // sub-tiles per block iteration
-  uint32_t matches = 0;
   __shared__ uint32_t s_w[4];
   __shared__ uint32_t s_base[SUBS];
   uint32_t lo, hi;
@@ -252,25 +248,11 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint64_t* __restrict_
           }
           p = sub * (64u * TPL) + (uint32_t)TPL * (uint32_t)L + (uint32_t)j;
         }
-        if (idx < ccap) {
-          cpos[idx] = p;
-          if (VERIFY) {
-            uint32_t w = 0, kept = 0;
-            const uint32_t gram = verify_window(c, g, p, &w, &kept);
-            cg[idx] = gram;
-            if (gram != FS_NONE) { cw[idx] = w; matches += kept; }
-          }
-        }
+        if (idx < ccap) cpos[idx] = p;
       }
     }
     __syncthreads();
     carry += tile_total;
-  }
-  if (VERIFY) {
-    // (window, script window) pairs of this block; summed by k_rows
-    uint32_t tot;
-    block_excl_scan(matches, s_w, &tot);
-    if (threadIdx.x == 0 && blockIdx.x < kNB) bmatch[blockIdx.x] = tot;
   }
 }
 
@@ -824,21 +806,17 @@ int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
 // bitmap + counts -> candidate positions (w_cpos), n_cands in the status block
 // counted: the scan already wrote the chunk sums and cleared the status block
 int fs_launch_expand(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t ccap, int tpl,
-                     bool verify, hipStream_t s, bool counted) {
+                     hipStream_t s, bool counted) {
   uint32_t* bsum32 = ix->cur->w_bsum.p;
   if (!counted)
     hipLaunchKernelGGL((k_reduce<SubTileCountF, uint32_t>), dim3(kNB), dim3(kThreads), 0, s,
                        SubTileCountF{ix->cur->w_qcnt.p}, NSrc{nullptr, 0, 0, n_sub}, bsum32,
                        ix->cur->d_status.p);
-  const CorpusDev cd = c->dev();
-  const GramIndexDev g = ix->gram_dev();
-  uint32_t* bmatch = ix->cur->w_bsum.p + kNB;
-#define FS_EXPAND(T, V)                                                                      \
-  hipLaunchKernelGGL((k_expand<T, V>), dim3(kNB + 1), dim3(kThreads), 0, s, ix->cur->w_qbm.p,         \
-                     ix->cur->w_qcnt.p, n_sub, bsum32, ix->cur->w_cpos.p, ccap, ix->cur->d_status.p, cd, g, \
-                     ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch)
-  if (tpl == 8) { if (verify) FS_EXPAND(8, true); else FS_EXPAND(8, false); }
-  else { if (verify) FS_EXPAND(4, true); else FS_EXPAND(4, false); }
+  (void)c;
+#define FS_EXPAND(T)                                                                          \
+  hipLaunchKernelGGL((k_expand<T>), dim3(kNB + 1), dim3(kThreads), 0, s, ix->cur->w_qbm.p,    \
+                     ix->cur->w_qcnt.p, n_sub, bsum32, ix->cur->w_cpos.p, ccap, ix->cur->d_status.p)
+  if (tpl == 8) FS_EXPAND(8); else FS_EXPAND(4);
 #undef FS_EXPAND
   FS_HIP(hipGetLastError());
   return FS_OK;
@@ -902,14 +880,9 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
                        scan.recs, scan.info, scan.capw, ccap, ix->cur->w_cpos.p,
                        ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch, st);
   } else {
-    // Verifying inside k_expand (FS_POST_FUSED=1) saves a launch but measured slower
-    // (110 vs 84 us per C2 step): the thread that decodes a ballot word then runs the
-    // dependent-load chain of each of its candidates one after the other.
-    const bool fused = ix->sw.post_fused;
-    FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, fused, s, scan.counted));
-    if (!fused)
-      hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,
-                         ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
+    FS_TRY(fs_launch_expand(ix, c, n_sub, ccap, tpl, s, scan.counted));
+    hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,
+                       ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
   }
   if (per_cand) {
     hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->cur->w_cpos.p,

@@ -16,11 +16,11 @@
 //     Bloom test of the whole n-gram); a lane's eight answers are one byte
 // and candidates are verified, turned into records and put into place by the same wave.
 //
-// The kernels of round 1 remain for batches with string ids, n >= 9 and as the fallback:
-// k_scan8 (same loop, Bloom test, candidate records or byte bitmap out), k_scan (four
-// tokens per lane, four __ballot words per 256 tokens), k_scan_simple (any n, cross-check);
-// counting, expansion and verification are then left to fs_post.hip.  k_scan_near is the
-// integer prefilter of the LSH pipeline (script 3-grams, at most one differing slot).
+// ONE chained fallback remains for batches with string ids, window sizes k_scan_rows does
+// not take and a given-up in-launch wait: k_scan8 (n = 2..8: same loop, Bloom test, candidate
+// records or byte bitmap out) or k_scan_simple (any n); counting, expansion and verification
+// are then left to fs_post.hip.  k_scan_near is the integer prefilter of the LSH pipeline
+// (script 3-grams, at most one differing slot).
 // No global atomics on the data path; a record's bytes and place are functions of token
 // positions, so the result is deterministic.  Algorithmic HBM traffic: 4 B read per
 // token + 32 B per record written.
@@ -66,151 +66,6 @@ __device__ __forceinline__ void store_ballots(const uint64_t* b, int lane, uint3
     qbm[(size_t)word * 4 + lane] = mine;
     if (lane == 0)
       qcnt[word] = __popcll(b[0]) + __popcll(b[1]) + __popcll(b[2]) + __popcll(b[3]);
-  }
-}
-
-// m[0 .. 4+N-1): premixed ids of this lane's four tokens and their halo.
-// Window 0 pays the full XOR-rotate fold, windows 1..3 slide (fs_hash.h).  The
-// Bloom test is a compare whose result is the wave mask itself (no per-lane flag
-// word).  TAIL: the tile touches the end of the buffer; a window at p is real
-// only if p + N <= n_tok.
-// Alternative: collect the four tests in a per-lane flag word first, ballot after.
-template <int N, bool TAIL>
-__device__ __forceinline__ void window_ballots_word(const uint32_t* m, const uint32_t* s_filter,
-                                                    int word_shift, uint32_t p0, uint32_t n_tok,
-                                                    uint64_t* b) {
-  uint32_t x = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) x ^= fs_rotl(m[k], fs_rot_of(N - 1 - k));
-  uint32_t flags = 0;
-#pragma unroll
-  for (int j = 0; j < kTokPerLane; ++j) {
-    if (j) x = fs_rotl(x ^ fs_rotl(m[j - 1], fs_rot_of(N - 1)), 7) ^ m[j - 1 + N];
-    const uint32_t word = s_filter[x >> word_shift];
-    flags |= fs_bloom_test(word, x) << j;
-  }
-  if (TAIL) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
-  }
-  b[0] = __ballot(flags & 1u); b[1] = __ballot(flags & 2u);
-  b[2] = __ballot(flags & 4u); b[3] = __ballot(flags & 8u);
-}
-
-template <int N, bool TAIL>
-__device__ __forceinline__ void window_ballots(const uint32_t* m, const uint32_t* s_filter,
-                                               int word_shift, uint32_t p0, uint32_t n_tok,
-                                               uint64_t* b) {
-  uint32_t x = 0;
-#pragma unroll
-  for (int k = 0; k < N; ++k) x ^= fs_rotl(m[k], fs_rot_of(N - 1 - k));
-#pragma unroll
-  for (int j = 0; j < kTokPerLane; ++j) {
-    if (j) x = fs_rotl(x ^ fs_rotl(m[j - 1], fs_rot_of(N - 1)), 7) ^ m[j - 1 + N];
-    const uint32_t word = s_filter[x >> word_shift];
-    const uint32_t mask = fs_bloom_mask(x);
-    bool hit = (word & mask) == mask;
-    if (TAIL) hit = hit && ((uint64_t)p0 + j + N <= n_tok);
-    b[j] = __ballot(hit);
-  }
-}
-
-// U sub-tiles (U x 256 tokens) per wave iteration, all loads issued before the
-// first use.  HALO_LOADS: the n-1 tokens behind a lane's own four come from
-// further global loads at immediate offsets (+16 B, +32 B ...: the same cache
-// lines the neighbouring lanes fetch, no VALU); otherwise from the neighbouring
-// lanes by ds_bpermute.
-template <int N, int U, bool HALO_LOADS, bool DIRECT, bool NT>
-__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ tok, uint32_t n_tok,
-                                               const uint32_t* __restrict__ filter,
-                                               int log2_words, uint64_t* __restrict__ qbm,
-                                               uint32_t* __restrict__ qcnt,
-                                               uint32_t n_bm_words, uint32_t n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
-  {
-    copy_filter_to_lds(filter, s_filter, log2_words);
-  }
-  __syncthreads();
-
-  constexpr int HALO = N - 1;
-  constexpr int NV = (HALO + 3) / 4;            // neighbour vectors needed
-  const int word_shift = 32 - log2_words;
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-
-  for (uint32_t tile = wave; tile < n_tiles; tile += n_waves) {
-    const uint32_t base = tile * (uint32_t)(kSubTile * U);
-    uint32_t a[U][4 + 4 * NV];
-    if constexpr (HALO_LOADS) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t* p = tok + base + u * kSubTile + 4 * lane;
-#pragma unroll
-        for (int d = 0; d <= NV; ++d) {
-          const int need = d == 0 ? 4 : ((HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4);
-          if (need == 1) {
-            a[u][4 * d] = p[4 * d];
-          } else if (need == 2) {
-            const uint2 t = *reinterpret_cast<const uint2*>(p + 4 * d);
-            a[u][4 * d] = t.x; a[u][4 * d + 1] = t.y;
-          } else {
-            const uint4 t = *reinterpret_cast<const uint4*>(p + 4 * d);
-            a[u][4 * d] = t.x; a[u][4 * d + 1] = t.y; a[u][4 * d + 2] = t.z;
-            if (need > 3) a[u][4 * d + 3] = t.w;
-          }
-        }
-      }
-    } else {
-      uint4 v[U + 1];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint4* src = reinterpret_cast<const uint4*>(tok + base + u * kSubTile + 4 * lane);
-        if constexpr (NT) {
-          // the id stream is read once: keep it out of the caches' way
-          v[u].x = __builtin_nontemporal_load(&src->x); v[u].y = __builtin_nontemporal_load(&src->y);
-          v[u].z = __builtin_nontemporal_load(&src->z); v[u].w = __builtin_nontemporal_load(&src->w);
-        } else {
-          v[u] = *src;
-        }
-      }
-      // first vectors of the next tile, in lanes 0..3 (the buffer is padded)
-      v[U] = *reinterpret_cast<const uint4*>(tok + base + U * kSubTile + 4 * (lane & 3));
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        a[u][0] = v[u].x; a[u][1] = v[u].y; a[u][2] = v[u].z; a[u][3] = v[u].w;
-#pragma unroll
-        for (int d = 1; d <= NV; ++d) {
-          // lane L needs the vector of lane L+d; past lane 63 that is a vector of
-          // the next sub-tile, which lanes 0..d-1 publish instead of their own
-          const bool wrap = lane < d;
-          const int src = (lane + d) & 63;
-          const int need = (HALO - 4 * (d - 1)) < 4 ? (HALO - 4 * (d - 1)) : 4;
-          a[u][4 * d + 0] = __shfl(wrap ? v[u + 1].x : v[u].x, src);
-          if (need > 1) a[u][4 * d + 1] = __shfl(wrap ? v[u + 1].y : v[u].y, src);
-          if (need > 2) a[u][4 * d + 2] = __shfl(wrap ? v[u + 1].z : v[u].z, src);
-          if (need > 3) a[u][4 * d + 3] = __shfl(wrap ? v[u + 1].w : v[u].w, src);
-        }
-      }
-    }
-
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int i = 0; i < 4 + HALO; ++i) a[u][i] = fs_premix(a[u][i]);
-      const uint32_t p0 = base + u * kSubTile + 4 * lane;
-      uint64_t b[4];
-      const bool tail = base + (uint32_t)(kSubTile * U) + HALO > n_tok;   // wave-uniform
-      if constexpr (DIRECT) {
-        if (tail) window_ballots<N, true>(a[u], s_filter, word_shift, p0, n_tok, b);
-        else window_ballots<N, false>(a[u], s_filter, word_shift, p0, n_tok, b);
-      } else {
-        if (tail) window_ballots_word<N, true>(a[u], s_filter, word_shift, p0, n_tok, b);
-        else window_ballots_word<N, false>(a[u], s_filter, word_shift, p0, n_tok, b);
-      }
-      store_ballots(b, lane, tile * U + u, n_bm_words, qbm, qcnt);
-    }
   }
 }
 
@@ -866,31 +721,6 @@ static int ensure_dynamic_lds(const void* kern, int device, size_t lds) {
   return FS_OK;
 }
 
-template <int N, int U, bool HL, bool DIRECT, bool NT>
-int launch_fast_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  const uint32_t tile_tok = kSubTile * U;
-  const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
-  if (n_tiles == 0) return FS_OK;
-  const size_t lds = (size_t)4 << ix->log2_words;
-  int threads = 1024;
-  const uint32_t waves_per_block = threads / 64;
-  uint32_t blocks_per_cu = lds <= 64 * 1024 ? 2 : 1;
-  if (ix->sw.scan_blocks_per_cu > 0) blocks_per_cu = ix->sw.scan_blocks_per_cu;
-  uint32_t max_blocks = ix->num_cu * blocks_per_cu;
-  uint32_t blocks = (n_tiles + waves_per_block - 1) / waves_per_block;
-  if (blocks > max_blocks) blocks = max_blocks;
-  auto kern = k_scan<N, U, HL, DIRECT, NT>;
-  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
-  // start/stop events attached to the dispatch itself: their difference is the
-  // kernel's execution time (what rocprofv3 reports), not kernel + marker gaps
-  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(threads), (uint32_t)lds, s, e0, e1, 0u, c.tok,
-                        c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
-                        n_bm_words, n_tiles);
-  FS_HIP(hipGetLastError());
-  return FS_OK;
-}
-
 template <int N, bool NT>
 int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
                   uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
@@ -902,9 +732,7 @@ int launch_tpl8_k(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_
   const uint32_t chunk = std::max<uint32_t>(1, (n_bm_words + fsdev::kNB - 1) / fsdev::kNB);
   const bool direct = ex && ex->bsum && ex->recs && ex->info && ex->capw && fs_scan_direct_ok(ix, c.n_tok);
   auto kern = ix->log2_words == 14 ? k_scan8<N, NT, true> : k_scan8<N, NT, false>;
-  // FS_SCAN_LDS_PAD: dynamic LDS beyond the filter, i.e. fewer workgroups per CU (leaves wave
-  // slots to the kernels of a search on another lane)
-  const size_t lds = lds_filter + (size_t)std::max(0, ix->sw.scan_lds_pad);
+  const size_t lds = lds_filter;
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok,
                         c.n_tok, (const uint32_t*)ix->d_filter.p, ix->log2_words, qbm, qcnt,
@@ -927,56 +755,15 @@ int launch_tpl8(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t*
             : launch_tpl8_k<N, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, ex);
 }
 
-template <int N, int U, bool HL>
-int launch_fast(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-  // Variants measured in one process (tools/scan_sweep.py, profiles/r01_scan_ab_*.log):
-  //   word   per-lane flag word, then four ballots: 3-4 % faster than comparing
-  //          straight into the ballot ("direct")
-  //   nt     non-temporal id loads: +6 % once the ids cannot stay in the 256 MiB
-  //          Infinity Cache (2 GB), -7 % when a resident corpus is scanned again
-  const char e = ix->sw.scan_flags;
-  const bool big = (uint64_t)c.n_tok * 4 > (256ull << 20);
-  if (e == 'd') return launch_fast_k<N, U, HL, true, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-  if (e == 'n' || (!e && big))
-    return launch_fast_k<N, U, HL, false, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-  return launch_fast_k<N, U, HL, false, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-}
-
-template <int N>
-int launch_fast_u(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
-                  uint32_t n_bm_words, hipStream_t s, int unroll, bool halo_loads, hipEvent_t e0,
-                  hipEvent_t e1) {
-  if (halo_loads) {
-    switch (unroll) {
-      case 1: return launch_fast<N, 1, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 2: return launch_fast<N, 2, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      case 8: return launch_fast<N, 8, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-      default: return launch_fast<N, 4, true>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    }
-  }
-  switch (unroll) {
-    case 1: return launch_fast<N, 1, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 2: return launch_fast<N, 2, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 8: return launch_fast<N, 8, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    default: return launch_fast<N, 4, false>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-  }
-}
-
 }  // namespace
 
-// tokens per lane (bitmap layout) of the scan over n_tok ids.  Measured in
-// alternating runs on one box: eight tokens per lane is 3-4 % faster while the ids
-// fit the Infinity Cache (80 MB: 19.7 -> 19.1 us, 250 MB: 50.6 -> 48.8 us) and 6 %
-// slower at 2 GB (413 -> 438 us), where the 32-byte lane stride of its loads costs
-// more than the saved VALU work.
+// tokens per lane (bitmap layout) of the chained kernels' scan: eight with k_scan8
+// (n = 2..8), four with k_scan_simple (any n; FS_SCAN_TPL=4 or FS_SCAN_VARIANT=simple ask for it)
 int fs_scan_tpl(const fs_index* ix, uint64_t n_tok) {
-  if (ix->sw.scan_simple) return 4;
-  int tpl = n_tok * 4 <= (256ull << 20) ? 8 : 4;
-  if (ix->sw.scan_tpl) tpl = ix->sw.scan_tpl;
+  (void)n_tok;
+  if (ix->sw.scan_simple || ix->sw.scan_tpl == 4) return 4;
   const int n = ix->cfg.window_size;
-  const bool has8 = n == 2 || n == 3 || n == 4 || n == 5 || n == 6 || n == 7 || n == 8;
-  return (tpl == 8 && has8) ? 8 : 4;
+  return n >= 2 && n <= 8 ? 8 : 4;
 }
 
 // tokens of zero padding the corpus buffer carries behind n_tok so that the
@@ -997,12 +784,6 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
                    fs_scan_extra* extra) {
   if (extra) { extra->counted = false; extra->direct = false; }
   const int n = ix->cfg.window_size;
-  const bool simple = ix->sw.scan_simple;
-  // measured on MI355X (tools/scan_sweep.py, profiles/): two sub-tiles per wave
-  // iteration and the shuffle halo are fastest up to the Infinity Cache size, four beyond (2 GB of ids)
-  int unroll = (uint64_t)c.n_tok * 4 > (256ull << 20) ? 4 : 2;
-  if (ix->sw.scan_unroll) unroll = ix->sw.scan_unroll;
-  const bool halo_loads = ix->sw.scan_halo_loads;
   if (fs_scan_tpl(ix, c.n_tok) == 8) {
     switch (n) {
       case 2: return launch_tpl8<2>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
@@ -1012,20 +793,6 @@ int fs_launch_scan(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32
       case 6: return launch_tpl8<6>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
       case 7: return launch_tpl8<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
       case 8: return launch_tpl8<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1, extra);
-      default: break;
-    }
-  }
-  if (!simple) {
-    switch (n) {
-      case 2: return launch_fast_u<2>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 3: return launch_fast_u<3>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 4: return launch_fast_u<4>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 5: return launch_fast_u<5>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 6: return launch_fast_u<6>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 7: return launch_fast_u<7>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 8: return launch_fast_u<8>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 10: return launch_fast_u<10>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
-      case 12: return launch_fast_u<12>(ix, c, qbm, qcnt, n_bm_words, s, unroll, halo_loads, e0, e1);
       default: break;
     }
   }
@@ -1116,9 +883,7 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
   if (!ix->sw.scan_rows || n < 2 || n > 8 || c->has_str || !c->d_ctab.p || !ix->ctab_ok) return 0;
   // a switch that asks for one of the other scan kernels or paths
   const fs_switches& sw = ix->sw;
-  if (sw.scan_simple || sw.scan_tpl == 4 || sw.scan_unroll || sw.scan_halo_loads || !sw.scan_direct ||
-      sw.scan_capw)
-    return 0;
+  if (sw.scan_simple || sw.scan_tpl == 4 || !sw.scan_direct || sw.scan_capw) return 0;
   // (1 KB: the kernel's static LDS, s_cnt)
   const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 1024;
   const size_t cu_lds = 160 * 1024;

@@ -62,15 +62,11 @@ def test_single_short_and_no_works(synth_base):
     _case(synth_base, [0, 0], 1000)
 
 
-@pytest.mark.parametrize("unroll", [1, 2, 4, 8])
-def test_scan_unroll_variants(synth_base, unroll):
-    _case(synth_base, [1500] * 40 + [77, 5000], 4000, FS_SCAN_UNROLL=unroll)
-
-
 @pytest.mark.parametrize("tpl", [4, 8])
 @pytest.mark.parametrize("n", [2, 5, 6])
 def test_scan_tokens_per_lane_layouts(synth_base, tpl, n):
-    """Both bitmap layouts of the scan: 4 or 8 tokens per lane."""
+    """Both bitmap layouts of the chained kernels' scan: 8 tokens per lane (k_scan8) and 4
+    (k_scan_simple)."""
     _case(synth_base, [1500] * 20 + [0, 511, 512, 513, 1, 4000], 4000, n=n, FS_SCAN_TPL=tpl)
 
 

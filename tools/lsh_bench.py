@@ -55,7 +55,21 @@ def main():
     for _ in range(a.reps):
         rows, st = ix.search(corpus)
         best = st.total_ms if best is None else min(best, st.total_ms)
-    out = {"table": a.table, "window": a.window, "works": a.works, "tokens": a.tokens,
+    # k_lsh_scan reads, per fan window, the n float32 projection rows of its tokens (Cp = H * B
+    # rounded up to 4 columns): a random-row gather from a table of n * V * Cp * 4 bytes that
+    # lives in the Infinity Cache (MI355X_MICROARCH.md "Indexed rows": 8.6 TB/s for a 38 MB
+    # table); the pair-table and bucket reads of the candidate phase come on top and are not
+    # in the model
+    cp = (cfg.number_of_hashes * cfg.hash_dimensions + 3) & ~3
+    row_bytes = float(st.windows_processed) * a.window * cp * 4
+    roof = {"bound": "infinity-cache gather", "kernel": ix.kernel_name(corpus),
+            "bytes_model": "n rows of %d float32 projections (%d B) per window" % (cp, 4 * cp),
+            "table_bytes": a.window * emb.shape[0] * cp * 4,
+            "algorithmic_bytes_per_launch": row_bytes, "launch_ms": st.scan_ms,
+            "achieved": row_bytes / (st.scan_ms * 1e-3) / 1e9 if st.scan_ms else None,
+            "peak": 8600.0, "unit": "GB/s",
+            "frac": row_bytes / (st.scan_ms * 1e-3) / 1e9 / 8600.0 if st.scan_ms else None}
+    out = {"table": a.table, "window": a.window, "works": a.works, "tokens": a.tokens, "roofline": roof,
            "c_max": ix.info["c_max"], "index_s": round(t_index, 2), "total_ms": best,
            "scan_ms": st.scan_ms, "rows": len(rows), "matches": int(st.matches),
            "candidates": int(st.candidates), "kernel": ix.kernel_name(corpus),
