@@ -70,8 +70,10 @@ def get_vocab():
         path = os.environ.get("FANDOM_SEARCH_VECTORS")
         if path:
             data = np.load(path, allow_pickle=False)
-            _VOCAB = vocab_mod.Vocab([str(w) for w in data["words"]],
-                                     data["vectors"])
+            # 'words' + 'vectors' (+ 'rows': the row of each word when words share rows, as
+            # tools/export_spacy_vectors.py writes for spaCy's key2row)
+            _VOCAB = vocab_mod.Vocab([str(w) for w in data["words"]], data["vectors"],
+                                     rows=data["rows"] if "rows" in data.files else None)
         elif os.environ.get("FANDOM_SEARCH_SYNTHETIC_VOCAB", "") not in ("", "0"):
             _VOCAB = vocab_mod.Vocab(synth.vocab_words(), synth.embedding())
         else:

@@ -6,9 +6,10 @@ tokenizer: the algorithm of `spacy/tokenizer.pyx` and the English data of
 `spacy/lang/punctuation.py`, `char_classes.py`, `tokenizer_exceptions.py` and
 `lang/en/tokenizer_exceptions.py` (2.1/2.2 era, the reference's README dates it to 2019).
 It is a restatement from the published rules, pinned by the examples in spaCy's
-documentation (tests/test_tokenizer.py), not by running spaCy: parity with spaCy on
-arbitrary text is UNPINNED, and the rarer exception lists (US state abbreviations,
-emoticons, unit lists for other languages) are abridged.
+documentation and test-suite (tests/test_tokenizer.py), not by running spaCy: parity with
+spaCy on arbitrary text is UNPINNED.  The exception tables are the full generated sets
+(contraction stems x suffixes x case, times, abbreviations, months, US states, emoticons);
+the URL pattern keeps the structure of spaCy's and not every clause of it.
 
 Algorithm (spaCy `Tokenizer.__call__` / `_tokenize`):
   1. split on whitespace; runs of whitespace beyond a single space would be whitespace
@@ -125,8 +126,10 @@ URL_RE = re.compile(
     r"^(?:(?:[\w\+\-\.]{2,})://)?(?:\S+(?::\S*)?@)?"
     r"(?:(?:[1-9]\d?|1\d\d|2[01]\d|22[0-3])(?:\.(?:1?\d{1,2}|2[0-4]\d|25[0-5])){2}"
     r"(?:\.(?:[1-9]\d?|1\d\d|2[0-4]\d|25[0-4]))"
-    r"|(?:(?:[A-Za-z0-9¡-￿][A-Za-z0-9¡-￿_-]{0,62})?[A-Za-z0-9¡-￿]\.)+"
-    r"(?:[A-Za-z¡-￿]{2,63}))"
+    # host and TLD in lower case only, as in spaCy's pattern (no IGNORECASE): "Hello.World" is
+    # not a URL and is split at the period by the infix rule
+    r"|(?:(?:[a-z0-9\u00a1-\uffff][a-z0-9\u00a1-\uffff_-]{0,62})?[a-z0-9\u00a1-\uffff]\.)+"
+    r"(?:[a-z\u00a1-\uffff]{2,63}))"
     r"(?::\d{2,5})?(?:[/?#]\S*)?$")
 
 
@@ -136,7 +139,34 @@ def token_match(s):
 
 # ---- special cases (tokenizer_exceptions.py, lang/en/tokenizer_exceptions.py) ------------------
 
+_EMOTICONS = r"""
+:) :-) :)) :-)) :))) :-))) (: (-: =) (= ") :] :-] [: [-: :o) (o: :} :-} 8) 8-) (-8 ;) ;-) (; (-;
+:( :-( :(( :-(( :((( :-((( ): )-: =( >:( :') :'-) :'( :'-( :/ :-/ =/ =| :| :-| :1 :P :-P :p :-p
+:O :-O :o :-o :0 :-0 :() >:o :* :-* :3 :-3 =3 :> :-> :X :-X :x :-x :D :-D ;D ;-D =D xD XD xDD XDD
+8D 8-D ^_^ ^__^ ^___^ >.< >.> <.< ._. ;_; -_- -__- v.v V.V v_v V_V o_o o_O O_o O_O 0_o o_0 0_0
+o.O O.o O.O o.o 0.0 o.0 0.o @_@ <3 <33 <333 </3 (^_^) (-_-) (._.) (>_<) (*_*) (¬_¬)
+ಠ_ಠ ಠ︵ಠ (ಠ_ಠ) ¯\(ツ)/¯ (╯°□°）╯︵┻━┻ ><(((*>
+""".split()
+
+
+def _base_exceptions():
+    """spacy/lang/tokenizer_exceptions.py BASE_EXCEPTIONS (the whitespace entries cannot
+    occur: chunks come from a whitespace split)."""
+    exc = {}
+    for orth in ["\\t", "\\n", "\u2014", "'", '\\")', "<space>", "''", "C++"]:
+        exc[orth] = [orth]
+    for c in "abcdefghijklmnopqrstuvwxyz\xe4\xf6\xfc":
+        exc[c + "."] = [c + "."]
+    for orth in _EMOTICONS:
+        exc[orth] = [orth]
+    return exc
+
+
 def _english_exceptions():
+    """spacy/lang/en/tokenizer_exceptions.py (2.x), every generated form: pronoun, wh-word
+    and verb stems x 'm / 'll / 'll've / 'd / 'd've / 've / 're / 's / n't / n't've, each
+    with and without the apostrophe and in lower and title case; times; the fixed lists of
+    contractions, abbreviations, months and US states."""
     exc = {}
 
     def add(orth, pieces):
@@ -201,57 +231,47 @@ def _english_exceptions():
         for orth in [verb, verb.title()]:
             add(orth + "n't", [orth, "n't"])
             add(orth + "nt", [orth, "nt"])
-    for orth in ["'s", "'S", "’s", "’S", "'re", "'ll", "'d", "'m", "'ve", "’re", "’ll", "’d", "’m", "’ve"]:
-        add(orth, [orth])
-    for a, b in [("cannot", ("can", "not")), ("Cannot", ("Can", "not")),
-                 ("gonna", ("gon", "na")), ("Gonna", ("Gon", "na")),
-                 ("gotta", ("got", "ta")), ("Gotta", ("Got", "ta")),
-                 ("let's", ("let", "'s")), ("Let's", ("Let", "'s")),
-                 ("lets", ("let", "s")), ("Lets", ("Let", "s")),
-                 ("and/or", ("and/or",)), ("w/o", ("w/o",)),
-                 ("'Cause", ("'Cause",)), ("'cause", ("'cause",)), ("'cos", ("'cos",)),
-                 ("'Cos", ("'Cos",)), ("'coz", ("'coz",)), ("'Coz", ("'Coz",)),
-                 ("'cuz", ("'cuz",)), ("'Cuz", ("'Cuz",)), ("'bout", ("'bout",)),
-                 ("'Bout", ("'Bout",)), ("'em", ("'em",)), ("'Em", ("'Em",)),
-                 ("'nuff", ("'nuff",)), ("'Nuff", ("'Nuff",)), ("ma'am", ("ma'am",)),
-                 ("Ma'am", ("Ma'am",)), ("o'clock", ("o'clock",)), ("O'clock", ("O'clock",)),
-                 ("y'all", ("y'", "all")), ("Y'all", ("Y'", "all")),
-                 ("c'mon", ("c'm", "on")), ("C'mon", ("C'm", "on")),
-                 ("ol'", ("ol'",)), ("Ol'", ("Ol'",)), ("'til", ("'til",)), ("'Til", ("'Til",)),
-                 ("nothin'", ("nothin'",)), ("nuthin'", ("nuthin'",)), ("doin'", ("doin'",)),
-                 ("goin'", ("goin'",)), ("havin'", ("havin'",)), ("lovin'", ("lovin'",)),
-                 ("somethin'", ("somethin'",))]:
-        add(a, b)
+    # contractions that end or begin with an apostrophe: one token with and without it
+    for stem in ["doin", "goin", "nothin", "nuthin", "ol", "somethin", "lovin", "havin"]:
+        for orth in [stem, stem.title()]:
+            add(orth, [orth])
+            add(orth + "'", [orth + "'"])
+    for stem in ["cause", "em", "ll", "nuff"]:
+        add(stem, [stem])
+        add("'" + stem, ["'" + stem])
     for h in range(1, 13):
-        for period in ["a.m.", "am"]:
+        for period in ["a.m.", "am", "p.m.", "pm"]:
             add("%d%s" % (h, period), ["%d" % h, period])
-        for period in ["p.m.", "pm"]:
-            add("%d%s" % (h, period), ["%d" % h, period])
-    for orth in ["a.m.", "A.M.", "p.m.", "P.M.", "Adm.", "Bros.", "co.", "Co.", "Corp.", "D.C.",
-                 "Dr.", "e.g.", "E.g.", "E.G.", "Gen.", "Gov.", "i.e.", "I.e.", "I.E.", "Inc.",
-                 "Jr.", "Ltd.", "Md.", "Messrs.", "Mo.", "Mont.", "Mr.", "Mrs.", "Ms.", "p.m.",
-                 "Ph.D.", "Prof.", "Rep.", "Rev.", "Sen.", "St.", "vs.", "v.s.", "Mt.", "Ave.",
-                 "Blvd.", "Rd.", "Sgt.", "Capt.", "Col.", "Lt.", "Maj.", "Cmdr.", "Hon.",
-                 "Jan.", "Feb.", "Mar.", "Apr.", "Jun.", "Jul.", "Aug.", "Sep.", "Sept.", "Oct.",
-                 "Nov.", "Dec.", "Ala.", "Ariz.", "Ark.", "Calif.", "Colo.", "Conn.", "Del.",
-                 "Fla.", "Ga.", "Ia.", "Id.", "Ill.", "Ind.", "Kan.", "Kans.", "Ky.", "La.",
-                 "Mass.", "Mich.", "Minn.", "Miss.", "N.C.", "N.D.", "N.H.", "N.J.", "N.M.",
-                 "N.Y.", "Neb.", "Nebr.", "Nev.", "Okla.", "Ore.", "Pa.", "S.C.", "Tenn.", "Va.",
-                 "Wash.", "Wis."]:
-        add(orth, [orth])
-    # base exceptions: single letters with a period, emoticons, a few symbols
-    for c in "abcdefghijklmnopqrstuvwxyzäöü":
-        add(c + ".", [c + "."])
-    for orth in [":)", ":-)", ":))", ":-))", ":(", ":-(", ":((", ":-((", ";)", ";-)", ":D", ":-D",
-                 ":P", ":-P", ":p", ":-p", ":O", ":-O", ":o", ":-o", ":/", ":-/", ":|", ":-|",
-                 ":*", ":-*", ":'(", ":')", "<3", "</3", "^_^", "^__^", "-_-", "-__-", ">.<",
-                 "o.O", "O.o", "o_O", "O_o", "o.o", "O.O", "xD", "XD", "=)", "=(", "=D", "(:",
-                 "(-:", "):", ")-:", "8)", "8-)", ":]", ":-]", ":3", ":-3", "C++", "\\t", "\\n"]:
+    for orth, pieces in [
+            ("y'all", ("y'", "all")), ("yall", ("y", "all")),
+            ("how'd'y", ("how", "'d", "'y")), ("How'd'y", ("How", "'d", "'y")),
+            ("not've", ("not", "'ve")), ("notve", ("not", "ve")),
+            ("Not've", ("Not", "'ve")), ("Notve", ("Not", "ve")),
+            ("cannot", ("can", "not")), ("Cannot", ("Can", "not")),
+            ("gonna", ("gon", "na")), ("Gonna", ("Gon", "na")),
+            ("gotta", ("got", "ta")), ("Gotta", ("Got", "ta")),
+            ("let's", ("let", "'s")), ("Let's", ("Let", "'s"))]:
+        add(orth, pieces)
+    for orth in ["'S", "'s", "\u2018S", "\u2018s", "and/or", "w/o", "'re", "'Cause", "'cause", "'cos",
+                 "'Cos", "'coz", "'Coz", "'cuz", "'Cuz", "'bout", "ma'am", "Ma'am", "o'clock",
+                 "O'clock",
+                 "Mt.", "Ak.", "Ala.", "Apr.", "Ariz.", "Ark.", "Aug.", "Calif.", "Colo.", "Conn.",
+                 "Dec.", "Del.", "Feb.", "Fla.", "Ga.", "Ia.", "Id.", "Ill.", "Ind.", "Jan.", "Jul.",
+                 "Jun.", "Kan.", "Kans.", "Ky.", "La.", "Mar.", "Mass.", "May.", "Mich.", "Minn.",
+                 "Miss.", "N.C.", "N.D.", "N.H.", "N.J.", "N.M.", "N.Y.", "Neb.", "Nebr.", "Nev.",
+                 "Nov.", "Oct.", "Okla.", "Ore.", "Pa.", "S.C.", "Sep.", "Sept.", "Tenn.", "Va.",
+                 "Wash.", "Wis.",
+                 "'d", "a.m.", "Adm.", "Bros.", "co.", "Co.", "Corp.", "D.C.", "Dr.", "e.g.", "E.g.",
+                 "E.G.", "Gen.", "Gov.", "i.e.", "I.e.", "I.E.", "Inc.", "Jr.", "Ltd.", "Md.",
+                 "Messrs.", "Mo.", "Mont.", "Mr.", "Mrs.", "Ms.", "p.m.", "Ph.D.", "Prof.", "Rep.",
+                 "Rev.", "Sen.", "St.", "vs.", "v.s."]:
         add(orth, [orth])
     for excluded in ["Ill", "ill", "Its", "its", "Hell", "hell", "Shell", "shell", "Shed", "shed",
                      "were", "Were", "Well", "well", "Whore", "whore"]:
         exc.pop(excluded, None)
-    return exc
+    merged = _base_exceptions()
+    merged.update(exc)                 # update_exc(BASE_EXCEPTIONS, _exc)
+    return merged
 
 
 SPECIAL_CASES = _english_exceptions()

@@ -118,19 +118,30 @@ def chunk_text(txt, size=100000):
 class Vocab(object):
     """Growable string table + fixed vector table."""
 
-    def __init__(self, words, vectors, oov_hash=default_oov_hash):
+    def __init__(self, words, vectors, oov_hash=default_oov_hash, rows=None):
+        """`rows` (optional): row of `vectors` per word, as spaCy's key2row -- several words
+        may share a row (en_core_web_md keeps 20k rows for 685k keys) and then share a vector
+        id; without it word i has row i."""
         vectors = np.ascontiguousarray(vectors, dtype=np.float32)
-        if vectors.ndim != 2 or len(words) != vectors.shape[0]:
-            raise ValueError("one vector row per word expected")
+        if vectors.ndim != 2:
+            raise ValueError("vectors must be (rows, dim)")
+        if rows is None:
+            if len(words) != vectors.shape[0]:
+                raise ValueError("one vector row per word expected (or pass rows=)")
+            rows = range(len(words))
+        else:
+            rows = [int(r) for r in rows]
+            if len(rows) != len(words) or (rows and not (0 <= min(rows) and max(rows) < vectors.shape[0])):
+                raise ValueError("rows must name a row of the vector table for every word")
         self.vectors = vectors
         self.dim = vectors.shape[1]
-        self.key2row = {w: i for i, w in enumerate(words)}
+        self.key2row = {w: r for w, r in zip(words, rows)}
         self.oov_hash = oov_hash
         self.strings = []
         self._string_id = {}
         self._vec_id = []        # per string id
         self._orth = []          # per string id: spaCy hash
-        for w in words:          # string id == row id for table words
+        for w in words:          # (string id == row id while every word has a row of its own)
             self.string_id(w)
 
     def string_id(self, text):

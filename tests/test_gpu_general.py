@@ -298,3 +298,40 @@ def test_crowded_buckets_keep_insertion_order(synth_base, unique):
     ix, got, st = _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(6),
                        tok, off, synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL and len(got) > 20
+
+
+def test_table_with_identical_rows_and_a_zero_row(synth_base):
+    """What a real export holds (tools/export_spacy_vectors.py): two ids with the same vector
+    (c_max = 1: the exact-n-gram proof fails, a window that swaps one for the other is at
+    distance 0 of the script's) and an all-zero row (a window of nothing else has no direction:
+    0/0, no match; inside a window it only shortens the vector).  LSH pipeline == oracle."""
+    words = synth_base["words"][:600]
+    rng = np.random.default_rng(5)
+    emb = synth_base["emb"][:600].copy()
+    for i in range(0, 60, 2):
+        emb[i + 1] = emb[i]                          # ids i and i + 1: the same vector
+    emb[100] = 0.0
+    emb[101] = 0.0
+    script = rng.integers(0, 120, size=900).astype(np.uint32)
+    script[50:56] = 100                              # a script window of zero vectors only
+    script[200:203] = [100, 7, 101]
+    works = []
+    for w in range(8):
+        t = rng.integers(120, 600, size=500).astype(np.uint32)
+        for _ in range(5):
+            ln = int(rng.integers(6, 18))
+            src = int(rng.integers(0, len(script) - ln))
+            dst = int(rng.integers(0, 500 - ln))
+            span = script[src:src + ln].copy()
+            twin = (span < 60) & (rng.random(ln) < 0.4)
+            span[twin] ^= 1                           # the other id of the same vector
+            t[dst:dst + ln] = span
+        t[490:496] = 100                              # and a fan window of zero vectors only
+        works.append(t)
+    tok = np.concatenate(works)
+    off = np.arange(9, dtype=np.uint64) * np.uint64(500)
+    chars, coff = pack_strings(words)
+    ix, got, st = _run(abi.make_config(), script, [words[int(t)] for t in script], emb,
+                       synth.lsh_normals(6), tok, off, chars, coff)
+    assert ix.info["proof_ok"] == 0 and st.path == abi.FS_MODE_GENERAL
+    assert len(got) > 50 and not np.isnan(got["dist"]).any()

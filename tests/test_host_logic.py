@@ -173,3 +173,28 @@ def test_matrix_empty(tmp_path, monkeypatch):
     _match_csv("m.csv", [("a.txt", 0, 10, 3)])
     out = matrix.process(types.SimpleNamespace(i="m.csv", m="x", n=6))
     assert list(csv.reader(open(out))) == [["FILENAME"], ["(total)"]]
+
+
+def test_vector_table_with_shared_and_zero_rows(tmp_path, monkeypatch):
+    """The .npz of tools/export_spacy_vectors.py: words that share a row (spaCy's key2row; most
+    keys of en_core_web_md do) share a vector id, a word on an all-zero row keeps its row
+    (has_vector is true for it in the reference, search.py:74-75), a word without a row is OOV."""
+    import numpy as np
+    from fandom_search_amd import search, vocab as vocab_mod
+    vec = np.zeros((4, 300), dtype=np.float32)
+    vec[0, 0] = 1.0
+    vec[1, 1] = 1.0
+    vec[2, 2] = 1.0                       # row 3 stays all zero
+    path = tmp_path / "vectors.npz"
+    np.savez(path, words=np.array(["cat", "feline", "dog", "nil", "kitty"]),
+             rows=np.array([0, 0, 1, 3, 0]), vectors=vec)
+    monkeypatch.setenv("FANDOM_SEARCH_VECTORS", str(path))
+    monkeypatch.setattr(search, "_VOCAB", None)
+    v = search.get_vocab()
+    sid, vid = v.encode(["cat", "feline", "kitty", "dog", "nil", "unknown", "cat"])
+    assert vid[0] == vid[1] == vid[2] == 0 and vid[3] == 1 and vid[4] == 3 and vid[6] == 0
+    assert len(set(sid[:5].tolist())) == 5            # five different strings
+    assert vid[5] & vocab_mod.OOV_FLAG and v.has_vector(int(sid[4])) and not v.has_vector(int(sid[5]))
+    assert not np.any(v.vector(int(sid[4])))
+    with pytest.raises(ValueError):
+        vocab_mod.Vocab(["a", "b"], vec, rows=[0, 9])

@@ -63,3 +63,138 @@ def test_synthetic_text_is_split_on_spaces_only():
     words = synth.vocab_words()[:500]
     text = " ".join(words)
     assert tokenizer.tokenize(text) == words
+
+
+# ---- spaCy's own test-suite (spacy/tests/lang/en/test_exceptions.py, test_punct.py,
+# test_prefix_suffix_infix.py, test_contractions; spacy/tests/tokenizer/test_exceptions.py,
+# test_urls.py), the cases whose expected tokens follow from the rules restated here ----------
+
+SPACY_SUITE = [
+    # test_exceptions.py: basic contractions, abbreviations, times
+    ("don't giggle", ["do", "n't", "giggle"]),
+    ("i said don't!", ["i", "said", "do", "n't", "!"]),
+    ("e.g.", ["e.g."]), ("p.m.", ["p.m."]), ("Jan.", ["Jan."]), ("Dec.", ["Dec."]), ("Inc.", ["Inc."]),
+    ("It's mediocre i.e. bad.", ["It", "'s", "mediocre", "i.e.", "bad", "."]),
+    ("1am", ["1", "am"]), ("12a.m.", ["12", "a.m."]), ("11p.m.", ["11", "p.m."]), ("4pm", ["4", "pm"]),
+    ("We'll", ["We", "'ll"]), ("You'll", ["You", "'ll"]), ("there'll", ["there", "'ll"]),
+    ("can't", ["ca", "n't"]), ("Can't", ["Ca", "n't"]), ("ain't", ["ai", "n't"]), ("Ain't", ["Ai", "n't"]),
+    ("Ill", ["Ill"]), ("ill", ["ill"]), ("Hell", ["Hell"]), ("hell", ["hell"]), ("Well", ["Well"]),
+    ("Shell", ["Shell"]), ("shed", ["shed"]), ("Its", ["Its"]), ("Were", ["Were"]), ("whore", ["whore"]),
+    ("We've", ["We", "'ve"]), ("we've", ["we", "'ve"]), ("I've", ["I", "'ve"]), ("They've", ["They", "'ve"]),
+    ("couldn't've", ["could", "n't", "'ve"]), ("Wouldn't've", ["Would", "n't", "'ve"]),
+    ("shan't", ["sha", "n't"]), ("Won't", ["Wo", "n't"]), ("mustn't", ["must", "n't"]),
+    ("needn't", ["need", "n't"]), ("oughtn't", ["ought", "n't"]), ("mightn't", ["might", "n't"]),
+    ("daren't", ["dare", "n't"]), ("hasn't", ["has", "n't"]), ("Haven't", ["Have", "n't"]),
+    ("wasn't", ["was", "n't"]), ("Weren't", ["Were", "n't"]), ("aren't", ["are", "n't"]),
+    ("didn't", ["did", "n't"]), ("Doesn't", ["Does", "n't"]), ("hadn't", ["had", "n't"]),
+    ("should've", ["should", "'ve"]), ("Could've", ["Could", "'ve"]), ("would've", ["would", "'ve"]),
+    ("might've", ["might", "'ve"]), ("must've", ["must", "'ve"]),
+    ("dont", ["do", "nt"]), ("cant", ["ca", "nt"]), ("wont", ["wo", "nt"]), ("Im", ["I", "m"]),
+    ("youre", ["you", "re"]), ("theyve", ["they", "ve"]), ("hes", ["he", "s"]), ("shes", ["she", "s"]),
+    ("I'd", ["I", "'d"]), ("you'd've", ["you", "'d", "'ve"]), ("She'd", ["She", "'d"]),
+    ("he'll've", ["he", "'ll", "'ve"]), ("It'll", ["It", "'ll"]), ("they'd", ["they", "'d"]),
+    ("He's", ["He", "'s"]), ("she's", ["she", "'s"]), ("You're", ["You", "'re"]), ("they're", ["they", "'re"]),
+    ("who's", ["who", "'s"]), ("What's", ["What", "'s"]), ("where'd", ["where", "'d"]),
+    ("How'll", ["How", "'ll"]), ("why've", ["why", "'ve"]), ("There's", ["There", "'s"]),
+    ("that's", ["that", "'s"]), ("That'll", ["That", "'ll"]), ("who're", ["who", "'re"]),
+    ("when's", ["when", "'s"]), ("whats", ["what", "s"]), ("thats", ["that", "s"]),
+    ("I'ma", ["I", "'m", "a"]), ("Ima", ["I", "m", "a"]), ("i'm", ["i", "'m"]),
+    ("y'all", ["y'", "all"]), ("yall", ["y", "all"]), ("how'd'y", ["how", "'d", "'y"]),
+    ("not've", ["not", "'ve"]), ("Cannot", ["Can", "not"]), ("Gonna", ["Gon", "na"]),
+    ("gotta", ["got", "ta"]), ("let's", ["let", "'s"]),
+    ("'cause", ["'cause"]), ("'Cause", ["'Cause"]), ("'em", ["'em"]), ("'nuff", ["'nuff"]),
+    ("'bout", ["'bout"]), ("'cos", ["'cos"]), ("'Coz", ["'Coz"]), ("'cuz", ["'cuz"]),
+    ("ma'am", ["ma'am"]), ("Ma'am", ["Ma'am"]), ("o'clock", ["o'clock"]), ("O'clock", ["O'clock"]),
+    ("doin'", ["doin'"]), ("Goin'", ["Goin'"]), ("nothin'", ["nothin'"]), ("nuthin'", ["nuthin'"]),
+    ("ol'", ["ol'"]), ("somethin'", ["somethin'"]), ("and/or", ["and/or"]), ("w/o", ["w/o"]),
+    ("Mt.", ["Mt."]), ("Calif.", ["Calif."]), ("N.Y.", ["N.Y."]), ("Ph.D.", ["Ph.D."]),
+    ("Messrs.", ["Messrs."]), ("vs.", ["vs."]), ("Gov.", ["Gov."]), ("Sept.", ["Sept."]),
+    ("Mrs. Dalloway", ["Mrs.", "Dalloway"]), ("Dr. No", ["Dr.", "No"]), ("St. Louis", ["St.", "Louis"]),
+    # test_punct.py
+    ("(Hello", ["(", "Hello"]), ("[Hello", ["[", "Hello"]), ("{Hello", ["{", "Hello"]), ("*Hello", ["*", "Hello"]),
+    ("Hello)", ["Hello", ")"]), ("Hello]", ["Hello", "]"]), ("Hello}", ["Hello", "}"]), ("Hello*", ["Hello", "*"]),
+    ("(`Hello", ["(", "`", "Hello"]), ("Hello)'", ["Hello", ")", "'"]),
+    ("(((Hello", ["(", "(", "(", "Hello"]), ("Hello)))", ["Hello", ")", ")", ")"]),
+    ("'The", ["'", "The"]), ("(Hello)", ["(", "Hello", ")"]), ("[Hello]", ["[", "Hello", "]"]),
+    ("Hello!", ["Hello", "!"]), ("Hello?", ["Hello", "?"]), ("Hello,", ["Hello", ","]),
+    ("Hello;", ["Hello", ";"]), ("Hello:", ["Hello", ":"]),
+    ("''", ["''"]),
+    # test_prefix_suffix_infix.py
+    ("(can)", ["(", "can", ")"]), ("can)", ["can", ")"]), ("(can", ["(", "can"]),
+    ("(can't", ["(", "ca", "n't"]), ("can't)", ["ca", "n't", ")"]), ("(can't)", ["(", "ca", "n't", ")"]),
+    ("(can't?)", ["(", "ca", "n't", "?", ")"]), ("U.S.)", ["U.S.", ")"]), ("(U.S.)", ["(", "U.S.", ")"]),
+    ("best-known", ["best", "-", "known"]), ("0.1-13.5", ["0.1", "-", "13.5"]),
+    ("0.0-0.1", ["0.0", "-", "0.1"]), ("103.27-300", ["103.27", "-", "300"]),
+    ("Hello,world", ["Hello", ",", "world"]), ("best...Known", ["best", "...", "Known"]),
+    ("best...known", ["best", "...", "known"]), ("google.com", ["google.com"]),
+    ("best.Known", ["best", ".", "Known"]), ("Hello.World", ["Hello", ".", "World"]),
+    ("The U.S. Army likes Shock and Awe.",
+     ["The", "U.S.", "Army", "likes", "Shock", "and", "Awe", "."]),
+    ("No decent--let alone well-bred--people.",
+     ["No", "decent", "--", "let", "alone", "well", "-", "bred", "--", "people", "."]),
+    ("ain't", ["ai", "n't"]), ("10-20", ["10", "-", "20"]), ("2*3", ["2", "*", "3"]), ("2+3", ["2", "+", "3"]),
+    ("a-b-c", ["a", "-", "b", "-", "c"]), ("mother-in-law", ["mother", "-", "in", "-", "law"]),
+    ("x—y", ["x", "—", "y"]), ("one~two", ["one", "~", "two"]),
+    ("Hello—", ["Hello", "—"]), ("–Hello", ["–", "Hello"]),
+    # quotes, currency, units, percent
+    ('"Hello"', ['"', "Hello", '"']), ("“Hello”", ["“", "Hello", "”"]), ("‘Hi’", ["‘", "Hi", "’"]),
+    ("$10", ["$", "10"]), ("£5", ["£", "5"]), ("€7", ["€", "7"]), ("10$", ["10", "$"]), ("10€", ["10", "€"]),
+    ("5km", ["5", "km"]), ("3kg", ["3", "kg"]), ("100mph", ["100", "mph"]), ("20%", ["20", "%"]),
+    ("%20", ["%", "20"]), ("12cm", ["12", "cm"]), ("7mb", ["7", "mb"]),
+    ("John's", ["John", "'s"]), ("JOHN'S", ["JOHN", "'S"]), ("dog’s", ["dog", "’s"]),
+    ("Mr. Smith's dog.", ["Mr.", "Smith", "'s", "dog", "."]),
+    ("wait...", ["wait", "..."]), ("...and", ["...", "and"]), ("wait…", ["wait", "…"]),
+    ("So..what", ["So", "..", "what"]),
+    # sentence-final period rules
+    ("the end.", ["the", "end", "."]), ("in 1999.", ["in", "1999", "."]), ("at 5%.", ["at", "5", "%", "."]),
+    ("the FBI.", ["the", "FBI", "."]), ("a U.N.", ["a", "U.N."]), ("ok).", ["ok", ")", "."]),
+    # tokenizer/test_exceptions.py: emoticons in running text
+    (":o :/ :'( >:o (: :) >.< XD -__- o.O ;D :-) @_@ :P 8D :1 >:( :D =| :> ....",
+     [":o", ":/", ":'(", ">:o", "(:", ":)", ">.<", "XD", "-__-", "o.O", ";D", ":-)", "@_@", ":P",
+      "8D", ":1", ">:(", ":D", "=|", ":>", "...."]),
+    ("Hello :) world <3", ["Hello", ":)", "world", "<3"]),
+    ("¯\\(ツ)/¯", ["¯\\(ツ)/¯"]), ("(ಠ_ಠ)", ["(ಠ_ಠ)"]),
+    # test_urls.py (the plain cases) and prefix / suffix around a URL
+    ("http://www.nytimes.com", ["http://www.nytimes.com"]), ("www.red-stars.com", ["www.red-stars.com"]),
+    ("mailto:foo.bar@baz.com", ["mailto:foo.bar@baz.com"]),
+    ("http://foo.com/blah_blah", ["http://foo.com/blah_blah"]),
+    ("https://example.org:8080/p?q=1#frag", ["https://example.org:8080/p?q=1#frag"]),
+    ("(http://www.nytimes.com)", ["(", "http://www.nytimes.com", ")"]),
+    ('"http://www.nytimes.com"', ['"', "http://www.nytimes.com", '"']),
+    ("http://www.nytimes.com.", ["http://www.nytimes.com", "."]),
+    ("http://www.nytimes.com!", ["http://www.nytimes.com", "!"]),
+    ("http://www.nytimes.com,", ["http://www.nytimes.com", ","]),
+    # letters with a period, C++
+    ("a.", ["a."]), ("z.", ["z."]), ("ä.", ["ä."]), ("C++", ["C++"]), ("I like C++.", ["I", "like", "C++", "."]),
+]
+
+
+@pytest.mark.parametrize("text,want", SPACY_SUITE)
+def test_spacy_suite_known_answers(text, want):
+    assert tokenizer.tokenize(text) == want
+
+
+def test_known_answer_count():
+    assert len(SPACY_SUITE) >= 150
+
+
+def test_exception_tables_are_complete():
+    """Every generated contraction of lang/en/tokenizer_exceptions.py is a special case:
+    15 verb stems x {n't, nt, n't've, ntve} x 2 cases, 7 pronouns x 8 forms x 2, 8 wh-words
+    x 14 forms x 2 ... (the abridged lists of round 2 held a fraction of them)."""
+    sc = tokenizer.SPECIAL_CASES
+    assert len(sc) > 850
+    for verb in ["ca", "could", "do", "does", "did", "had", "may", "might", "must", "need", "ought",
+                 "sha", "should", "wo", "would"]:
+        for stem in (verb, verb.title()):
+            for suf, pieces in (("n't", ["n't"]), ("nt", ["nt"]), ("n't've", ["n't", "'ve"]),
+                                ("ntve", ["nt", "ve"])):
+                assert sc[stem + suf] == [stem] + pieces
+    for word in ["who", "what", "when", "where", "why", "how", "there", "that"]:
+        for stem in (word, word.title()):
+            assert sc[stem + "'d've"] == [stem, "'d", "'ve"] and sc[stem + "llve"] == [stem, "ll", "ve"]
+    for excluded in ["Ill", "ill", "Its", "its", "Hell", "hell", "Shell", "shell", "Shed", "shed",
+                     "were", "Were", "Well", "well", "Whore", "whore"]:
+        assert excluded not in sc
+    for emoticon in [":-)))", "(-8", ":'-(", "^___^", "0_o", "<333", "(>_<)", "><(((*>"]:
+        assert sc[emoticon] == [emoticon]
