@@ -95,6 +95,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_SCAN_SUB")) sw->scan_sub = e[0] != '0';
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
+  if (const char* e = getenv("FS_LSH_MEMO")) sw->lsh_memo = atoi(e) != 0;
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);

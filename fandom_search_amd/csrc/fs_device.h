@@ -128,6 +128,67 @@ __device__ __forceinline__ uint32_t work_of_token(const CorpusDev& c, uint64_t p
   return w;
 }
 
+// ids of a window: two (n <= 8) or four 16-byte loads.  The window start is only
+// 4-byte aligned; gfx950 global loads accept that (unaligned access mode), and
+// the token buffers are padded, so reading up to 16 ids is always in bounds.
+struct Ids16 { uint32_t v[16]; };
+__device__ __forceinline__ void load_ids(const uint32_t* p, int n, Ids16* out) {
+  __builtin_memcpy(out->v, p, 32);
+  if (n > 8) __builtin_memcpy(out->v + 8, p + 8, 32);
+}
+
+// Exact check of the window at token p: the script n-gram with the same n vector
+// ids (found through the open-addressing table, compared id for id), or FS_NONE;
+// FS_NONE also for a window that crosses a work boundary (windows are built per
+// file, search.py:170-173).  *w = the work, *kept = NearestFilter entries it has.
+__device__ __forceinline__ uint32_t verify_window(const CorpusDev& c, const GramIndexDev& g,
+                                                  uint64_t p, uint32_t* w_out, uint32_t* kept) {
+  if (p + g.n > c.n_tok) return FS_NONE;
+  const uint32_t slot_mask = (1u << g.log2_slots) - 1;
+  // two independent chains of two reads each: ids -> table entry (which carries the
+  // script n-gram's ids), and block -> work
+  Ids16 f;
+  load_ids(c.tok + p, g.n, &f);
+  uint64_t work_end;
+  const uint32_t w = work_of_token(c, p, &work_end);
+  const bool inside = p + g.n <= work_end;
+  uint32_t h = 0;
+#pragma unroll
+  for (int k = 0; k < FS_MAX_WINDOW; ++k)
+    if (k < g.n) h ^= fs_rotl(fs_premix(f.v[k]), fs_rot_of(g.n - 1 - k));
+  // hash-and-displace: the bucket's displacement seed sends every script n-gram of the
+  // bucket to a slot of its own, so one entry read decides (hit, or not a script
+  // n-gram).  Only buckets holding n-grams with identical 32-bit hashes carry the
+  // overflow flag and continue by linear probing.
+  const uint32_t d = g.disp[fs_table_bucket(h, g.log2_buckets)];
+  uint32_t slot = fs_table_slot_d(h, d & FS_DISP_MASK, g.log2_slots);
+  const int quads = g.tstride >> 2;              // 16-byte pieces of an entry: 2 (n <= 6) .. 5
+  for (;;) {
+    // {gram + 1 (0 = empty), occurrences kept, ids[n], pad}
+    const uint4* e = reinterpret_cast<const uint4*>(g.table + (size_t)slot * g.tstride);
+    uint32_t ew[20];
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (q < quads) {
+        const uint4 t = e[q];
+        ew[4 * q] = t.x; ew[4 * q + 1] = t.y; ew[4 * q + 2] = t.z; ew[4 * q + 3] = t.w;
+      }
+    if (ew[0] == 0) return FS_NONE;
+    bool same = true;
+#pragma unroll
+    for (int k = 0; k < FS_MAX_WINDOW; ++k)
+      if (k < g.n) same = same && (ew[2 + k] == f.v[k]);
+    if (same) {
+      if (!inside) return FS_NONE;
+      *w_out = w;
+      *kept = ew[1];
+      return ew[0] - 1;
+    }
+    if (!(d & FS_DISP_OVERFLOW)) return FS_NONE;
+    slot = (slot + 1) & slot_mask;
+  }
+}
+
 // Levenshtein.distance(match_str, fan_context), search.py:189-190:
 //   match_str   = script words s .. s+n-1 joined by single spaces
 //   fan_context = '[' + ', '.join(fan token texts) + ']'

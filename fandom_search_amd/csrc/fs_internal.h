@@ -171,6 +171,7 @@ struct fs_switches {
   bool str_levtab = true;         // FS_STR_LEVTAB=0: batches with string ids compute every Levenshtein distance per match
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
+  bool lsh_memo = true;           // FS_LSH_MEMO=0: k_lsh_verify computes every window with a script n-gram's ids anew
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
   int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
@@ -297,6 +298,8 @@ struct fs_corpus {
   DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
   bool ctab_ready = false;
+  DBuf<unsigned long long> d_lshmemo_best;   // LSH pipeline: per script n-gram, what a window with its ids gets
+  DBuf<uint32_t> d_lshmemo_cnt;        //   (fs_best; count of kept matches + 1, 0: not computed yet)
   DBuf<uint32_t> d_selflev;            // LSH pipeline, string id == vector id: Levenshtein of script window w
   bool selflev_ready = false;          // against the strings of its own ids (k_selflev), FS_NONE: not known
   CorpusDev dev() const;

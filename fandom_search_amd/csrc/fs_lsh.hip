@@ -762,8 +762,11 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
                                                     uint32_t* __restrict__ cg,
                                                     uint32_t* __restrict__ cw,
                                                     fs_best* __restrict__ cbest,
-                                                    uint32_t* __restrict__ bmatch, fs_status* st) {
+                                                    uint32_t* __restrict__ bmatch, fs_status* st,
+                                                    unsigned long long* __restrict__ memo_best,
+                                                    uint32_t* __restrict__ memo_cnt) {
   __shared__ uint64_t s_bal[4][32];
+  __shared__ uint32_t s_gram[4][64];
   __shared__ uint32_t s_key[4][64];
   __shared__ uint32_t s_top_s[4][64];
   __shared__ double s_top_d[4][64];
@@ -792,13 +795,15 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
      const uint64_t p = cpos[il];
      bool pass = true;
      if (p + L.n <= c.n_tok) {
+       Ids16 f;
+       load_ids(c.tok + p, L.n, &f);
        uint32_t term[FS_MAX_WINDOW];
        uint32_t fold = 0;
 #pragma unroll
        for (int k = 0; k < FS_MAX_WINDOW; ++k) {
          term[k] = 0;
          if (k < L.n) {
-           term[k] = fs_rotl(fs_premix(c.tok[p + k]), fs_rot_of(L.n - 1 - k));
+           term[k] = fs_rotl(fs_premix(f.v[k]), fs_rot_of(L.n - 1 - k));
            fold ^= term[k];
          }
        }
@@ -813,9 +818,41 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
      }
      if (!pass) { cg[il] = FS_NONE; live = false; }
    }
+   // What the reference returns for a window is a function of its vector, i.e. of its ids (and,
+   // for the Levenshtein distances, of the strings of those ids): a window with the ids of a
+   // script n-gram gets what the first such window of this string table got (memo_*: per
+   // corpus, filled as the searches go; one lane per candidate, no bucket is walked again).
+   uint32_t gram = FS_NONE;
+   if (memo_cnt && live) {
+     uint32_t w = 0, kept = 0;
+     gram = verify_window(c, g, cpos[il], &w, &kept);
+     if (gram != FS_NONE) {
+       const uint32_t have = __hip_atomic_load(&memo_cnt[gram], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+       if (have) {
+         if (have == 1) {
+           cg[il] = FS_NONE;                           // (no neighbour within the threshold)
+         } else {
+           const unsigned long long* m = memo_best + 4 * (size_t)gram;
+           unsigned long long q[4];
+#pragma unroll
+           for (int k = 0; k < 4; ++k) q[k] = __hip_atomic_load(&m[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+           unsigned long long* dst = reinterpret_cast<unsigned long long*>(&cbest[il]);
+           dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
+           cg[il] = 0;
+           cw[il] = w;
+           matches += have - 1;
+         }
+         live = false;
+       }
+     }
+   }
+   s_gram[wave][lane] = gram;
+   __builtin_amdgcn_wave_barrier();
    uint64_t todo = __ballot(live);
    while (todo) {
-    const uint32_t i = (t0 + (uint32_t)(__ffsll((unsigned long long)todo) - 1)) * NWAVES + gw;
+    const int todo_lane = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t i = (t0 + (uint32_t)todo_lane) * NWAVES + gw;
+    const uint32_t my_gram = s_gram[wave][todo_lane];
     todo &= todo - 1;
     const uint64_t p = cpos[i];
     bool ok = p + L.n <= c.n_tok;
@@ -917,7 +954,11 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
       cnt = s_n[wave];
     }
     if (cnt == 0) {
-      if (lane == 0) cg[i] = FS_NONE;
+      if (lane == 0) {
+        cg[i] = FS_NONE;
+        if (memo_cnt && my_gram != FS_NONE)
+          __hip_atomic_store(&memo_cnt[my_gram], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       continue;
     }
     // Levenshtein of every kept match (search.py:189-190), the wave working on one
@@ -951,6 +992,15 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
       cg[i] = 0;
       cw[i] = w;
       matches += (uint32_t)cnt;
+      if (memo_cnt && my_gram != FS_NONE) {
+        // the record first (write-through, waited for), then the count that says it is there
+        unsigned long long* m = memo_best + 4 * (size_t)my_gram;
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) __hip_atomic_store(&m[k], src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&memo_cnt[my_gram], (uint32_t)cnt + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
    }
   }
@@ -1166,9 +1216,22 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   }
   fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
+  // per-n-gram results of this string table (see the kernel): windows whose strings are those
+  // of their ids only, and ids with rows only
+  unsigned long long* memo_best = nullptr;
+  uint32_t* memo_cnt = nullptr;
+  if (ix->sw.lsh_memo && !c->has_str && !c->has_oov && !ix->script_oov && ix->n_grams) {
+    if (!c->d_lshmemo_cnt.p) {
+      FS_TRY(c->d_lshmemo_best.reserve(4 * (size_t)ix->n_grams));
+      FS_TRY(c->d_lshmemo_cnt.reserve(ix->n_grams));
+      FS_HIP(hipMemsetAsync(c->d_lshmemo_cnt.p, 0, (size_t)ix->n_grams * sizeof(uint32_t), s));
+    }
+    memo_best = c->d_lshmemo_best.p;
+    memo_cnt = c->d_lshmemo_cnt.p;
+  }
   hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
-                     ix->cur->w_bsum.p + kNB, st);
+                     ix->cur->w_bsum.p + kNB, st, memo_best, memo_cnt);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
