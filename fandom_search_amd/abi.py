@@ -51,7 +51,9 @@ class FsStats(C.Structure):
                 ("scan_ms", C.c_double),
                 ("total_ms", C.c_double),
                 ("path", C.c_uint32),
-                ("scan_launches", C.c_uint32)]
+                ("scan_launches", C.c_uint32),
+                ("lsh_pending", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

@@ -96,6 +96,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
   if (const char* e = getenv("FS_LSH_MEMO")) sw->lsh_memo = atoi(e) != 0;
+  if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e);
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);
@@ -973,6 +974,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     st->total_ms = total_ms;
     st->path = sl.exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
     st->scan_launches = sl.launches;
+    st->lsh_pending = sl.exact ? 0 : hs.lsh_pending;
   }
   if (hs.n_rows > sl.cap) return FS_E_CAPACITY;
   if (sl.mode == FS_ROWS_HOST && hs.n_rows) {

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kThreads) void k_reduce(F f, NSrc ns, V* __restrict
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
     zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
     zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->max_rows = 0;
+    zero->lsh_pending = 0;
   }
   uint32_t lo, hi;
   chunk_of_block(ns.get(), &lo, &hi);

@@ -87,6 +87,7 @@ struct fs_status {
   uint32_t lev_overflow; // a Levenshtein operand exceeded FS_LEV_MAX
   uint32_t bad_string;   // string id outside the string table
   uint32_t max_rows;     // k_scan_rows: largest record count of a wave range beyond its staging capacity
+  uint32_t lsh_pending;  // general pipeline: candidate windows k_lsh_sift left to k_lsh_verify (a wave each)
 };
 
 // what one hit offers to the fan words of its window (first-minimum rank)
@@ -171,6 +172,7 @@ struct fs_switches {
   bool str_levtab = true;         // FS_STR_LEVTAB=0: batches with string ids compute every Levenshtein distance per match
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
+  int lsh_wmap = 1;               // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path; 2: exact map at every n
   bool lsh_memo = true;           // FS_LSH_MEMO=0: k_lsh_verify computes every window with a script n-gram's ids anew
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
@@ -214,6 +216,8 @@ struct fs_index {
   DBuf<uint32_t> d_sfilter3; // one bit per script 3-gram: the <= 1 mismatch prefilter (fs_scan.hip)
   DBuf<uint32_t> d_wild;     // one-slot-wildcard keys of the script windows (fs_hash.h; k_lsh_verify)
   int log2_wild = 0;
+  DBuf<uint32_t> d_wmap;     // the same keys as an exact map {key, first window of the n-gram + 1}
+  int log2_wmap = 0;
 
   // Lanes: a stream with its own workspaces (grown on demand) and status block.
   // Searches are spread over n_lanes of them (FS_LANES in the environment, default
@@ -224,7 +228,7 @@ struct fs_index {
   struct Lane {
     hipStream_t stream = nullptr;
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
-    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
+    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum, w_cgram;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range

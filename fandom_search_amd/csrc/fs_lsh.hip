@@ -72,6 +72,8 @@ struct LshDev {
                            // this batch's string table (FS_NONE: compute), or nullptr
   const uint32_t* wild;    // one-slot-wildcard keys of the script windows (fs_hash.h), or nullptr
   int log2_wild;
+  const uint2* wmap;       // the same keys as an exact map {key, script window + 1}, or nullptr
+  int log2_wmap;
   uint32_t V, W;
   int n, H, B, D, C, Cp, nn, unique;
   double thr, cmax;
@@ -757,50 +759,43 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
 }
 
 // one wave per flagged window
-__global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
-                                                    const uint32_t* __restrict__ cpos, NSrc nc,
-                                                    uint32_t* __restrict__ cg,
-                                                    uint32_t* __restrict__ cw,
-                                                    fs_best* __restrict__ cbest,
-                                                    uint32_t* __restrict__ bmatch, fs_status* st,
-                                                    unsigned long long* __restrict__ memo_best,
-                                                    uint32_t* __restrict__ memo_cnt) {
-  __shared__ uint64_t s_bal[4][32];
-  __shared__ uint32_t s_gram[4][64];
-  __shared__ uint32_t s_key[4][64];
-  __shared__ uint32_t s_top_s[4][64];
-  __shared__ double s_top_d[4][64];
-  __shared__ uint32_t s_lev[4][64];
-  __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];
-  __shared__ uint32_t s_f[4][FS_MAX_WINDOW];
-  __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];
-  __shared__ int s_n[4];
+// One lane per candidate, in front of k_lsh_verify: most candidates end here.
+//   cg[i] = FS_NONE      no neighbour within the threshold
+//   cg[i] = 0            a record: cbest[i], cw[i] (from the memo of its n-gram)
+//   cg[i] = FS_PENDING   k_lsh_verify works the window out, a wave at a time;
+//                        cgram[i] = its n-gram (to leave the result in the memo) or FS_NONE
+// A kernel of its own: k_lsh_verify carries the scratch arrays and registers of the neighbour
+// lists and the Levenshtein code, which these steps do not need; consecutive candidates sit
+// in consecutive lanes, so the per-candidate arrays move in whole cache lines.
+constexpr uint32_t FS_PENDING = 0xFFFFFFFEu;
+template <int NW, bool WMAP>
+__global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramIndexDev g,
+                                                  const uint32_t* __restrict__ cpos, NSrc nc,
+                                                  uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
+                                                  uint32_t* __restrict__ cgram,
+                                                  fs_best* __restrict__ cbest,
+                                                  uint32_t* __restrict__ bmatch,
+                                                  const unsigned long long* __restrict__ memo_best,
+                                                  const uint32_t* __restrict__ memo_cnt) {
   __shared__ uint32_t s_w32[4];
-  __shared__ uint32_t s_pre[4][64], s_e0[4][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t total = nc.get();
-  const int NW = (L.C + 63) >> 6;
   uint32_t matches = 0;
-  // 64 candidates per wave and step, NWAVES apart (neighbouring candidates -- the windows
-  // of one quoted passage, all of them expensive -- go to neighbouring waves).  First one
-  // lane per candidate: with the wildcard filter (no OOV anywhere, at most one slot may
-  // differ) a window none of whose n keys is a script window's cannot have a neighbour
-  // within the threshold and is dropped here; then the wave takes the survivors one at a
-  // time.
-  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
-  for (uint32_t t0 = 0; (uint64_t)t0 * NWAVES < total; t0 += 64) {
-   const uint64_t il = (uint64_t)(t0 + lane) * NWAVES + gw;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < total; i0 += (uint64_t)gridDim.x * 256) {
+   const uint64_t il = i0 + threadIdx.x;
    bool live = il < total;
+   // -- one lane per candidate --
+   // 1. (no OOV anywhere, at most one slot may differ) a window none of whose n one-slot-
+   //    wildcard keys is a script window's key has no neighbour within the threshold
+   Ids16 f;
+   uint32_t term[NW], fold = 0;
+   bool keyed = false;
    if (L.wild && live) {
      const uint64_t p = cpos[il];
      bool pass = true;
      if (p + L.n <= c.n_tok) {
-       Ids16 f;
        load_ids(c.tok + p, L.n, &f);
-       uint32_t term[FS_MAX_WINDOW];
-       uint32_t fold = 0;
 #pragma unroll
-       for (int k = 0; k < FS_MAX_WINDOW; ++k) {
+       for (int k = 0; k < NW; ++k) {
          term[k] = 0;
          if (k < L.n) {
            term[k] = fs_rotl(fs_premix(f.v[k]), fs_rot_of(L.n - 1 - k));
@@ -808,8 +803,9 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
          }
        }
        pass = false;
+       keyed = true;
 #pragma unroll
-       for (int k = 0; k < FS_MAX_WINDOW; ++k)
+       for (int k = 0; k < NW; ++k)
          if (k < L.n) {
            const uint32_t h = fs_wild_key(fold, term[k], k);
            const uint32_t m = fs_wild_mask(h);
@@ -818,10 +814,10 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
      }
      if (!pass) { cg[il] = FS_NONE; live = false; }
    }
-   // What the reference returns for a window is a function of its vector, i.e. of its ids (and,
-   // for the Levenshtein distances, of the strings of those ids): a window with the ids of a
-   // script n-gram gets what the first such window of this string table got (memo_*: per
-   // corpus, filled as the searches go; one lane per candidate, no bucket is walked again).
+   // 2. What the reference returns for a window is a function of its vector, i.e. of its ids
+   //    (and, for the Levenshtein distances, of the strings of those ids): a window with the
+   //    ids of a script n-gram gets what the first such window of this string table got
+   //    (memo_*: per corpus, filled as the searches go; no bucket is walked again).
    uint32_t gram = FS_NONE;
    if (memo_cnt && live) {
      uint32_t w = 0, kept = 0;
@@ -846,12 +842,115 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
        }
      }
    }
+   // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
+   //    slots but one (every neighbour within the threshold is one of them: m_min = n - 1) and
+   //    take their canonical distances.  None within the threshold: whatever the buckets hold,
+   //    nothing survives the threshold, and the window needs no LSH work.  The n first probes
+   //    go out together; a hit costs the script window's ids, its record and one pair-table
+   //    entry (the canonical sum of window_distance with n - 1 slots known to be q(v_k)).
+   if (WMAP && live && keyed && gram == FS_NONE) {
+     double qf[NW], ff = 0.0;
+     uint32_t hk[NW];
+     uint2 e0[NW];
+#pragma unroll
+     for (int k = 0; k < NW; ++k)
+       if (k < L.n) {
+         hk[k] = fs_wild_key(fold, term[k], k);
+         e0[k] = L.wmap[fs_wmap_slot(hk[k], L.log2_wmap)];
+         qf[k] = L.q[f.v[k]];
+       }
+#pragma unroll
+     for (int k = 0; k < NW; ++k)
+       if (k < L.n) ff = __dadd_rn(ff, qf[k]);
+     const double rff = __dsqrt_rn(ff);
+     bool possible = false;
+     const uint32_t mask = (1u << L.log2_wmap) - 1;
+#pragma unroll
+     for (int k = 0; k < NW; ++k)
+       if (k < L.n && !possible) {
+         uint32_t slot = fs_wmap_slot(hk[k], L.log2_wmap);
+         uint2 e = e0[k];
+         while (e.y != 0) {
+           if (e.x == hk[k]) {
+             const uint32_t s = e.y - 1;
+             Ids16 u;
+             load_ids(L.stok + s, L.n, &u);
+             bool agree = true;
+#pragma unroll
+             for (int t = 0; t < NW; ++t)
+               if (t < L.n && t != k) agree = agree && u.v[t] == f.v[t];
+             if (agree) {
+               const fs_swin sw = L.sw[s];
+               const double g = u.v[k] == f.v[k] ? qf[k] : g_of(L, u.v[k], f.v[k]);
+               double sf = 0.0;
+#pragma unroll
+               for (int t = 0; t < NW; ++t)
+                 if (t < L.n) sf = __dadd_rn(sf, t == k ? g : qf[t]);
+               const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(sw.rss, rff)));
+               if (d == d && d < L.thr) { possible = true; break; }
+             }
+           }
+           slot = (slot + 1) & mask;
+           e = L.wmap[slot];
+         }
+       }
+     if (!possible) { cg[il] = FS_NONE; live = false; }
+   }
+   if (il < total) {
+     cgram[il] = gram;
+     if (live) cg[il] = FS_PENDING;
+   }
+  }
+  uint32_t tot;
+  block_excl_scan(matches, s_w32, &tot);
+  if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
+                                                    const uint32_t* __restrict__ cpos, NSrc nc,
+                                                    uint32_t* __restrict__ cg,
+                                                    uint32_t* __restrict__ cw,
+                                                    fs_best* __restrict__ cbest,
+                                                    uint32_t* __restrict__ bmatch, fs_status* st,
+                                                    unsigned long long* __restrict__ memo_best,
+                                                    uint32_t* __restrict__ memo_cnt,
+                                                    const uint32_t* __restrict__ cgram) {
+  __shared__ uint64_t s_bal[4][32];
+  __shared__ uint32_t s_gram[4][64];
+  __shared__ uint32_t s_key[4][64];
+  __shared__ uint32_t s_top_s[4][64];
+  __shared__ double s_top_d[4][64];
+  __shared__ uint32_t s_lev[4][64];
+  __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];
+  __shared__ uint32_t s_f[4][FS_MAX_WINDOW];
+  __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];
+  __shared__ int s_n[4];
+  __shared__ uint32_t s_w32[4];
+  __shared__ uint32_t s_pre[4][64], s_e0[4][64];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t total = nc.get();
+  const int NW = (L.C + 63) >> 6;
+  uint32_t matches = 0, pending = 0;
+  // 64 candidates per wave and step.  First one lane per candidate (steps 1-3 below: most
+  // candidates end there); then the wave takes the survivors one at a time.
+  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
+  // (a wave takes 64 CONSECUTIVE candidates per step, blocks of 64 dealt round-robin over the
+  // waves: the per-candidate arrays are read and written in whole cache lines.  Candidates
+  // NWAVES apart, as in round 2, spread the windows of one quoted passage over the waves, but
+  // made every access of the one-lane-per-candidate steps a line of its own: 340 us per C2
+  // batch at n = 8; with the memo few windows are left that a whole wave works on.)
+  for (uint64_t blk = gw; blk * 64 < total; blk += NWAVES) {
+   const uint64_t il = blk * 64 + lane;
+   // (k_lsh_sift has been over every candidate: what it left pending is worked out here)
+   const bool live = il < total && cg[il] == FS_PENDING;
+   const uint32_t gram = live ? cgram[il] : FS_NONE;
    s_gram[wave][lane] = gram;
    __builtin_amdgcn_wave_barrier();
    uint64_t todo = __ballot(live);
+   pending += (uint32_t)__popcll(todo);
    while (todo) {
     const int todo_lane = __ffsll((unsigned long long)todo) - 1;
-    const uint32_t i = (t0 + (uint32_t)todo_lane) * NWAVES + gw;
+    const uint32_t i = (uint32_t)(blk * 64) + (uint32_t)todo_lane;
     const uint32_t my_gram = s_gram[wave][todo_lane];
     todo &= todo - 1;
     const uint64_t p = cpos[i];
@@ -1006,7 +1105,8 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
-  if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+  if (threadIdx.x == 0) bmatch[blockIdx.x] += tot;       // (on top of k_lsh_sift's)
+  if (lane == 0 && pending) atomicAdd(&st->lsh_pending, pending);
 }
 
 }  // namespace
@@ -1019,7 +1119,7 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
-  L.wild = nullptr; L.log2_wild = 0; L.selflev = nullptr;
+  L.wild = nullptr; L.log2_wild = 0; L.selflev = nullptr; L.wmap = nullptr; L.log2_wmap = 0;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
   L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
@@ -1089,6 +1189,40 @@ int fs_lsh_build(fs_index* ix) {
     }
     FS_TRY(ix->d_wild.upload(wild.data(), wild.size(), ix->stream));
     ix->log2_wild = lwild;
+    // ... and as an exact map, one entry per distinct n-gram (its first window) and slot
+    {
+      std::vector<uint32_t> first;                       // first window of every distinct n-gram
+      {
+        std::vector<uint32_t> order(W);
+        for (uint64_t w = 0; w < W; ++w) order[w] = (uint32_t)w;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+          return std::lexicographical_compare(st.begin() + a, st.begin() + a + n, st.begin() + b, st.begin() + b + n);
+        });
+        for (uint64_t i = 0; i < W; ++i)
+          if (i == 0 || !std::equal(st.begin() + order[i], st.begin() + order[i] + n, st.begin() + order[i - 1]))
+            first.push_back(order[i]);
+      }
+      int lm = 10;
+      while (lm < 28 && ((uint64_t)1 << lm) < 2 * first.size() * (uint64_t)n) ++lm;
+      std::vector<uint32_t> wmap((size_t)2 << lm, 0u);
+      const uint32_t mask = (1u << lm) - 1;
+      for (uint32_t w : first) {
+        uint32_t term[FS_MAX_WINDOW], fold = 0;
+        for (int k = 0; k < n; ++k) {
+          term[k] = fs_rotl(fs_premix(st[w + k]), fs_rot_of(n - 1 - k));
+          fold ^= term[k];
+        }
+        for (int k = 0; k < n; ++k) {
+          const uint32_t h = fs_wild_key(fold, term[k], k);
+          uint32_t slot = fs_wmap_slot(h, lm);
+          while (wmap[2 * (size_t)slot + 1]) slot = (slot + 1) & mask;
+          wmap[2 * (size_t)slot] = h;
+          wmap[2 * (size_t)slot + 1] = w + 1;
+        }
+      }
+      FS_TRY(ix->d_wmap.upload(wmap.data(), wmap.size(), ix->stream));
+      ix->log2_wmap = lm;
+    }
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
   if (!ix->d_normals.p) { fs_set_error("normals are required for the LSH pipeline"); return FS_E_INVALID; }
@@ -1213,6 +1347,16 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
       (int)ix->cfg.window_size - ix->lsh_m_min == 1) {
     L.wild = ix->d_wild.p;
     L.log2_wild = ix->log2_wild;
+    // The exact map pays where a one-slot neighbour is rarely within the threshold: its cosine
+    // is (n - 1 + c) / n with c the cosine of the two differing vectors, within the threshold
+    // iff c > 1 - n * thr.  At n = 8 (c > 0.2) nearly every such window ends in k_lsh_sift; at
+    // n = 10 (c > 0) half of them are real neighbours and the enumeration is work on top.
+    // FS_LSH_WMAP=2 forces it.
+    const bool pays = 1.0 - (double)ix->cfg.window_size * L.thr > 0.1;
+    if ((ix->sw.lsh_wmap > 1 || (ix->sw.lsh_wmap && pays)) && ix->d_wmap.p) {
+      L.wmap = reinterpret_cast<const uint2*>(ix->d_wmap.p);
+      L.log2_wmap = ix->log2_wmap;
+    }
   }
   fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
@@ -1229,9 +1373,15 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
     memo_best = c->d_lshmemo_best.p;
     memo_cnt = c->d_lshmemo_cnt.p;
   }
+  FS_TRY(ix->cur->w_cgram.reserve(ccap));
+  auto sift = L.n <= 8 ? (L.wmap ? k_lsh_sift<8, true> : k_lsh_sift<8, false>)
+                       : (L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true> : k_lsh_sift<FS_MAX_WINDOW, false>);
+  hipLaunchKernelGGL(sift, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+                     ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cgram.p,
+                     ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, memo_best, memo_cnt);
   hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
-                     ix->cur->w_bsum.p + kNB, st, memo_best, memo_cnt);
+                     ix->cur->w_bsum.p + kNB, st, memo_best, memo_cnt, ix->cur->w_cgram.p);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

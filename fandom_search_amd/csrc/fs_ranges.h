@@ -454,7 +454,7 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
     }
     if (lane == 0) {
       fs_status o;
-      if (fin.fresh) { o.max_recs = 0; o.lev_overflow = 0; o.bad_string = 0; }
+      if (fin.fresh) { o.max_recs = 0; o.lev_overflow = 0; o.bad_string = 0; o.lsh_pending = 0; }
       else o = *fin.st;
       o.n_rows = before + s_cnt[n_waves + 1];
       o.n_hits = h; o.n_matches = pr; o.n_cands = cd;

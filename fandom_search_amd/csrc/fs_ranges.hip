@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void k_compact(
     if (threadIdx.x == 0) {
       fs_status out;
       if (fresh) {                    // k_scan_rows: nothing before this kernel wrote the block
-        out.max_recs = 0; out.lev_overflow = 0; out.bad_string = 0;
+        out.max_recs = 0; out.lev_overflow = 0; out.bad_string = 0; out.lsh_pending = 0;
       } else {
         out = *st;                    // flags and maxima written by the kernels before
       }

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   if (zero && blockIdx.x == 0 && threadIdx.x == 0) {
     zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
     zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->max_rows = 0;
+    zero->lsh_pending = 0;
   }
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6;

@@ -100,6 +100,10 @@ typedef struct fs_stats {
                                   searches without timing, fs_index_set_scan_timing) */
   uint32_t path;               /* FS_MODE_GENERAL or FS_MODE_EXACT            */
   uint32_t scan_launches;      /* launches of the dominant kernel in the call */
+  uint32_t lsh_pending;        /* general pipeline: candidate windows that took the full LSH
+                                  path (keys, buckets, distances), a wave each; the others
+                                  ended in the lane-per-candidate steps                  */
+  uint32_t reserved;
 } fs_stats;
 
 typedef struct fs_index_info {

@@ -46,7 +46,7 @@ def test_version_and_strerror_without_a_device():
 def test_struct_layouts():
     assert C.sizeof(abi.FsConfig) == 48
     assert abi.FsConfig.distance_threshold.offset == 40
-    assert C.sizeof(abi.FsStats) == 56
+    assert C.sizeof(abi.FsStats) == 64
     assert C.sizeof(abi.FsIndexInfo) == 72
     assert abi.ROW_DTYPE.itemsize == 32
     assert [abi.ROW_DTYPE.fields[n][1] for n in abi.ROW_DTYPE.names] == [0, 4, 8, 12, 16, 24]

@@ -78,6 +78,7 @@ def main():
             tickets.append(ix.search_begin(corpus, bufs[i % len(bufs)].data_ptr(), cap, header=True))
             if len(tickets) >= a.inflight:
                 n, st = ix.search_end(tickets.pop(0))
+                s["last"] = (int(st.candidates), int(st.lsh_pending))
                 if st.scan_ms > 0:
                     scan.append(st.scan_ms)
         while tickets:
@@ -100,6 +101,7 @@ def main():
         print(json.dumps(dict(variant=s["name"], step_us=round(best * 1e3, 2),
                               step_us_median=round(sorted(s["ms"])[len(s["ms"]) // 2] * 1e3, 2),
                               scan_kernel_us=round(min(s["scan"]) * 1e3, 2), rows=s["n_rows"],
+                              candidates=s.get("last", (0, 0))[0], lsh_pending=s.get("last", (0, 0))[1],
                               step_frac_of_8TBs=round((4.0 * n_tok + 32.0 * s["n_rows"]) / (best * 1e-3) / 8e12, 4))),
               flush=True)
 
