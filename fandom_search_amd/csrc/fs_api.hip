@@ -95,7 +95,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_SCAN_SUB")) sw->scan_sub = e[0] != '0';
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
-  if (const char* e = getenv("FS_LSH_MEMO")) sw->lsh_memo = atoi(e) != 0;
+  if (const char* e = getenv("FS_LSH_GRAMTAB")) sw->lsh_gramtab = atoi(e) != 0;
   if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e);
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
@@ -623,6 +623,19 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
     FS_TRY(fs_launch_selflev(ix, c, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     c->selflev_ready = true;
+  }
+  if (!c->has_str && !c->has_oov && ix->info.path != FS_MODE_EXACT && !ix->script_oov && !c->gramtab_ready &&
+      ix->sw.lsh_gramtab && ix->n_grams) {
+    // ... and what a window with the ids of a script n-gram gets (keys, buckets, distances,
+    // Levenshtein, first minimum): once per n-gram and string table instead of once per such
+    // window of every batch.  A string the table lacks or an over-long text leaves the table
+    // unused: the search then reports the error if and when such a window occurs.
+    ix->cur = &ix->lanes[0];
+    FS_HIP(hipMemsetAsync(ix->cur->d_status.p, 0, sizeof(fs_status), ix->stream));
+    FS_TRY(fs_launch_lsh_gramtab(ix, c, ix->stream));
+    FS_HIP(hipMemcpyAsync(ix->h_status, ix->cur->d_status.p, sizeof(fs_status), hipMemcpyDeviceToHost, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    c->gramtab_ready = !ix->h_status->bad_string && !ix->h_status->lev_overflow;
   }
   return FS_OK;
 }

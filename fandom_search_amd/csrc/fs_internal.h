@@ -173,7 +173,7 @@ struct fs_switches {
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
   int lsh_wmap = 1;               // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path; 2: exact map at every n
-  bool lsh_memo = true;           // FS_LSH_MEMO=0: k_lsh_verify computes every window with a script n-gram's ids anew
+  bool lsh_gramtab = true;        // FS_LSH_GRAMTAB=0: no per-n-gram records (k_lsh_gramtab): every window with a script n-gram's ids walks the buckets
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
   int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
@@ -228,7 +228,7 @@ struct fs_index {
   struct Lane {
     hipStream_t stream = nullptr;
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
-    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum, w_cgram;
+    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range
@@ -302,8 +302,9 @@ struct fs_corpus {
   DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
   bool ctab_ready = false;
-  DBuf<unsigned long long> d_lshmemo_best;   // LSH pipeline: per script n-gram, what a window with its ids gets
-  DBuf<uint32_t> d_lshmemo_cnt;        //   (fs_best; count of kept matches + 1, 0: not computed yet)
+  DBuf<unsigned long long> d_gramtab_best;   // LSH pipeline: per script n-gram, what a window with its ids and
+  DBuf<uint32_t> d_gramtab_cnt;        //   their strings gets (fs_best; kept matches + 1), k_lsh_gramtab
+  bool gramtab_ready = false;
   DBuf<uint32_t> d_selflev;            // LSH pipeline, string id == vector id: Levenshtein of script window w
   bool selflev_ready = false;          // against the strings of its own ids (k_selflev), FS_NONE: not known
   CorpusDev dev() const;
@@ -352,6 +353,7 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
                        uint32_t n_sub, hipStream_t s, hipEvent_t e0 = nullptr,
                        hipEvent_t e1 = nullptr);
 int fs_launch_selflev(fs_index* ix, fs_corpus* c, hipStream_t s);
+int fs_launch_lsh_gramtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 // fs_scan.hip: the integer prefilter of the LSH pipeline ("all but one slot identical")
 bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c);

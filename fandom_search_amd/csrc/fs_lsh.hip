@@ -761,9 +761,8 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
 // one wave per flagged window
 // One lane per candidate, in front of k_lsh_verify: most candidates end here.
 //   cg[i] = FS_NONE      no neighbour within the threshold
-//   cg[i] = 0            a record: cbest[i], cw[i] (from the memo of its n-gram)
-//   cg[i] = FS_PENDING   k_lsh_verify works the window out, a wave at a time;
-//                        cgram[i] = its n-gram (to leave the result in the memo) or FS_NONE
+//   cg[i] = 0            a record: cbest[i], cw[i] (the record of its n-gram, k_lsh_gramtab)
+//   cg[i] = FS_PENDING   k_lsh_verify works the window out, a wave at a time
 // A kernel of its own: k_lsh_verify carries the scratch arrays and registers of the neighbour
 // lists and the Levenshtein code, which these steps do not need; consecutive candidates sit
 // in consecutive lanes, so the per-candidate arrays move in whole cache lines.
@@ -772,11 +771,10 @@ template <int NW, bool WMAP>
 __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramIndexDev g,
                                                   const uint32_t* __restrict__ cpos, NSrc nc,
                                                   uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
-                                                  uint32_t* __restrict__ cgram,
                                                   fs_best* __restrict__ cbest,
                                                   uint32_t* __restrict__ bmatch,
-                                                  const unsigned long long* __restrict__ memo_best,
-                                                  const uint32_t* __restrict__ memo_cnt) {
+                                                  const unsigned long long* __restrict__ tab_best,
+                                                  const uint32_t* __restrict__ tab_cnt) {
   __shared__ uint32_t s_w32[4];
   const uint32_t total = nc.get();
   uint32_t matches = 0;
@@ -814,32 +812,25 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
      }
      if (!pass) { cg[il] = FS_NONE; live = false; }
    }
-   // 2. What the reference returns for a window is a function of its vector, i.e. of its ids
-   //    (and, for the Levenshtein distances, of the strings of those ids): a window with the
-   //    ids of a script n-gram gets what the first such window of this string table got
-   //    (memo_*: per corpus, filled as the searches go; no bucket is walked again).
+   // 2. A window with the ids of a script n-gram (and the strings of those ids) takes the
+   //    n-gram's record of this string table (k_lsh_gramtab): no bucket is walked for it.
    uint32_t gram = FS_NONE;
-   if (memo_cnt && live) {
+   if (tab_cnt && live) {
      uint32_t w = 0, kept = 0;
      gram = verify_window(c, g, cpos[il], &w, &kept);
      if (gram != FS_NONE) {
-       const uint32_t have = __hip_atomic_load(&memo_cnt[gram], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-       if (have) {
-         if (have == 1) {
-           cg[il] = FS_NONE;                           // (no neighbour within the threshold)
-         } else {
-           const unsigned long long* m = memo_best + 4 * (size_t)gram;
-           unsigned long long q[4];
-#pragma unroll
-           for (int k = 0; k < 4; ++k) q[k] = __hip_atomic_load(&m[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-           unsigned long long* dst = reinterpret_cast<unsigned long long*>(&cbest[il]);
-           dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
-           cg[il] = 0;
-           cw[il] = w;
-           matches += have - 1;
-         }
-         live = false;
+       const uint32_t have = tab_cnt[gram];
+       if (have == 1) {
+         cg[il] = FS_NONE;                             // (no neighbour within the threshold)
+       } else {
+         const uint4* m = reinterpret_cast<const uint4*>(tab_best + 4 * (size_t)gram);
+         uint4* dst = reinterpret_cast<uint4*>(&cbest[il]);
+         dst[0] = m[0]; dst[1] = m[1];
+         cg[il] = 0;
+         cw[il] = w;
+         matches += have - 1;
        }
+       live = false;
      }
    }
    // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
@@ -896,14 +887,197 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
        }
      if (!possible) { cg[il] = FS_NONE; live = false; }
    }
-   if (il < total) {
-     cgram[il] = gram;
-     if (live) cg[il] = FS_PENDING;
-   }
+   if (live) cg[il] = FS_PENDING;
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
   if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+}
+
+// The LDS a wave needs for one window (private to the wave).
+struct LshWaveLds {
+  uint64_t* bal;      // [32] sign ballots of the projection columns
+  uint32_t* key;      // [64]
+  uint32_t* top_s;    // [64] kept matches in NearestFilter order
+  double* top_d;      // [64]
+  uint32_t* lev;      // [64]
+  uint32_t *la, *lb;  // [FS_LEV_MAX + 2] Levenshtein operands
+  uint32_t* f;        // [FS_MAX_WINDOW] vector ids of the window
+  uint32_t* fs;       // [FS_MAX_WINDOW] string ids of the window
+  int* n;             // [1]
+  uint32_t *pre, *e0; // [64]
+};
+
+// What the reference returns for one fan window, worked out by a whole wave (all 64 lanes
+// call it with the same arguments): keys of the window (search.py:176 -> nearpy), the
+// buckets' members with their canonical distances, threshold, NearestFilter, the
+// Levenshtein distance of every kept match (search.py:189-190) and the first minimum of
+// dist * lev in rank order.  S.f / S.fs hold the window's vector and string ids.  Returns the
+// number of kept matches; *b (lane 0) is the record when that is not 0.
+__device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, const GramIndexDev& g,
+                                          const LshWaveLds& S, fs_status* st, fs_best* b) {
+  const int lane = threadIdx.x & 63;
+  const int NW = (L.C + 63) >> 6;
+  // keys.  Fast path as in k_lsh_scan: lane l holds projection columns 4l .. 4l+3, one
+  // 16-byte load per lane and slot fetches the float32 row, all slots requested together;
+  // the float32 sums decide the signs when every column is farther from zero than the
+  // worst-case distance to the canonical float64 sum, else (and with an OOV token) the
+  // window is redone in float64.
+  bool keys_done = false;
+  if (L.atab32 && L.C <= 256 && !(L.diag & 8)) {
+    float am = 0.0f;
+    bool oov = false;
+    if (lane < L.n) {
+      const uint32_t id = S.f[lane];
+      oov = (id & FS_OOV_FLAG) != 0;
+      if (!oov) am = L.amax[(size_t)lane * L.V + id];
+    }
+#pragma unroll
+    for (int d = 8; d > 0; d >>= 1) am += __shfl_xor(am, d);      // n <= 16 lanes hold a value
+    am = __shfl(am, 0);
+    if (!__any(oov)) {
+      const float bnd = L.bound_scale * am;
+      const int col = 4 * lane;
+      const int left = L.C - col;
+      const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
+      const int colc = left > 0 ? col : 0;
+      // (eight rows in flight at a time; summed in slot order like k_lsh_scan)
+      float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int k0 = 0; k0 < L.n; k0 += 8) {
+        float4 r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < L.n)
+            r[k] = *reinterpret_cast<const float4*>(
+                L.atab32 + ((size_t)(k0 + k) * L.V + S.f[k0 + k]) * L.Cp + colc);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (k0 + k < L.n) {
+            if (k0 + k == 0) { acc = r[0]; continue; }
+            acc.x = __fadd_rn(acc.x, r[k].x); acc.y = __fadd_rn(acc.y, r[k].y);
+            acc.z = __fadd_rn(acc.z, r[k].z); acc.w = __fadd_rn(acc.w, r[k].w);
+          }
+      }
+      const uint32_t sure = (fabsf(acc.x) > bnd ? 1u : 0u) | (fabsf(acc.y) > bnd ? 2u : 0u) |
+                            (fabsf(acc.z) > bnd ? 4u : 0u) | (fabsf(acc.w) > bnd ? 8u : 0u);
+      if (!__any((~sure & cmask) != 0u)) {
+        uint32_t x = ((acc.x > 0.0f ? 1u : 0u) | (acc.y > 0.0f ? 2u : 0u) |
+                      (acc.z > 0.0f ? 4u : 0u) | (acc.w > 0.0f ? 8u : 0u)) & cmask;
+        // eight lanes -> one 32-bit piece of the column bit string
+        x |= (uint32_t)__shfl_down((int)x, 1) << 4;
+        x |= (uint32_t)__shfl_down((int)x, 2) << 8;
+        x |= (uint32_t)__shfl_down((int)x, 4) << 16;
+        uint32_t* pieces = reinterpret_cast<uint32_t*>(S.bal);
+        if ((lane & 7) == 0 && (lane >> 3) < 2 * NW) pieces[lane >> 3] = x;
+        keys_done = true;
+      }
+    }
+  }
+  for (int ch = 0; ch < NW && !keys_done; ++ch) {
+    const int col = ch * 64 + lane;
+    bool bit = false;
+    if (col < L.C && !(L.diag & 8)) {
+      double acc = a_value(L, 0, S.f[0], col);
+      for (int k = 1; k < L.n; ++k) acc = __dadd_rn(acc, a_value(L, k, S.f[k], col));
+      bit = acc > 0.0;
+    }
+    const uint64_t b = __ballot(bit);
+    if (lane == 0) S.bal[ch] = b;
+  }
+  if (lane == 0) S.bal[NW] = 0;
+  __builtin_amdgcn_wave_barrier();
+  if (lane < L.H) S.key[lane] = assemble_key(S.bal, lane, L.B);
+  __builtin_amdgcn_wave_barrier();
+  int cnt;
+  if (L.diag & 32) {
+    cnt = 0;
+  } else if (L.nn <= 48 && L.H <= 64 && !L.serial_neighbours) {
+    cnt = lsh_neighbours_wave(L, S.key, S.f, S.top_s, S.top_d, S.pre,
+                              S.e0);
+  } else {                                    // NearestFilter(N > 48): one lane walks the buckets
+    if (lane == 0)
+      S.n[0] = lsh_neighbours<false>(L, S.key, S.f, S.top_s, S.top_d);
+    __builtin_amdgcn_wave_barrier();
+    cnt = S.n[0];
+  }
+  if (cnt == 0) return 0;
+  // Levenshtein of every kept match (search.py:189-190), the wave working on one
+  // match at a time
+  for (int r = 0; r < cnt; ++r) {
+    uint32_t lv = FS_NONE;
+    if (L.selflev) {
+      // a match with the same id in every slot has the same strings as the script window's
+      // own ids: its distance was computed once per string table (k_selflev)
+      const uint32_t sr = S.top_s[r];
+      const bool differs = lane < L.n && L.stok[sr + lane] != S.f[lane];
+      if (!__any(differs)) lv = L.selflev[sr];
+    }
+    if (lv == FS_NONE)
+      lv = (L.diag & 16) ? 1u :
+                        lev_wave(g, S.top_s[r], S.fs, c.chars, c.coff, c.n_str, st,
+                                 S.la, S.lb);
+    if (lane == 0) S.lev[r] = lv;
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) {
+    b->pad = 0.0;
+    for (int r = 0; r < cnt; ++r) {           // first minimum of dist * lev in rank order
+      const double comb = __dmul_rn(S.top_d[r], (double)S.lev[r]);
+      if (r == 0 || comb < b->comb) {
+        b->s = S.top_s[r]; b->lev = S.lev[r]; b->dist = S.top_d[r]; b->comb = comb;
+      }
+    }
+  }
+  return cnt;
+}
+
+#define FS_LSH_WAVE_LDS                                                                       \
+  __shared__ uint64_t s_bal[4][32];                                                           \
+  __shared__ uint32_t s_key[4][64];                                                           \
+  __shared__ uint32_t s_top_s[4][64];                                                         \
+  __shared__ double s_top_d[4][64];                                                           \
+  __shared__ uint32_t s_lev[4][64];                                                           \
+  __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];                       \
+  __shared__ uint32_t s_f[4][FS_MAX_WINDOW];                                                  \
+  __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];                                                 \
+  __shared__ int s_n[4];                                                                      \
+  __shared__ uint32_t s_pre[4][64], s_e0[4][64];                                              \
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                   \
+  const LshWaveLds S{s_bal[wave], s_key[wave], s_top_s[wave], s_top_d[wave], s_lev[wave],     \
+                     s_la[wave], s_lb[wave], s_f[wave], s_fs[wave], &s_n[wave], s_pre[wave],   \
+                     s_e0[wave]}
+
+// Per script n-gram, once per string table (fs_corpus_update_end, like the exact path's
+// ctab): what a fan window with the n-gram's ids and the strings of those ids gets.  The
+// reference's result for a window is a function of its vector (i.e. of its ids) and, for the
+// Levenshtein distances, of its strings, so every such window of a batch takes this record
+// (k_lsh_sift) and no bucket is walked for it.  tab_cnt = kept matches + 1.  One wave per
+// n-gram.
+__global__ __launch_bounds__(256, 4) void k_lsh_gramtab(CorpusDev c, LshDev L, GramIndexDev g,
+                                                        unsigned long long* __restrict__ tab_best,
+                                                        uint32_t* __restrict__ tab_cnt, fs_status* st) {
+  FS_LSH_WAVE_LDS;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t gram = blockIdx.x * 4 + wave; gram < g.n_grams; gram += gridDim.x * 4) {
+    const uint32_t first = g.gpos[(size_t)gram * g.nn];
+    if (lane < L.n) {
+      const uint32_t id = g.stok[first + lane];
+      S.f[lane] = id;
+      S.fs[lane] = id;
+    }
+    __builtin_amdgcn_wave_barrier();
+    fs_best b;
+    const int cnt = lsh_window(c, L, g, S, st, &b);
+    if (lane == 0) {
+      if (cnt) {
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&b);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tab_best[4 * (size_t)gram + k] = src[k];
+      }
+      tab_cnt[gram] = (uint32_t)cnt + 1u;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
@@ -911,197 +1085,55 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
                                                     uint32_t* __restrict__ cg,
                                                     uint32_t* __restrict__ cw,
                                                     fs_best* __restrict__ cbest,
-                                                    uint32_t* __restrict__ bmatch, fs_status* st,
-                                                    unsigned long long* __restrict__ memo_best,
-                                                    uint32_t* __restrict__ memo_cnt,
-                                                    const uint32_t* __restrict__ cgram) {
-  __shared__ uint64_t s_bal[4][32];
-  __shared__ uint32_t s_gram[4][64];
-  __shared__ uint32_t s_key[4][64];
-  __shared__ uint32_t s_top_s[4][64];
-  __shared__ double s_top_d[4][64];
-  __shared__ uint32_t s_lev[4][64];
-  __shared__ uint32_t s_la[4][FS_LEV_MAX + 2], s_lb[4][FS_LEV_MAX + 2];
-  __shared__ uint32_t s_f[4][FS_MAX_WINDOW];
-  __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];
-  __shared__ int s_n[4];
+                                                    uint32_t* __restrict__ bmatch, fs_status* st) {
+  FS_LSH_WAVE_LDS;
   __shared__ uint32_t s_w32[4];
-  __shared__ uint32_t s_pre[4][64], s_e0[4][64];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int lane = threadIdx.x & 63;
   const uint32_t total = nc.get();
-  const int NW = (L.C + 63) >> 6;
   uint32_t matches = 0, pending = 0;
-  // 64 candidates per wave and step.  First one lane per candidate (steps 1-3 below: most
-  // candidates end there); then the wave takes the survivors one at a time.
+  // k_lsh_sift has been over every candidate: what it left pending is worked out here, a wave
+  // per window.  A wave takes 64 CONSECUTIVE candidates per step (blocks of 64 dealt round-
+  // robin over the waves), so the per-candidate arrays are read in whole cache lines.
   const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
-  // (a wave takes 64 CONSECUTIVE candidates per step, blocks of 64 dealt round-robin over the
-  // waves: the per-candidate arrays are read and written in whole cache lines.  Candidates
-  // NWAVES apart, as in round 2, spread the windows of one quoted passage over the waves, but
-  // made every access of the one-lane-per-candidate steps a line of its own: 340 us per C2
-  // batch at n = 8; with the memo few windows are left that a whole wave works on.)
   for (uint64_t blk = gw; blk * 64 < total; blk += NWAVES) {
-   const uint64_t il = blk * 64 + lane;
-   // (k_lsh_sift has been over every candidate: what it left pending is worked out here)
-   const bool live = il < total && cg[il] == FS_PENDING;
-   const uint32_t gram = live ? cgram[il] : FS_NONE;
-   s_gram[wave][lane] = gram;
-   __builtin_amdgcn_wave_barrier();
-   uint64_t todo = __ballot(live);
-   pending += (uint32_t)__popcll(todo);
-   while (todo) {
-    const int todo_lane = __ffsll((unsigned long long)todo) - 1;
-    const uint32_t i = (uint32_t)(blk * 64) + (uint32_t)todo_lane;
-    const uint32_t my_gram = s_gram[wave][todo_lane];
-    todo &= todo - 1;
-    const uint64_t p = cpos[i];
-    bool ok = p + L.n <= c.n_tok;
-    uint32_t w = 0;
-    if (ok) {
-      uint64_t work_end;
-      w = work_of_token(c, p, &work_end);
-      ok = p + L.n <= work_end;                 // a window never crosses a work boundary
-    }
-    if (!ok) {                                  // wave-uniform
-      if (lane == 0) cg[i] = FS_NONE;
-      continue;
-    }
-    if (lane < L.n) {
-      s_f[wave][lane] = c.tok[p + lane];
-      s_fs[wave][lane] = c.str ? c.str[p + lane] : c.tok[p + lane];
-    }
-    __builtin_amdgcn_wave_barrier();
-    // keys.  Fast path as in k_lsh_scan: lane l holds projection columns 4l .. 4l+3, one
-    // 16-byte load per lane and slot fetches the float32 row, all slots requested together;
-    // the float32 sums decide the signs when every column is farther from zero than the
-    // worst-case distance to the canonical float64 sum, else (and with an OOV token) the
-    // window is redone in float64.
-    bool keys_done = false;
-    if (L.atab32 && L.C <= 256 && !(L.diag & 8)) {
-      float am = 0.0f;
-      bool oov = false;
+    const uint64_t il = blk * 64 + lane;
+    const bool live = il < total && cg[il] == FS_PENDING;
+    uint64_t todo = __ballot(live);
+    pending += (uint32_t)__popcll(todo);
+    while (todo) {
+      const uint32_t i = (uint32_t)(blk * 64) + (uint32_t)(__ffsll((unsigned long long)todo) - 1);
+      todo &= todo - 1;
+      const uint64_t p = cpos[i];
+      bool ok = p + L.n <= c.n_tok;
+      uint32_t w = 0;
+      if (ok) {
+        uint64_t work_end;
+        w = work_of_token(c, p, &work_end);
+        ok = p + L.n <= work_end;                 // a window never crosses a work boundary
+      }
+      if (!ok) {                                  // wave-uniform
+        if (lane == 0) cg[i] = FS_NONE;
+        continue;
+      }
       if (lane < L.n) {
-        const uint32_t id = s_f[wave][lane];
-        oov = (id & FS_OOV_FLAG) != 0;
-        if (!oov) am = L.amax[(size_t)lane * L.V + id];
+        S.f[lane] = c.tok[p + lane];
+        S.fs[lane] = c.str ? c.str[p + lane] : c.tok[p + lane];
       }
-#pragma unroll
-      for (int d = 8; d > 0; d >>= 1) am += __shfl_xor(am, d);      // n <= 16 lanes hold a value
-      am = __shfl(am, 0);
-      if (!__any(oov)) {
-        const float bnd = L.bound_scale * am;
-        const int col = 4 * lane;
-        const int left = L.C - col;
-        const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
-        const int colc = left > 0 ? col : 0;
-        // (eight rows in flight at a time; summed in slot order like k_lsh_scan)
-        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (int k0 = 0; k0 < L.n; k0 += 8) {
-          float4 r[8];
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k0 + k < L.n)
-              r[k] = *reinterpret_cast<const float4*>(
-                  L.atab32 + ((size_t)(k0 + k) * L.V + s_f[wave][k0 + k]) * L.Cp + colc);
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (k0 + k < L.n) {
-              if (k0 + k == 0) { acc = r[0]; continue; }
-              acc.x = __fadd_rn(acc.x, r[k].x); acc.y = __fadd_rn(acc.y, r[k].y);
-              acc.z = __fadd_rn(acc.z, r[k].z); acc.w = __fadd_rn(acc.w, r[k].w);
-            }
-        }
-        const uint32_t sure = (fabsf(acc.x) > bnd ? 1u : 0u) | (fabsf(acc.y) > bnd ? 2u : 0u) |
-                              (fabsf(acc.z) > bnd ? 4u : 0u) | (fabsf(acc.w) > bnd ? 8u : 0u);
-        if (!__any((~sure & cmask) != 0u)) {
-          uint32_t x = ((acc.x > 0.0f ? 1u : 0u) | (acc.y > 0.0f ? 2u : 0u) |
-                        (acc.z > 0.0f ? 4u : 0u) | (acc.w > 0.0f ? 8u : 0u)) & cmask;
-          // eight lanes -> one 32-bit piece of the column bit string
-          x |= (uint32_t)__shfl_down((int)x, 1) << 4;
-          x |= (uint32_t)__shfl_down((int)x, 2) << 8;
-          x |= (uint32_t)__shfl_down((int)x, 4) << 16;
-          uint32_t* pieces = reinterpret_cast<uint32_t*>(s_bal[wave]);
-          if ((lane & 7) == 0 && (lane >> 3) < 2 * NW) pieces[lane >> 3] = x;
-          keys_done = true;
-        }
-      }
-    }
-    for (int ch = 0; ch < NW && !keys_done; ++ch) {
-      const int col = ch * 64 + lane;
-      bool bit = false;
-      if (col < L.C && !(L.diag & 8)) {
-        double acc = a_value(L, 0, s_f[wave][0], col);
-        for (int k = 1; k < L.n; ++k) acc = __dadd_rn(acc, a_value(L, k, s_f[wave][k], col));
-        bit = acc > 0.0;
-      }
-      const uint64_t b = __ballot(bit);
-      if (lane == 0) s_bal[wave][ch] = b;
-    }
-    if (lane == 0) s_bal[wave][NW] = 0;
-    __builtin_amdgcn_wave_barrier();
-    if (lane < L.H) s_key[wave][lane] = assemble_key(s_bal[wave], lane, L.B);
-    __builtin_amdgcn_wave_barrier();
-    int cnt;
-    if (L.diag & 32) {
-      cnt = 0;
-    } else if (L.nn <= 48 && L.H <= 64 && !L.serial_neighbours) {
-      cnt = lsh_neighbours_wave(L, s_key[wave], s_f[wave], s_top_s[wave], s_top_d[wave], s_pre[wave],
-                                s_e0[wave]);
-    } else {                                    // NearestFilter(N > 48): one lane walks the buckets
-      if (lane == 0)
-        s_n[wave] = lsh_neighbours<false>(L, s_key[wave], s_f[wave], s_top_s[wave], s_top_d[wave]);
       __builtin_amdgcn_wave_barrier();
-      cnt = s_n[wave];
-    }
-    if (cnt == 0) {
-      if (lane == 0) {
-        cg[i] = FS_NONE;
-        if (memo_cnt && my_gram != FS_NONE)
-          __hip_atomic_store(&memo_cnt[my_gram], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      continue;
-    }
-    // Levenshtein of every kept match (search.py:189-190), the wave working on one
-    // match at a time
-    for (int r = 0; r < cnt; ++r) {
-      uint32_t lv = FS_NONE;
-      if (L.selflev) {
-        // a match with the same id in every slot has the same strings as the script window's
-        // own ids: its distance was computed once per string table (k_selflev)
-        const uint32_t sr = s_top_s[wave][r];
-        const bool differs = lane < L.n && L.stok[sr + lane] != s_f[wave][lane];
-        if (!__any(differs)) lv = L.selflev[sr];
-      }
-      if (lv == FS_NONE)
-        lv = (L.diag & 16) ? 1u :
-                          lev_wave(g, s_top_s[wave][r], s_fs[wave], c.chars, c.coff, c.n_str, st,
-                                   s_la[wave], s_lb[wave]);
-      if (lane == 0) s_lev[wave][r] = lv;
-      __builtin_amdgcn_wave_barrier();
-    }
-    if (lane == 0) {
       fs_best b;
-      b.pad = 0.0;
-      for (int r = 0; r < cnt; ++r) {           // first minimum of dist * lev in rank order
-        const double comb = __dmul_rn(s_top_d[wave][r], (double)s_lev[wave][r]);
-        if (r == 0 || comb < b.comb) {
-          b.s = s_top_s[wave][r]; b.lev = s_lev[wave][r]; b.dist = s_top_d[wave][r]; b.comb = comb;
+      const int cnt = lsh_window(c, L, g, S, st, &b);
+      if (lane == 0) {
+        if (cnt) {
+          cbest[i] = b;
+          cg[i] = 0;
+          cw[i] = w;
+          matches += (uint32_t)cnt;
+        } else {
+          cg[i] = FS_NONE;
         }
       }
-      cbest[i] = b;
-      cg[i] = 0;
-      cw[i] = w;
-      matches += (uint32_t)cnt;
-      if (memo_cnt && my_gram != FS_NONE) {
-        // the record first (write-through, waited for), then the count that says it is there
-        unsigned long long* m = memo_best + 4 * (size_t)my_gram;
-        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(&b);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) __hip_atomic_store(&m[k], src[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&memo_cnt[my_gram], (uint32_t)cnt + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+      __builtin_amdgcn_wave_barrier();
     }
-   }
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
@@ -1339,6 +1371,21 @@ int fs_launch_selflev(fs_index* ix, fs_corpus* c, hipStream_t s) {
   return FS_OK;
 }
 
+// the strings of the batch's table against every script n-gram, once per string table; the
+// status block of lane 0 collects string errors (bad_string, lev_overflow) for the caller
+int fs_launch_lsh_gramtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
+  if (!ix->n_grams) return FS_OK;
+  LshDev L = lsh_dev(ix);
+  if (c->selflev_ready) L.selflev = c->d_selflev.p;
+  FS_TRY(c->d_gramtab_best.reserve(4 * (size_t)ix->n_grams));
+  FS_TRY(c->d_gramtab_cnt.reserve(ix->n_grams));
+  const uint32_t blocks = (ix->n_grams + 3) / 4;
+  hipLaunchKernelGGL(k_lsh_gramtab, dim3(blocks > kNB ? kNB : blocks), dim3(256), 0, s, c->dev(), L,
+                     ix->gram_dev(), c->d_gramtab_best.p, c->d_gramtab_cnt.p, ix->cur->d_status.p);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s) {
   LshDev L = lsh_dev(ix);
   if (c->selflev_ready && !c->has_str) L.selflev = c->d_selflev.p;
@@ -1360,28 +1407,21 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   }
   fs_status* st = ix->cur->d_status.p;
   const NSrc nc{&st->n_cands, 1, ccap, 0};
-  // per-n-gram results of this string table (see the kernel): windows whose strings are those
-  // of their ids only, and ids with rows only
-  unsigned long long* memo_best = nullptr;
-  uint32_t* memo_cnt = nullptr;
-  if (ix->sw.lsh_memo && !c->has_str && !c->has_oov && !ix->script_oov && ix->n_grams) {
-    if (!c->d_lshmemo_cnt.p) {
-      FS_TRY(c->d_lshmemo_best.reserve(4 * (size_t)ix->n_grams));
-      FS_TRY(c->d_lshmemo_cnt.reserve(ix->n_grams));
-      FS_HIP(hipMemsetAsync(c->d_lshmemo_cnt.p, 0, (size_t)ix->n_grams * sizeof(uint32_t), s));
-    }
-    memo_best = c->d_lshmemo_best.p;
-    memo_cnt = c->d_lshmemo_cnt.p;
+  // per-n-gram records of this string table (k_lsh_gramtab, fs_corpus_update_end)
+  const unsigned long long* tab_best = nullptr;
+  const uint32_t* tab_cnt = nullptr;
+  if (c->gramtab_ready && !c->has_str && !c->has_oov) {
+    tab_best = c->d_gramtab_best.p;
+    tab_cnt = c->d_gramtab_cnt.p;
   }
-  FS_TRY(ix->cur->w_cgram.reserve(ccap));
   auto sift = L.n <= 8 ? (L.wmap ? k_lsh_sift<8, true> : k_lsh_sift<8, false>)
                        : (L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true> : k_lsh_sift<FS_MAX_WINDOW, false>);
   hipLaunchKernelGGL(sift, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
-                     ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cgram.p,
-                     ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, memo_best, memo_cnt);
+                     ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p,
+                     ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, tab_best, tab_cnt);
   hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
-                     ix->cur->w_bsum.p + kNB, st, memo_best, memo_cnt, ix->cur->w_cgram.p);
+                     ix->cur->w_bsum.p + kNB, st);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -80,8 +80,8 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
     assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near<%d>" % n
     assert int((got["dist"] > 0.01).sum()) > 0           # inexact neighbours are records
     assert len(set(got["lev"].tolist())) > 1
-    # a second search of the same corpus takes the windows with a script n-gram's ids from
-    # the per-n-gram results the first one left (k_lsh_verify's memo): the same bytes
+    # the windows with a script n-gram's ids take the n-gram's record of this string table
+    # (k_lsh_gramtab, built with the corpus); a second search gives the same bytes
     c0 = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
     first, st_a = ix.search(c0)
     again, st_b = ix.search(c0)
@@ -89,9 +89,9 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
     c0.close()
     # without the 3-gram prefilter (keys and buckets for every window), without the
     # wildcard-key filter in front of k_lsh_verify, with every Levenshtein distance
-    # computed per match, without the per-n-gram memo: the same bytes
+    # computed per match, without the per-n-gram records: the same bytes
     for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near<%d>" % n),
-                        ("FS_LSH_SELFLEV", "k_scan_near<%d>" % n), ("FS_LSH_MEMO", "k_scan_near<%d>" % n)):
+                        ("FS_LSH_SELFLEV", "k_scan_near<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near<%d>" % n)):
         monkeypatch.setenv(env, "0")
         full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
         c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
