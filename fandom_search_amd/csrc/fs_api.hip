@@ -96,7 +96,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
   if (const char* e = getenv("FS_LSH_GRAMTAB")) sw->lsh_gramtab = atoi(e) != 0;
-  if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e);
+  if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e) != 0;
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);

@@ -128,9 +128,9 @@ FS_HD uint32_t fs_wild_key(uint32_t fold_all, uint32_t term_j, int j) {
   return h;
 }
 FS_HD uint32_t fs_wild_word(uint32_t h, int log2_words) { return h >> (32 - log2_words); }
-// The same keys in an exact map (open addressing, linear probing; {key, script window + 1}, one
-// entry per distinct script n-gram and slot): the script windows that equal a fan window in
-// all slots but one can be enumerated, not just shown to be possible.
+// The same keys in an exact map (buckets of four {key, script window + 1}, one entry per distinct
+// script n-gram and slot, a full bucket spills into the next): the script windows that equal a
+// fan window in all slots but one can be enumerated, not just shown to be possible.
 FS_HD uint32_t fs_wmap_slot(uint32_t h, int log2_slots) { return (h * 0x9E3779B1u) >> (32 - log2_slots); }
 FS_HD uint32_t fs_wild_mask(uint32_t h) {
   const uint32_t b = h * 0x9E3779B1u;

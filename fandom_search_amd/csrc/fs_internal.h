@@ -172,7 +172,7 @@ struct fs_switches {
   bool str_levtab = true;         // FS_STR_LEVTAB=0: batches with string ids compute every Levenshtein distance per match
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
-  int lsh_wmap = 1;               // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path; 2: exact map at every n
+  bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
   bool lsh_gramtab = true;        // FS_LSH_GRAMTAB=0: no per-n-gram records (k_lsh_gramtab): every window with a script n-gram's ids walks the buckets
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
@@ -228,7 +228,7 @@ struct fs_index {
   struct Lane {
     hipStream_t stream = nullptr;
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
-    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum;
+    DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum, w_pend;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range

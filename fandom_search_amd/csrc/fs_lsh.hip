@@ -72,7 +72,7 @@ struct LshDev {
                            // this batch's string table (FS_NONE: compute), or nullptr
   const uint32_t* wild;    // one-slot-wildcard keys of the script windows (fs_hash.h), or nullptr
   int log2_wild;
-  const uint2* wmap;       // the same keys as an exact map {key, script window + 1}, or nullptr
+  const uint2* wmap;       // the same keys as an exact map: 2^log2_wmap buckets of four {key, script window + 1}, or nullptr
   int log2_wmap;
   uint32_t V, W;
   int n, H, B, D, C, Cp, nn, unique;
@@ -758,7 +758,41 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
   }
 }
 
-// one wave per flagged window
+// Is script window s, which has the ids of fan window f in every slot but k, within the
+// threshold?  The canonical distance of window_distance with n - 1 slots known to add q(v_t);
+// true also when the premise does not hold in a way that cannot be decided here (the caller
+// then takes the full path).  A key collision (other slots differ) is not a neighbour.
+template <int NW>
+__device__ __forceinline__ bool one_slot_within(const LshDev& L, uint32_t s, int k, const Ids16& f) {
+  Ids16 u;
+  load_ids(L.stok + s, L.n, &u);
+  uint32_t uk = 0, fk = 0;
+  bool agree = true;
+#pragma unroll
+  for (int t = 0; t < NW; ++t)
+    if (t < L.n) {
+      if (t == k) { uk = u.v[t]; fk = f.v[t]; }
+      else agree = agree && u.v[t] == f.v[t];
+    }
+  if (!agree) return false;
+  if (uk == fk) return true;
+  double q[NW];
+#pragma unroll
+  for (int t = 0; t < NW; ++t)
+    if (t < L.n) q[t] = L.q[f.v[t]];
+  const double g = g_of(L, uk, fk);
+  const fs_swin sw = L.sw[s];
+  double ff = 0.0, sf = 0.0;
+#pragma unroll
+  for (int t = 0; t < NW; ++t)
+    if (t < L.n) {
+      ff = __dadd_rn(ff, q[t]);
+      sf = __dadd_rn(sf, t == k ? g : q[t]);
+    }
+  const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(sw.rss, __dsqrt_rn(ff))));
+  return !(d == d) || d < L.thr;
+}
+
 // One lane per candidate, in front of k_lsh_verify: most candidates end here.
 //   cg[i] = FS_NONE      no neighbour within the threshold
 //   cg[i] = 0            a record: cbest[i], cw[i] (the record of its n-gram, k_lsh_gramtab)
@@ -774,7 +808,9 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
                                                   fs_best* __restrict__ cbest,
                                                   uint32_t* __restrict__ bmatch,
                                                   const unsigned long long* __restrict__ tab_best,
-                                                  const uint32_t* __restrict__ tab_cnt) {
+                                                  const uint32_t* __restrict__ tab_cnt,
+                                                  uint32_t* __restrict__ pend,
+                                                  uint32_t* __restrict__ pend_cnt) {
   __shared__ uint32_t s_w32[4];
   const uint32_t total = nc.get();
   uint32_t matches = 0;
@@ -836,58 +872,49 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
    // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
    //    slots but one (every neighbour within the threshold is one of them: m_min = n - 1) and
    //    take their canonical distances.  None within the threshold: whatever the buckets hold,
-   //    nothing survives the threshold, and the window needs no LSH work.  The n first probes
-   //    go out together; a hit costs the script window's ids, its record and one pair-table
-   //    entry (the canonical sum of window_distance with n - 1 slots known to be q(v_k)).
+   //    nothing survives the threshold, and the window needs no LSH work.  One 32-byte bucket
+   //    of the map per slot, all n requested together; a window with more than two such
+   //    n-grams, or a full bucket in its way, is left to k_lsh_verify.
    if (WMAP && live && keyed && gram == FS_NONE) {
-     double qf[NW], ff = 0.0;
-     uint32_t hk[NW];
-     uint2 e0[NW];
+     uint32_t s0 = 0, s1 = 0, nh = 0;
+     int k0 = 0, k1 = 0;
+     bool possible = false;
 #pragma unroll
      for (int k = 0; k < NW; ++k)
        if (k < L.n) {
-         hk[k] = fs_wild_key(fold, term[k], k);
-         e0[k] = L.wmap[fs_wmap_slot(hk[k], L.log2_wmap)];
-         qf[k] = L.q[f.v[k]];
-       }
+         const uint32_t h = fs_wild_key(fold, term[k], k);
+         const uint4* bp = reinterpret_cast<const uint4*>(L.wmap + 4 * (size_t)fs_wmap_slot(h, L.log2_wmap));
+         const uint4 a = bp[0], b = bp[1];
+         const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
 #pragma unroll
-     for (int k = 0; k < NW; ++k)
-       if (k < L.n) ff = __dadd_rn(ff, qf[k]);
-     const double rff = __dsqrt_rn(ff);
-     bool possible = false;
-     const uint32_t mask = (1u << L.log2_wmap) - 1;
-#pragma unroll
-     for (int k = 0; k < NW; ++k)
-       if (k < L.n && !possible) {
-         uint32_t slot = fs_wmap_slot(hk[k], L.log2_wmap);
-         uint2 e = e0[k];
-         while (e.y != 0) {
-           if (e.x == hk[k]) {
-             const uint32_t s = e.y - 1;
-             Ids16 u;
-             load_ids(L.stok + s, L.n, &u);
-             bool agree = true;
-#pragma unroll
-             for (int t = 0; t < NW; ++t)
-               if (t < L.n && t != k) agree = agree && u.v[t] == f.v[t];
-             if (agree) {
-               const fs_swin sw = L.sw[s];
-               const double g = u.v[k] == f.v[k] ? qf[k] : g_of(L, u.v[k], f.v[k]);
-               double sf = 0.0;
-#pragma unroll
-               for (int t = 0; t < NW; ++t)
-                 if (t < L.n) sf = __dadd_rn(sf, t == k ? g : qf[t]);
-               const double d = __dsub_rn(1.0, __ddiv_rn(sf, __dmul_rn(sw.rss, rff)));
-               if (d == d && d < L.thr) { possible = true; break; }
-             }
+         for (int e = 0; e < 4; ++e)
+           if (val[e] && key[e] == h) {
+             if (nh == 0) { s0 = val[e] - 1; k0 = k; }
+             else if (nh == 1) { s1 = val[e] - 1; k1 = k; }
+             ++nh;
            }
-           slot = (slot + 1) & mask;
-           e = L.wmap[slot];
-         }
+         possible = possible || val[3] != 0;       // (filled in order: the bucket is full)
        }
+     possible = possible || nh > 2;
+     if (!possible && nh > 0) possible = one_slot_within<NW>(L, s0, k0, f);
+     if (!possible && nh > 1) possible = one_slot_within<NW>(L, s1, k1, f);
      if (!possible) { cg[il] = FS_NONE; live = false; }
    }
-   if (live) cg[il] = FS_PENDING;
+   // what is left: onto the list k_lsh_verify deals out window by window (pending windows
+   // come in runs, the boundary windows of one quoted passage, so dealing out blocks of
+   // candidates leaves a few waves with most of the work)
+   const uint64_t pb = __ballot(live);
+   if (pb) {
+     const int lane = threadIdx.x & 63;
+     const int leader = __ffsll((unsigned long long)pb) - 1;
+     uint32_t base = 0;
+     if (lane == leader) base = atomicAdd(pend_cnt, (uint32_t)__popcll(pb));
+     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+     if (live) {
+       cg[il] = FS_PENDING;
+       pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
+     }
+   }
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
@@ -1085,24 +1112,19 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
                                                     uint32_t* __restrict__ cg,
                                                     uint32_t* __restrict__ cw,
                                                     fs_best* __restrict__ cbest,
-                                                    uint32_t* __restrict__ bmatch, fs_status* st) {
+                                                    uint32_t* __restrict__ bmatch, fs_status* st,
+                                                    const uint32_t* __restrict__ pend) {
   FS_LSH_WAVE_LDS;
   __shared__ uint32_t s_w32[4];
   const int lane = threadIdx.x & 63;
-  const uint32_t total = nc.get();
-  uint32_t matches = 0, pending = 0;
+  uint32_t matches = 0;
   // k_lsh_sift has been over every candidate: what it left pending is worked out here, a wave
-  // per window.  A wave takes 64 CONSECUTIVE candidates per step (blocks of 64 dealt round-
-  // robin over the waves), so the per-candidate arrays are read in whole cache lines.
+  // per window, the windows of its list dealt round-robin over the waves.
   const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
-  for (uint64_t blk = gw; blk * 64 < total; blk += NWAVES) {
-    const uint64_t il = blk * 64 + lane;
-    const bool live = il < total && cg[il] == FS_PENDING;
-    uint64_t todo = __ballot(live);
-    pending += (uint32_t)__popcll(todo);
-    while (todo) {
-      const uint32_t i = (uint32_t)(blk * 64) + (uint32_t)(__ffsll((unsigned long long)todo) - 1);
-      todo &= todo - 1;
+  const uint32_t n_pend = min(st->lsh_pending, nc.cap);
+  {
+    for (uint32_t j = gw; j < n_pend; j += NWAVES) {
+      const uint32_t i = pend[j];
       const uint64_t p = cpos[i];
       bool ok = p + L.n <= c.n_tok;
       uint32_t w = 0;
@@ -1138,7 +1160,6 @@ __global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, Gr
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
   if (threadIdx.x == 0) bmatch[blockIdx.x] += tot;       // (on top of k_lsh_sift's)
-  if (lane == 0 && pending) atomicAdd(&st->lsh_pending, pending);
 }
 
 }  // namespace
@@ -1234,9 +1255,11 @@ int fs_lsh_build(fs_index* ix) {
           if (i == 0 || !std::equal(st.begin() + order[i], st.begin() + order[i] + n, st.begin() + order[i - 1]))
             first.push_back(order[i]);
       }
-      int lm = 10;
-      while (lm < 28 && ((uint64_t)1 << lm) < 2 * first.size() * (uint64_t)n) ++lm;
-      std::vector<uint32_t> wmap((size_t)2 << lm, 0u);
+      // buckets of four {key, window + 1}, about one entry per bucket; a full bucket spills
+      // into the next one (the kernel gives a window up when it meets a full bucket)
+      int lm = 8;
+      while (lm < 26 && ((uint64_t)1 << lm) < first.size() * (uint64_t)n) ++lm;
+      std::vector<uint32_t> wmap((size_t)8 << lm, 0u);
       const uint32_t mask = (1u << lm) - 1;
       for (uint32_t w : first) {
         uint32_t term[FS_MAX_WINDOW], fold = 0;
@@ -1246,10 +1269,14 @@ int fs_lsh_build(fs_index* ix) {
         }
         for (int k = 0; k < n; ++k) {
           const uint32_t h = fs_wild_key(fold, term[k], k);
-          uint32_t slot = fs_wmap_slot(h, lm);
-          while (wmap[2 * (size_t)slot + 1]) slot = (slot + 1) & mask;
-          wmap[2 * (size_t)slot] = h;
-          wmap[2 * (size_t)slot + 1] = w + 1;
+          uint32_t bkt = fs_wmap_slot(h, lm);
+          for (;;) {
+            uint32_t* e = wmap.data() + 8 * (size_t)bkt;
+            int at = 0;
+            while (at < 4 && e[2 * at + 1]) ++at;
+            if (at < 4) { e[2 * at] = h; e[2 * at + 1] = w + 1; break; }
+            bkt = (bkt + 1) & mask;
+          }
         }
       }
       FS_TRY(ix->d_wmap.upload(wmap.data(), wmap.size(), ix->stream));
@@ -1394,13 +1421,11 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
       (int)ix->cfg.window_size - ix->lsh_m_min == 1) {
     L.wild = ix->d_wild.p;
     L.log2_wild = ix->log2_wild;
-    // The exact map pays where a one-slot neighbour is rarely within the threshold: its cosine
-    // is (n - 1 + c) / n with c the cosine of the two differing vectors, within the threshold
-    // iff c > 1 - n * thr.  At n = 8 (c > 0.2) nearly every such window ends in k_lsh_sift; at
-    // n = 10 (c > 0) half of them are real neighbours and the enumeration is work on top.
-    // FS_LSH_WMAP=2 forces it.
-    const bool pays = 1.0 - (double)ix->cfg.window_size * L.thr > 0.1;
-    if ((ix->sw.lsh_wmap > 1 || (ix->sw.lsh_wmap && pays)) && ix->d_wmap.p) {
+    // A one-slot neighbour has cosine (n - 1 + c) / n with c the cosine of the two differing
+    // vectors: within the threshold iff c > 1 - n * thr.  At n = 8 (c > 0.2) nearly every such
+    // window ends in k_lsh_sift; at n = 10 (c > 0) half of them are real neighbours and stay
+    // pending, the other half still ends there.
+    if (ix->sw.lsh_wmap && ix->d_wmap.p) {
       L.wmap = reinterpret_cast<const uint2*>(ix->d_wmap.p);
       L.log2_wmap = ix->log2_wmap;
     }
@@ -1414,14 +1439,16 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
     tab_best = c->d_gramtab_best.p;
     tab_cnt = c->d_gramtab_cnt.p;
   }
+  FS_TRY(ix->cur->w_pend.reserve(ccap));
   auto sift = L.n <= 8 ? (L.wmap ? k_lsh_sift<8, true> : k_lsh_sift<8, false>)
                        : (L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true> : k_lsh_sift<FS_MAX_WINDOW, false>);
   hipLaunchKernelGGL(sift, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p,
-                     ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, tab_best, tab_cnt);
+                     ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, tab_best, tab_cnt, ix->cur->w_pend.p,
+                     &st->lsh_pending);
   hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
-                     ix->cur->w_bsum.p + kNB, st);
+                     ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

@@ -89,9 +89,11 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
     c0.close()
     # without the 3-gram prefilter (keys and buckets for every window), without the
     # wildcard-key filter in front of k_lsh_verify, with every Levenshtein distance
-    # computed per match, without the per-n-gram records: the same bytes
+    # computed per match, without the per-n-gram records, without the exact one-slot map: the
+    # same bytes
     for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near<%d>" % n),
-                        ("FS_LSH_SELFLEV", "k_scan_near<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near<%d>" % n)):
+                        ("FS_LSH_SELFLEV", "k_scan_near<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near<%d>" % n),
+                        ("FS_LSH_WMAP", "k_scan_near<%d>" % n)):
         monkeypatch.setenv(env, "0")
         full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
         c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
