@@ -109,6 +109,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_LSH_SELFLEV")) sw->lsh_selflev = e[0] != '0';
   if (const char* e = getenv("FS_ROWS_DISP_LDS")) sw->rows_disp_lds = e[0] != '0';
   if (const char* e = getenv("FS_STR_LEVTAB")) sw->str_levtab = e[0] != '0';
+  if (const char* e = getenv("FS_STR_FAST")) sw->str_fast = e[0] != '0';
   sw->rows_waves = num("FS_ROWS_WAVES");
   sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
@@ -312,6 +313,58 @@ static int prove_exact(fs_index* ix, const uint32_t* stok) {
   return FS_OK;
 }
 
+// Script text for the lane-per-pair Levenshtein (k_strbest, batches with string ids): the
+// distinct code points of the script become classes 1 .. K (0 = any other code point, which
+// equals no script character), and every script window's text "w0 w1 .. wn-1" (search.py:189)
+// of at most 64 code points is stored as 7 bit planes of its classes (bit j of plane b = bit b
+// of the class of character j; positions behind the text hold class 127, which no fan
+// character has).  More than 125 distinct code points: the path is not used.
+static int fs_build_str_patterns(fs_index* ix, const uint32_t* script_chars, const uint64_t* script_off,
+                                 uint64_t n_script) {
+  ix->strfast_ok = false;
+  const int n = (int)ix->cfg.window_size;
+  if (!ix->n_windows || !script_chars) return FS_OK;
+  const uint64_t n_chars = script_off[n_script];
+  std::vector<uint32_t> cps(script_chars, script_chars + n_chars);
+  cps.push_back((uint32_t)' ');
+  std::sort(cps.begin(), cps.end());
+  cps.erase(std::unique(cps.begin(), cps.end()), cps.end());
+  if (cps.size() > 125) return FS_OK;
+  auto cls = [&](uint32_t cp) -> uint32_t {
+    const auto it = std::lower_bound(cps.begin(), cps.end(), cp);
+    return it != cps.end() && *it == cp ? (uint32_t)(it - cps.begin()) + 1u : 0u;
+  };
+  std::vector<uint8_t> ccls(n_chars);
+  for (uint64_t i = 0; i < n_chars; ++i) ccls[i] = (uint8_t)cls(script_chars[i]);
+  const uint8_t space = (uint8_t)cls(' ');
+  const uint64_t W = ix->n_windows;
+  std::vector<unsigned long long> pat(8 * W, 0ull);
+  for (uint64_t s = 0; s < W; ++s) {
+    unsigned long long* P = pat.data() + 8 * s;
+    const uint64_t la = script_off[s + n] - script_off[s] + (uint64_t)(n - 1);
+    P[7] = la;
+    if (la > 64 || la == 0) { P[7] = 0xFFFFFFFFull; continue; }
+    uint8_t text[64];
+    uint32_t at = 0;
+    for (int k = 0; k < n; ++k) {
+      if (k) text[at++] = space;
+      for (uint64_t i = script_off[s + k]; i < script_off[s + k + 1]; ++i) text[at++] = ccls[i];
+    }
+    for (uint32_t j = 0; j < 64; ++j) {
+      const uint32_t cj = j < la ? text[j] : 127u;
+      for (int b = 0; b < 7; ++b)
+        if ((cj >> b) & 1u) P[b] |= 1ull << j;
+    }
+  }
+  FS_TRY(ix->d_clsmap.upload(cps.data(), cps.size(), ix->stream));
+  FS_TRY(ix->d_pat.upload(pat.data(), pat.size(), ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  ix->n_cls = (uint32_t)cps.size();
+  ix->str_punct = cls('[') | (cls(',') << 8) | (cls(' ') << 16) | (cls(']') << 24);
+  ix->strfast_ok = true;
+  return FS_OK;
+}
+
 extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
                                const uint32_t* script_chars, const uint64_t* script_off,
                                uint64_t n_script, const float* emb, uint64_t n_vec,
@@ -411,6 +464,7 @@ extern "C" int fs_index_create(const fs_config* cfg, const uint32_t* script_vec,
     FS_TRY(ix->d_soff.upload(soff.data(), soff.size(), ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
+  FS_TRY(fs_build_str_patterns(ix, script_chars, script_off, n_script));
   FS_TRY(ix->d_emb.upload(emb, (size_t)n_vec * cfg->emb_dim, ix->stream));
   if (normals) {
     const size_t nn = (size_t)cfg->number_of_hashes * cfg->hash_dimensions * cfg->emb_dim *
@@ -607,6 +661,13 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
       return FS_E_UNSUPPORTED;
     }
     c->levtab_ready = true;
+  }
+  if (c->has_str && !c->has_oov && ix->info.path == FS_MODE_EXACT && ix->strfast_ok && ix->sw.str_fast &&
+      !c->strrec_ready) {
+    // the string table as character classes of the script's alphabet, once per string table
+    FS_TRY(fs_launch_strrec(ix, c, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    c->strrec_ready = true;
   }
   // the batch table of k_scan_rows (ids + this string table's best records), on its own
   // flag: a corpus that is reused (fs_corpus_update_begin) may see its first batch without

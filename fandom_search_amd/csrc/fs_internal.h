@@ -137,6 +137,15 @@ struct CorpusDev {
   uint32_t n_str;
 };
 
+// What the lane-per-pair Levenshtein needs (fs_post.hip, k_strbest)
+struct StrFast {
+  const unsigned long long* pat;   // fs_index::d_pat
+  const uint32_t* clsmap;
+  uint32_t n_cls;
+  uint32_t punct;
+  const uint4* strrec;             // fs_corpus::d_strrec
+};
+
 // LSH pipeline: per script window, everything the first slot of a candidate's
 // distance needs, in one 32-byte record
 struct alignas(32) fs_swin {
@@ -169,6 +178,7 @@ struct fs_switches {
   bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
   bool lsh_prefilter = true;      // FS_LSH_PREFILTER=0: always the full key scan
   bool rows_disp_lds = true;      // FS_ROWS_DISP_LDS=0: k_scan_rows reads the displacement seeds from memory (as with > 16 K buckets)
+  bool str_fast = true;           // FS_STR_FAST=0: batches with string ids take k_matchlev + k_cbest (a wave per pair) instead of k_strbest
   bool str_levtab = true;         // FS_STR_LEVTAB=0: batches with string ids compute every Levenshtein distance per match
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
@@ -196,6 +206,11 @@ struct fs_index {
 
   DBuf<uint32_t> d_stok, d_filter, d_sfilter, d_table, d_disp, d_gpos, d_gcnt, d_schars, d_cproto, d_disp8;
   DBuf<uint64_t> d_soff;
+  // lane-per-pair Levenshtein of batches with string ids (k_strbest): script characters as classes
+  DBuf<uint32_t> d_clsmap;             // sorted distinct code points of the script text (and ' '): class = index + 1
+  DBuf<unsigned long long> d_pat;      // [n_windows][8]: 7 bit planes of the window text's classes, its length (> 64: none)
+  uint32_t n_cls = 0, str_punct = 0;   // classes of '[', ',', ' ', ']' (a byte each)
+  bool strfast_ok = false;
   DBuf<double> d_q, d_selfdist;
   std::vector<double> h_selfdist;   // host copy (host-row searches expand 8-byte records on the host)
   void* h_stage = nullptr;          // pinned landing buffer of those records
@@ -299,6 +314,8 @@ struct fs_corpus {
   bool pending = false;                // an upload is queued and not yet waited for
   DBuf<uint64_t> d_work_off, d_coff;
   DBuf<fs_best> d_gbest;
+  DBuf<uint4> d_strrec;                // [n_str] {length, classes of the first 15 code points} (k_strrec)
+  bool strrec_ready = false;
   DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
   bool ctab_ready = false;
@@ -368,6 +385,7 @@ int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_bl
                        uint2* blk_work, uint4* blk4, hipStream_t s);
 
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
+int fs_launch_strrec(fs_index* ix, fs_corpus* c, hipStream_t s);
 
 // fs_ranges.hip: helpers of the records path of k_scan_rows
 int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s);

@@ -392,6 +392,162 @@ __global__ __launch_bounds__(256) void k_matchlev(GramIndexDev g, CorpusDev c,
   }
 }
 
+// ---- lane-per-pair Levenshtein (batches with string ids) ------------------------------
+// class of a code point in the script's alphabet (StrFast), 0: not a script character
+__device__ __forceinline__ uint32_t cls_of(const StrFast& F, uint32_t cp) {
+  uint32_t lo = 0, hi = F.n_cls;                 // clsmap[lo - 1] < cp <= clsmap[hi - 1] or hi = n
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (F.clsmap[mid] < cp) lo = mid + 1; else hi = mid;
+  }
+  return lo < F.n_cls && F.clsmap[lo] == cp ? lo + 1 : 0u;
+}
+
+// the string table as classes: {length (capped at 255), classes of code points 0 .. 14}
+__global__ void k_strrec(const uint32_t* __restrict__ chars, const uint64_t* __restrict__ coff,
+                         uint32_t n_str, StrFast F, uint4* __restrict__ rec) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_str) return;
+  const uint64_t a = coff[i], b = coff[i + 1];
+  const uint64_t len = b - a;
+  uint32_t w[4] = {len < 255 ? (uint32_t)len : 255u, 0u, 0u, 0u};
+  for (uint32_t j = 0; j < 15 && j < len; ++j) {
+    const uint32_t cl = cls_of(F, chars[a + j]);
+    w[(j + 1) >> 2] |= cl << (8 * ((j + 1) & 3));
+  }
+  rec[i] = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Levenshtein.distance(match_str, fan_context) of search.py:189-190 by ONE lane: Myers'
+// bit-vector recurrence over the script window's text (the pattern, at most 64 code points,
+// as 7 bit planes of character classes: the match mask of a fan character is seven xnor/and
+// pairs, no table and no load inside the loop), the fan text '[' + ', '.join(words) + ']'
+// streamed class by class from the string records.  Words of more than 15 code points read
+// their text; windows of more than 64 code points take the scratch DP of lev_device.
+__device__ inline uint32_t lev_lane(const GramIndexDev& g, const CorpusDev& c, const StrFast& F,
+                                    uint32_t s, const uint32_t* __restrict__ sid, fs_status* st) {
+  const uint4* P4 = reinterpret_cast<const uint4*>(F.pat + 8 * (size_t)s);
+  const uint4 t0 = P4[0], t1 = P4[1], t2 = P4[2], t3 = P4[3];
+  const uint32_t la = t3.z;
+  if (la > 64) return lev_device(g, s, sid, c.chars, c.coff, c.n_str, st);
+  const uint32_t plo[7] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x};
+  const uint32_t phi[7] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y};
+  const unsigned long long last = 1ull << (la - 1);
+  unsigned long long pv = ~0ull, mv = 0ull;
+  uint32_t score = la;
+  auto step = [&](uint32_t cl) {
+    uint32_t elo = 0xFFFFFFFFu, ehi = 0xFFFFFFFFu;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      const uint32_t m = 0u - ((cl >> b) & 1u);
+      elo &= ~(plo[b] ^ m);
+      ehi &= ~(phi[b] ^ m);
+    }
+    const unsigned long long eq = (unsigned long long)elo | ((unsigned long long)ehi << 32);
+    const unsigned long long xv = eq | mv;
+    const unsigned long long xh = (((eq & pv) + pv) ^ pv) | eq;
+    unsigned long long ph = mv | ~(xh | pv);
+    unsigned long long mh = pv & xh;
+    score += (ph & last) ? 1u : 0u;
+    score -= (mh & last) ? 1u : 0u;
+    ph = (ph << 1) | 1ull;
+    mh <<= 1;
+    pv = mh | ~(xv | ph);
+    mv = ph & xv;
+  };
+  step(F.punct & 0xFFu);                                   // '['
+  uint4 nxt = F.strrec[sid[0]];
+  for (int k = 0; k < g.n; ++k) {
+    uint4 cur = nxt;
+    const uint32_t id = sid[k];
+    if (k + 1 < g.n) nxt = F.strrec[sid[k + 1]];           // (requested before this word is walked)
+    if (k) { step((F.punct >> 8) & 0xFFu); step((F.punct >> 16) & 0xFFu); }   // ', '
+    const uint32_t len = cur.x & 0xFFu;
+    if (len <= 15) {
+      for (uint32_t j = 0; j < len; ++j) {
+        cur.x = __builtin_amdgcn_alignbit(cur.y, cur.x, 8);
+        cur.y = __builtin_amdgcn_alignbit(cur.z, cur.y, 8);
+        cur.z = __builtin_amdgcn_alignbit(cur.w, cur.z, 8);
+        cur.w >>= 8;
+        step(cur.x & 0xFFu);
+      }
+    } else {
+      for (uint64_t a = c.coff[id]; a < c.coff[id + 1]; ++a) step(cls_of(F, c.chars[a]));
+    }
+  }
+  step(F.punct >> 24);                                     // ']'
+  return score;
+}
+
+// Batches with string ids: the record every hit offers (best_of_ranks over its own Levenshtein
+// distances).  64 consecutive candidates per wave and step, a lane each: no hit -> nothing;
+// every token of the window with string id == vector id -> the n-gram's record of this string
+// table (k_gbest); the rest queue up in LDS and are worked off 64 at a time, a lane per hit,
+// all its ranks (lev_lane), so that the lanes of the expensive part are all busy.
+__global__ __launch_bounds__(256) void k_strbest(GramIndexDev g, CorpusDev c, StrFast F,
+                                                 const uint32_t* __restrict__ cpos,
+                                                 const uint32_t* __restrict__ cg, NSrc nc,
+                                                 const uint32_t* __restrict__ levtab,
+                                                 const fs_best* __restrict__ gbest,
+                                                 fs_best* __restrict__ cbest, fs_status* st) {
+  __shared__ uint32_t s_q[4][128];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t total = nc.get();
+  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
+  uint32_t head = 0, tail = 0;                             // (wave-uniform) ring of candidate indices
+  auto work_off = [&](uint32_t count) {                    // the `count` <= 64 oldest of the queue
+    if ((uint32_t)lane < count) {
+      const uint32_t i = s_q[wave][(head + lane) & 127];
+      const uint32_t gram = cg[i], m = g.gcnt[gram], p = cpos[i];
+      fs_best b;
+      b.s = 0; b.lev = 0; b.dist = 0.0; b.comb = 0.0; b.pad = 0.0;
+      for (uint32_t r = 0; r < m; ++r) {
+        const uint32_t s = g.gpos[(size_t)gram * g.nn + r];
+        const uint32_t lev = lev_lane(g, c, F, s, c.str + p, st);
+        const double dist = g.selfdist[s];
+        const double comb = __dmul_rn(dist, (double)lev);
+        if (r == 0 || comb < b.comb) { b.s = s; b.lev = lev; b.dist = dist; b.comb = comb; }
+      }
+      cbest[i] = b;
+    }
+    head += count;
+  };
+  for (uint64_t blk = gw; blk * 64 < total; blk += NWAVES) {
+    const uint64_t il = blk * 64 + lane;
+    bool slow = false;
+    if (il < total) {
+      const uint32_t gram = cg[il];
+      if (gram != FS_NONE) {
+        slow = true;
+        if (levtab) {
+          const uint32_t p = cpos[il];
+          bool same = true;
+          for (int k = 0; k < g.n; ++k) same = same && c.str[p + k] == c.tok[p + k];
+          if (same) {
+            const uint32_t m = g.gcnt[gram];
+            bool all = true;
+            for (uint32_t r = 0; r < m; ++r) all = all && levtab[(size_t)gram * g.nn + r] != FS_NONE;
+            if (all) {
+              const uint4* src = reinterpret_cast<const uint4*>(gbest + gram);
+              uint4* dst = reinterpret_cast<uint4*>(cbest + il);
+              dst[0] = src[0]; dst[1] = src[1];
+              slow = false;
+            }
+          }
+        }
+      }
+    }
+    const uint64_t sb = __ballot(slow);
+    if (slow)
+      s_q[wave][(tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))) & 127] = (uint32_t)il;
+    tail += (uint32_t)__popcll(sb);
+    __builtin_amdgcn_wave_barrier();
+    if (tail - head >= 64) work_off(64);
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (tail != head) work_off(tail - head);
+}
+
 // The record a hit offers to every fan word of its window: the first minimum of
 // dist*lev over its NearestFilter ranks (all ranks of one hit precede all ranks
 // of the next in the reference's insertion order, so the per-word first minimum
@@ -726,6 +882,17 @@ int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_bl
   return FS_OK;
 }
 
+int fs_launch_strrec(fs_index* ix, fs_corpus* c, hipStream_t s) {
+  FS_TRY(c->d_strrec.reserve(c->n_str + 1));
+  if (c->n_str) {
+    const StrFast F{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, nullptr};
+    hipLaunchKernelGGL(k_strrec, dim3((uint32_t)((c->n_str + 255) / 256)), dim3(256), 0, s, c->d_chars.p,
+                       c->d_coff.p, (uint32_t)c->n_str, F, c->d_strrec.p);
+    FS_HIP(hipGetLastError());
+  }
+  return FS_OK;
+}
+
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   const size_t total = (size_t)ix->n_grams * ix->cfg.nearest_n;
   FS_TRY(c->d_levtab.reserve(total));
@@ -823,7 +990,13 @@ int fs_launch_post(fs_index* ix, fs_corpus* c, uint32_t n_sub, int tpl, uint32_t
     hipLaunchKernelGGL(k_verify, dim3(kNB), dim3(kThreads), 0, s, cd, g, ix->cur->w_cpos.p, nc,
                        ix->cur->w_cg.p, ix->cur->w_cw.p, bmatch);
   }
-  if (per_cand) {
+  if (per_cand && c->strrec_ready && ix->strfast_ok && ix->sw.str_fast) {
+    const StrFast F{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, c->d_strrec.p};
+    hipLaunchKernelGGL(k_strbest, dim3(kNB), dim3(kThreads), 0, s, g, cd, F, ix->cur->w_cpos.p,
+                       ix->cur->w_cg.p, nc,
+                       c->levtab_ready && ix->sw.str_levtab ? (const uint32_t*)c->d_levtab.p : nullptr,
+                       c->d_gbest.p, ix->cur->w_cbest.p, st);
+  } else if (per_cand) {
     hipLaunchKernelGGL(k_matchlev, dim3(kNB), dim3(kThreads), 0, s, g, cd, ix->cur->w_cpos.p,
                        ix->cur->w_cg.p, nc,
                        c->levtab_ready && ix->sw.str_levtab ? (const uint32_t*)c->d_levtab.p : nullptr,

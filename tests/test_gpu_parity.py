@@ -127,6 +127,48 @@ def test_separate_string_ids(synth_base, monkeypatch, plain):
     ix2.close()
 
 
+def test_string_ids_lane_levenshtein(synth_base, monkeypatch):
+    """k_strbest (a lane per hit: Myers' recurrence over character classes of the script's
+    alphabet) against the oracle where its special cases meet: fan words of more than 15 code
+    points, code points outside the script's alphabet and outside ASCII, script windows of
+    more than 64 code points (scratch DP), n-grams that occur several times in the script
+    with different text (several ranks per hit); FS_STR_FAST=0 (a wave per pair): same bytes."""
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+    words, emb = synth_base["words"], synth_base["emb"]
+    n = 6
+    normals = synth.lsh_normals(n)
+    script = synth.script_tokens(3000).copy()
+    script[400:440] = script[40:80]                       # the same n-grams again ...
+    swords = [words[int(t)] for t in script]
+    for i in range(400, 440, 3):
+        swords[i] = swords[i].upper()                      # ... with other text: ranks differ
+    for i in range(900, 960):
+        swords[i] = swords[i] * 4                          # windows of more than 64 code points
+    for i in range(1500, 1510):
+        swords[i] = swords[i] + "\u00e9\u4e16"            # non-ASCII script characters
+    tok, off = util.ragged_corpus([700] * 25 + [0, 9, 1300], script)
+    rng = np.random.default_rng(17)
+    V = len(words)
+    strings = (list(words) + [w.capitalize() for w in words] + [w * 5 for w in words] +
+               [w + "\u00e9" for w in words] + [w[:1] + "\U0001F600" + w[1:] for w in words])
+    variant = rng.choice(5, size=len(tok), p=[0.6, 0.1, 0.1, 0.1, 0.1]).astype(np.uint32)
+    tok_str = (tok + variant * V).astype(np.uint32)
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config(window_size=n)
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    got, st = ix.search(ix.corpus(tok, off, chars, coff, tok_str=tok_str))
+    oi = util.oracle_index(cfg, script, words, emb, normals, swords=swords)
+    want, ost = oi.search(tok, off, chars, coff, tok_str=tok_str)
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and len(set(got["lev"].tolist())) > 6
+    monkeypatch.setenv("FS_STR_FAST", "0")
+    ix2 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    got2, st2 = ix2.search(ix2.corpus(tok, off, chars, coff, tok_str=tok_str))
+    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+    ix2.close()
+
+
 def test_packed_wire_rows_round_trip(synth_base):
     """16-byte wire records of the exact pipeline expand to the same fs_row bytes."""
     import torch
@@ -159,9 +201,11 @@ def test_packed_wire_rows_round_trip(synth_base):
     assert e.value.code == abi.FS_E_UNSUPPORTED
 
 
-def test_long_tokens_and_levenshtein_limit(synth_base):
-    """Levenshtein operands up to 512 code points per side are computed on the
-    device (bit-equal to the oracle); longer n-gram texts are refused loudly."""
+def test_long_tokens_and_levenshtein_limit(synth_base, monkeypatch):
+    """Fan texts of any length are computed on the device by the lane-per-hit Levenshtein of
+    batches with string ids (bit-equal to the oracle); the wave-per-pair kernels behind
+    FS_STR_FAST=0 hold their operands in LDS: up to 512 code points per side, longer n-gram
+    texts are refused loudly."""
     from fandom_search_amd import _lib
     from fandom_search_amd.engine import ScriptIndex
     from fandom_search_amd.vocab import pack_strings
@@ -175,17 +219,26 @@ def test_long_tokens_and_levenshtein_limit(synth_base):
     cfg = abi.make_config(window_size=n)
     normals = synth.lsh_normals(n)
     swords = [words[int(t)] for t in script]
-    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
-    got, st = ix.search(ix.corpus(tok, off, chars, coff, tok_str=tok))
-    oi = util.oracle_index(cfg, script, words, emb, normals)
-    want, _ = oi.search(tok, off, chars, coff, tok_str=tok)
-    util.assert_rows_equal(got, want)
-    assert int(got["lev"].max()) > 200
     too_long = [w * 30 for w in words]                # 120 code points per word: 6*120+12 > 512
     chars2, coff2 = pack_strings(too_long)
-    with pytest.raises(_lib.FsError) as e:
-        ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
-    assert e.value.code == abi.FS_E_UNSUPPORTED and "512" in str(e.value)
+    oi = util.oracle_index(cfg, script, words, emb, normals)
+    want, _ = oi.search(tok, off, chars, coff, tok_str=tok)
+    want2, _ = oi.search(tok, off, chars2, coff2, tok_str=tok)
+    for fast in ("1", "0"):
+        monkeypatch.setenv("FS_STR_FAST", fast)
+        ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+        got, st = ix.search(ix.corpus(tok, off, chars, coff, tok_str=tok))
+        util.assert_rows_equal(got, want)
+        assert int(got["lev"].max()) > 200
+        if fast == "1":
+            got2, _ = ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
+            util.assert_rows_equal(got2, want2)
+            assert int(got2["lev"].max()) > 512
+        else:
+            with pytest.raises(_lib.FsError) as e:
+                ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
+            assert e.value.code == abi.FS_E_UNSUPPORTED and "512" in str(e.value)
+        ix.close()
 
 
 def test_searches_in_flight(synth_base):

@@ -26,10 +26,10 @@ def assert_rows_equal(got, want):
         assert bad.size == 0, (name, int(bad[0]), got[bad[0]], want[bad[0]])
 
 
-def oracle_index(cfg, script, words, emb, normals, threads=8):
+def oracle_index(cfg, script, words, emb, normals, threads=8, swords=None):
     from oracle import c_oracle
     from fandom_search_amd.vocab import pack_strings
-    sch, so = pack_strings([words[int(t)] for t in script])
+    sch, so = pack_strings(swords if swords is not None else [words[int(t)] for t in script])
     return c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads)
 
 
