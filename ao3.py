@@ -3,6 +3,10 @@
 reference documents for this path, served by fandom_search_amd.cli."""
 import os
 import sys
+import time
+
+if os.environ.get('FANDOM_SEARCH_TIMING'):
+    os.environ.setdefault('FANDOM_SEARCH_T0', repr(time.time()))   # (before the imports below)
 
 from fandom_search_amd.cli import main
 

@@ -27,6 +27,7 @@ What differs, and why:
 import csv
 import datetime
 import os
+import time
 import random
 import re
 import shutil
@@ -294,8 +295,9 @@ class TokenPool(object):
 
 
 def default_workers(world=1):
-    """Tokeniser processes per rank: FANDOM_SEARCH_WORKERS, else up to 8 of this rank's
-    share of the cores the process may use (0 or 1: tokenise in the parent)."""
+    """Tokeniser (and batch-file writer) processes per rank: FANDOM_SEARCH_WORKERS, else up
+    to 16 of this rank's share of the cores the process may use (0 or 1: tokenise in the
+    parent)."""
     env = os.environ.get("FANDOM_SEARCH_WORKERS")
     if env is not None:
         return max(0, int(env))
@@ -303,7 +305,7 @@ def default_workers(world=1):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return max(1, min(8, cores // max(1, world)))
+    return max(1, min(16, cores // max(1, world)))
 
 
 class AnnIndexSearch(object):
@@ -497,6 +499,32 @@ def write_records(records, filename):
         wr.writerows(records)
 
 
+_script_columns_cache = {}
+
+
+def _script_columns(script_filename):
+    """(word_lowercase, orth_id, character, scene) of a marked-up script, as
+    AnnIndexSearch.__init__ keeps them; cached per process."""
+    cols = _script_columns_cache.get(script_filename)
+    if cols is None:
+        orig_csv = load_markup_script(script_filename)[1:]
+        cols = (tuple(r[0] for r in orig_csv), tuple(r[1] for r in orig_csv),
+                tuple(r[3] for r in orig_csv), tuple(r[2] for r in orig_csv))
+        _script_columns_cache[script_filename] = cols
+    return cols
+
+
+def _write_batch(script_filename, out_name, filenames, row_bytes, words):
+    """One batch CSV, in a worker of the token pool: join the numeric rows with the script
+    columns and write them (join_records + write_records), while the parent goes on to the
+    next cluster.  The rows travel as bytes."""
+    rows = np.frombuffer(row_bytes, dtype=abi.ROW_DTYPE)
+    word_lowercase, orth_id, character, scene = _script_columns(script_filename)
+    write_records(join_records(filenames, rows, words, word_lowercase, orth_id, character, scene),
+                  out_name)
+    return len(rows)
+
+
 def list_fan_works(fan_work_directory, skip_works=0, num_works=-1):
     """Work list of analyze (search.py:345-358): directory listing (sorted
     here; filesystem order in the reference), the reference's seeded shuffle,
@@ -522,6 +550,16 @@ def unused_result_name(filename_base):
     return name_check
 
 
+_startup = []
+
+
+def _startup_lap(what):
+    """FANDOM_SEARCH_TIMING: seconds since ao3.py started (FANDOM_SEARCH_T0), at the named point."""
+    t0 = os.environ.get("FANDOM_SEARCH_T0")
+    if os.environ.get("FANDOM_SEARCH_TIMING") and t0:
+        _startup.append((what, time.time() - float(t0)))
+
+
 def analyze(args,
             window_size=6,
             number_of_hashes=15,
@@ -543,9 +581,13 @@ def analyze(args,
     # cluster i and the parent writes its records (the reference's Pool(4) does its whole
     # search in the workers, search.py:381-385)
     pool = None
+    _startup_lap("interpreter, imports, arguments")
     if searcher is None:
-        get_vocab()               # (host only) the workers inherit the string table
+        get_vocab()               # (host only) the workers inherit the string table ...
+        from . import tokenizer   # noqa: F401  ... and the compiled tokenizer rules
+        _startup_lap("vector table")
         pool = TokenPool(default_workers(dist.env_world()[2]))
+        _startup_lap("fork the token pool")
     try:
         return _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_threshold,
                         chunk_size, searcher, pool)
@@ -602,6 +644,8 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
             t_last[0] = now
 
     lap("index")
+    _startup_lap("script index on the GPU (library load, HIP start-up, fs_index_create)")
+    writes = []
     for i, fan_cluster in enumerate(fan_clusters):
         if pool is not None and i + 1 < len(fan_clusters):
             pool.start(share(fan_clusters[i + 1]))
@@ -624,6 +668,17 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
                   file=sys.stderr)
         if rank != 0:
             continue
+        if pool is not None and pool.pool is not None and searcher is None:
+            # the batch file is written by a worker of the token pool (they are forked, and
+            # parse the script's columns themselves) while this process searches the next
+            # cluster; the reference writes every batch file before the next pool.map
+            # (search.py:386-388), the bytes are the same
+            writes.append(pool.pool.apply_async(
+                _write_batch, (args.script, batch_filename.format(i), list(fan_cluster),
+                               np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).tobytes(), words)))
+            n_batches = i + 1
+            lap("hand batch to a writer")
+            continue
         records = join_records(fan_cluster, rows, words,
                                ann_index.word_lowercase, ann_index.orth_id,
                                ann_index.character, ann_index.scene)
@@ -631,6 +686,9 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
         write_records(records, batch_filename.format(i))
         n_batches = i + 1
         lap("write batch csv")
+    for job in writes:
+        job.get()                                   # (raises what the writer raised)
+    lap("wait for the writers")
 
     if pool is not None:
         ann_index.token_pool = None
@@ -647,6 +705,8 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
     lap("write dated csv")
     if timing is not None:
         import sys
+        if _startup:
+            print("since process start: " + ", ".join("%s %.3f s" % kv for kv in _startup), file=sys.stderr)
         print("analyze: " + ", ".join("%s %.3f s" % kv for kv in timing.items()), file=sys.stderr)
     if world > 1:
         dist.finalize()

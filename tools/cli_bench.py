@@ -51,7 +51,7 @@ def main():
         print(json.dumps({"works": a.works, "tokens_per_work": a.tokens, "write_inputs_s": round(t_write, 2),
                           "search_command_s": round(dt, 2), "works_per_s": round(a.works / dt, 1),
                           "rows": rows, "csv_files": len(csvs), "rc": out.returncode,
-                          "stderr_tail": out.stderr[-400:]}))
+                          "stderr_tail": out.stderr[-900:]}))
 
 
 if __name__ == "__main__":

@@ -88,6 +88,9 @@ if [ "$part" = part2 ]; then
     run ${R}_c4_n${n}_bench.json bench.py --steps 100 --window $n $B
     prof_stats ${R}_c4_n$n $ROOTDIR/bench.py --steps 40 --window $n $B
   done
+  echo "== the same without the per-n-gram records and the one-slot map (round 2's k_lsh_verify work)"
+  run ${R}_c4_ab.log tools/step_bench.py --window 8 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=4 FS_LSH_WMAP=0" "FS_LANES=4 FS_LSH_GRAMTAB=0 FS_LSH_WMAP=0"
+  run ${R}_c4_n10_ab.log tools/step_bench.py --window 10 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=4 FS_LSH_WMAP=0" "FS_LANES=4 FS_LSH_GRAMTAB=0 FS_LSH_WMAP=0"
   echo "== N = 2 rehearsal: bench.py --gpus 2 typed as is (both ranks on this GPU, gloo)"
   run ${R}_gloo2_rehearsal.json bench.py --gpus 2 --steps 30 --warmup 5 --backend gloo $B
   echo "== LSH pipeline on the synonym-rich table: 5000 works, kernel stats, SQ counters"
@@ -97,6 +100,7 @@ if [ "$part" = part2 ]; then
   cp $OUT/sq_lsh/sq_counters.json $OUT/${R}_lsh_scan_pmc_sq.json
   echo "== mixed-case companion by itself, kernel stats"
   run ${R}_tokstr.json tools/tokstr_bench.py 30
+  FS_STR_FAST=0 run ${R}_tokstr_wave_per_pair.json tools/tokstr_bench.py 30
   prof_stats ${R}_tokstr $ROOTDIR/tools/tokstr_bench.py 30
   echo "== streamed corpus (configs[4])"
   run ${R}_stream_c5.log tools/stream_bench.py
