@@ -203,11 +203,11 @@ def test_exception_tables_are_complete():
 def test_differential_against_spacy_where_installed():
     """Where spaCy is installed (not in this image) the restated rules are held against the
     real English tokenizer on prose with the features fan works and scripts carry: the rate of
-    texts whose token boundaries differ is printed and must stay below 2 %.  Every known answer
-    of this file is part of the sample, so a spaCy release that changed a rule shows up here."""
+    texts whose token boundaries differ is printed and must stay below 2 %.  The suite's known
+    answers are part of the sample, so a spaCy release that changed a rule shows up here."""
     spacy = pytest.importorskip("spacy")
     nlp = spacy.blank("en")
-    sample = [text for text, _ in KNOWN] + [text for text, _ in SPACY_SUITE] + [
+    sample = [text for text, _ in SPACY_SUITE] + [
         "\"I don't know,\" she said. \"Maybe it's over there--by the U.S. embassy?\"",
         "He'd've gone at 10:30p.m., e.g. after Mr. O'Neil's call (see http://example.com/a?b=1).",
         "LUKE: I'm not afraid.  YODA: You will be... you *will* be!",
