@@ -9,6 +9,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <thread>
 #include <cmath>
@@ -69,6 +73,7 @@ fs_index::~fs_index() {
   if (ev_scan1) (void)hipEventDestroy(ev_scan1);
   if (h_status) (void)hipHostFree(h_status);
   if (h_stage) (void)hipHostFree(h_stage);
+  if (host_pool) fs_host_pool_free(host_pool);
   for (int l = 0; l < FS_LANES; ++l)
     if (lanes[l].stream) (void)hipStreamDestroy(lanes[l].stream);
   for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
@@ -806,7 +811,26 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   }
   // (host rows of the exact pipeline leave the device as 8-byte records: a quarter of the
   // bytes over PCIe; w_rows is sized in fs_row either way)
-  if (sl.mode == FS_ROWS_HOST) { FS_TRY(ln.w_rows.reserve(sl.host_wire8 ? (sl.rcap + 3) / 4 : sl.rcap)); d_rows = ln.w_rows.p; }
+  static const bool zero_copy = !getenv("FS_HOST_ZEROCOPY") || atoi(getenv("FS_HOST_ZEROCOPY")) != 0;
+  sl.host_direct = false;
+  if (sl.mode == FS_ROWS_HOST && sl.host_wire8 && zero_copy) {
+    // the search's last kernel stores the 8-byte records straight into pinned host memory
+    // (2.4 MB per C2 batch over PCIe as the workgroups finish): no copy to queue and wait
+    // for behind the search
+    const size_t bytes = (size_t)sl.rcap * 8 + 4096;
+    if (ix->h_stage_bytes < bytes) {
+      if (ix->h_stage) (void)hipHostFree(ix->h_stage);
+      ix->h_stage = nullptr; ix->h_stage_bytes = 0; ix->d_stage = nullptr;
+      FS_HIP(hipHostMalloc(&ix->h_stage, bytes, hipHostMallocDefault));
+      ix->h_stage_bytes = bytes;
+    }
+    if (!ix->d_stage) FS_HIP(hipHostGetDevicePointer(&ix->d_stage, ix->h_stage, 0));
+    d_rows = reinterpret_cast<fs_row*>(ix->d_stage);
+    sl.host_direct = true;
+  } else if (sl.mode == FS_ROWS_HOST) {
+    FS_TRY(ln.w_rows.reserve(sl.host_wire8 ? (sl.rcap + 3) / 4 : sl.rcap));
+    d_rows = ln.w_rows.p;
+  }
   const int wire = sl.mode == FS_ROWS_DEVICE_PACKED ? 16 : (sl.mode == FS_ROWS_DEVICE_PACKED8 || sl.host_wire8) ? 8 : 0;
 
   // the status block is cleared by the chain's first kernel (k_reduce) and its final
@@ -942,11 +966,68 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
 }
 
 // 8-byte wire records {token position, orig_ix | k << 18 | lev << 22} (ascending positions) ->
+// A few threads that stay with the index (host rows are expanded once per search: starting
+// eight threads per call cost more than their work).  A worker that has finished keeps
+// polling for about 0.2 ms before it sleeps, so back-to-back searches do not pay a wake-up.
+struct fs_host_pool {
+  std::vector<std::thread> threads;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void(unsigned)> job;      // called with the worker's number 1 .. n
+  std::atomic<uint64_t> generation{0};
+  std::atomic<unsigned> pending{0};
+  bool stop = false;
+  void worker(unsigned id) {
+    uint64_t seen = 0;
+    for (;;) {
+      // poll, then sleep
+      bool got = false;
+      const auto t0 = std::chrono::steady_clock::now();
+      while (std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(200)) {
+        if (generation.load(std::memory_order_acquire) != seen) { got = true; break; }
+        __builtin_ia32_pause();
+      }
+      if (!got) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || generation.load(std::memory_order_acquire) != seen; });
+        if (stop) return;
+      }
+      seen = generation.load(std::memory_order_acquire);
+      job(id);
+      pending.fetch_sub(1, std::memory_order_acq_rel);
+    }
+  }
+  void start(unsigned n) {
+    for (unsigned i = 1; i <= n; ++i) threads.emplace_back([this, i] { worker(i); });
+  }
+  void run(const std::function<void(unsigned)>& f) {      // f(0) here, f(1..n) on the workers
+    job = f;
+    pending.store((unsigned)threads.size(), std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      generation.fetch_add(1, std::memory_order_acq_rel);
+    }
+    cv.notify_all();
+    f(0);
+    while (pending.load(std::memory_order_acquire)) __builtin_ia32_pause();
+  }
+  ~fs_host_pool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (std::thread& t : threads) t.join();
+  }
+};
+
+void fs_host_pool_free(fs_host_pool* p) { delete p; }
+
 // fs_row on the host, as fs_rows_unpack8 does on the device: the work of a record by a walk
 // along the work offsets, dist = the matched script window's distance to itself, comb =
 // dist * lev (one IEEE multiplication, as __dmul_rn).  A few threads, each over a slice.
-static void fs_expand_rows8_host(const uint32_t* rec, uint64_t n, const uint64_t* work_off, uint64_t n_works,
-                                 const double* selfdist, fs_row* rows) {
+static void fs_expand_rows8_host(fs_index* ix, const uint32_t* rec, uint64_t n, const uint64_t* work_off,
+                                 uint64_t n_works, const double* selfdist, fs_row* rows) {
   auto slice = [=](uint64_t lo, uint64_t hi) {
     if (lo >= hi) return;
     // the work of the slice's first record: last w with work_off[w] <= position
@@ -968,13 +1049,14 @@ static void fs_expand_rows8_host(const uint32_t* rec, uint64_t n, const uint64_t
       rows[i] = r;
     }
   };
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const uint64_t nt = std::min<uint64_t>(std::min<uint64_t>(8, hw), n / 16384 + 1);
-  if (nt <= 1) { slice(0, n); return; }
-  std::vector<std::thread> th;
-  for (uint64_t t = 1; t < nt; ++t) th.emplace_back(slice, n * t / nt, n * (t + 1) / nt);
-  slice(0, n / nt);
-  for (std::thread& t : th) t.join();
+  if (n < 32768) { slice(0, n); return; }
+  if (!ix->host_pool) {
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    ix->host_pool = new fs_host_pool;
+    ix->host_pool->start(std::min(12u, hw) - 1);
+  }
+  const uint64_t nt = ix->host_pool->threads.size() + 1;
+  ix->host_pool->run([&](unsigned t) { slice(n * t / nt, n * (t + 1) / nt); });
 }
 
 extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_rows, fs_stats* st) {
@@ -988,6 +1070,14 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
   if (!sl.c) { fs_set_error("the corpus of this search has been destroyed"); return FS_E_INVALID; }
   float scan_ms = 0, total_ms = 0;
   for (int attempt = 0;; ++attempt) {
+    if (sl.mode == FS_ROWS_HOST) {
+      // the caller waits for the rows right here: poll for a while (a blocking wait wakes up
+      // some 20 us after the event), then block
+      const auto t0 = std::chrono::steady_clock::now();
+      while (hipEventQuery(sl.ev_end) == hipErrorNotReady &&
+             std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(2))
+        __builtin_ia32_pause();
+    }
     FS_HIP(hipEventSynchronize(sl.ev_end));
     scan_ms = 0;
     if (sl.n_bm && sl.timed) FS_HIP(hipEventElapsedTime(&scan_ms, sl.ev_scan0, sl.ev_scan1));
@@ -1057,15 +1147,17 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
       // 8-byte records into pinned memory (a quarter of fs_row over PCIe, and no pageable
       // landing buffer in the copy's way), then fs_row on the host cores
       const size_t bytes = (size_t)hs.n_rows * 8;
-      if (ix->h_stage_bytes < bytes) {
-        if (ix->h_stage) (void)hipHostFree(ix->h_stage);
-        ix->h_stage = nullptr; ix->h_stage_bytes = 0;
-        FS_HIP(hipHostMalloc(&ix->h_stage, bytes + bytes / 4 + 4096, hipHostMallocDefault));
-        ix->h_stage_bytes = bytes + bytes / 4 + 4096;
+      if (!sl.host_direct) {
+        if (ix->h_stage_bytes < bytes) {
+          if (ix->h_stage) (void)hipHostFree(ix->h_stage);
+          ix->h_stage = nullptr; ix->h_stage_bytes = 0; ix->d_stage = nullptr;
+          FS_HIP(hipHostMalloc(&ix->h_stage, bytes + bytes / 4 + 4096, hipHostMallocDefault));
+          ix->h_stage_bytes = bytes + bytes / 4 + 4096;
+        }
+        FS_HIP(hipMemcpyAsync(ix->h_stage, ln.w_rows.p, bytes, hipMemcpyDeviceToHost, ln.stream));
+        FS_HIP(hipStreamSynchronize(ln.stream));
       }
-      FS_HIP(hipMemcpyAsync(ix->h_stage, ln.w_rows.p, bytes, hipMemcpyDeviceToHost, ln.stream));
-      FS_HIP(hipStreamSynchronize(ln.stream));
-      fs_expand_rows8_host(reinterpret_cast<const uint32_t*>(ix->h_stage), hs.n_rows, sl.c->h_work_off.data(),
+      fs_expand_rows8_host(ix, reinterpret_cast<const uint32_t*>(ix->h_stage), hs.n_rows, sl.c->h_work_off.data(),
                            sl.c->n_works, ix->h_selfdist.data(), sl.rows);
     } else {
       FS_HIP(hipMemcpyAsync(sl.rows, ln.w_rows.p, (size_t)hs.n_rows * sizeof(fs_row),

@@ -215,6 +215,8 @@ struct fs_index {
   std::vector<double> h_selfdist;   // host copy (host-row searches expand 8-byte records on the host)
   void* h_stage = nullptr;          // pinned landing buffer of those records
   size_t h_stage_bytes = 0;
+  void* d_stage = nullptr;          // the same buffer as the device sees it (records stored there by the search itself)
+  struct fs_host_pool* host_pool = nullptr;   // threads that expand host rows (fs_api.hip)
   DBuf<float> d_emb;
   DBuf<double> d_normals;
 
@@ -274,6 +276,7 @@ struct fs_index {
     int mode = 0;
     bool header = false;              // FS_ROWS_HEADER: rows = 32-byte header + records
     bool host_wire8 = false;          // FS_ROWS_HOST: 8-byte records cross PCIe, fs_row made on the host
+    bool host_direct = false;         //   ... stored into pinned host memory by the search's last kernel
     bool exact = false;
     uint32_t n_bm = 0, launches = 0;
     bool timed = false;               // this search's scan carries timing events
@@ -384,6 +387,7 @@ int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_r
 int fs_launch_blk_work(const uint64_t* work_off, uint32_t n_works, uint32_t n_blocks,
                        uint2* blk_work, uint4* blk4, hipStream_t s);
 
+void fs_host_pool_free(struct fs_host_pool* p);
 int fs_launch_levtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_strrec(fs_index* ix, fs_corpus* c, hipStream_t s);
 
