@@ -115,6 +115,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_ROWS_DISP_LDS")) sw->rows_disp_lds = e[0] != '0';
   if (const char* e = getenv("FS_STR_LEVTAB")) sw->str_levtab = e[0] != '0';
   if (const char* e = getenv("FS_STR_FAST")) sw->str_fast = e[0] != '0';
+  if (const char* e = getenv("FS_STR_FUSED")) sw->str_fused = e[0] != '0';
   sw->rows_waves = num("FS_ROWS_WAVES");
   sw->rows_blocks_per_cu = num("FS_ROWS_BLOCKS_PER_CU");
 }
@@ -677,11 +678,17 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
   // the batch table of k_scan_rows (ids + this string table's best records), on its own
   // flag: a corpus that is reused (fs_corpus_update_begin) may see its first batch without
   // string ids only after one with them
-  if (!c->has_oov && !c->has_str && ix->info.path == FS_MODE_EXACT && c->levtab_ready && !c->ctab_ready) {
+  // (a batch with string ids of its own gets the table too, for k_scan_rows' per-hit
+  // Levenshtein form: its entries mark the n-grams whose table distance is not known; the
+  // flavour is rebuilt when a reused corpus changes sides)
+  const bool ctab_wanted = !c->has_str || (c->strrec_ready && ix->sw.str_fused);
+  if (!c->has_oov && ctab_wanted && ix->info.path == FS_MODE_EXACT && c->levtab_ready &&
+      (!c->ctab_ready || c->ctab_str != c->has_str)) {
     ix->cur = &ix->lanes[0];
     FS_TRY(fs_launch_ctab(ix, c, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
     c->ctab_ready = true;
+    c->ctab_str = c->has_str;
   }
   if (!c->has_str && !c->has_oov && ix->info.path != FS_MODE_EXACT && !c->selflev_ready && ix->sw.lsh_selflev) {
     // LSH pipeline, string id == vector id: the Levenshtein distance of a match with the

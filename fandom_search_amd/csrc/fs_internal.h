@@ -178,6 +178,7 @@ struct fs_switches {
   bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
   bool lsh_prefilter = true;      // FS_LSH_PREFILTER=0: always the full key scan
   bool rows_disp_lds = true;      // FS_ROWS_DISP_LDS=0: k_scan_rows reads the displacement seeds from memory (as with > 16 K buckets)
+  bool str_fused = true;          // FS_STR_FUSED=0: batches with string ids take the chained kernels instead of k_scan_rows with per-hit Levenshtein
   bool str_fast = true;           // FS_STR_FAST=0: batches with string ids take k_matchlev + k_cbest (a wave per pair) instead of k_strbest
   bool str_levtab = true;         // FS_STR_LEVTAB=0: batches with string ids compute every Levenshtein distance per match
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
@@ -322,6 +323,7 @@ struct fs_corpus {
   DBuf<uint32_t> d_ctab;               // batch table of k_scan_rows: ids + this batch's best records (k_ctab)
   bool levtab_ready = false;
   bool ctab_ready = false;
+  bool ctab_str = false;               // ... built for a batch with string ids of its own (entries mark unknown table distances)
   DBuf<unsigned long long> d_gramtab_best;   // LSH pipeline: per script n-gram, what a window with its ids and
   DBuf<uint32_t> d_gramtab_cnt;        //   their strings gets (fs_best; kept matches + 1), k_lsh_gramtab
   bool gramtab_ready = false;

@@ -392,17 +392,6 @@ __global__ __launch_bounds__(256) void k_matchlev(GramIndexDev g, CorpusDev c,
   }
 }
 
-// ---- lane-per-pair Levenshtein (batches with string ids) ------------------------------
-// class of a code point in the script's alphabet (StrFast), 0: not a script character
-__device__ __forceinline__ uint32_t cls_of(const StrFast& F, uint32_t cp) {
-  uint32_t lo = 0, hi = F.n_cls;                 // clsmap[lo - 1] < cp <= clsmap[hi - 1] or hi = n
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (F.clsmap[mid] < cp) lo = mid + 1; else hi = mid;
-  }
-  return lo < F.n_cls && F.clsmap[lo] == cp ? lo + 1 : 0u;
-}
-
 // the string table as classes: {length (capped at 255), classes of code points 0 .. 14}
 __global__ void k_strrec(const uint32_t* __restrict__ chars, const uint64_t* __restrict__ coff,
                          uint32_t n_str, StrFast F, uint4* __restrict__ rec) {
@@ -416,67 +405,6 @@ __global__ void k_strrec(const uint32_t* __restrict__ chars, const uint64_t* __r
     w[(j + 1) >> 2] |= cl << (8 * ((j + 1) & 3));
   }
   rec[i] = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// Levenshtein.distance(match_str, fan_context) of search.py:189-190 by ONE lane: Myers'
-// bit-vector recurrence over the script window's text (the pattern, at most 64 code points,
-// as 7 bit planes of character classes: the match mask of a fan character is seven xnor/and
-// pairs, no table and no load inside the loop), the fan text '[' + ', '.join(words) + ']'
-// streamed class by class from the string records.  Words of more than 15 code points read
-// their text; windows of more than 64 code points take the scratch DP of lev_device.
-__device__ inline uint32_t lev_lane(const GramIndexDev& g, const CorpusDev& c, const StrFast& F,
-                                    uint32_t s, const uint32_t* __restrict__ sid, fs_status* st) {
-  const uint4* P4 = reinterpret_cast<const uint4*>(F.pat + 8 * (size_t)s);
-  const uint4 t0 = P4[0], t1 = P4[1], t2 = P4[2], t3 = P4[3];
-  const uint32_t la = t3.z;
-  if (la > 64) return lev_device(g, s, sid, c.chars, c.coff, c.n_str, st);
-  const uint32_t plo[7] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x};
-  const uint32_t phi[7] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y};
-  const unsigned long long last = 1ull << (la - 1);
-  unsigned long long pv = ~0ull, mv = 0ull;
-  uint32_t score = la;
-  auto step = [&](uint32_t cl) {
-    uint32_t elo = 0xFFFFFFFFu, ehi = 0xFFFFFFFFu;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-      const uint32_t m = 0u - ((cl >> b) & 1u);
-      elo &= ~(plo[b] ^ m);
-      ehi &= ~(phi[b] ^ m);
-    }
-    const unsigned long long eq = (unsigned long long)elo | ((unsigned long long)ehi << 32);
-    const unsigned long long xv = eq | mv;
-    const unsigned long long xh = (((eq & pv) + pv) ^ pv) | eq;
-    unsigned long long ph = mv | ~(xh | pv);
-    unsigned long long mh = pv & xh;
-    score += (ph & last) ? 1u : 0u;
-    score -= (mh & last) ? 1u : 0u;
-    ph = (ph << 1) | 1ull;
-    mh <<= 1;
-    pv = mh | ~(xv | ph);
-    mv = ph & xv;
-  };
-  step(F.punct & 0xFFu);                                   // '['
-  uint4 nxt = F.strrec[sid[0]];
-  for (int k = 0; k < g.n; ++k) {
-    uint4 cur = nxt;
-    const uint32_t id = sid[k];
-    if (k + 1 < g.n) nxt = F.strrec[sid[k + 1]];           // (requested before this word is walked)
-    if (k) { step((F.punct >> 8) & 0xFFu); step((F.punct >> 16) & 0xFFu); }   // ', '
-    const uint32_t len = cur.x & 0xFFu;
-    if (len <= 15) {
-      for (uint32_t j = 0; j < len; ++j) {
-        cur.x = __builtin_amdgcn_alignbit(cur.y, cur.x, 8);
-        cur.y = __builtin_amdgcn_alignbit(cur.z, cur.y, 8);
-        cur.z = __builtin_amdgcn_alignbit(cur.w, cur.z, 8);
-        cur.w >>= 8;
-        step(cur.x & 0xFFu);
-      }
-    } else {
-      for (uint64_t a = c.coff[id]; a < c.coff[id + 1]; ++a) step(cls_of(F, c.chars[a]));
-    }
-  }
-  step(F.punct >> 24);                                     // ']'
-  return score;
 }
 
 // Batches with string ids: the record every hit offers (best_of_ranks over its own Levenshtein

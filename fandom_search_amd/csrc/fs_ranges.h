@@ -71,12 +71,19 @@ struct RangeOut {
 // lanes; FS_NONE = none).  F = first position whose hit status is not known after this
 // round; a = first token of the range.  A candidate lies inside the token buffer (the
 // scan masks windows that run past it; a halo window is in front of the range).
-template <int N>
+// STR (batches whose fan tokens carry string ids of their own, search.py:151 vs :166): a hit
+// whose tokens do not all have string id == vector id cannot take the table's record; its
+// lane works out the Levenshtein distance of every kept occurrence (lev_lane, fs_device.h)
+// and the first minimum of dist * lev right here.  `sf`: the character classes;
+// `give_up`: the host word that sends the search through the chained kernels (set when a
+// text is too long for this path: they report it).
+template <int N, bool STR = false>
 __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexDev& g,
                                             uint32_t disp_off, RangeLds& S,
                                             uint32_t p, uint32_t F, uint32_t a,
                                             uint32_t range_id, const RangeOut& out,
-                                            RangeState& R) {
+                                            RangeState& R, const StrFast* sf = nullptr,
+                                            uint32_t* give_up = nullptr) {
   const int lane = threadIdx.x & 63;
   if (F < R.E) F = R.E;
   // 1. verification, one candidate per lane, two levels of loads: ids + work of the
@@ -88,7 +95,17 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   double comb = 0.0;
   if (p != FS_NONE) {
     uint32_t f[8];
+    uint32_t sid[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint4 bw;
+    if constexpr (STR) {
+      // (the string ids with the same requests as the vector ids; the buffer is padded)
+      const uint4 t0 = *reinterpret_cast<const uint4*>(c.str + p);
+      sid[0] = t0.x; sid[1] = t0.y; sid[2] = t0.z; sid[3] = t0.w;
+      if constexpr (N > 4) {
+        const uint4 t1 = *reinterpret_cast<const uint4*>(c.str + p + 4);
+        sid[4] = t1.x; sid[5] = t1.y; sid[6] = t1.z; sid[7] = t1.w;
+      }
+    }
     {
       const uint4 q0 = *reinterpret_cast<const uint4*>(c.tok + p);   // unaligned 16-byte loads;
       f[0] = q0.x; f[1] = q0.y; f[2] = q0.z; f[3] = q0.w;            // the buffer is padded
@@ -155,6 +172,26 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       while (we <= p) { ++w; wbase = we; we = (uint32_t)c.work_off[w + 1]; }
     }
     hit = same & (p + N <= we);
+    if constexpr (STR) {
+      uint32_t differ_s = 0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) differ_s |= sid[k] ^ f[k];
+      if (hit && (differ_s != 0 || blev == FS_NONE)) {
+        const uint32_t gram = q0.x - 1;
+        fs_status tmp;
+        tmp.bad_string = 0; tmp.lev_overflow = 0;
+        // (the distinct occurrences: `kept` counts a window once per table without UniqueFilter)
+        const uint32_t ranks = g.gcnt[gram];
+        for (uint32_t r = 0; r < ranks; ++r) {
+          const uint32_t sw = g.gpos[(size_t)gram * g.nn + r];
+          const uint32_t lev = lev_lane(g, c, *sf, sw, c.str + p, &tmp);
+          const double cb = __dmul_rn(g.selfdist[sw], (double)lev);
+          if (r == 0 || cb < comb) { bs = sw; blev = lev; comb = cb; }
+        }
+        if (tmp.bad_string | tmp.lev_overflow)
+          __hip_atomic_store(give_up, FS_WAIT_GAVE_UP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   }
   // 2. hits behind the carried ones, in position order
   const uint64_t hb = __ballot(hit);

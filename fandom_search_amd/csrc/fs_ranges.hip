@@ -145,8 +145,12 @@ __global__ __launch_bounds__(kThreads) void k_compact(
 }
 
 // per-corpus copy of the best record of every script n-gram, indexed by table slot
+// `levtab` (batches with string ids of their own: the table may lack the string of a vector
+// id): an n-gram with a rank whose distance is not known gets lev = FS_NONE, which sends its
+// hits to the per-hit computation
 __global__ void k_ctab(const uint4* __restrict__ proto, uint32_t slots,
-                       const fs_best* __restrict__ gbest, uint4* __restrict__ ctab) {
+                       const fs_best* __restrict__ gbest, uint4* __restrict__ ctab,
+                       const uint32_t* __restrict__ levtab, const uint32_t* __restrict__ gcnt, int nn) {
   for (uint32_t s = blockIdx.x * blockDim.x + threadIdx.x; s < slots; s += gridDim.x * blockDim.x) {
     const uint4 q0 = proto[4 * (size_t)s], q1 = proto[4 * (size_t)s + 1];
     uint4 q2 = proto[4 * (size_t)s + 2], q3 = make_uint4(0, 0, 0, 0);
@@ -154,6 +158,9 @@ __global__ void k_ctab(const uint4* __restrict__ proto, uint32_t slots,
       const fs_best b = gbest[q0.x - 1];
       const uint64_t db = (uint64_t)__double_as_longlong(b.dist), cb = (uint64_t)__double_as_longlong(b.comb);
       q2.z = b.s; q2.w = b.lev;
+      if (levtab)
+        for (uint32_t r = 0; r < gcnt[q0.x - 1]; ++r)
+          if (levtab[(size_t)(q0.x - 1) * nn + r] == FS_NONE) q2.w = FS_NONE;
       q3 = make_uint4((uint32_t)db, (uint32_t)(db >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
     }
     uint4* e = ctab + 4 * (size_t)s;
@@ -171,7 +178,9 @@ int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   const uint32_t blocks = (uint32_t)std::min<size_t>((slots + 255) / 256, 1024);
   hipLaunchKernelGGL(k_ctab, dim3(blocks), dim3(256), 0, s,
                      reinterpret_cast<const uint4*>(ix->d_cproto.p), (uint32_t)slots, c->d_gbest.p,
-                     reinterpret_cast<uint4*>(c->d_ctab.p));
+                     reinterpret_cast<uint4*>(c->d_ctab.p),
+                     c->has_str ? (const uint32_t*)c->d_levtab.p : (const uint32_t*)nullptr,
+                     (const uint32_t*)ix->d_gcnt.p, (int)ix->cfg.nearest_n);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

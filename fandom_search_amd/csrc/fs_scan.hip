@@ -442,12 +442,13 @@ struct alignas(16) FusedLds {         // per wave
   uint16_t rk[kRecQueue];             // candidates (halo included) in front of the record's
 };
 
-template <int N, int K, bool NT, bool LW14>
+template <int N, int K, bool NT, bool LW14, bool STR = false>
 __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     uint32_t n_sub, fsdev::RangeOut out,
                                                     fsdev::RowSync sy, fsdev::RowFinal fin,
                                                     uint32_t disp_lds, uint32_t diag,
-                                                    unsigned long long* __restrict__ dbg) {
+                                                    unsigned long long* __restrict__ dbg,
+                                                    StrFast strf) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
   // FS_DIAG & 2: eight words per wave range {entry, filter in LDS, scan done, rounds done,
@@ -634,7 +635,8 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
           if (nx < F) F = nx;
         }
         if (!(diag & 1))
-          range_round<N>(c, g, disp_off, S, (uint32_t)lane < take ? p : FS_NONE, F, a, range_id, out, R);
+          range_round<N, STR>(c, g, disp_off, S, (uint32_t)lane < take ? p : FS_NONE, F, a, range_id, out, R,
+                              &strf, reinterpret_cast<uint32_t*>(fin.host_st + 1));
         r0 += take;
         ++n_rounds;
       } while (r0 < total);
@@ -848,9 +850,16 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   constexpr int K = fs_sub_k(N);
   auto kern = nt ? (lw14 ? k_scan_rows<N, 0, true, true> : k_scan_rows<N, 0, true, false>)
                  : (lw14 ? k_scan_rows<N, 0, false, true> : k_scan_rows<N, 0, false, false>);
-  if (K != 0 && ix->sw.scan_sub && ix->d_sfilter.p)
+  const bool sub = K != 0 && ix->sw.scan_sub && ix->d_sfilter.p;
+  if (sub)
     kern = nt ? (lw14 ? k_scan_rows<N, K, true, true> : k_scan_rows<N, K, true, false>)
               : (lw14 ? k_scan_rows<N, K, false, true> : k_scan_rows<N, K, false, false>);
+  StrFast strf{nullptr, nullptr, 0, 0, nullptr};
+  if (c->has_str) {                    // (fs_scan_rows_shape has checked that the path applies)
+    strf = StrFast{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, c->d_strrec.p};
+    if (sub) kern = lw14 ? k_scan_rows<N, K, false, true, true> : k_scan_rows<N, K, false, false, true>;
+    else kern = lw14 ? k_scan_rows<N, 0, false, true, true> : k_scan_rows<N, 0, false, false, true>;
+  }
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   {
     // the kernel addresses its filter from LDS address 0: it must not own static LDS
@@ -866,7 +875,7 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   }
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), n_sub, out,
-                        sy, fin, disp_lds, (uint32_t)ix->sw.diag, dbg);
+                        sy, fin, disp_lds, (uint32_t)ix->sw.diag, dbg, strf);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -881,7 +890,10 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
 uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* blocks) {
   const uint32_t n = ix->cfg.window_size;
   *blocks = 0;
-  if (!ix->sw.scan_rows || n < 2 || n > 8 || c->has_str || !c->d_ctab.p || !ix->ctab_ok) return 0;
+  if (!ix->sw.scan_rows || n < 2 || n > 8 || !c->d_ctab.p || !c->ctab_ready || !ix->ctab_ok) return 0;
+  // (string ids of their own: the per-hit Levenshtein form, when the character classes exist)
+  if (c->has_str && !(c->ctab_str && c->strrec_ready && ix->strfast_ok && ix->sw.str_fused && ix->sw.str_fast)) return 0;
+  if (!c->has_str && c->ctab_str) return 0;
   // a switch that asks for one of the other scan kernels or paths
   const fs_switches& sw = ix->sw;
   if (sw.scan_simple || sw.scan_tpl == 4 || !sw.scan_direct || sw.scan_capw) return 0;

@@ -128,11 +128,12 @@ def test_separate_string_ids(synth_base, monkeypatch, plain):
 
 
 def test_string_ids_lane_levenshtein(synth_base, monkeypatch):
-    """k_strbest (a lane per hit: Myers' recurrence over character classes of the script's
-    alphabet) against the oracle where its special cases meet: fan words of more than 15 code
+    """lev_lane (a lane per hit: Myers' recurrence over character classes of the script's
+    alphabet; inside k_scan_rows' rounds, and in k_strbest of the chained kernels) against the
+    oracle where its special cases meet: fan words of more than 15 code
     points, code points outside the script's alphabet and outside ASCII, script windows of
     more than 64 code points (scratch DP), n-grams that occur several times in the script
-    with different text (several ranks per hit); FS_STR_FAST=0 (a wave per pair): same bytes."""
+    with different text (several ranks per hit); all three forms give the same bytes."""
     from fandom_search_amd.engine import ScriptIndex
     from fandom_search_amd.vocab import pack_strings
     words, emb = synth_base["words"], synth_base["emb"]
@@ -162,11 +163,18 @@ def test_string_ids_lane_levenshtein(synth_base, monkeypatch):
     want, ost = oi.search(tok, off, chars, coff, tok_str=tok_str)
     util.assert_rows_equal(got, want)
     assert st.matches == ost.matches and len(set(got["lev"].tolist())) > 6
-    monkeypatch.setenv("FS_STR_FAST", "0")
-    ix2 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
-    got2, st2 = ix2.search(ix2.corpus(tok, off, chars, coff, tok_str=tok_str))
-    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
-    ix2.close()
+    c0 = ix.corpus(tok, off, chars, coff, tok_str=tok_str)
+    assert ix.kernel_name(c0) == "k_scan_rows<6,4>"        # per-hit Levenshtein inside the rounds
+    # the chained kernels with k_strbest (a lane per hit), and with the wave-per-pair kernels
+    for env in ("FS_STR_FUSED", "FS_STR_FAST"):
+        monkeypatch.setenv(env, "0")
+        ix2 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+        c2 = ix2.corpus(tok, off, chars, coff, tok_str=tok_str)
+        assert ix2.kernel_name(c2) == "k_scan8<6>"
+        got2, st2 = ix2.search(c2)
+        assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+        ix2.close()
+        monkeypatch.delenv(env)
 
 
 def test_packed_wire_rows_round_trip(synth_base):
@@ -234,6 +242,11 @@ def test_long_tokens_and_levenshtein_limit(synth_base, monkeypatch):
             got2, _ = ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
             util.assert_rows_equal(got2, want2)
             assert int(got2["lev"].max()) > 512
+            # ... up to what the 8-byte wire records hold (a distance below 1024)
+            chars3, coff3 = pack_strings([w * 70 for w in words])
+            with pytest.raises(_lib.FsError) as e:
+                ix.search(ix.corpus(tok, off, chars3, coff3, tok_str=tok))
+            assert e.value.code == abi.FS_E_UNSUPPORTED
         else:
             with pytest.raises(_lib.FsError) as e:
                 ix.search(ix.corpus(tok, off, chars2, coff2, tok_str=tok))
