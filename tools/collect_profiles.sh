@@ -100,8 +100,14 @@ if [ "$part" = part2 ]; then
   cp $OUT/sq_lsh/sq_counters.json $OUT/${R}_lsh_scan_pmc_sq.json
   echo "== mixed-case companion by itself, kernel stats"
   run ${R}_tokstr.json tools/tokstr_bench.py 30
+  FS_LANES=1 run ${R}_tokstr_lanes1.json tools/tokstr_bench.py 30
+  FS_STR_FUSED=0 run ${R}_tokstr_chain.json tools/tokstr_bench.py 30
   FS_STR_FAST=0 run ${R}_tokstr_wave_per_pair.json tools/tokstr_bench.py 30
   prof_stats ${R}_tokstr $ROOTDIR/tools/tokstr_bench.py 30
+  FS_STR_FUSED=0 prof_stats ${R}_tokstr_chain $ROOTDIR/tools/tokstr_bench.py 30
+  echo "== host rows: wall time of the synchronous call against the GPU time inside it"
+  run ${R}_host_rows.log tools/host_rows_time.py
+  FS_HOST_ZEROCOPY=0 run ${R}_host_rows_copy.log tools/host_rows_time.py
   echo "== streamed corpus (configs[4])"
   run ${R}_stream_c5.log tools/stream_bench.py
   echo "== the reference's command end to end"
