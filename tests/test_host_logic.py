@@ -198,3 +198,37 @@ def test_vector_table_with_shared_and_zero_rows(tmp_path, monkeypatch):
     assert not np.any(v.vector(int(sid[4])))
     with pytest.raises(ValueError):
         vocab_mod.Vocab(["a", "b"], vec, rows=[0, 9])
+
+
+def test_batch_csv_from_a_pool_worker_equals_the_inline_form(tmp_path, monkeypatch):
+    """ao3.py search hands every batch CSV to a forked worker (search._write_batch: the worker
+    parses the script's columns itself and gets the numeric rows as bytes); the file must be
+    what join_records + write_records give in the parent, also from a real worker process."""
+    import multiprocessing
+    monkeypatch.setenv("FANDOM_SEARCH_SYNTHETIC_VOCAB", "1")
+    words = synth.vocab_words()
+    script = synth.script_tokens(200)
+    spath = tmp_path / "script.txt"
+    spath.write_text(synth.script_markup(script, words), encoding="utf8")
+    orig = search.load_markup_script(str(spath))[1:]
+    rng = np.random.default_rng(3)
+    n = 300
+    rows = np.zeros(n, dtype=abi.ROW_DTYPE)
+    rows["work"] = np.sort(rng.integers(0, 4, n))
+    rows["fan_ix"] = np.arange(n)
+    rows["orig_ix"] = rng.integers(0, len(orig), n)
+    rows["lev"] = rng.integers(0, 30, n)
+    rows["dist"] = rng.random(n) * 1e-15 - 2e-16
+    rows["comb"] = rows["dist"] * rows["lev"]
+    filenames = ["fan/%d.txt" % i for i in range(4)]
+    fan_words = [words[int(i)] if i % 7 else "Café," for i in rng.integers(0, len(words), n)]
+    inline = tmp_path / "inline.csv"
+    search.write_records(search.join_records(
+        filenames, rows, fan_words, tuple(r[0] for r in orig), tuple(r[1] for r in orig),
+        tuple(r[3] for r in orig), tuple(r[2] for r in orig)), str(inline))
+    direct = tmp_path / "direct.csv"
+    assert search._write_batch(str(spath), str(direct), filenames, rows.tobytes(), fan_words) == n
+    with multiprocessing.get_context("fork").Pool(1) as pool:
+        forked = tmp_path / "forked.csv"
+        assert pool.apply(search._write_batch, (str(spath), str(forked), filenames, rows.tobytes(), fan_words)) == n
+    assert inline.read_bytes() == direct.read_bytes() == forked.read_bytes() and inline.stat().st_size > 0
