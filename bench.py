@@ -10,7 +10,8 @@ verification, Levenshtein records, per-word dedupe, records left in HBM).
           ids, more than the 256 MiB Infinity Cache), so every step reads its ids
           from HBM; `--rotate 1` re-scans one resident batch (bound: infinity-cache).
   N > 1   weak scaling: every rank (one GPU each) holds its own c2 batches, the match
-          records of all ranks gathered to rank 0 over RCCL inside the step
+          records of all ranks gathered over RCCL inside the step, to rank (step mod N):
+          every pair of GPUs has its own xGMI link (--gather-root 0: always to rank 0)
           (fandom_search_amd.dist.RowGather: 8-byte wire records, count and records in
           one collective, gather of step i beside the search of step i+1).
           `--scaling strong`: configs[2] ("c3": 100k works x 5k tokens) split N ways,
@@ -65,6 +66,8 @@ def parse(argv=None):
                     help="c2 (default at N=1), c3 (default at N>1, split over the ranks), c3shard, c1")
     ap.add_argument("--scaling", default="weak",
                     help="N > 1: weak (one c2-sized shard per rank) or strong (c3 split N ways)")
+    ap.add_argument("--gather-root", default="rotate",
+                    help="N > 1: rotate (step i's records to rank i mod N, default) or 0 (always rank 0)")
     ap.add_argument("--reps", type=int, default=0,
                     help="timed regions of --steps steps (default: 7 when steps <= 64, else 3); "
                          "the median is reported")
@@ -413,7 +416,11 @@ def main():
                 probe = torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
     del probe
     NB = inflight + 1
-    gather = RowGather(ix, cap, rec_bytes, n_buffers=NB, rehearsal=rehearsal)
+    # the receiver of a step's records goes round (step i to rank i mod N): every pair of GPUs
+    # has its own xGMI link, and the seven links that end at one GPU carry less than eight
+    # searches produce (--gather-root 0: always rank 0)
+    any_root = world > 1 and args.gather_root == "rotate"
+    gather = RowGather(ix, cap, rec_bytes, n_buffers=NB, rehearsal=rehearsal, any_root=any_root)
     cap = gather.cap
     if packed == 8:
         gather.set_offsets(offs[0])
@@ -433,7 +440,7 @@ def main():
         if st.scan_ms > 0 and last["timing"]:
             scan_ms.append(st.scan_ms)
         last["st"], last["rows"] = st, n
-        gather.start(b)
+        gather.start(b, i % world if any_root else 0)
         last["buf"] = b
 
     def step(i):
@@ -500,11 +507,16 @@ def main():
         crc = torch.tensor([zlib.crc32(own.tobytes()), len(own)], dtype=torch.int64, device=gather.cdev)
         crcs = torch.zeros(2 * world, dtype=torch.int64, device=gather.cdev)
         dist.all_gather_into_tensor(crcs, crc)
-        if rank == 0:
+        holder = gather.roots[last["buf"]]          # the rank that received the last step's records
+        ok = 1
+        if rank == holder:
             parts, cnts = gather.rows(last["buf"])
             crcs = crcs.cpu().tolist()
-            gather_verified = all(cnts[r] == crcs[2 * r + 1] and
-                                  zlib.crc32(parts[r].tobytes()) == crcs[2 * r] for r in range(world))
+            ok = int(all(cnts[r] == crcs[2 * r + 1] and
+                         zlib.crc32(parts[r].tobytes()) == crcs[2 * r] for r in range(world)))
+        flag = torch.tensor([ok], dtype=torch.int64, device=gather.cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_verified = bool(int(flag.item()))
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -598,8 +610,9 @@ def main():
                        "pipeline": "%d searches in flight (fs_search_corpus_begin/_end, %d record "
                                    "buffers) on %s lane(s) = stream(s) of the library"
                                    % (inflight, NB, os.environ.get("FS_LANES", "1")),
-                       "gather": ("%s gather to rank 0, overlapped" % ("gloo (rehearsal)" if rehearsal
-                                                                        else "rccl")) if world > 1 else "none",
+                       "gather": ("%s gather to rank %s, overlapped" % ("gloo (rehearsal)" if rehearsal else "rccl",
+                                                                    "(step mod N)" if any_root else "0"))
+                       if world > 1 else "none",
                        "path": ("exact-ngram-scan (synthetic table only: the exact-n-gram proof holds, "
                                 "c_max %.3f); tables with near-synonyms take the LSH pipeline, see "
                                 "companions.lsh_clustered_table" % ix.info["c_max"]) if exact else "lsh"},

@@ -105,7 +105,7 @@ class RowGather(object):
     This is what stands where the reference concatenates the lists its pool workers
     return (/root/reference/search.py:381-386)."""
 
-    def __init__(self, index, cap, rec_bytes, n_buffers=1, group=None, rehearsal=False):
+    def __init__(self, index, cap, rec_bytes, n_buffers=1, group=None, rehearsal=False, any_root=False):
         import torch
         import torch.distributed as dist
         self.index, self.rec_bytes, self.group, self.rehearsal = index, int(rec_bytes), group, rehearsal
@@ -121,8 +121,13 @@ class RowGather(object):
         self.stride = HDR + self.cap * self.rec_bytes
         self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device=self.dev)
                      for _ in range(n_buffers)]
+        # any_root: start(b, root) may name any rank as the receiver (the bench lets the root go
+        # round, step i to rank i mod N: every pair of GPUs has its own xGMI link, and seven
+        # links ending at one GPU carry less than the ranks' searches produce)
+        self.any_root = bool(any_root)
+        self.roots = [0] * n_buffers
         self.landing = None
-        if self.world > 1 and self.rank == 0:
+        if self.world > 1 and (self.rank == 0 or self.any_root):
             self.landing = [torch.zeros(self.world * self.stride, dtype=torch.uint8, device=self.cdev)
                             for _ in range(n_buffers)]
         self.pending = [None] * n_buffers
@@ -150,16 +155,19 @@ class RowGather(object):
         mine = mine.to(self.cdev)
         out = torch.zeros(self.world * (self.off_len + 1), dtype=torch.int64, device=self.cdev)
         dist.all_gather_into_tensor(out, mine, group=self.group)
-        self.all_off = out.to(self.dev) if self.rank == 0 else None
+        self.all_off = out.to(self.dev) if (self.rank == 0 or self.any_root) else None
 
-    def start(self, b):
-        """Queue the gather of buffer b (after the search that fills it has ended)."""
+    def start(self, b, root=0):
+        """Queue the gather of buffer b to rank `root` (after the search that fills it has ended)."""
         import torch.distributed as dist
         if self.world == 1:
             return
+        if root != 0 and not self.any_root:
+            raise ValueError("RowGather(any_root=True) for a root other than rank 0")
+        self.roots[b] = root
         send = self.bufs[b].to(self.cdev)           # no copy unless the collective runs elsewhere
-        recv = list(self.landing[b].chunk(self.world)) if self.rank == 0 else None
-        self.pending[b] = dist.gather(send, recv, dst=0, group=self.group, async_op=True)
+        recv = list(self.landing[b].chunk(self.world)) if self.rank == root else None
+        self.pending[b] = dist.gather(send, recv, dst=root, group=self.group, async_op=True)
 
     def wait(self, b):
         """Buffer b may be written again / read on rank 0 after this.  Work.wait() on
@@ -174,14 +182,14 @@ class RowGather(object):
             torch.cuda.current_stream().synchronize()
 
     def counts(self, b):
-        """Record count per rank of the last completed gather of buffer b (rank 0)."""
+        """Record count per rank of the last completed gather of buffer b (on its root)."""
         import torch
         src = self.landing[b] if self.world > 1 else self.bufs[b]
         return src.view(self.world, self.stride)[:, :8].contiguous().view(torch.int64) \
             .flatten().cpu().tolist()
 
     def rows(self, b):
-        """fs_row records of all ranks in rank order (numpy, rank 0): the 8- or 16-byte
+        """fs_row records of all ranks in rank order (numpy, on the gather's root): the 8- or 16-byte
         wire records expanded on the GPU, work indices local to each rank's batch.
         Returns (rows, per-rank counts)."""
         import torch
@@ -300,7 +308,7 @@ class RankFailed(RuntimeError):
     """Another rank failed in its share of a batch; this rank stops too."""
 
 
-def search_sharded(filenames, weights, searcher, group=None):
+def search_sharded(filenames, weights, searcher, group=None, root=0):
     """Search one batch of works across all ranks.
 
     `searcher.search_shard(sub_filenames) -> Shard` (AnnIndexSearch: records left in HBM)
@@ -309,9 +317,12 @@ def search_sharded(filenames, weights, searcher, group=None):
     TWO collectives per batch: an 8-byte all_reduce(MAX) of {payload size, failure flag}
     -- RCCL has no gatherv, so the ranks must agree on the padded size, and the same
     word tells every rank when one of them failed, so that nobody waits in a gather for
-    a rank that has raised -- and ONE padded gather of the payloads to rank 0.  Returns
-    on rank 0 (fs_row records with work indices into `filenames`, fan words), elsewhere
-    (None, None)."""
+    a rank that has raised -- and ONE padded gather of the payloads to rank `root`.
+    Returns on that rank (fs_row records with work indices into `filenames`, fan words),
+    elsewhere (None, None).  analyze() lets the root go round (batch i to rank i mod N): on
+    xGMI every pair of GPUs has its own link, so the records of consecutive batches arrive
+    over different links instead of all over the seven that end at rank 0, and the ranks
+    take turns at joining and writing a batch's CSV."""
     import torch
     import torch.distributed as dist
     live = dist.is_initialized()
@@ -348,10 +359,10 @@ def search_sharded(filenames, weights, searcher, group=None):
     else:
         send = torch.zeros(size, dtype=torch.uint8, device=cdev)
         send[:payload.numel()] = payload
-        recv = [torch.empty_like(send) for _ in range(world)] if rank == 0 else None
-        dist.gather(send, recv, dst=0, group=group)
+        recv = [torch.empty_like(send) for _ in range(world)] if rank == root else None
+        dist.gather(send, recv, dst=root, group=group)
         blobs = recv
-    if rank != 0:
+    if rank != root:
         return None, None
     engine = getattr(searcher, "engine", None)
     all_rows, all_words = [], []

@@ -653,9 +653,12 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
             print('Processing cluster {} ({}-{})'.format(i,
                                                          chunk_size * i,
                                                          chunk_size * (i + 1)))
+        # the rank that receives, joins and writes this batch: they take turns (every pair of
+        # GPUs has its own xGMI link; FANDOM_SEARCH_GATHER_ROOT=0: always rank 0)
+        root = i % world if os.environ.get("FANDOM_SEARCH_GATHER_ROOT", "rotate") != "0" else 0
         if world > 1:
             weights = [os.path.getsize(f) for f in fan_cluster]
-            rows, words = dist.search_sharded(fan_cluster, weights, ann_index)
+            rows, words = dist.search_sharded(fan_cluster, weights, ann_index, root=root)
         else:
             rows, words = ann_index.search_rows(fan_cluster)
         lap("tokens + search")
@@ -666,7 +669,8 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
                   'table (out-of-vocabulary 3-hot vectors, search.py:79-83); check '
                   'FANDOM_SEARCH_VECTORS'.format('rank {}: '.format(rank) if world > 1 else '', oov),
                   file=sys.stderr)
-        if rank != 0:
+        n_batches = i + 1
+        if rank != root:
             continue
         if pool is not None and pool.pool is not None and searcher is None:
             # the batch file is written by a worker of the token pool (they are forked, and
@@ -689,6 +693,9 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
     for job in writes:
         job.get()                                   # (raises what the writer raised)
     lap("wait for the writers")
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()                             # every rank's batch files are on disk
 
     if pool is not None:
         ann_index.token_pool = None
