@@ -17,16 +17,21 @@
 //        table 0, 1, ... in order, UniqueFilter by script window, cosine
 //        distance (canonical), stable NearestFilter(N), threshold
 //
-// Two kernels use them:
+// The kernels that use them:
 //   k_lsh_scan     one block per 256-window sub-tile: keys for all 256 windows
-//                  (threads = projection columns, coalesced 8-byte reads of A
-//                  rows), then the (window, bucket candidate) pairs of the sub-tile
-//                  are dealt out evenly over the threads and each asks "within the
-//                  threshold?"; the per-window answers go out in the scan's bitmap
-//                  format, so k_expand / k_rows of fs_post.hip are shared
-//   k_lsh_verify   one wave per flagged window: keys again, the full
-//                  neighbours list, Levenshtein per kept match (one lane each),
-//                  best rank -> per-candidate record for k_rows
+//                  (threads = projection columns, coalesced reads of A rows), then
+//                  the (window, bucket candidate) pairs of the sub-tile are dealt out
+//                  evenly over the threads and each asks "within the threshold?"; the
+//                  per-window answers go out in the scan's bitmap format, so k_expand /
+//                  k_rows of fs_post.hip are shared
+//   k_lsh_sift     one lane per flagged window, where one slot at most may differ and no
+//                  OOV id is involved: wildcard-key Bloom test, the n-gram's record of
+//                  this string table (k_lsh_gramtab), the exact one-slot map; what is
+//                  left goes onto the pending list
+//   k_lsh_verify   one wave per pending window (lsh_window): keys again, the full
+//                  neighbours list, Levenshtein per kept match, best rank ->
+//                  per-candidate record for k_rows
+//   k_lsh_gramtab  lsh_window once per script n-gram and string table
 //
 // A candidate's exact distance is skipped only when a sound upper bound on its
 // cosine is already below 1 - threshold: too few identical slots for the table's

@@ -20,9 +20,10 @@
 //                            its record offset, then one thread per record: the
 //                            first minimum of dist*lev over all hits covering
 //                            the word (each hit offers its best rank)
-// plus the Levenshtein kernels (per (n-gram, rank) once per corpus, or per
-// (candidate, rank) when fan tokens carry their own strings), the wire-record
-// unpack, the `format` histogram and corpus-build helpers.
+// plus the Levenshtein kernels (k_levtab: per (n-gram, rank) once per string table;
+// k_strbest: a lane per hit when fan tokens carry their own strings, k_strrec its string
+// records; k_matchlev + k_cbest: the wave-per-pair form behind FS_STR_FAST=0), the
+// wire-record unpack, the `format` histogram and corpus-build helpers.
 //
 // Reference semantics reproduced here (file:line in /root/reference):
 //   search.py:182-184  keep candidates with distance < threshold: in the exact

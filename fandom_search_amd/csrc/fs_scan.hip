@@ -5,8 +5,8 @@
 // (/root/reference/search.py:176-178): every fan window's n vector ids are
 // tested against the script's n-gram set.
 //
-// k_scan_rows (n = 2..8, string id == vector id: the benchmark's case) is the whole
-// search in one kernel, token ids in, output records out; the comment in front of it and
+// k_scan_rows (n = 2..8; the STR variant for batches whose fan tokens carry string ids of
+// their own) is the whole search in one kernel, token ids in, output records out; the comment in front of it and
 // fs_ranges.h describe it.  Per wave and 512-token sub-tile its scan does
 //   * two coalesced global_load_dwordx4 per lane: tokens [8L, 8L+8), requested a pair of
 //     sub-tiles ahead
@@ -16,8 +16,8 @@
 //     Bloom test of the whole n-gram); a lane's eight answers are one byte
 // and candidates are verified, turned into records and put into place by the same wave.
 //
-// ONE chained fallback remains for batches with string ids, window sizes k_scan_rows does
-// not take and a given-up in-launch wait: k_scan8 (n = 2..8: same loop, Bloom test, candidate
+// ONE chained fallback remains for window sizes k_scan_rows does not take, scripts whose
+// alphabet is too large for the per-hit Levenshtein form, and a given-up in-launch wait: k_scan8 (n = 2..8: same loop, Bloom test, candidate
 // records or byte bitmap out) or k_scan_simple (any n); counting, expansion and verification
 // are then left to fs_post.hip.  k_scan_near is the integer prefilter of the LSH pipeline
 // (script 3-grams, at most one differing slot).
