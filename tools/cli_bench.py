@@ -27,13 +27,39 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--works", type=int, default=5000)
     ap.add_argument("--tokens", type=int, default=2000)
+    ap.add_argument("--prose", action="store_true",
+                    help="write the works as prose: sentences of 4-18 words with a capital first letter and "
+                         "closing punctuation, commas, quotes and contractions (the tokenizer's rule path, "
+                         "string ids next to vector ids, out-of-vocabulary tokens: the LSH pipeline)")
     a = ap.parse_args()
     words = synth.vocab_words()
     script = synth.script_tokens(20000)
     with tempfile.TemporaryDirectory() as tmp:
         t0 = time.time()
         fan = os.path.join(tmp, "fan")
-        synth.write_corpus(fan, a.works, a.tokens, script, words)
+        names = synth.write_corpus(fan, a.works, a.tokens, script, words)
+        if a.prose:
+            import random
+            rnd = random.Random(5)
+            for path in names:
+                with open(path, encoding="utf8") as fh:
+                    toks = fh.read().split(" ")
+                out, i = [], 0
+                while i < len(toks):
+                    sent = toks[i:i + rnd.randint(4, 18)]
+                    i += len(sent)
+                    sent[0] = sent[0].capitalize()
+                    if rnd.random() < 0.3:
+                        sent[rnd.randrange(len(sent))] += ","
+                    if rnd.random() < 0.15:
+                        sent.insert(rnd.randrange(len(sent)), "don't")
+                    sent[-1] += rnd.choice([".", "?", "!"])
+                    if rnd.random() < 0.2:
+                        sent[0] = '"' + sent[0]
+                        sent[-1] += '"'
+                    out += sent
+                with open(path, "w", encoding="utf8") as fh:
+                    fh.write(" ".join(out))
         spath = os.path.join(tmp, "script.txt")
         with open(spath, "w", encoding="utf8") as fh:
             fh.write(synth.script_markup(script, words))
@@ -48,7 +74,7 @@ def main():
             if "batch" not in f:
                 with open(os.path.join(tmp, f)) as fh:
                     rows = sum(1 for _ in fh) - 1
-        print(json.dumps({"works": a.works, "tokens_per_work": a.tokens, "write_inputs_s": round(t_write, 2),
+        print(json.dumps({"works": a.works, "tokens_per_work": a.tokens, "prose": bool(a.prose), "write_inputs_s": round(t_write, 2),
                           "search_command_s": round(dt, 2), "works_per_s": round(a.works / dt, 1),
                           "rows": rows, "csv_files": len(csvs), "rc": out.returncode,
                           "stderr_tail": out.stderr[-900:]}))

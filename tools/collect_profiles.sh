@@ -113,5 +113,7 @@ if [ "$part" = part2 ]; then
   echo "== the reference's command end to end"
   run ${R}_cli_bench.json tools/cli_bench.py
   run ${R}_cli_bench_20000.json tools/cli_bench.py --works 20000
+  echo "== ... on prose (capitals, punctuation, contractions: the tokenizer's rule path, OOV tokens, LSH pipeline)"
+  run ${R}_cli_bench_prose_20000.json tools/cli_bench.py --works 20000 --prose
   ls -la $OUT
 fi
