@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Randomised cross-check of the LSH pipeline's integer prefilters (3-gram prefilter,
-wildcard keys, identical-id shortcuts, per-window Levenshtein table) against the same
-pipeline with all of them switched off (both on the GPU; the unfiltered pipeline is held
+"""Randomised cross-check of the LSH pipeline's integer prefilters and shortcuts (3-gram
+prefilter, wildcard keys, identical-id shortcuts, per-window Levenshtein table, per-n-gram
+records, exact one-slot map) against the same pipeline with all of them switched off (both on the GPU; the unfiltered pipeline is held
 against the oracle by tests/): window sizes 8..12 on the synthetic table, planted spans with
 zero, one or two substituted tokens, script words spelled differently from the table.
 
@@ -17,7 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SWITCHES = ("FS_LSH_PREFILTER", "FS_LSH_WILD", "FS_LSH_SELFLEV")
+SWITCHES = ("FS_LSH_PREFILTER", "FS_LSH_WILD", "FS_LSH_SELFLEV", "FS_LSH_GRAMTAB", "FS_LSH_WMAP")
 
 
 def main():
