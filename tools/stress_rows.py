@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--strings", action="store_true",
                     help="batches with string ids of their own (a random share of the tokens capitalised): "
-                         "the per-gram Levenshtein table of k_matchlev against FS_STR_LEVTAB=0")
+                         "k_scan_rows' per-hit Levenshtein form against the chained wave-per-pair kernels")
     a = ap.parse_args()
     import torch
     from fandom_search_amd import abi, synth
@@ -73,7 +73,10 @@ def main():
         for rows_kernel in (1, 0):
             os.environ["FS_SCAN_ROWS"] = str(rows_kernel)
             if a.strings:
+                # 1: k_scan_rows with the per-hit Levenshtein in the hit's lane and the table's
+                # records; 0: the chained kernels, a wave per (hit, rank) pair, no table
                 os.environ["FS_STR_LEVTAB"] = str(rows_kernel)
+                os.environ["FS_STR_FAST"] = str(rows_kernel)
             os.environ["FS_LANES"] = str(lanes)
             if caprow and rows_kernel:
                 os.environ["FS_RANGES_CAPROW"] = str(caprow)
