@@ -76,6 +76,9 @@ if [ "$part" = part1 ]; then
   run ${R}_c2_scan_rows_timeline.json tools/scan_timeline.py
   echo "== c3shard: one GPU's share of configs[2] (12.5k works x 5k tokens, 250 MB)"
   run ${R}_c3shard_bench.json bench.py --workload c3shard --steps 100 $B
+  echo "== larger batches in one launch: the N = 4 / N = 2 shares of configs[2] (500 MB / 1 GB of ids)"
+  run ${R}_c3_quarter_bench.json bench.py --workload c3 --works 25000 --steps 40 --warmup 4 $B
+  run ${R}_c3_half_bench.json bench.py --workload c3 --works 50000 --steps 40 --warmup 4 $B
   echo "== lanes A/B in one process"
   run ${R}_step_ab.log tools/step_bench.py --inflight 4 "FS_LANES=1" "FS_LANES=1 FS_DIAG=16" "FS_LANES=2" "FS_LANES=4" \
       "FS_LANES=4 FS_ROWS_BLOCKS_PER_CU=1" "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=0 FS_LANES=4"
