@@ -10,8 +10,9 @@ verification, Levenshtein records, per-word dedupe, records left in HBM).
           ids, more than the 256 MiB Infinity Cache), so every step reads its ids
           from HBM; `--rotate 1` re-scans one resident batch (bound: infinity-cache).
   N > 1   weak scaling: every rank (one GPU each) holds its own c2 batches, the match
-          records of all ranks gathered over RCCL inside the step, to rank (step mod N):
-          every pair of GPUs has its own xGMI link (--gather-root 0: always to rank 0)
+          records of all ranks delivered over RCCL inside the step to rank (step mod N):
+          one all_to_all per N steps, every pair of GPUs having its own xGMI link
+          (--gather-root step: a gather per step; --gather-root 0: always to rank 0)
           (fandom_search_amd.dist.RowGather: 8-byte wire records, count and records in
           one collective, gather of step i beside the search of step i+1).
           `--scaling strong`: configs[2] ("c3": 100k works x 5k tokens) split N ways,
@@ -67,7 +68,8 @@ def parse(argv=None):
     ap.add_argument("--scaling", default="weak",
                     help="N > 1: weak (one c2-sized shard per rank) or strong (c3 split N ways)")
     ap.add_argument("--gather-root", default="rotate",
-                    help="N > 1: rotate (step i's records to rank i mod N, default) or 0 (always rank 0)")
+                    help="N > 1: rotate (step i's records to rank i mod N, one all_to_all per N steps; default), "
+                         "step (the same with one gather per step) or 0 (a gather per step, always to rank 0)")
     ap.add_argument("--reps", type=int, default=0,
                     help="timed regions of --steps steps (default: 7 when steps <= 64, else 3); "
                          "the median is reported")
@@ -419,8 +421,13 @@ def main():
     # the receiver of a step's records goes round (step i to rank i mod N): every pair of GPUs
     # has its own xGMI link, and the seven links that end at one GPU carry less than eight
     # searches produce (--gather-root 0: always rank 0)
-    any_root = world > 1 and args.gather_root == "rotate"
-    gather = RowGather(ix, cap, rec_bytes, n_buffers=NB, rehearsal=rehearsal, any_root=any_root)
+    any_root = world > 1 and args.gather_root in ("rotate", "step")
+    # ... and one all_to_all per N steps carries them (every link of every rank at once) instead
+    # of one gather per step (one link per rank and step); --gather-root step: a gather per step
+    exchange = world > 1 and args.gather_root == "rotate"
+    gather = RowGather(ix, cap, rec_bytes, n_buffers=max(NB, 3 * world) if exchange else NB,
+                       rehearsal=rehearsal, any_root=any_root, exchange=exchange)
+    NB = gather.n_buffers
     cap = gather.cap
     if packed == 8:
         gather.set_offsets(offs[0])
@@ -456,6 +463,7 @@ def main():
     def drain():
         for i in sorted(tickets):
             complete(i)
+        gather.flush()
         for b in range(NB):
             gather.wait(b)
 
@@ -610,8 +618,9 @@ def main():
                        "pipeline": "%d searches in flight (fs_search_corpus_begin/_end, %d record "
                                    "buffers) on %s lane(s) = stream(s) of the library"
                                    % (inflight, NB, os.environ.get("FS_LANES", "1")),
-                       "gather": ("%s gather to rank %s, overlapped" % ("gloo (rehearsal)" if rehearsal else "rccl",
-                                                                    "(step mod N)" if any_root else "0"))
+                       "gather": ("%s %s to rank %s, overlapped" % ("gloo (rehearsal)" if rehearsal else "rccl",
+                                                                "all_to_all per N steps," if exchange else "gather",
+                                                                "(step mod N)" if any_root else "0"))
                        if world > 1 else "none",
                        "path": ("exact-ngram-scan (synthetic table only: the exact-n-gram proof holds, "
                                 "c_max %.3f); tables with near-synonyms take the LSH pipeline, see "

@@ -105,7 +105,8 @@ class RowGather(object):
     This is what stands where the reference concatenates the lists its pool workers
     return (/root/reference/search.py:381-386)."""
 
-    def __init__(self, index, cap, rec_bytes, n_buffers=1, group=None, rehearsal=False, any_root=False):
+    def __init__(self, index, cap, rec_bytes, n_buffers=1, group=None, rehearsal=False, any_root=False,
+                 exchange=False):
         import torch
         import torch.distributed as dist
         self.index, self.rec_bytes, self.group, self.rehearsal = index, int(rec_bytes), group, rehearsal
@@ -119,15 +120,39 @@ class RowGather(object):
             cap = int(t.item())
         self.cap = int(cap)
         self.stride = HDR + self.cap * self.rec_bytes
-        self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device=self.dev)
-                     for _ in range(n_buffers)]
+        # exchange: the buffers come in groups of `world` (buffer b belongs to group b // world and
+        # is meant for rank b % world); when a group is full ONE all_to_all_single sends every
+        # buffer to its rank.  What arrives is what `world` gathers with the root going round
+        # deliver, but every rank uses all its links at once instead of one link per step
+        # (2.4 MB per C2 step: 40 us over one xGMI link, 5 us per step over seven).
+        self.exchange = bool(exchange) and self.world > 1
+        if self.exchange:
+            any_root = True
+            n_groups = max(2, -(-n_buffers // self.world))
+            n_buffers = n_groups * self.world
+            self.gsend = [torch.zeros(self.world * self.stride, dtype=torch.uint8, device=self.dev)
+                          for _ in range(n_groups)]
+            self.bufs = [self.gsend[b // self.world][(b % self.world) * self.stride:
+                                                     (b % self.world + 1) * self.stride]
+                         for b in range(n_buffers)]
+            self.gfilled = [0] * n_groups
+            self.gpending = [None] * n_groups
+        else:
+            self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device=self.dev)
+                         for _ in range(n_buffers)]
+        self.n_buffers = n_buffers
         # any_root: start(b, root) may name any rank as the receiver (the bench lets the root go
         # round, step i to rank i mod N: every pair of GPUs has its own xGMI link, and seven
         # links ending at one GPU carry less than the ranks' searches produce)
         self.any_root = bool(any_root)
         self.roots = [0] * n_buffers
         self.landing = None
-        if self.world > 1 and (self.rank == 0 or self.any_root):
+        if self.exchange:
+            # (the buffers of a group share the group's landing area: a rank receives one step of it)
+            self.glanding = [torch.zeros(self.world * self.stride, dtype=torch.uint8, device=self.cdev)
+                             for _ in range(len(self.gsend))]
+            self.landing = [self.glanding[b // self.world] for b in range(n_buffers)]
+        elif self.world > 1 and (self.rank == 0 or self.any_root):
             self.landing = [torch.zeros(self.world * self.stride, dtype=torch.uint8, device=self.cdev)
                             for _ in range(n_buffers)]
         self.pending = [None] * n_buffers
@@ -162,6 +187,13 @@ class RowGather(object):
         import torch.distributed as dist
         if self.world == 1:
             return
+        if self.exchange:
+            g = b // self.world
+            self.roots[b] = b % self.world
+            self.gfilled[g] += 1
+            if b % self.world == self.world - 1:      # the group's last buffer: steps come in order
+                self.flush_group(g)
+            return
         if root != 0 and not self.any_root:
             raise ValueError("RowGather(any_root=True) for a root other than rank 0")
         self.roots[b] = root
@@ -169,11 +201,34 @@ class RowGather(object):
         recv = list(self.landing[b].chunk(self.world)) if self.rank == root else None
         self.pending[b] = dist.gather(send, recv, dst=root, group=self.group, async_op=True)
 
+    def flush_group(self, g):
+        """exchange: send group g now (also when it is not full: the end of a run)."""
+        import torch.distributed as dist
+        if not self.exchange or self.gfilled[g] == 0:
+            return
+        self.gfilled[g] = 0
+        send = self.gsend[g].to(self.cdev)
+        self.gpending[g] = dist.all_to_all_single(self.glanding[g], send, group=self.group, async_op=True)
+
+    def flush(self):
+        """exchange: send every group that holds unsent buffers."""
+        if self.exchange:
+            for g in range(len(self.gsend)):
+                self.flush_group(g)
+
     def wait(self, b):
-        """Buffer b may be written again / read on rank 0 after this.  Work.wait() on
+        """Buffer b may be written again / read on its root after this.  Work.wait() on
         RCCL only orders torch's current stream, and the library writes the buffers
         from its own streams, so the host also waits for that stream."""
         import torch
+        if self.exchange:
+            g = b // self.world
+            if self.gpending[g] is not None:
+                self.gpending[g].wait()
+                self.gpending[g] = None
+                if self.cdev == "cuda":
+                    torch.cuda.current_stream().synchronize()
+            return
         if self.pending[b] is None:
             return
         self.pending[b].wait()

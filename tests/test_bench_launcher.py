@@ -46,12 +46,16 @@ def test_defaults_follow_the_contract():
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_bench_starts_its_own_ranks(tmp_path):
+@pytest.mark.parametrize("gather_root", ["rotate", "step", "0"])
+def test_bench_starts_its_own_ranks(tmp_path, gather_root):
     """`python bench.py --gpus 2 ...` exactly as the driver types it (no launcher): two ranks
-    (gloo between them, both on this one GPU), one JSON line from rank 0, the gather checked."""
+    (gloo between them, both on this one GPU), one JSON line from rank 0, the records every
+    rank sent checked on the rank that received the last step -- for the all_to_all per N
+    steps (default), a gather per step with the root going round, and a gather to rank 0."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
-                        "--works", "200", "--steps", "3", "--warmup", "1", "--reps", "2"],
+                        "--works", "200", "--steps", "3", "--warmup", "1", "--reps", "2",
+                        "--gather-root", gather_root],
                        env=env, cwd=str(tmp_path), timeout=800, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
