@@ -78,6 +78,9 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
                        synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL
     assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near<%d>" % n
+    # (what k_lsh_sift leaves to the wave-per-window kernel: the windows one slot away from a
+    # script n-gram that may be within the threshold, a small share of the candidates)
+    assert 0 < st.lsh_pending < st.candidates
     assert int((got["dist"] > 0.01).sum()) > 0           # inexact neighbours are records
     assert len(set(got["lev"].tolist())) > 1
     # the windows with a script n-gram's ids take the n-gram's record of this string table

@@ -254,6 +254,34 @@ def test_long_tokens_and_levenshtein_limit(synth_base, monkeypatch):
         ix.close()
 
 
+def test_host_rows_stored_by_the_search_or_copied(synth_base, monkeypatch):
+    """Host rows of the exact pipeline: 8-byte records stored into pinned host memory by the
+    search's last kernel (default), copied after the search (FS_HOST_ZEROCOPY=0) or copied as
+    32-byte rows (FS_HOST_WIRE8=0): the same bytes, also with several lanes (k_compact stores
+    them) and into a caller's buffer that is too small at first."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(4000)
+    tok, off = util.ragged_corpus([900] * 40 + [0, 5, 2500], script)
+    cfg = abi.make_config()
+    swords = [words[int(t)] for t in script]
+    want = None
+    for env in ({}, {"FS_HOST_ZEROCOPY": "0"}, {"FS_HOST_WIRE8": "0"}, {"FS_LANES": "4"},
+                {"FS_LANES": "4", "FS_HOST_ZEROCOPY": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ix = ScriptIndex(script, swords, emb, synth.lsh_normals(6), cfg=cfg)
+        c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        got, st = ix.search(c, cap=16)                   # (grows to what the search reports)
+        again, _ = ix.search(c, reuse=True)
+        assert len(got) > 500 and got.tobytes() == again.tobytes()
+        want = got.tobytes() if want is None else want
+        assert got.tobytes() == want, env
+        ix.close()
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 def test_searches_in_flight(synth_base):
     """fs_search_corpus_begin/_end: several searches queued before the first is
     collected give the rows of the synchronous call."""
