@@ -9,14 +9,15 @@ verification, Levenshtein records, per-word dedupe, records left in HBM).
           6-gram).  The timed steps rotate over four DISTINCT c2 batches (320 MB of
           ids, more than the 256 MiB Infinity Cache), so every step reads its ids
           from HBM; `--rotate 1` re-scans one resident batch (bound: infinity-cache).
-  N > 1   weak scaling: every rank (one GPU each) holds its own c2 batches, the match
+  N > 1   BASELINE.json configs[2] ("c3": 100k works x 5k tokens) split N ways (strong
+          scaling: rank r holds works [r W/N, (r+1) W/N), one GPU each), the match
           records of all ranks delivered over RCCL inside the step to rank (step mod N):
           one all_to_all per N steps, every pair of GPUs having its own xGMI link
           (--gather-root step: a gather per step; --gather-root 0: always to rank 0)
           (fandom_search_amd.dist.RowGather: 8-byte wire records, count and records in
-          one collective, gather of step i beside the search of step i+1).
-          `--scaling strong`: configs[2] ("c3": 100k works x 5k tokens) split N ways,
-          rank r holding works [r W/N, (r+1) W/N).
+          one collective, gather of step i beside the search of step i+1).  The N = 1
+          line carries the same corpus as companions.c3_full (eight 12.5k-work shards
+          on one GPU), so 1 -> 8 is one corpus.  `--scaling weak`: one c2 batch per rank.
           `python bench.py --gpus N` typed as is starts the N ranks itself
           (torch.distributed.run as a child process); under a launcher (WORLD_SIZE set)
           it is one of the ranks.
@@ -65,8 +66,8 @@ def parse(argv=None):
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="",
                     help="c2 (default at N=1), c3 (default at N>1, split over the ranks), c3shard, c1")
-    ap.add_argument("--scaling", default="weak",
-                    help="N > 1: weak (one c2-sized shard per rank) or strong (c3 split N ways)")
+    ap.add_argument("--scaling", default="",
+                    help="N > 1: strong (default: configs[2] = c3 split N ways) or weak (one c2 batch per rank)")
     ap.add_argument("--gather-root", default="rotate",
                     help="N > 1: rotate (step i's records to rank i mod N, one all_to_all per N steps; default), "
                          "step (the same with one gather per step) or 0 (a gather per step, always to rank 0)")
@@ -102,18 +103,22 @@ def launcher_command(args, argv, env, port=None):
     """`python bench.py --gpus N` typed without a launcher: the command that starts the N
     ranks (None when this process is a rank already, or N == 1).  The parent never touches
     the GPU; the ranks run as a child process whose exit code it returns."""
-    if args.gpus <= 1 or "WORLD_SIZE" in env:
+    if args.gpus <= 1:
+        return None
+    # under a launcher: RANK / LOCAL_RANK are set next to WORLD_SIZE (an image that merely
+    # exports WORLD_SIZE=1 has not launched anything)
+    if "WORLD_SIZE" in env and ("RANK" in env or "LOCAL_RANK" in env or env["WORLD_SIZE"] != "1"):
         return None
     if port is None:
         port = args.master_port
-    if not port:
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
-            "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus)]
+    if port:
+        head += ["--master-addr", "127.0.0.1", "--master-port", str(port)]
+    else:
+        # no port named: the launcher's own rendezvous picks a free one (nothing to collide on
+        # between concurrent runs of one box)
+        head += ["--standalone", "--local-addr", "127.0.0.1"]
+    return head + [os.path.abspath(__file__)] + list(argv)
 
 
 def host_cores():
@@ -287,9 +292,9 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     dt = time.perf_counter() - t0
     out["tok_str"] = {"value": n_works * reps / dt, "unit": "fanworks/s", "ms_per_step": dt / reps * 1e3,
                       "rows_per_step": int(len(rows)), "kernel": ix.kernel_name(cs),
-                      "note": "8 % of the fan tokens capitalised: string ids next to vector "
-                              "ids, Levenshtein per (match, rank) inside the timed region "
-                              "(k_scan8 + k_verify_direct + k_matchlev + k_cbest + k_hitrows + k_rows)"}
+                      "note": "8 % of the fan tokens capitalised: string ids next to vector ids; a hit "
+                              "whose tokens are not all written as their vector row's word takes its "
+                              "Levenshtein distances inside the same kernel (`kernel`), two searches in flight"}
     cs.close()
     # (4) the LSH pipeline on a table with near-synonyms (c_max ~ 1: the exact-n-gram proof
     # fails, every real embedding table is of this kind)
@@ -328,6 +333,90 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     return out
 
 
+def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
+    """BASELINE.json configs[2] (100k works x 5k tokens) on ONE GPU, as the eight 12.5k-work
+    shards an 8-GPU run deals out (the script is configs[1]'s, so the index is the same):
+      c3shard  a step = one shard (250 MB of ids), rotating over the eight distinct ones
+      c3_full  a step = the whole corpus, eight searches (the N = 1 point of the 1 -> 8 curve)"""
+    import torch
+    from fandom_search_amd import _lib, abi, synth
+    conf = synth.CONFIGS["c3"]
+    per, tpw = conf["n_works"] // shards, conf["tokens_per_work"]
+    t0 = time.perf_counter()
+    corpora, rows = [], []
+    for k in range(shards):
+        t, o = synth.corpus_tokens_parallel(per, tpw, script, first_work=k * per)
+        corpora.append(ix.corpus(t, o, chars, coff))
+    t_gen = time.perf_counter() - t0
+    n_tok = corpora[0].n_tok
+    cap = n_tok // 64
+    probe = torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda")
+    for c in corpora:
+        while True:
+            try:
+                rows.append(ix.search_device(c, probe.data_ptr() + 32, cap)[0])
+                break
+            except _lib.FsError as e:
+                if e.code != abi.FS_E_CAPACITY:
+                    raise
+                cap = int(e.required * 1.05) + 64
+                probe = torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda")
+    del probe
+    bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(inflight + 1)]
+
+    def run(n_steps):
+        tickets = []
+        for i in range(n_steps):
+            tickets.append(ix.search_begin(corpora[i % shards], bufs[i % len(bufs)].data_ptr(), cap, header=True))
+            if len(tickets) >= inflight:
+                ix.search_end(tickets.pop(0))
+        while tickets:
+            ix.search_end(tickets.pop(0))
+
+    ix.set_scan_timing(0)
+    run(shards)
+    samples = []
+    for _ in range(passes):                       # one pass = the whole corpus
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(shards)
+        torch.cuda.synchronize()
+        samples.append(time.perf_counter() - t0)
+    dt = float(np.median(samples))
+    ix.set_scan_timing(1)
+    alone = [ix.search_end(ix.search_begin(corpora[i % shards], bufs[0].data_ptr(), cap, header=True))[1].scan_ms
+             for i in range(10)]
+    alone_ms = float(np.mean(alone[2:]))
+    shard_bytes = 4.0 * n_tok + 32.0 * float(np.mean(rows))
+    total_bytes = 4.0 * n_tok * shards + 32.0 * float(np.sum(rows))
+    kernel = ix.kernel_name(corpora[0])
+    out = {
+        "c3shard": {"value": per * shards / dt, "unit": "fanworks/s", "ms_per_step": dt / shards * 1e3,
+                    "tokens_per_s": per * tpw * shards / dt, "works": per, "tokens_per_work": tpw,
+                    "rows_per_step": int(round(float(np.mean(rows)))),
+                    "roofline": {"bound": "hbm", "kernel": kernel, "launch_ms_alone": alone_ms,
+                                 "frac_alone": shard_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                 "step": shard_bytes / (dt / shards) / 1e9 / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": shard_bytes, "peak": HBM_PEAK_GBS,
+                                 "unit": "GB/s"},
+                    "note": "one GPU's share of configs[2] per step (12.5k works x 5k tokens, 250 MB of ids), "
+                            "eight distinct shards in rotation (2 GB), %d searches in flight, records left in HBM"
+                            % inflight},
+        "c3_full": {"value": conf["n_works"] / dt, "unit": "fanworks/s", "ms_per_step": dt * 1e3,
+                    "tokens_per_s": conf["n_works"] * tpw / dt, "works": conf["n_works"],
+                    "tokens_per_work": tpw, "launches": shards, "rows": int(np.sum(rows)),
+                    "samples_ms": [round(x * 1e3, 4) for x in samples],
+                    "roofline_step": total_bytes / dt / 1e9 / HBM_PEAK_GBS,
+                    "corpus_s": round(t_gen, 1),
+                    "note": "configs[2] whole on one GPU: a step = the eight shards of an 8-GPU run searched "
+                            "one behind the other (the N = 1 point of the strong-scaling curve `--gpus N` "
+                            "measures; same works, same shards)"},
+    }
+    for c in corpora:
+        c.close()
+    return out
+
+
 def main():
     args = parse()
     cmd = launcher_command(args, sys.argv[1:], os.environ)
@@ -363,7 +452,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload -------------------------------------------------------------------
-    strong = world > 1 and args.scaling == "strong"
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    if scaling not in ("strong", "weak"):
+        raise SystemExit("--scaling strong|weak")
+    strong = world > 1 and scaling == "strong"
     wl = args.workload or ("c3" if strong else "c2")
     conf = dict(synth.CONFIGS[wl])
     tpw = conf["tokens_per_work"]
@@ -386,8 +478,10 @@ def main():
     swords = [words[int(t)] for t in script]
     chars, coff = vocab.pack_strings(words)
     toks, offs = [], []
+    gen_procs = max(2, host_cores() // max(1, world))
     for r in range(rotate):          # distinct works per batch (and per rank)
-        t, o = synth.corpus_tokens(n_works, tpw, script, first_work=first_work + r * total_works)
+        t, o = synth.corpus_tokens_parallel(n_works, tpw, script, first_work=first_work + r * total_works,
+                                            procs=gen_procs)
         toks.append(t)
         offs.append(o)
 
@@ -425,8 +519,11 @@ def main():
     # ... and one all_to_all per N steps carries them (every link of every rank at once) instead
     # of one gather per step (one link per rank and step); --gather-root step: a gather per step
     exchange = world > 1 and args.gather_root == "rotate"
-    gather = RowGather(ix, cap, rec_bytes, n_buffers=max(NB, 3 * world) if exchange else NB,
-                       rehearsal=rehearsal, any_root=any_root, exchange=exchange)
+    # (exchange: a buffer is free again when its group's all_to_all has been queued and waited
+    # for, i.e. world + inflight - 1 buffers are in use at once, in whole groups)
+    gather = RowGather(ix, cap, rec_bytes,
+                       n_buffers=max(NB, 3 * world, -(-(world + inflight - 1) // world) * world) if exchange else NB,
+                       rehearsal=rehearsal, any_root=any_root, exchange=exchange, inflight=inflight)
     NB = gather.n_buffers
     cap = gather.cap
     if packed == 8:
@@ -447,7 +544,7 @@ def main():
         if st.scan_ms > 0 and last["timing"]:
             scan_ms.append(st.scan_ms)
         last["st"], last["rows"] = st, n
-        gather.start(b, i % world if any_root else 0)
+        gather.start(b, (b % world if exchange else i % world) if any_root else 0)
         last["buf"] = b
 
     def step(i):
@@ -542,6 +639,24 @@ def main():
                                                        packed=packed, header=True))[1].scan_ms)
         alone_ms = float(np.mean(alone[2:]))
         kernel = ix.kernel_name(corpora[0])
+        # ... and a whole search alone: an index with one lane puts the records into place
+        # inside the same launch (no k_compact behind it), one search at a time.  This is the
+        # figure `frac` is made of: what rocprofv3 reports for the kernel under --lanes 1
+        # (profiles/*_lanes1_kernel_stats.csv)
+        search_alone_ms, kernel1 = alone_ms, kernel
+        if int(os.environ.get("FS_LANES", "1")) > 1:
+            os.environ["FS_LANES"] = "1"
+            ix1 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+            os.environ["FS_LANES"] = str(max(1, args.lanes))
+            c1s = [ix1.corpus(t, o, chars, coff) for t, o in zip(toks, offs)]
+            ix1.set_scan_timing(1)
+            one = []
+            for i in range(12):
+                one.append(ix1.search_end(ix1.search_begin(c1s[i % rotate], gather.bufs[0].data_ptr(), cap,
+                                                           packed=packed, header=True))[1].scan_ms)
+            search_alone_ms = float(np.mean(one[2:]))
+            kernel1 = ix1.kernel_name(c1s[0])
+            ix1.close()
         rows_step = float(np.mean(rows_per_corpus))
         exact = st.path == abi.FS_MODE_EXACT
         fused = kernel.startswith("k_scan_rows")
@@ -560,7 +675,7 @@ def main():
             algo_bytes = float(st.windows_processed) * args.window * 212 * 4
             note = "n rows of 212 float32 projections (848 B) per window (cache-served gather)"
         step_bytes = 4.0 * n_tok + 32.0 * rows_step
-        achieved = algo_bytes / (kernel_ms * 1e-3) / 1e9
+        achieved = algo_bytes / (search_alone_ms * 1e-3) / 1e9
         resident = rotate * shard_bytes <= MALL_BYTES
         traffic, traffic_src = None, None
         build = _lib.source_hash()
@@ -630,19 +745,29 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "build": build,
-                         "avg_launch_ms": kernel_ms, "timed_launches": len(scan_ms),
+                         "search_ms_alone": search_alone_ms, "kernel_alone": kernel1,
                          "launch_ms_alone": alone_ms,
                          "frac_alone": algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "overlapped_launch_ms": kernel_ms, "timed_launches": len(scan_ms),
+                         "frac_overlapped": algo_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "step_bytes": step_bytes,
-                         "note": "%d searches in flight share the GPU: avg_launch_ms is the kernel's "
-                                 "dispatch-to-completion time inside the timed region, launch_ms_alone "
-                                 "the same kernel with nothing else running; step = (4 B x tokens + "
-                                 "32 B x records) / ms_per_step" % inflight},
+                         "note": "achieved / frac: a whole search by itself (search_ms_alone: an index with one "
+                                 "lane, the one launch of `kernel_alone` takes ids in and puts the records into "
+                                 "place, HIP events on its dispatch, nothing else on the GPU).  launch_ms_alone: "
+                                 "the kernel in the shape the timed region launches it in (%d lanes: k_compact "
+                                 "puts the records into place behind it), also by itself; overlapped_launch_ms: "
+                                 "its dispatch-to-completion time inside the timed region, where %d searches "
+                                 "share the GPU; step = (4 B x tokens + 32 B x records) / ms_per_step"
+                                 % (int(os.environ.get("FS_LANES", "1")), inflight)},
         }
         if world == 1 and not args.no_companions:
             out["companions"] = companions(ix, corpora, toks, offs, chars, coff, words, script,
                                            swords, emb, args.window, n_works)
+            if wl == "c2" and args.window == 6 and not args.works:
+                for c in corpora:
+                    c.close()
+                out["companions"].update(c3_companions(ix, script, chars, coff, inflight))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, script, swords, words, emb, normals, tpw,
                                                chars, coff, args.cpu_seconds)

@@ -1031,7 +1031,7 @@ struct fs_host_pool {
 void fs_host_pool_free(fs_host_pool* p) { delete p; }
 
 // fs_row on the host, as fs_rows_unpack8 does on the device: the work of a record by a walk
-// along the work offsets, dist = the matched script window's distance to itself, comb =
+// along the work offsets (a new bisection where a record lies in front of the one before it), dist = the matched script window's distance to itself, comb =
 // dist * lev (one IEEE multiplication, as __dmul_rn).  A few threads, each over a slice.
 static void fs_expand_rows8_host(fs_index* ix, const uint32_t* rec, uint64_t n, const uint64_t* work_off,
                                  uint64_t n_works, const double* selfdist, fs_row* rows) {
@@ -1047,6 +1047,16 @@ static void fs_expand_rows8_host(fs_index* ix, const uint32_t* rec, uint64_t n, 
     uint64_t w = a;
     for (uint64_t i = lo; i < hi; ++i) {
       const uint32_t x = rec[2 * i], y = rec[2 * i + 1];
+      if (x < work_off[w]) {
+        // a record behind its successor (the search's own records ascend; a caller's need
+        // not): look its work up from scratch, as k_unpack8 does for every record
+        uint64_t l = 0, r = w;
+        while (r - l > 1) {
+          const uint64_t mid = l + ((r - l) >> 1);
+          if (work_off[mid] <= x) l = mid; else r = mid;
+        }
+        w = l;
+      }
       while (w + 1 < n_works && work_off[w + 1] <= x) ++w;
       const uint32_t orig = y & 0x3FFFFu, k = (y >> 18) & 0xFu, lev = y >> 22;
       fs_row r;

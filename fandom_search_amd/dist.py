@@ -106,7 +106,7 @@ class RowGather(object):
     return (/root/reference/search.py:381-386)."""
 
     def __init__(self, index, cap, rec_bytes, n_buffers=1, group=None, rehearsal=False, any_root=False,
-                 exchange=False):
+                 exchange=False, inflight=1):
         import torch
         import torch.distributed as dist
         self.index, self.rec_bytes, self.group, self.rehearsal = index, int(rec_bytes), group, rehearsal
@@ -128,14 +128,17 @@ class RowGather(object):
         self.exchange = bool(exchange) and self.world > 1
         if self.exchange:
             any_root = True
-            n_groups = max(2, -(-n_buffers // self.world))
+            # a buffer is written again only after its group's all_to_all has been queued: with
+            # `inflight` searches queued ahead that takes world + inflight - 1 buffers, whole groups
+            need = -(-(self.world + max(1, int(inflight)) - 1) // self.world)
+            n_groups = max(2, need, -(-n_buffers // self.world))
             n_buffers = n_groups * self.world
             self.gsend = [torch.zeros(self.world * self.stride, dtype=torch.uint8, device=self.dev)
                           for _ in range(n_groups)]
             self.bufs = [self.gsend[b // self.world][(b % self.world) * self.stride:
                                                      (b % self.world + 1) * self.stride]
                          for b in range(n_buffers)]
-            self.gfilled = [0] * n_groups
+            self.gfilled = [set() for _ in range(n_groups)]   # slots filled since the group's last send
             self.gpending = [None] * n_groups
         else:
             self.bufs = [torch.zeros(self.stride, dtype=torch.uint8, device=self.dev)
@@ -189,8 +192,11 @@ class RowGather(object):
             return
         if self.exchange:
             g = b // self.world
+            if root != b % self.world:
+                raise ValueError("RowGather(exchange=True): buffer %d goes to rank %d, not %d"
+                                 % (b, b % self.world, root))
             self.roots[b] = b % self.world
-            self.gfilled[g] += 1
+            self.gfilled[g].add(b % self.world)
             if b % self.world == self.world - 1:      # the group's last buffer: steps come in order
                 self.flush_group(g)
             return
@@ -202,11 +208,17 @@ class RowGather(object):
         self.pending[b] = dist.gather(send, recv, dst=root, group=self.group, async_op=True)
 
     def flush_group(self, g):
-        """exchange: send group g now (also when it is not full: the end of a run)."""
+        """exchange: send group g now (also when it is not full: the end of a run; no search
+        may be in flight on the group's buffers then).  Slots that hold nothing new -- not
+        filled yet, or delivered by an earlier send of this group -- travel with a record
+        count of zero, so a receiver never takes a stale step for a new one."""
         import torch.distributed as dist
-        if not self.exchange or self.gfilled[g] == 0:
+        if not self.exchange or not self.gfilled[g]:
             return
-        self.gfilled[g] = 0
+        for slot in range(self.world):
+            if slot not in self.gfilled[g]:
+                self.bufs[g * self.world + slot][:8].zero_()
+        self.gfilled[g] = set()
         send = self.gsend[g].to(self.cdev)
         self.gpending[g] = dist.all_to_all_single(self.glanding[g], send, group=self.group, async_op=True)
 
@@ -428,3 +440,73 @@ def search_sharded(filenames, weights, searcher, group=None, root=0):
         all_words += words
     rows = np.concatenate(all_rows) if all_rows else np.zeros(0, dtype=abi.ROW_DTYPE)
     return rows, all_words
+
+
+def collect_batch_files(pattern, n_batches, mine, failure, t_start, group=None):
+    """End of a sharded `search` run: every rank has written the batch CSVs of the batches
+    it was the root of (`mine`, file names `pattern.format(i)`), rank 0 is about to
+    concatenate all `n_batches` of them into the dated file (search.analyze).
+
+    One all_gather of {failure, sizes of my files}: a rank whose writer failed (`failure`)
+    raises it, every other rank raises RankFailed -- nobody waits in a barrier for a rank
+    that has left.  Rank 0 then checks that every batch file is in ITS directory with the
+    size its writer reports and not older than this run (ranks of one node share the
+    working directory; ranks with directories of their own, or on several nodes, do not);
+    what is missing or stale is sent over: a broadcast of the list, a gather of the bytes,
+    written by rank 0 under the same names."""
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    info = {"failed": None if failure is None else repr(failure), "sizes": {}}
+    if failure is None:
+        try:
+            info["sizes"] = {i: os.path.getsize(pattern.format(i)) for i in mine}
+        except OSError as e:
+            failure = e
+            info["failed"] = repr(e)
+    infos = [None] * world
+    dist.all_gather_object(infos, info, group=group)
+    if failure is not None:
+        raise failure
+    bad = [r for r, x in enumerate(infos) if x["failed"]]
+    if bad:
+        raise RankFailed("rank %d failed writing its batch files: %s" % (bad[0], infos[bad[0]]["failed"]))
+    need = [None]
+    if rank == 0:
+        sizes = {}
+        for x in infos:
+            sizes.update(x["sizes"])
+        lost = [i for i in range(n_batches) if i not in sizes]
+        if lost:
+            need = [RuntimeError("no rank wrote batch %d" % lost[0])]
+        else:
+            need = [[]]
+            for i in range(n_batches):
+                try:
+                    st = os.stat(pattern.format(i))
+                    ok = st.st_size == sizes[i] and st.st_mtime >= t_start - 2.0
+                except OSError:
+                    ok = False
+                if not ok:
+                    need[0].append(i)
+    dist.broadcast_object_list(need, src=0, group=group)
+    need = need[0]
+    if isinstance(need, Exception):
+        raise need
+    if not need:
+        return
+    parts = {}
+    for i in need:
+        if i in info["sizes"] and rank != 0:
+            with open(pattern.format(i), "rb") as fh:
+                parts[i] = fh.read()
+    got = [None] * world if rank == 0 else None
+    dist.gather_object(parts, got, dst=0, group=group)
+    if rank == 0:
+        for x in got:
+            for i, data in x.items():
+                with open(pattern.format(i), "wb") as fh:
+                    fh.write(data)
+        still = [i for i in need if not any(i in x for x in got)]
+        if still:
+            raise RuntimeError("batch file %s is stale or missing and no other rank holds it"
+                               % pattern.format(still[0]))

@@ -646,6 +646,8 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
     lap("index")
     _startup_lap("script index on the GPU (library load, HIP start-up, fs_index_create)")
     writes = []
+    failure = None
+    t_start = time.time()
     for i, fan_cluster in enumerate(fan_clusters):
         if pool is not None and i + 1 < len(fan_clusters):
             pool.start(share(fan_clusters[i + 1]))
@@ -670,32 +672,46 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
                   'FANDOM_SEARCH_VECTORS'.format('rank {}: '.format(rank) if world > 1 else '', oov),
                   file=sys.stderr)
         n_batches = i + 1
-        if rank != root:
+        if rank != root or failure is not None:
             continue
-        if pool is not None and pool.pool is not None and searcher is None:
-            # the batch file is written by a worker of the token pool (they are forked, and
-            # parse the script's columns themselves) while this process searches the next
-            # cluster; the reference writes every batch file before the next pool.map
-            # (search.py:386-388), the bytes are the same
-            writes.append(pool.pool.apply_async(
-                _write_batch, (args.script, batch_filename.format(i), list(fan_cluster),
-                               np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).tobytes(), words)))
-            n_batches = i + 1
-            lap("hand batch to a writer")
-            continue
-        records = join_records(fan_cluster, rows, words,
-                               ann_index.word_lowercase, ann_index.orth_id,
-                               ann_index.character, ann_index.scene)
-        lap("join records")
-        write_records(records, batch_filename.format(i))
-        n_batches = i + 1
-        lap("write batch csv")
-    for job in writes:
-        job.get()                                   # (raises what the writer raised)
+        try:
+            if pool is not None and pool.pool is not None and searcher is None:
+                # the batch file is written by a worker of the token pool (they are forked, and
+                # parse the script's columns themselves) while this process searches the next
+                # cluster; the reference writes every batch file before the next pool.map
+                # (search.py:386-388), the bytes are the same
+                writes.append(pool.pool.apply_async(
+                    _write_batch, (args.script, batch_filename.format(i), list(fan_cluster),
+                                   np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).tobytes(), words)))
+                lap("hand batch to a writer")
+                continue
+            records = join_records(fan_cluster, rows, words,
+                                   ann_index.word_lowercase, ann_index.orth_id,
+                                   ann_index.character, ann_index.scene)
+            lap("join records")
+            write_records(records, batch_filename.format(i))
+            lap("write batch csv")
+        except Exception as e:
+            # with other ranks around, a failure of the host work is told to them at the end (they
+            # are inside the next batch's collectives by now); alone, it is raised here
+            if world == 1:
+                raise
+            failure = e
+    try:
+        for job in writes:
+            job.get()                               # (raises what the writer raised)
+    except Exception as e:                          # told to the other ranks below, then raised
+        failure = failure or e
     lap("wait for the writers")
     if world > 1:
-        import torch.distributed as tdist
-        tdist.barrier()                             # every rank's batch files are on disk
+        # every rank's batch files are on disk -- or one of them failed, and then every rank
+        # raises instead of waiting in a barrier for a rank that is gone; rank 0 also makes
+        # sure the files the other ranks wrote are the ones it is about to concatenate
+        mine = [i for i in range(n_batches)
+                if (i % world if os.environ.get("FANDOM_SEARCH_GATHER_ROOT", "rotate") != "0" else 0) == rank]
+        dist.collect_batch_files(batch_filename, n_batches, mine, failure, t_start)
+    elif failure is not None:
+        raise failure
 
     if pool is not None:
         ann_index.token_pool = None

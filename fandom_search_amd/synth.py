@@ -201,3 +201,43 @@ CONFIGS = {
     "c3shard": dict(n_works=12_500, tokens_per_work=5000, script_tokens=20_000),
     "c5": dict(n_works=1_000_000, tokens_per_work=1000, script_tokens=20_000),
 }
+
+
+def corpus_tokens_parallel(n_works, tokens_per_work, script, first_work=0,
+                           vocab_size=VOCAB_SIZE, procs=0):
+    """corpus_tokens() over `procs` child processes (same bytes: every work has its own
+    seed).  The children are fresh interpreters (`python -m fandom_search_amd.synth`:
+    numpy and this module only), so this may be called from a process that has touched
+    the GPU, from any kind of __main__."""
+    import subprocess
+    import sys
+    import tempfile
+    procs = procs or min(16, len(os.sched_getaffinity(0)))
+    if procs <= 1 or n_works < 4096:
+        return corpus_tokens(n_works, tokens_per_work, script, first_work, vocab_size)
+    per = -(-n_works // procs)
+    tok = np.empty(n_works * tokens_per_work, dtype=np.uint32)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as tmp:
+        spath = os.path.join(tmp, "script.npy")
+        np.save(spath, np.ascontiguousarray(script, dtype=np.uint32))
+        jobs = []
+        for lo in range(0, n_works, per):
+            n = min(per, n_works - lo)
+            out = os.path.join(tmp, "part%d.bin" % lo)
+            cmd = [sys.executable, "-m", "fandom_search_amd.synth", spath, out, str(n),
+                   str(tokens_per_work), str(first_work + lo), str(vocab_size)]
+            jobs.append((lo, n, out, subprocess.Popen(cmd, cwd=root)))
+        for lo, n, out, p in jobs:
+            if p.wait() != 0:
+                raise RuntimeError("corpus worker failed (exit code %d)" % p.returncode)
+            tok[lo * tokens_per_work:(lo + n) * tokens_per_work] = np.fromfile(out, dtype=np.uint32)
+    off = np.arange(n_works + 1, dtype=np.uint64) * np.uint64(tokens_per_work)
+    return tok, off
+
+
+if __name__ == "__main__":          # worker of corpus_tokens_parallel
+    import sys
+    _script = np.load(sys.argv[1])
+    _n, _tpw, _first, _vs = (int(x) for x in sys.argv[3:7])
+    corpus_tokens(_n, _tpw, _script, _first, _vs)[0].tofile(sys.argv[2])

@@ -80,26 +80,42 @@ WORKER = textwrap.dedent('''
             pos = off[rows["work"]].astype(np.int64) + rows["fan_ix"].astype(np.int64)
             return rows, [self.words[t] for t in tok[pos].tolist()]
 
-    os.chdir(sys.argv[1])
+    out, me = sys.argv[1], int(os.environ.get("RANK", "0"))
+    if os.environ.get("PER_RANK_CWD") and me > 0:      # ranks that do not share a directory
+        out = os.path.join(out, "rank%%d" %% me)
+        os.makedirs(out, exist_ok=True)
+    os.chdir(out)
+    if os.environ.get("STALE_BATCH") and me == 0:      # left behind by an earlier run
+        with open("match-6gram-batch-1.csv", "w") as fh:
+            fh.write("stale" + chr(10))
+        os.utime("match-6gram-batch-1.csv", (1, 1))
+    if os.environ.get("FAIL_WRITE_RANK") == str(me):
+        def full(records, name):
+            raise OSError("no space left on rank %%d" %% me)
+        search.write_records = full
     args = types.SimpleNamespace(fan_works=sys.argv[2], script=sys.argv[3],
                                  skip_works=0, num_works=-1)
     search.analyze(args, chunk_size=7, searcher=OracleSearcher(sys.argv[3]))
 ''')
 
 
-def _run(tmp_path, outdir, fandir, script, world):
+def _run(tmp_path, outdir, fandir, script, world, check=True, **extra):
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER % dict(root=ROOT))
     os.makedirs(outdir, exist_ok=True)
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", **extra)
     if world == 1:
         cmd = [sys.executable, str(worker), outdir, fandir, script]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", "29533", str(worker), outdir, fandir, script]
-    subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
-    return {f: open(os.path.join(outdir, f), "rb").read() for f in sorted(os.listdir(outdir))}
+    r = subprocess.run(cmd, check=check, env=env, timeout=600, cwd=ROOT,
+                       stdout=None if check else subprocess.PIPE, stderr=None if check else subprocess.STDOUT, text=True)
+    if not check:
+        return r
+    return {f: open(os.path.join(outdir, f), "rb").read() for f in sorted(os.listdir(outdir))
+            if os.path.isfile(os.path.join(outdir, f))}
 
 
 @pytest.mark.timeout(900)
@@ -125,6 +141,50 @@ def test_gloo_runs_write_identical_csvs(tmp_path):
         assert list(one) == list(many)
         for name in one:
             assert one[name] == many[name], (world, name)
+
+
+def _small_corpus(tmp_path):
+    from fandom_search_amd import synth
+    words = synth.vocab_words()
+    script = synth.script_tokens(1500)
+    fandir = str(tmp_path / "fan")
+    os.makedirs(fandir)
+    for i, n in enumerate([300, 120, 260, 310, 90, 200, 150, 333, 70, 128, 256, 64, 180, 222, 199]):
+        with open(os.path.join(fandir, synth.work_name(i)), "w") as fh:
+            fh.write(" ".join(words[int(t)] for t in synth.fanwork_tokens(i, n, script)))
+    spath = str(tmp_path / "script.txt")
+    with open(spath, "w") as fh:
+        fh.write(synth.script_markup(script, words))
+    return fandir, spath
+
+
+@pytest.mark.timeout(900)
+def test_ranks_without_a_shared_directory_and_a_stale_batch_file(tmp_path):
+    """the ranks take turns at writing batch files and rank 0 concatenates them.
+    Ranks with a working directory of their own (several nodes), and a batch file an earlier
+    run left in rank 0's directory: rank 0 notices (size and age against what the writer
+    reports) and has the bytes sent over; its directory ends up as a one-rank run's."""
+    fandir, spath = _small_corpus(tmp_path)
+    one = _run(tmp_path, str(tmp_path / "out1"), fandir, spath, 1)
+    assert len(one) == 4
+    two = _run(tmp_path, str(tmp_path / "out2"), fandir, spath, 2, PER_RANK_CWD="1", STALE_BATCH="1")
+    assert list(one) == list(two)
+    for name in one:
+        assert one[name] == two[name], name
+
+
+@pytest.mark.timeout(600)
+def test_a_rank_that_cannot_write_its_batch_file_stops_every_rank(tmp_path):
+    """the writer of a batch fails on one rank (disk full): the others must not wait
+    in a barrier for it -- every rank ends, the failing one with its own exception."""
+    import time
+    fandir, spath = _small_corpus(tmp_path)
+    t0 = time.time()
+    r = _run(tmp_path, str(tmp_path / "outf"), fandir, spath, 2, check=False, FAIL_WRITE_RANK="1")
+    assert r.returncode != 0
+    assert time.time() - t0 < 120, "a rank waited for the failed one"
+    assert "no space left on rank 1" in r.stdout
+    assert "RankFailed" in r.stdout
 
 
 MIXED_WORKER = textwrap.dedent('''

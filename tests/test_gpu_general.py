@@ -26,28 +26,34 @@ def _run(cfg, script, swords, emb, normals, tok, off, chars, coff, tok_str=None,
     return ix, got, st
 
 
+@pytest.mark.parametrize("unique", [1, 0])
 @pytest.mark.parametrize("n", [8, 10])
-def test_window_sizes_without_proof(synth_base, n):
+def test_window_sizes_without_proof(synth_base, n, unique):
     """BASELINE.json configs[3] (n-gram sweep): for n = 8 and 10 one substituted
     token can stay within the threshold ((n-1+c_max)/n > 0.9), so the index must
-    take the LSH pipeline."""
+    take the LSH pipeline.  `unique`: with and without NearPy's UniqueFilter (1.0.0's
+    Engine.neighbours() applies fetch filters only when given one)."""
     words, emb = synth_base["words"], synth_base["emb"]
     script = synth.script_tokens(3000)
     tok, off = util.ragged_corpus([700] * 12 + [0, n - 1, n, 1500], script)
-    cfg = abi.make_config(window_size=n)
+    cfg = abi.make_config(window_size=n, unique_filter=unique)
     ix, got, st = _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(n),
                        tok, off, synth_base["chars"], synth_base["off"])
     assert ix.info["proof_ok"] == 0 and st.path == abi.FS_MODE_GENERAL
     assert len(got) > 0
 
 
+@pytest.mark.parametrize("unique", [1, 0])
 @pytest.mark.parametrize("n", [8, 9, 10, 12])
-def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
+def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, unique):
     """Where the proof fails by one slot only, k_scan_near flags the windows that equal a
     script window in all but one slot (failed 3-gram tests confined to three consecutive
     positions) and the LSH work runs on those; FS_LSH_PREFILTER=0 computes keys and
     buckets for every window.  Same bytes, equal to the oracle, with planted spans whose
-    odd token sits at every slot of a window (records with a distance well above 0)."""
+    odd token sits at every slot of a window (records with a distance well above 0).
+    `unique` = 0: without NearPy's UniqueFilter a window comes back once per table whose
+    bucket holds it, the ten nearest are then copies of the nearest few (the
+    whole shortcut stack -- per-n-gram records, one-slot map, sift -- under both settings)."""
     from fandom_search_amd.engine import ScriptIndex
     words, emb = synth_base["words"], synth_base["emb"]
     script = synth.script_tokens(4000)
@@ -69,7 +75,7 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n):
         tok[at:at + n] = script[900 + 30 * j:900 + 30 * j + n]
         tok[at + 1] = (int(tok[at + 1]) + 5) % len(words)
         tok[at + n - 2] = (int(tok[at + n - 2]) + 9) % len(words)
-    cfg = abi.make_config(window_size=n)
+    cfg = abi.make_config(window_size=n, unique_filter=unique)
     normals = synth.lsh_normals(n)
     # (script words as written in the script, not always the table's spelling: the
     # Levenshtein distance of an identical-id match is not a constant)
