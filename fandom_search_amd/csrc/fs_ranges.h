@@ -42,13 +42,16 @@ __device__ __forceinline__ void wave_sync() {
 constexpr uint32_t FS_NO_LDS = 0xFFFFFFFFu;
 constexpr int kHitPad = 72;     // 64 hits + the n-1 <= 7 slots the first-minimum walk may look at
 
+// A hit is one 16-byte LDS record {combined distance of the best rank (two words), window
+// position relative to the range | Levenshtein distance << 22, script position of the best
+// rank}: what the record loop needs of the <= n hits covering a word comes with one
+// ds_read_b128 each, all requested together.  (Position: p - a + 8 < 2^22, the n-1 <= 7 halo
+// windows in front of the range included -- checked at launch; Levenshtein distance <= 1023,
+// the most lev_lane / lev_device report.)
+constexpr uint32_t kHitPosBits = 22;
 struct alignas(16) RangeLds {
-  double comb[kHitPad];       // hits: combined distance of the best rank
-  uint32_t p[kHitPad];        //       window position
-  uint32_t s[64];             //       script position of the best rank
-  uint32_t lev[64];           //       its Levenshtein distance
-  uint32_t w[64];             //       work
-  uint32_t wbase[64];         //       first token of that work
+  uint4 hit[kHitPad];         // hits: {comb lo, comb hi, (p - a + 8) | lev << 22, s}
+  uint2 wb[64];               //       {work, first token of that work}
   uint32_t lo[64];            // hit -> (first word it emits in this round) - (its first record)
   uint8_t owner[64 * 8];      // record of the round -> hit
 };
@@ -59,7 +62,29 @@ struct RangeState {
   uint32_t rows_run;   // records of the range so far
   uint32_t hits_run;   // hits inside the range (not the halo)
   uint32_t match_acc;  // per lane: (window, script window) pairs of its hits
+  // the range's first 128 records stay in registers (lane L: records L and L + 64, in the
+  // staged form) when the launch itself puts the records into place: they go from here to
+  // their final place, never through the staging area
+  uint4 k0, k1;
 };
+
+// FS_DIAG & 2: time per phase of the rounds, summed per wave range, in ticks of the 100 MHz
+// constant clock: {candidates picked, ids + block entry arrived, table line arrived, hits
+// stored, records emitted, carried hits moved}
+struct RoundClock {
+  bool on;
+  uint32_t t0, t1, t2, t3, t4, t5;
+  uint32_t last;
+};
+template <int PHASE>
+__device__ __forceinline__ void round_lap(RoundClock& k, bool drain) {
+  if (!k.on) return;
+  if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const uint32_t now = (uint32_t)__builtin_amdgcn_s_memrealtime();
+  uint32_t& t = PHASE == 0 ? k.t0 : PHASE == 1 ? k.t1 : PHASE == 2 ? k.t2 : PHASE == 3 ? k.t3 : PHASE == 4 ? k.t4 : k.t5;
+  t += now - k.last;
+  k.last = now;
+}
 
 struct RangeOut {
   uint8_t* stage;      // caprow records per range
@@ -82,10 +107,11 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
                                             uint32_t disp_off, RangeLds& S,
                                             uint32_t p, uint32_t F, uint32_t a,
                                             uint32_t range_id, const RangeOut& out,
-                                            RangeState& R, const StrFast* sf = nullptr,
-                                            uint32_t* give_up = nullptr) {
+                                            RangeState& R, const StrFast* sf,
+                                            uint32_t* give_up, bool keep_regs, RoundClock& clk) {
   const int lane = threadIdx.x & 63;
   if (F < R.E) F = R.E;
+  round_lap<0>(clk, false);
   // 1. verification, one candidate per lane, two levels of loads: ids + work of the
   // token block, then (seed from LDS) the 64-byte entry of the n-gram, which holds the
   // ids and the batch's best record.  Every load of a level is requested before
@@ -121,6 +147,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       bw = c.blk4[p >> 8];
       asm volatile("" : "+v"(bw.x), "+v"(bw.y), "+v"(bw.z), "+v"(bw.w), "+v"(f[0]));
     }
+    round_lap<1>(clk, true);
     uint32_t h = 0;
 #pragma unroll
     for (int k = 0; k < N; ++k) h ^= fs_rotl(fs_premix(f[k]), fs_rot_of(N - 1 - k));
@@ -162,6 +189,7 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
       if (same | (q0.x == 0) | !(d & FS_DISP_OVERFLOW)) break;
       slot = (slot + 1) & ((1u << g.log2_slots) - 1);
     }
+    round_lap<2>(clk, true);
     kept = q0.y; bs = q2.z; blev = q2.w;
     comb = __longlong_as_double((long long)(q3.z | ((uint64_t)q3.w << 32)));
     // the work of p: the block's first work or the one behind it, else walk on
@@ -197,21 +225,25 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   const uint64_t hb = __ballot(hit);
   const uint32_t hidx = R.hc + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32),
                                    __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0));
+  const uint32_t pbias = a - 8u;                     // position field of a hit: p - pbias
+  constexpr uint32_t kPosMask = (1u << kHitPosBits) - 1u;
   if (hit) {
-    S.p[hidx] = p; S.s[hidx] = bs; S.lev[hidx] = blev; S.w[hidx] = w; S.wbase[hidx] = wbase;
-    S.comb[hidx] = comb;
+    const uint64_t cbits = (uint64_t)__double_as_longlong(comb);
+    S.hit[hidx] = make_uint4((uint32_t)cbits, (uint32_t)(cbits >> 32), (p - pbias) | (blev << kHitPosBits), bs);
+    S.wb[hidx] = make_uint2(w, wbase);
     if (p >= a) R.match_acc += kept;                 // a halo hit belongs to the range before
   }
   const uint32_t nh = R.hc + (uint32_t)__popcll(hb);
   R.hits_run += (uint32_t)__popcll(__ballot(hit && p >= a));
   wave_sync();
+  round_lap<3>(clk, false);
   // 3. words [E, F): lane j = hit j
-  uint32_t cnt = 0, lo = 0;
+  uint32_t cnt = 0, lo = 0, pj = 0;
   if ((uint32_t)lane < nh) {
-    const uint32_t pj = S.p[lane];
+    pj = (S.hit[lane].z & kPosMask) + pbias;
     uint32_t first = pj;
     if (lane > 0) {
-      const uint32_t pv = S.p[lane - 1] + N;
+      const uint32_t pv = (S.hit[lane - 1].z & kPosMask) + pbias + N;
       if (pv > first) first = pv;
     }
     lo = first > R.E ? first : R.E;
@@ -227,57 +259,64 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
   for (uint32_t k = 0; k < (uint32_t)N; ++k)
     if (k < cnt) S.owner[excl + k] = (uint8_t)lane;
   wave_sync();
-  for (uint32_t rr = lane; rr < tot; rr += 64) {
+  // record r of the range is made by lane r % 64 (so that lane L makes the records L and
+  // L + 64 it may keep in registers)
+  for (uint32_t rr = ((uint32_t)lane - R.rows_run) & 63u; rr < tot; rr += 64) {
     const uint32_t j = S.owner[rr];
+    // one level of LDS reads: the word, the owner's work, the <= n hits that may cover the word
     const uint32_t x = rr + S.lo[j];
-    double best = S.comb[j];
-    uint32_t bj = j;
+    const uint2 wbj = S.wb[j];
+    uint4 hs[N];
+#pragma unroll
+    for (uint32_t t = 0; t < (uint32_t)N; ++t) hs[t] = S.hit[j + t];
+    double best = __longlong_as_double((long long)(hs[0].x | ((uint64_t)hs[0].y << 32)));
+    uint32_t bz = hs[0].z, bsp = hs[0].w;
 #pragma unroll
     for (uint32_t t = 1; t < (uint32_t)N; ++t) {       // the <= n-1 later hits that cover x too
-      const uint32_t jn = j + t;
-      const double cj = S.comb[jn];
-      const bool ok = (jn < nh) & (S.p[jn] <= x) & (cj < best);
+      const double cj = __longlong_as_double((long long)(hs[t].x | ((uint64_t)hs[t].y << 32)));
+      const bool ok = (j + t < nh) & ((hs[t].z & kPosMask) + pbias <= x) & (cj < best);
       best = ok ? cj : best;
-      bj = ok ? jn : bj;
+      bz = ok ? hs[t].z : bz;
+      bsp = ok ? hs[t].w : bsp;
     }
     const uint32_t ridx = R.rows_run + rr;
     if (ridx >= out.caprow) continue;
-    const uint32_t koff = x - S.p[bj];
-    const uint32_t orig = S.s[bj] + koff, lev = S.lev[bj];
-    const size_t at = (size_t)range_id * out.caprow + ridx;
-    if (out.wire == 8) {
-      reinterpret_cast<uint2*>(out.stage)[at] = make_uint2(x, orig | (koff << 18) | (lev << 22));
-    } else {
-      // 16-byte wire record, also when the caller wants fs_row: the distances of a record are
-      // functions of the matched script window (its distance to itself, times the Levenshtein
-      // distance) and are filled in where the record is put into place
-      uint4 qv;
-      qv.x = S.w[j]; qv.y = x - S.wbase[j]; qv.z = orig; qv.w = lev | (koff << 16);
-      reinterpret_cast<uint4*>(out.stage)[at] = qv;
+    const uint32_t koff = x - ((bz & kPosMask) + pbias);
+    const uint32_t orig = bsp + koff, lev = bz >> kHitPosBits;
+    // 16-byte wire record, also when the caller wants fs_row: the distances of a record are
+    // functions of the matched script window (its distance to itself, times the Levenshtein
+    // distance) and are filled in where the record is put into place; 8-byte form in x, y
+    uint4 qv;
+    if (out.wire == 8) { qv.x = x; qv.y = orig | (koff << 18) | (lev << 22); qv.z = 0; qv.w = 0; }
+    else { qv.x = wbj.x; qv.y = x - wbj.y; qv.z = orig; qv.w = lev | (koff << 16); }
+    if (keep_regs && ridx < 128) {
+      if (ridx < 64) R.k0 = qv; else R.k1 = qv;
+      continue;
     }
+    const size_t at = (size_t)range_id * out.caprow + ridx;
+    if (out.wire == 8) reinterpret_cast<uint2*>(out.stage)[at] = make_uint2(qv.x, qv.y);
+    else reinterpret_cast<uint4*>(out.stage)[at] = qv;
   }
+  round_lap<4>(clk, false);
   R.rows_run += tot;
   // 4. hits that may cover words >= F move to the front
-  const bool keep = (uint32_t)lane < nh && S.p[lane] + N > F;
+  const bool keep = (uint32_t)lane < nh && pj + N > F;
   const uint64_t kb = __ballot(keep);
   const uint32_t first_keep = kb ? (uint32_t)(__ffsll((unsigned long long)kb) - 1) : nh;
   if (kb) {                                                        // wave-uniform
-    uint32_t tp = 0, ts = 0, tl = 0, tw = 0, tb = 0;
-    double tc = 0.0;
-    if (keep) {
-      tp = S.p[lane]; ts = S.s[lane]; tl = S.lev[lane]; tw = S.w[lane]; tb = S.wbase[lane];
-      tc = S.comb[lane];
-    }
+    uint4 th = make_uint4(0, 0, 0, 0);
+    uint2 tw = make_uint2(0, 0);
+    if (keep) { th = S.hit[lane]; tw = S.wb[lane]; }
     wave_sync();
     if (keep) {
       const uint32_t dd = lane - first_keep;
-      S.p[dd] = tp; S.s[dd] = ts; S.lev[dd] = tl; S.w[dd] = tw; S.wbase[dd] = tb;
-      S.comb[dd] = tc;
+      S.hit[dd] = th; S.wb[dd] = tw;
     }
   }
   R.hc = nh - first_keep;
   R.E = F;
   wave_sync();
+  round_lap<5>(clk, false);
 }
 
 // ---- records into place ------------------------------------------------------------
@@ -303,6 +342,15 @@ __device__ __forceinline__ StagedRec fetch_staged(const uint8_t* __restrict__ st
     // combined distance its product with the Levenshtein distance (as fs_rows_unpack)
     if (wire == 0) v.dist = selfdist[v.q.z - (v.q.w >> 16)];
   }
+  return v;
+}
+
+// the same for a record that stayed in registers (RangeState::k0 / k1)
+__device__ __forceinline__ StagedRec kept_staged(const uint4& q, int wire,
+                                                 const double* __restrict__ selfdist, bool have) {
+  StagedRec v;
+  v.have = have; v.dist = 0.0; v.q = q;
+  if (have && wire == 0) v.dist = selfdist[q.z - (q.w >> 16)];
   return v;
 }
 
@@ -370,7 +418,8 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
                                             const RangeOut& out, const double* __restrict__ selfdist,
                                             uint32_t range_id,
                                             uint32_t my_rows, uint32_t hits, uint32_t pairs,
-                                            uint32_t cands, uint32_t* s_cnt) {
+                                            uint32_t cands, uint32_t* s_cnt,
+                                            const RangeState* kept = nullptr) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const uint32_t L = blockIdx.x;
@@ -401,10 +450,17 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   }
   // the staged records of this wave have reached memory before it reads them back
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  // this lane's first two records: requested now, stored once their place is known
+  // this lane's first two records: in registers since they were made, or requested from the
+  // staging area now; stored once their place is known
   const size_t sbase = (size_t)range_id * out.caprow;
-  const StagedRec r0 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane, (uint32_t)lane < staged);
-  const StagedRec r1 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane + 64, (uint32_t)lane + 64 < staged);
+  StagedRec r0, r1;
+  if (kept) {
+    r0 = kept_staged(kept->k0, out.wire, selfdist, (uint32_t)lane < staged);
+    r1 = kept_staged(kept->k1, out.wire, selfdist, (uint32_t)lane + 64 < staged);
+  } else {
+    r0 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane, (uint32_t)lane < staged);
+    r1 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane + 64, (uint32_t)lane + 64 < staged);
+  }
   __syncthreads();
   bool gave_up = false;
   uint32_t total = 0;

@@ -439,7 +439,7 @@ constexpr uint32_t kRecFlush = 34;    // flush threshold: about 1.35 candidates 
 struct alignas(16) FusedLds {         // per wave
   fsdev::RangeLds R;
   uint32_t rec[kRecQueue];            // {(position - range start) / 8 << 8 | flag byte}
-  uint16_t rk[kRecQueue];             // candidates (halo included) in front of the record's
+  uint32_t cand[64];                  // window positions of the round being made up
 };
 
 template <int N, int K, bool NT, bool LW14, bool STR = false>
@@ -451,8 +451,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     StrFast strf) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
-  // FS_DIAG & 2: eight words per wave range {entry, filter in LDS, scan done, rounds done,
-  // finished, rounds, flushes, -} in ticks of the 100 MHz constant clock (tools/scan_timeline.py)
+  // FS_DIAG & 2: sixteen words per wave range {entry, filter in LDS, scan done, rounds done,
+  // finished, rounds, flushes, records, six phase sums of the rounds (RoundClock), -, -} in
+  // ticks of the 100 MHz constant clock (tools/scan_timeline.py)
   unsigned long long t_entry = 0, t_ready = 0, t_scan = 0, t_rounds = 0;
   uint32_t n_rounds = 0, n_flushes = 0;
   if (dbg) t_entry = __builtin_amdgcn_s_memrealtime();
@@ -498,7 +499,6 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   constexpr uint32_t HALO = N - 1;
   constexpr uint32_t SUB = 512;
   const int word_shift = 32 - lw;
-  const int src_lane = (lane + 1) & 63;
   uint32_t mask_fffc = 0xFFFCu;
   asm volatile("" : "+v"(mask_fffc));          // keep the SDWA operand in a register
   uint32_t mask_words = ((1u << lw) - 1u) << 2;
@@ -532,13 +532,31 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     asm volatile("" : "+v"(v.a0), "+v"(v.a1), "+v"(v.b0), "+v"(v.b1), "+v"(v.h0), "+v"(v.h1));
     return v;
   };
+  // Prologue: seeds and filter into LDS through registers, four 16-byte pieces per thread
+  // in flight.  (Round 4 measured the LDS-DMA form -- global_load_lds_dwordx4 pieces behind
+  // the range's first id request: the filter is in LDS at 4.35 us instead of 2.7 us, one
+  // loader stream per wave lands 1 KB per ~0.65 us, and the kernel is 0.5 us slower.)
   for (uint32_t e = threadIdx.x; e < disp_lds / 16; e += blockDim.x)     // (a multiple of 16 bytes)
     reinterpret_cast<uint4*>(s_dyn + (1u << lw))[e] = reinterpret_cast<const uint4*>(g.disp8)[e];
   copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
+  // FS_DIAG & 128: instruction priority by SIMD slot age (the youngest wave of a SIMD first)
+  if (diag & 128) {
+    const uint32_t age = wave >> 2;
+    if (age == 3) __builtin_amdgcn_s_setprio(3);
+    else if (age == 2) __builtin_amdgcn_s_setprio(2);
+    else if (age == 1) __builtin_amdgcn_s_setprio(1);
+  }
   __syncthreads();
   if (dbg) t_ready = __builtin_amdgcn_s_memrealtime();
   RangeState R;
   R.E = 0; R.hc = 0; R.rows_run = 0; R.hits_run = 0; R.match_acc = 0;
+  R.k0 = make_uint4(0, 0, 0, 0); R.k1 = make_uint4(0, 0, 0, 0);
+  // the launch puts the records into place itself: a range's first 128 stay in registers
+  // (FS_DIAG & 32: all of them through the staging area)
+  const bool keep_regs = !STR && !sy.rinfo && !(diag & 32);   // (STR: the per-hit Levenshtein needs the registers)
+  RoundClock clk;
+  clk.on = !STR && dbg != nullptr;
+  clk.t0 = clk.t1 = clk.t2 = clk.t3 = clk.t4 = clk.t5 = 0; clk.last = 0;
   uint32_t cacc = 0;                           // per lane: candidates seen
   if (s1 > s0) {
     const uint32_t a = s0 * SUB, bnd = s1 * SUB;
@@ -547,21 +565,25 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     // The next pair is requested as soon as this one has arrived, a whole pair of work
     // (and its flushes) ahead; every step issues a request, the last one for the range's
     // last sub-tiles again (a request under a condition would only complicate the waits).
-    auto scan = [&](const v4u& v00, const v4u& v01, const v4u& v10, const v4u& v11, uint32_t j) {
+    // premixed ids of a lane's eight tokens (pinned: left to itself the compiler folds the
+    // premix into the first K-gram's shifts as three quarter-rate 32-bit multiplies)
+    struct M8 { uint32_t v[8]; };
+    auto premix8 = [&](const v4u& lo, const v4u& hi) {
+      M8 m;
+      m.v[0] = fs_premix(lo.x); m.v[1] = fs_premix(lo.y); m.v[2] = fs_premix(lo.z); m.v[3] = fs_premix(lo.w);
+      m.v[4] = fs_premix(hi.x); m.v[5] = fs_premix(hi.y); m.v[6] = fs_premix(hi.z); m.v[7] = fs_premix(hi.w);
+      asm volatile("" : "+v"(m.v[0]), "+v"(m.v[1]), "+v"(m.v[2]), "+v"(m.v[3]),
+                        "+v"(m.v[4]), "+v"(m.v[5]), "+v"(m.v[6]), "+v"(m.v[7]));
+      return m;
+    };
+    // one sub-tile: m = the lane's own premixed ids, halo[h] = premixed id h of the lane behind
+    auto scan = [&](const M8& m, const uint32_t* halo, uint32_t j) {
       const uint32_t base = j * SUB;
       uint32_t aa[16];
-      aa[0] = v00.x; aa[1] = v00.y; aa[2] = v00.z; aa[3] = v00.w;
-      aa[4] = v01.x; aa[5] = v01.y; aa[6] = v01.z; aa[7] = v01.w;
-      // halo: first HALO tokens of lane L+1; lane 0 publishes the next sub-tile's
-      const bool wrap = lane == 0;
-      const uint32_t n0[8] = {wrap ? v10.x : v00.x, wrap ? v10.y : v00.y,
-                              wrap ? v10.z : v00.z, wrap ? v10.w : v00.w,
-                              wrap ? v11.x : v01.x, wrap ? v11.y : v01.y,
-                              wrap ? v11.z : v01.z, wrap ? v11.w : v01.w};
 #pragma unroll
-      for (int h = 0; h < (int)HALO; ++h) aa[8 + h] = __shfl(n0[h], src_lane);
+      for (int k = 0; k < 8; ++k) aa[k] = m.v[k];
 #pragma unroll
-      for (int k = 0; k < 8 + (int)HALO; ++k) aa[k] = fs_premix(aa[k]);
+      for (int h = 0; h < (int)HALO; ++h) aa[8 + h] = halo[h];
       const uint32_t p0 = base + 8 * lane;
       uint32_t flags;
       if constexpr (K != 0) {
@@ -582,66 +604,54 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       rec_cnt += (uint32_t)__popcll(has);
       cacc += __popc(flags);
     };
-    // records queued so far -> rounds of candidates; F_end = the scan front
+    // records queued so far -> rounds of candidates; F_end = the scan front.  A round takes
+    // the records whose candidates fit the hit slots left by the carried hits (a record has
+    // at most eight, so the first always fits): lane t looks at record rt + t, a prefix sum of
+    // the candidate counts says which records fit and where their candidates go, and the
+    // lanes of those records write the window positions into cand[] -- three LDS round
+    // trips (records, positions, positions back), no search.
     auto flush = [&](uint32_t F_end) {
+      if (clk.on) clk.last = (uint32_t)__builtin_amdgcn_s_memrealtime();
       wave_sync();
-      // candidates in front of every queued record (lane t: records t and t + 64)
-      const uint32_t ra = (uint32_t)lane < rec_cnt ? W.rec[lane] : 0u;
-      const uint32_t rb = (uint32_t)lane + 64 < rec_cnt ? W.rec[lane + 64] : 0u;
-      const uint32_t ca = __popc(ra & 0xFFu), cb = __popc(rb & 0xFFu);
-      const uint32_t ia = wave_incl_scan_dpp(ca);
-      const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)ia, 63);
-      uint32_t nb = 0;
-      // (0xFFFF behind the last record: the search below needs no bound)
-      W.rk[lane] = (uint32_t)lane < rec_cnt ? (uint16_t)(halo_n + ia - ca) : (uint16_t)0xFFFFu;
-      uint16_t rkb = 0xFFFFu;
-      if (rec_cnt > 64) {
-        const uint32_t ib = wave_incl_scan_dpp(cb);
-        nb = (uint32_t)__builtin_amdgcn_readlane((int)ib, 63);
-        if ((uint32_t)lane + 64 < rec_cnt) rkb = (uint16_t)(halo_n + na + ib - cb);
-      }
-      W.rk[lane + 64] = rkb;
-      wave_sync();
-      const uint32_t total = halo_n + na + nb;
-      uint32_t r0 = 0;
+      uint32_t rt = 0;                             // records taken so far
       do {
-        // candidate r0 + lane: a halo window, or bit k of the last record with at most
-        // that many candidates in front of it (the lane behind the round's last: the next round's first)
-        const uint32_t ci = r0 + lane;
-        uint32_t p = FS_NONE;
-        if (ci < total) {
-          if (ci < halo_n) {
-            p = a - halo_n + ci;
-          } else {
-            uint32_t t = 0;
-#pragma unroll
-            for (uint32_t step = kRecQueue / 2; step > 0; step >>= 1) {
-              const uint32_t v = W.rk[t + step];
-              t = v <= ci ? t + step : t;
-            }
-            const uint32_t rec = W.rec[t];
-            // its k-th candidate: the k-th set bit of the flag byte (mostly the first)
-            uint32_t fb = rec & 0xFFu;
-            for (uint32_t k = ci - W.rk[t]; k > 0; --k) fb &= fb - 1;
-            p = a + ((rec >> 8) << 3) + ((uint32_t)__ffs(fb) - 1u);
-          }
-        }
-        // this round takes as many candidates as there are hit slots behind the carried
-        // hits (64 in all, one per lane), at most 63: the lane behind them looks ahead
         const uint32_t take = R.hc ? 64u - R.hc : 63u;
+        const uint32_t hn = halo_n;
+        const uint32_t rec = rt + (uint32_t)lane < rec_cnt ? W.rec[rt + lane] : 0u;
+        uint32_t fb = rec & 0xFFu;
+        const uint32_t cn = __popc(fb);
+        const uint32_t inc = wave_incl_scan_dpp(cn);
+        const bool fits = cn != 0 && hn + inc <= take;
+        const uint64_t fit = __ballot(fits);       // (a prefix of the lanes)
+        const uint32_t m = (uint32_t)__popcll(fit);
+        if (fits) {
+          uint32_t at = hn + inc - cn;
+          const uint32_t pb = a + ((rec >> 8) << 3) - 1u;
+          do {
+            W.cand[at++] = pb + (uint32_t)__ffs(fb);
+            fb &= fb - 1;
+          } while (fb);
+        }
+        if ((uint32_t)lane < hn) W.cand[lane] = a - hn + (uint32_t)lane;
+        const uint32_t total = hn + (m ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(m - 1)) : 0u);
+        // the first position whose hit status is not known after this round: the first
+        // candidate left behind, or the scan front
         uint32_t F = F_end;
-        if (r0 + take < total) {
-          const uint32_t nx = (uint32_t)__builtin_amdgcn_readlane((int)p, (int)take);
+        if (rt + m < rec_cnt) {
+          const uint32_t r2 = W.rec[rt + m];       // (the same word for every lane)
+          const uint32_t nx = a + ((r2 >> 8) << 3) + (uint32_t)__ffs(r2 & 0xFFu) - 1u;
           if (nx < F) F = nx;
         }
+        wave_sync();
+        const uint32_t p = (uint32_t)lane < total ? W.cand[lane] : FS_NONE;
         if (!(diag & 1))
-          range_round<N, STR>(c, g, disp_off, S, (uint32_t)lane < take ? p : FS_NONE, F, a, range_id, out, R,
-                              &strf, reinterpret_cast<uint32_t*>(fin.host_st + 1));
-        r0 += take;
+          range_round<N, STR>(c, g, disp_off, S, p, F, a, range_id, out, R,
+                              &strf, reinterpret_cast<uint32_t*>(fin.host_st + 1), keep_regs, clk);
+        rt += m;
+        halo_n = 0;
         ++n_rounds;
-      } while (r0 < total);
+      } while (rt < rec_cnt);
       rec_cnt = 0;
-      halo_n = 0;
       ++n_flushes;
     };
     const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
@@ -649,14 +659,29 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     for (uint32_t j = s0; j < s1; j += 2) {
       const Pair v = arrive(nx);
       nx = request(j + 2 < s1 ? j + 2 : j);
-      scan(v.a0, v.a1, v.b0, v.b1, j);
+      const M8 ma = premix8(v.a0, v.a1), mb = premix8(v.b0, v.b1);
+      uint32_t halo[8];
+      // A's halo: the first ids of the lane behind, lane 63: lane 0's first ids of B -- one
+      // DPP rotation of the wave per id (no LDS), lane 0 offering its B ids
+#pragma unroll
+      for (int h = 0; h < (int)HALO; ++h)
+        halo[h] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(lane == 0 ? mb.v[h] : ma.v[h]), 0x134, 0xF, 0xF, false);   // wave_rol:1
+      scan(ma, halo, j);
       // (a queue of kRecQueue records: at most 64 more come from one sub-tile)
       const bool odd_end = j + 1 == s1;
       if (dbg && odd_end) t_scan = __builtin_amdgcn_s_memrealtime();
       if (odd_end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt > kRecQueue - 64)
         flush(odd_end ? bnd : j * SUB + SUB);
       if (odd_end) break;
-      scan(v.b0, v.b1, v.h0, v.h1, j + 1);
+      // B's halo: lane 63 takes the ids behind B (the same in every lane): a DPP shift of
+      // the wave, the lane without a source keeps `old`
+      {
+        const uint32_t hv[8] = {v.h0.x, v.h0.y, v.h0.z, v.h0.w, v.h1.x, v.h1.y, v.h1.z, v.h1.w};
+#pragma unroll
+        for (int h = 0; h < (int)HALO; ++h)
+          halo[h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(hv[h]), (int)mb.v[h], 0x130, 0xF, 0xF, false);   // wave_shl:1
+      }
+      scan(mb, halo, j + 1);
       const bool end = j + 2 == s1;
       if (dbg && end) t_scan = __builtin_amdgcn_s_memrealtime();
       if (end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt >= flush_at) flush(end ? bnd : j * SUB + 2 * SUB);
@@ -668,11 +693,14 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     cacc += (uint32_t)__shfl_xor((int)cacc, d);
   }
   if (dbg) t_rounds = __builtin_amdgcn_s_memrealtime();
-  finish_rows(sy, fin, out, g.selfdist, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt);
+  finish_rows(sy, fin, out, g.selfdist, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt,
+              keep_regs ? &R : nullptr);
   if (dbg && lane == 0) {
-    unsigned long long* d = dbg + 8 * (size_t)range_id;
+    unsigned long long* d = dbg + 16 * (size_t)range_id;
     d[0] = t_entry; d[1] = t_ready; d[2] = t_scan; d[3] = t_rounds;
     d[4] = __builtin_amdgcn_s_memrealtime(); d[5] = n_rounds; d[6] = n_flushes; d[7] = R.rows_run;
+    d[8] = clk.t0; d[9] = clk.t1; d[10] = clk.t2; d[11] = clk.t3; d[12] = clk.t4; d[13] = clk.t5;
+    d[14] = 0; d[15] = 0;
   }
 }
 
@@ -836,9 +864,9 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
                      const fsdev::RowFinal& fin, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   unsigned long long* dbg = nullptr;
   if (ix->sw.diag & 2) {               // timeline stamps, read back by fs_debug_stamps
-    FS_TRY(ix->cur->w_dbg.reserve((size_t)blocks * waves * 8));
+    FS_TRY(ix->cur->w_dbg.reserve((size_t)blocks * waves * 16));
     dbg = ix->cur->w_dbg.p;
-    ix->cur->dbg_words = (size_t)blocks * waves * 8;
+    ix->cur->dbg_words = (size_t)blocks * waves * 16;
   }
   const uint32_t disp_lds = fs_scan_rows_disp_lds(ix);
   const int lw = rows_filter_log2(ix);
@@ -900,16 +928,27 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
   // (1 KB: the kernel's static LDS, s_cnt)
   const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 1024;
   const size_t cu_lds = 160 * 1024;
+  // a hit's LDS record holds its window position relative to the wave range in
+  // fsdev::kHitPosBits bits: the longest range of the shape must fit (a wave of sixteen
+  // takes at most 305/4096 of its workgroup's sub-tiles, else an equal share)
+  auto fits = [&](uint32_t waves, uint32_t nblocks) {
+    const uint64_t n_sub = (c->n_tok + 511) / 512;
+    const uint64_t len = n_sub / nblocks + 1;
+    const uint64_t longest = (waves == 16 && !(sw.diag & 16) ? (len * 305 + 4095) / 4096 : (len + waves - 1) / waves) + 1;
+    return longest * 512 + 16 < (1ull << fsdev::kHitPosBits);
+  };
   if (sw.rows_waves) {
     *blocks = (uint32_t)ix->num_cu * (uint32_t)std::max(1, sw.rows_blocks_per_cu);
+    if (!fits((uint32_t)sw.rows_waves, *blocks)) { *blocks = 0; return 0; }
     return (uint32_t)sw.rows_waves;
   }
-  if (sw.rows_blocks_per_cu != 1 && ix->n_lanes > 1 && 2 * (fixed + 8 * sizeof(FusedLds)) <= cu_lds) {
+  if (sw.rows_blocks_per_cu != 1 && ix->n_lanes > 1 && 2 * (fixed + 8 * sizeof(FusedLds)) <= cu_lds &&
+      fits(8, 2u * (uint32_t)ix->num_cu)) {
     *blocks = 2u * (uint32_t)ix->num_cu;
     return 8;
   }
   for (uint32_t w : {16u, 8u, 4u})
-    if (fixed + w * sizeof(FusedLds) <= cu_lds) { *blocks = (uint32_t)ix->num_cu; return w; }
+    if (fixed + w * sizeof(FusedLds) <= cu_lds && fits(w, (uint32_t)ix->num_cu)) { *blocks = (uint32_t)ix->num_cu; return w; }
   return 0;
 }
 

@@ -153,3 +153,53 @@ def test_c3_shard_properties(synth_base):
     want_pos, _ = _covered_words(tok, off, script, 6)
     assert np.array_equal(pos, want_pos)
     assert st.rows == len(rows) and st.windows_processed == int(np.maximum(lens - 5, 0).sum())
+
+
+@pytest.mark.timeout(1500)
+def test_c3_whole_corpus_is_independent_of_the_number_of_shards(synth_base):
+    """BASELINE.json configs[2] at full size: 100k works x 5k tokens (2 GB of ids).  The eight
+    12.5k-work shards an 8-GPU run deals out (bench.py --gpus 8, works [r W/8, (r+1) W/8)),
+    searched one after another on this GPU and concatenated in global work order, give the
+    bytes of the whole corpus in ONE launch: the output does not depend on N
+    (search.py:381-386 concatenates its pool's results in input order).  The whole-corpus
+    records are also checked against the numpy n-gram join and, for the first 200 works,
+    the oracle."""
+    from fandom_search_amd.engine import ScriptIndex
+    conf = synth.CONFIGS["c3"]
+    shards, n = 8, 6
+    per, tpw = conf["n_works"] // shards, conf["tokens_per_work"]
+    script = synth.script_tokens(conf["script_tokens"])
+    words, emb = synth_base["words"], synth_base["emb"]
+    normals = synth.lsh_normals(n)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=abi.make_config())
+    tok, off = synth.corpus_tokens_parallel(conf["n_works"], tpw, script)
+    assert len(tok) == conf["n_works"] * tpw == 500_000_000
+    parts, windows = [], 0
+    for r in range(shards):
+        lo, hi = r * per, (r + 1) * per
+        c = ix.corpus(tok[lo * tpw:hi * tpw], off[lo:hi + 1] - off[lo], synth_base["chars"], synth_base["off"])
+        rows, st = ix.search(c)
+        assert st.path == abi.FS_MODE_EXACT and st.scan_launches == 1
+        windows += st.windows_processed
+        rows = rows.copy()
+        rows["work"] += np.uint32(lo)
+        parts.append(rows)
+        c.close()
+    sharded = np.concatenate(parts)
+    whole_c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    whole, st = ix.search(whole_c)
+    assert st.path == abi.FS_MODE_EXACT and st.scan_launches == 1
+    assert st.windows_processed == windows == conf["n_works"] * (tpw - n + 1)
+    assert len(whole) == len(sharded) > 2_000_000
+    assert whole.tobytes() == sharded.tobytes()
+    whole_c.close()
+    # the records themselves: properties, completeness on a 10k-work slice, oracle on 200 works
+    cut_w = 10_000
+    cut = int(off[cut_w])
+    head = whole[whole["work"] < cut_w]
+    pos = _check_rows(head, tok[:cut], off[:cut_w + 1], script, n)
+    want_pos, _ = _covered_words(tok[:cut], off[:cut_w + 1], script, n)
+    assert np.array_equal(pos, want_pos)
+    oi = util.oracle_index(abi.make_config(), script, words, emb, normals)
+    want, _ = oi.search(tok[:int(off[200])], off[:201], synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(whole[whole["work"] < 200], want)

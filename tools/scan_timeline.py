@@ -63,7 +63,7 @@ def main():
     out = np.zeros(n.value, dtype=np.uint64)
     _lib.check(L.fs_debug_stamps(ix._h, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)),
                "fs_debug_stamps")
-    d = out.reshape(-1, 8).astype(np.int64)
+    d = out.reshape(-1, 16).astype(np.int64)
     if a.dump:
         np.save(a.dump, d)
     t0 = d[:, 0].min()
@@ -80,6 +80,11 @@ def main():
     res["rounds_per_range"] = {int(k): int(v) for k, v in zip(*np.unique(d[:, 5], return_counts=True))}
     res["flushes_per_range"] = {int(k): int(v) for k, v in zip(*np.unique(d[:, 6], return_counts=True))}
     res["records_per_range"] = [int(x) for x in np.percentile(d[:, 7], [0, 50, 100])]
+    # phase sums of the rounds (the diagnostic build drains its loads at the phase ends, so
+    # read the shares, not the lengths), microseconds per ROUND, mean over the ranges
+    phases = ["pick", "ids_arrive", "table_arrives", "hits_stored", "records_emitted", "carry"]
+    rounds = np.maximum(d[:, 5], 1)
+    res["round_phase_us"] = {nm: round(float(np.mean(d[:, 8 + k] / rounds)) / 100.0, 3) for k, nm in enumerate(phases)}
     print(json.dumps(res), flush=True)
 
 
