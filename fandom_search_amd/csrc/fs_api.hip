@@ -104,6 +104,14 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e) != 0;
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
+  sw->rows_xpool = num("FS_ROWS_XPOOL");
+  if (const char* e = getenv("FS_ROWS_SHARES")) {
+    int v[4] = {0, 0, 0, 0};
+    if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] > 0 && v[1] > 0 && v[2] > 0 && v[3] > 0 &&
+        v[0] <= 512 && v[1] <= 512 && v[2] <= 512 && v[3] <= 512 && v[0] + v[1] + v[2] + v[3] == 1024)
+      for (int i = 0; i < 4; ++i) sw->rows_shares[i] = v[i];
+  }
+  if (const char* e = getenv("FS_ROWS_COOP")) sw->rows_coop = e[0] != '0';
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);
   if (const char* e = getenv("FS_LSH_F32")) sw->lsh_f32 = e[0] != '0';
   sw->lsh_diag = num("FS_LSH_DIAG");
@@ -1112,6 +1120,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
       // finish_rows: a workgroup's wait for the workgroups in front of it ran out.  Run the
       // search again through the chained kernels (no hand-off inside a launch).
       *gave_up = 0;
+      gave_up[1] = 0;
       if (!sl.caprow) { fs_set_error("in-launch wait flagged on a search without one"); return FS_E_DEVICE; }
       const uint64_t T = sl.c->n_tok;
       sl.caprow = 0; sl.fused_waves = 0;
@@ -1122,6 +1131,14 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
       ix->wait_fallbacks++;
       FS_TRY(search_enqueue(ix, sl));
       continue;
+    }
+    // shared rounds: a workgroup's pool for the slices' records was too small (the word behind
+    // the give-up word holds what one of them needed)
+    if (gave_up[1]) {
+      fs_index::Lane& pl = ix->lanes[sl.lane];
+      pl.xpool_hint = std::max<uint32_t>(2 * pl.xpool, gave_up[1] + gave_up[1] / 4 + 64);
+      gave_up[1] = 0;
+      again = true;
     }
     if (!sl.caprow && hs.n_cands > sl.ccap) { sl.ccap = (uint64_t)hs.n_cands + hs.n_cands / 8; again = true; }
     if (sl.caprow && hs.max_rows > sl.caprow) {

@@ -188,6 +188,9 @@ struct fs_switches {
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
   int rows_finish = 0;            // FS_ROWS_FINISH: 1 inside the launch, 2 k_compact, 0: by number of lanes
+  int rows_shares[4] = {0, 0, 0, 0};   // FS_ROWS_SHARES=a,b,c,d: scan shares of a SIMD's waves by slot age, sum 1024
+  bool rows_coop = true;          // FS_ROWS_COOP=0: no shared rounds (every wave works off its own range's candidates)
+  int rows_xpool = 0;             // FS_ROWS_XPOOL: records in a workgroup's pool for the shared rounds (tests: force the growth)
   int ranges_caprow = 0;          // FS_RANGES_CAPROW: staged records per wave range of k_scan_rows to start with (tests)
 };
 void fs_read_switches(fs_switches* sw);
@@ -251,6 +254,8 @@ struct fs_index {
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range
     uint32_t caprow_hint = 0;      //   staged records per wave range the last searches needed
+    DBuf<uint8_t> w_xstage;        // k_scan_rows, shared rounds: a pool of records per workgroup
+    uint32_t xpool = 0, xpool_hint = 0;   //   its size in the last launch / what the last searches needed
     DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup, then four statistics granules each
     DBuf<uint4> w_rinfo, w_csum;   // k_compact: {records, hits, pairs, candidates} per range / per workgroup
     uint32_t sync_epoch = 0;

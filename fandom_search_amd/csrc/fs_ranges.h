@@ -66,6 +66,37 @@ struct RangeState {
   // staged form) when the launch itself puts the records into place: they go from here to
   // their final place, never through the staging area
   uint4 k0, k1;
+  uint32_t pool_base;  // a slice's round (below): its first record in the workgroup's pool
+};
+
+// ---- shared rounds ----------------------------------------------------------------
+// At the end of its range a wave holds the candidates its last sub-tiles queued; what does
+// not fit its next round it may post as *slices* -- runs of queued records that fit one round
+// each -- for whichever wave of the workgroup has nothing left to do (its own included).
+// A slice is a range boundary like any other: the n-1 windows in front of its first
+// candidate are verified again (the hits a serial continuation would have carried), it owns
+// the words [P, F) from its first candidate to the next slice's, and its records go to a
+// pool of the workgroup (allocated when their number is known), from where the hand-off
+// puts them behind the owner's own.  Same records, same order as the serial rounds: a
+// record is a function of the hits covering its word.
+constexpr uint32_t kCoopPerWave = 6;      // slices a wave may post
+constexpr uint32_t kCoopWaves = 16;
+constexpr uint32_t kCoopSlots = kCoopPerWave * kCoopWaves;
+struct CoopSlice {
+  uint32_t r0, r1;     // records [r0, r1) of the owner's queue (at most 64)
+  uint32_t P, F;       // the slice's words
+  uint32_t a;          // first token of the owner's range (queued positions are relative to it)
+  uint32_t base, rows; // out: its records in the pool
+  uint32_t hits, pairs;// out: statistics
+  uint32_t pad;
+};
+struct alignas(16) CoopLds {
+  CoopSlice slice[kCoopSlots];            // wave w posts into [w * kCoopPerWave, ...)
+  uint32_t ring[kCoopSlots + kCoopWaves]; // slot + 1 in posting order (0: not posted yet)
+  uint32_t head, tail;                    // tickets taken, slices posted
+  uint32_t posted;                        // waves that are through with their range
+  uint32_t pool;                          // records allocated in the pool
+  uint32_t stat[16];                      // finish_rows of the last workgroup: the statistics its last waves gather
 };
 
 // FS_DIAG & 2: time per phase of the rounds, summed per wave range, in ticks of the 100 MHz
@@ -90,6 +121,8 @@ struct RangeOut {
   uint8_t* stage;      // caprow records per range
   uint32_t caprow;
   int wire;            // what the caller gets: 0 fs_row, 16 / 8 wire records (staged: 8 for 8, else 16)
+  uint8_t* xstage;     // shared rounds: xpool records per workgroup (nullptr: none)
+  uint32_t xpool;
 };
 
 // One round: lane i < 64 - (N-1) holds candidate window position `p` (ascending over the
@@ -108,7 +141,8 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
                                             uint32_t p, uint32_t F, uint32_t a,
                                             uint32_t range_id, const RangeOut& out,
                                             RangeState& R, const StrFast* sf,
-                                            uint32_t* give_up, bool keep_regs, RoundClock& clk) {
+                                            uint32_t* give_up, bool keep_regs, RoundClock& clk,
+                                            uint32_t* pool = nullptr) {
   const int lane = threadIdx.x & 63;
   if (F < R.E) F = R.E;
   round_lap<0>(clk, false);
@@ -258,6 +292,13 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
 #pragma unroll
   for (uint32_t k = 0; k < (uint32_t)N; ++k)
     if (k < cnt) S.owner[excl + k] = (uint8_t)lane;
+  if (pool) {                                          // a slice: its records' place in the pool
+    uint32_t b = 0;
+    if (lane == 0) b = __hip_atomic_fetch_add(pool, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    R.pool_base = b;
+    R.rows_run = b;
+  }
   wave_sync();
   // record r of the range is made by lane r % 64 (so that lane L makes the records L and
   // L + 64 it may keep in registers)
@@ -295,7 +336,16 @@ __device__ __forceinline__ void range_round(const CorpusDev& c, const GramIndexD
     }
     const size_t at = (size_t)range_id * out.caprow + ridx;
     if (out.wire == 8) reinterpret_cast<uint2*>(out.stage)[at] = make_uint2(qv.x, qv.y);
-    else reinterpret_cast<uint4*>(out.stage)[at] = qv;
+    else if (out.wire == 16 || !pool) reinterpret_cast<uint4*>(out.stage)[at] = qv;
+    else {
+      // a slice's record for a caller of fs_row: in its final form (the hand-off copies it)
+      const double dist = g.selfdist[orig - koff];
+      const double cmb = __dmul_rn(dist, (double)lev);
+      const uint64_t db = (uint64_t)__double_as_longlong(dist), cb = (uint64_t)__double_as_longlong(cmb);
+      uint4* d4 = reinterpret_cast<uint4*>(out.stage) + 2 * at;
+      d4[0] = make_uint4(qv.x, qv.y, qv.z, lev);
+      d4[1] = make_uint4((uint32_t)db, (uint32_t)(db >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
+    }
   }
   round_lap<4>(clk, false);
   R.rows_run += tot;
@@ -354,20 +404,52 @@ __device__ __forceinline__ StagedRec kept_staged(const uint4& q, int wire,
   return v;
 }
 
-__device__ __forceinline__ void store_staged(uint8_t* __restrict__ rows, int wire, const StagedRec& v, size_t dst) {
+typedef uint32_t fs_v4u __attribute__((ext_vector_type(4)));
+typedef uint32_t fs_v2u __attribute__((ext_vector_type(2)));
+// (nt: streaming stores -- the records are written once and read by somebody else)
+__device__ __forceinline__ void put16(uint8_t* base, size_t idx16, const uint4& q, bool nt) {
+  fs_v4u v = {q.x, q.y, q.z, q.w};
+  fs_v4u* d = reinterpret_cast<fs_v4u*>(base) + idx16;
+  if (nt) __builtin_nontemporal_store(v, d); else *d = v;
+}
+__device__ __forceinline__ void put8(uint8_t* base, size_t idx8, uint32_t x, uint32_t y, bool nt) {
+  fs_v2u v = {x, y};
+  fs_v2u* d = reinterpret_cast<fs_v2u*>(base) + idx8;
+  if (nt) __builtin_nontemporal_store(v, d); else *d = v;
+}
+
+__device__ __forceinline__ void store_staged(uint8_t* __restrict__ rows, int wire, const StagedRec& v, size_t dst,
+                                             bool nt = false) {
   if (!v.have) return;
   if (wire == 8) {
-    reinterpret_cast<uint2*>(rows)[dst] = make_uint2(v.q.x, v.q.y);
+    put8(rows, dst, v.q.x, v.q.y, nt);
   } else if (wire == 16) {
-    reinterpret_cast<uint4*>(rows)[dst] = v.q;
+    put16(rows, dst, v.q, nt);
   } else {
     const uint32_t lev = v.q.w & 0xFFFFu;
     const double comb = __dmul_rn(v.dist, (double)lev);
     const uint64_t db = (uint64_t)__double_as_longlong(v.dist), cb = (uint64_t)__double_as_longlong(comb);
-    uint4* d4 = reinterpret_cast<uint4*>(rows) + 2 * dst;
-    d4[0] = make_uint4(v.q.x, v.q.y, v.q.z, lev);
-    d4[1] = make_uint4((uint32_t)db, (uint32_t)(db >> 32), (uint32_t)cb, (uint32_t)(cb >> 32));
+    put16(rows, 2 * dst, make_uint4(v.q.x, v.q.y, v.q.z, lev), nt);
+    put16(rows, 2 * dst + 1, make_uint4((uint32_t)db, (uint32_t)(db >> 32), (uint32_t)cb, (uint32_t)(cb >> 32)), nt);
   }
+}
+
+// A slice's records lie in the workgroup's pool in the caller's format (the wave that made
+// them has looked the distances up): the hand-off copies bytes.
+struct PoolRec { uint4 a, b; };
+__device__ __forceinline__ uint32_t pool_rec_bytes(int wire) { return wire == 8 ? 8u : wire == 16 ? 16u : 32u; }
+__device__ __forceinline__ PoolRec pool_load(const uint8_t* __restrict__ pool, int wire, size_t idx) {
+  PoolRec r;
+  r.a = make_uint4(0, 0, 0, 0); r.b = r.a;
+  if (wire == 8) { const uint2 t = reinterpret_cast<const uint2*>(pool)[idx]; r.a.x = t.x; r.a.y = t.y; }
+  else if (wire == 16) r.a = reinterpret_cast<const uint4*>(pool)[idx];
+  else { r.a = reinterpret_cast<const uint4*>(pool)[2 * idx]; r.b = reinterpret_cast<const uint4*>(pool)[2 * idx + 1]; }
+  return r;
+}
+__device__ __forceinline__ void pool_store(uint8_t* __restrict__ rows, int wire, const PoolRec& r, size_t dst, bool nt) {
+  if (wire == 8) put8(rows, dst, r.a.x, r.a.y, nt);
+  else if (wire == 16) put16(rows, dst, r.a, nt);
+  else { put16(rows, 2 * dst, r.a, nt); put16(rows, 2 * dst + 1, r.b, nt); }
 }
 
 // ---- records into place inside the launch ------------------------------------------
@@ -407,6 +489,7 @@ struct RowFinal {
   fs_status* host_st;      // pinned host copy; the word behind it: set when a wait gave up
   uint64_t* count_out;     // FS_ROWS_HEADER
   bool fresh;              // nothing before this kernel wrote *st
+  bool nt;                 // streaming stores for the records
 };
 
 // All threads of the workgroup call this once every wave has staged its records.
@@ -419,7 +502,10 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
                                             uint32_t range_id,
                                             uint32_t my_rows, uint32_t hits, uint32_t pairs,
                                             uint32_t cands, uint32_t* s_cnt,
-                                            const RangeState* kept = nullptr) {
+                                            const RangeState* kept = nullptr,
+                                            const CoopLds* coop = nullptr, uint32_t my_slices = 0,
+                                            uint32_t* pool_need = nullptr, uint32_t* s_stat = nullptr,
+                                            unsigned long long* stamps = nullptr) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const uint32_t L = blockIdx.x;
@@ -443,13 +529,18 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
     }
     return;
   }
+  // the staged records of this wave have reached memory before anybody reads them back
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // shared rounds: whoever worked a slice off has added its records to the count of the wave
+  // that posted it (s_cnt[owner], LDS atomics; cleared at the start of the launch) and its hits
+  // and pairs to its own statistics; this wave adds its own records
+  const uint32_t slot0 = wave * kCoopPerWave;
   if (lane == 0) {
-    s_cnt[wave] = staged;
+    if (coop) __hip_atomic_fetch_add(&s_cnt[wave], staged, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else s_cnt[wave] = staged;
     s_cnt[n_waves + 2 + 4 * wave] = hits; s_cnt[n_waves + 3 + 4 * wave] = pairs;
     s_cnt[n_waves + 4 + 4 * wave] = cands; s_cnt[n_waves + 5 + 4 * wave] = my_rows;
   }
-  // the staged records of this wave have reached memory before it reads them back
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // this lane's first two records: in registers since they were made, or requested from the
   // staging area now; stored once their place is known
   const size_t sbase = (size_t)range_id * out.caprow;
@@ -462,31 +553,56 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
     r1 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane + 64, (uint32_t)lane + 64 < staged);
   }
   __syncthreads();
+  if (stamps) stamps[0] = __builtin_amdgcn_s_memrealtime();      // every wave of the workgroup is here
+  // the records of this wave's first slice, from the workgroup's pool: asked for now (two per
+  // lane), stored once their place is known
+  PoolRec p0, p1;
+  bool hp0 = false, hp1 = false;
+  const size_t xbase = coop ? (size_t)blockIdx.x * out.xpool : 0;
+  if (coop) {
+    if (my_slices) {
+      const uint32_t rows0 = coop->slice[slot0].rows, base0 = coop->slice[slot0].base;
+      hp0 = (uint32_t)lane < rows0 && base0 + lane < out.xpool;
+      hp1 = (uint32_t)lane + 64 < rows0 && base0 + lane + 64 < out.xpool;
+      if (hp0) p0 = pool_load(out.xstage, out.wire, xbase + base0 + lane);
+      if (hp1) p1 = pool_load(out.xstage, out.wire, xbase + base0 + lane + 64);
+    }
+    if (threadIdx.x == 0 && coop->pool > out.xpool)      // the pool was too small: the host grows it
+      __hip_atomic_store(pool_need, coop->pool, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   bool gave_up = false;
-  uint32_t total = 0;
   const unsigned long long tag = (unsigned long long)sy.epoch << 32;
+  const uint32_t uwave = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+  // records of the workgroup and of the waves in front of this one: lane i looks at wave i
+  const uint32_t cw = (uint32_t)lane < n_waves ? s_cnt[lane] : 0u;
+  const uint32_t cincl = wave_incl_scan_dpp(cw);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)cincl, 63);
+  const uint32_t in_front = (uint32_t)__builtin_amdgcn_readlane((int)(cincl - cw), (int)uwave);
   if (wave == 0) {
-    uint4 bs = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = 0; i < n_waves; ++i) {
-      total += s_cnt[i];
-      bs.x += s_cnt[n_waves + 2 + 4 * i]; bs.y += s_cnt[n_waves + 3 + 4 * i];
-      bs.z += s_cnt[n_waves + 4 + 4 * i];
-      const uint32_t r = s_cnt[n_waves + 5 + 4 * i];
-      bs.w = r > bs.w ? r : bs.w;
+    // five granules, no ordering between them: each carries the epoch.  The count first
+    // (the workgroups behind wait for it), the statistics once they are summed.
+    if (lane == 0) __hip_atomic_store(sy.gran + L, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t h = 0, pr = 0, cd = 0, mr = 0;
+    if ((uint32_t)lane < n_waves) {
+      h = s_cnt[n_waves + 2 + 4 * lane]; pr = s_cnt[n_waves + 3 + 4 * lane];
+      cd = s_cnt[n_waves + 4 + 4 * lane]; mr = s_cnt[n_waves + 5 + 4 * lane];
     }
-    // five granules, no ordering between them: each carries the epoch
-    if (lane == 0) {
-      __hip_atomic_store(sy.gran + L, tag | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_cnt[n_waves + 1] = total;
+    h = wave_sum_lane63(h); pr = wave_sum_lane63(pr); cd = wave_sum_lane63(cd);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const uint32_t o = (uint32_t)__shfl_xor((int)mr, d);
+      mr = o > mr ? o : mr;
     }
-    if (lane < 4) {
-      const uint32_t v = lane == 0 ? bs.x : lane == 1 ? bs.y : lane == 2 ? bs.z : bs.w;
-      __hip_atomic_store(sy.sgran + 4 * (size_t)L + lane, tag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 63) {
+      __hip_atomic_store(sy.sgran + 4 * (size_t)L + 0, tag | h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sy.sgran + 4 * (size_t)L + 1, tag | pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sy.sgran + 4 * (size_t)L + 2, tag | cd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sy.sgran + 4 * (size_t)L + 3, tag | mr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   // records of the workgroups in front: every granule, once it carries this launch's
   // epoch.  Wave w takes the granules [64 w, 64 w + 64), and so on in steps of the
-  // workgroup: all waves poll side by side, one round trip when everybody is done.
+  // workgroup: the waves poll side by side, one round trip when everybody is done.
   uint32_t pre = 0;
   for (uint32_t i0 = wave * 64; i0 < L; i0 += n_waves * 64) {
     const uint32_t i = i0 + lane;
@@ -502,59 +618,92 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
     }
     pre += (i < L && ok) ? (uint32_t)v : 0u;
   }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) pre += (uint32_t)__shfl_xor((int)pre, d);
-  if (lane == 0) s_cnt[5 * n_waves + 2 + wave] = pre;
+  pre = wave_sum_lane63(pre);
+  if (lane == 63) s_cnt[5 * n_waves + 2 + wave] = pre;
+  if (stamps) stamps[1] = __builtin_amdgcn_s_memrealtime();      // the counts in front are known to this wave
   __syncthreads();
-  // this wave's records: from the staging area to their place
+  if (stamps) stamps[2] = __builtin_amdgcn_s_memrealtime();      // ... and to every wave of the workgroup
+  // this wave's records: from the registers / the staging area to their place
   uint32_t before = 0;                                   // records of the workgroups in front
   for (uint32_t i = 0; i < n_waves; ++i) before += s_cnt[5 * n_waves + 2 + i];
-  uint32_t first = before;
-  for (uint32_t i = 0; i < wave; ++i) first += s_cnt[i];
-  uint32_t n = staged;
-  if (first >= fin.rcap) n = 0;
-  else if (first + n > fin.rcap) n = fin.rcap - first;
-  if ((uint32_t)lane < n) store_staged(fin.rows, out.wire, r0, (size_t)first + lane);
-  if ((uint32_t)lane + 64 < n) store_staged(fin.rows, out.wire, r1, (size_t)first + lane + 64);
+  const uint32_t first = before + in_front;
+  const uint32_t lim = first < fin.rcap ? fin.rcap - first : 0u;      // records of this wave the caller's buffer holds
+  const uint32_t n = staged < lim ? staged : lim;
+  if ((uint32_t)lane < n) store_staged(fin.rows, out.wire, r0, (size_t)first + lane, fin.nt);
+  if ((uint32_t)lane + 64 < n) store_staged(fin.rows, out.wire, r1, (size_t)first + lane + 64, fin.nt);
   for (uint32_t i = lane + 128; i < n; i += 64)
-    store_staged(fin.rows, out.wire, fetch_staged(out.stage, out.wire, selfdist, sbase + i, true), (size_t)first + i);
-  // the last workgroup: every other one has published its count; their statistics are
-  // granules of their own, asked for together and again until every one is there
-  if (L + 1 == sy.n_blocks && wave == 0) {
-    uint32_t h = 0, pr = 0, cd = 0, mx = 0;
-    for (uint32_t i = lane; i < sy.n_blocks; i += 64) {
-      const unsigned long long* sg = sy.sgran + 4 * (size_t)i;
-      unsigned long long a = 0, b = 0, c2 = 0, d2 = 0;
-      for (uint32_t spins = 0;; ++spins) {
-        a = __hip_atomic_load(sg + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b = __hip_atomic_load(sg + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c2 = __hip_atomic_load(sg + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        d2 = __hip_atomic_load(sg + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(a >> 32) == sy.epoch && (uint32_t)(b >> 32) == sy.epoch &&
-            (uint32_t)(c2 >> 32) == sy.epoch && (uint32_t)(d2 >> 32) == sy.epoch) break;
-        if (spins > 16) __builtin_amdgcn_s_sleep(1);
-        if (spins >= sy.spin_limit) { gave_up = true; break; }
+    store_staged(fin.rows, out.wire, fetch_staged(out.stage, out.wire, selfdist, sbase + i, true), (size_t)first + i, fin.nt);
+  if (coop) {                       // the records of the wave's slices, from the workgroup's pool
+    if (hp0 && staged + lane < lim) pool_store(fin.rows, out.wire, p0, (size_t)first + staged + lane, fin.nt);
+    if (hp1 && staged + lane + 64 < lim) pool_store(fin.rows, out.wire, p1, (size_t)first + staged + lane + 64, fin.nt);
+    uint32_t off = staged;
+    for (uint32_t k = 0; k < my_slices; ++k) {
+      const uint32_t rows_k = coop->slice[slot0 + k].rows, base_k = coop->slice[slot0 + k].base;
+      for (uint32_t i = lane + (k ? 0u : 128u); i < rows_k; i += 64)
+        if (off + i < lim && base_k + i < out.xpool)
+          pool_store(fin.rows, out.wire, pool_load(out.xstage, out.wire, xbase + base_k + i), (size_t)first + off + i, fin.nt);
+      off += rows_k;
+    }
+  }
+  // The search's status: the record count from the last workgroup (it has seen every other
+  // one), the statistics from the first -- it waits for nobody's count, so once its records
+  // are in place its waves ask for the statistics granules of all workgroups (every one again
+  // until it is there) while the others are still busy with their hand-off.
+  const bool last = L + 1 == sy.n_blocks;
+  if (last && threadIdx.x == 0) {
+    const uint32_t n_rows = before + total;
+    if (fin.fresh) {
+      fin.st->max_recs = 0; fin.st->lev_overflow = 0; fin.st->bad_string = 0; fin.st->lsh_pending = 0;
+      fin.host_st->max_recs = 0; fin.host_st->lev_overflow = 0; fin.host_st->bad_string = 0; fin.host_st->lsh_pending = 0;
+    } else {
+      fin.host_st->max_recs = fin.st->max_recs; fin.host_st->lev_overflow = fin.st->lev_overflow;
+      fin.host_st->bad_string = fin.st->bad_string; fin.host_st->lsh_pending = fin.st->lsh_pending;
+    }
+    fin.st->n_rows = n_rows;
+    fin.host_st->n_rows = n_rows;
+    if (fin.count_out) *fin.count_out = n_rows;
+  }
+  if (L == 0) {
+    const uint32_t stat_waves = n_waves < 4 ? n_waves : 4u;
+    if (wave < stat_waves) {
+      uint32_t h = 0, pr = 0, cd = 0, mx = 0;
+      for (uint32_t i = wave * 64 + lane; i < sy.n_blocks; i += stat_waves * 64) {
+        const unsigned long long* sg = sy.sgran + 4 * (size_t)i;
+        unsigned long long a = 0, b = 0, c2 = 0, d2 = 0;
+        for (uint32_t spins = 0;; ++spins) {
+          // the four granules with two 16-byte loads in flight together (device-coherent: sc1;
+          // each granule carries its own epoch, so the pair need not be one access)
+          fs_v4u q0, q1;
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(q0), "=&v"(q1) : "v"(sg) : "memory");
+          a = q0.x | ((unsigned long long)q0.y << 32); b = q0.z | ((unsigned long long)q0.w << 32);
+          c2 = q1.x | ((unsigned long long)q1.y << 32); d2 = q1.z | ((unsigned long long)q1.w << 32);
+          if ((uint32_t)(a >> 32) == sy.epoch && (uint32_t)(b >> 32) == sy.epoch &&
+              (uint32_t)(c2 >> 32) == sy.epoch && (uint32_t)(d2 >> 32) == sy.epoch) break;
+          if (spins > 16) __builtin_amdgcn_s_sleep(8);
+          if (spins >= sy.spin_limit) { gave_up = true; break; }
+        }
+        h += (uint32_t)a; pr += (uint32_t)b; cd += (uint32_t)c2;
+        mx = (uint32_t)d2 > mx ? (uint32_t)d2 : mx;
       }
-      h += (uint32_t)a; pr += (uint32_t)b; cd += (uint32_t)c2;
-      mx = (uint32_t)d2 > mx ? (uint32_t)d2 : mx;
-    }
+      h = wave_sum_lane63(h); pr = wave_sum_lane63(pr); cd = wave_sum_lane63(cd);
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-      h += (uint32_t)__shfl_xor((int)h, d); pr += (uint32_t)__shfl_xor((int)pr, d);
-      cd += (uint32_t)__shfl_xor((int)cd, d);
-      const uint32_t o = (uint32_t)__shfl_xor((int)mx, d);
-      mx = o > mx ? o : mx;
+      for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)mx, d);
+        mx = o > mx ? o : mx;
+      }
+      if (lane == 63) { s_stat[4 * wave] = h; s_stat[4 * wave + 1] = pr; s_stat[4 * wave + 2] = cd; s_stat[4 * wave + 3] = mx; }
     }
-    if (lane == 0) {
-      fs_status o;
-      if (fin.fresh) { o.max_recs = 0; o.lev_overflow = 0; o.bad_string = 0; o.lsh_pending = 0; }
-      else o = *fin.st;
-      o.n_rows = before + s_cnt[n_waves + 1];
-      o.n_hits = h; o.n_matches = pr; o.n_cands = cd;
-      o.max_rows = mx > out.caprow ? mx : 0;
-      *fin.st = o;
-      *fin.host_st = o;
-      if (fin.count_out) *fin.count_out = o.n_rows;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t h = 0, pr = 0, cd = 0, mx = 0;
+      for (uint32_t k = 0; k < stat_waves; ++k) {
+        h += s_stat[4 * k]; pr += s_stat[4 * k + 1]; cd += s_stat[4 * k + 2];
+        mx = s_stat[4 * k + 3] > mx ? s_stat[4 * k + 3] : mx;
+      }
+      const uint32_t over = mx > out.caprow ? mx : 0;
+      fin.st->n_hits = h; fin.st->n_matches = pr; fin.st->n_cands = cd; fin.st->max_rows = over;
+      fin.host_st->n_hits = h; fin.host_st->n_matches = pr; fin.host_st->n_cands = cd; fin.host_st->max_rows = over;
     }
   }
   if (__any(gave_up) && lane == 0) {

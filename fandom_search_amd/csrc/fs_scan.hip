@@ -432,7 +432,10 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
 // requested before that, so their latency and the rounds' dependent loads overlap;
 // the other waves of the SIMD keep scanning meanwhile (flushes fall at data-dependent
 // times, so the waves drift apart instead of queueing at the end of the kernel).
-constexpr uint32_t kRecQueue = 128;   // queued records per wave (a sub-tile adds at most 64)
+#ifndef FS_REC_QUEUE
+#define FS_REC_QUEUE 192
+#endif
+constexpr uint32_t kRecQueue = FS_REC_QUEUE;   // queued records per wave (a sub-tile adds at most 64)
 constexpr uint32_t kRecFlush = 34;    // flush threshold: about 1.35 candidates per record, so
                                       // that queue + halo mostly fit one round
 
@@ -448,13 +451,16 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     fsdev::RowSync sy, fsdev::RowFinal fin,
                                                     uint32_t disp_lds, uint32_t diag,
                                                     unsigned long long* __restrict__ dbg,
-                                                    StrFast strf) {
+                                                    StrFast strf, uint4 shares) {
   using namespace fsdev;
   static_assert(N >= 2 && N <= 8, "halo must fit in the next lane's eight tokens");
-  // FS_DIAG & 2: sixteen words per wave range {entry, filter in LDS, scan done, rounds done,
-  // finished, rounds, flushes, records, six phase sums of the rounds (RoundClock), -, -} in
+  static_assert(kRecQueue >= 192, "a pair of sub-tiles adds up to 128 records to a queue of up to 63");
+  // FS_DIAG & 2: twenty words per wave range {entry, filter in LDS, scan done, rounds done,
+  // finished, rounds, flushes, records, six phase sums of the rounds (RoundClock), three stamps
+  // of the hand-off (workgroup together, counts known to the wave, to the workgroup), -, -, -} in
   // ticks of the 100 MHz constant clock (tools/scan_timeline.py)
   unsigned long long t_entry = 0, t_ready = 0, t_scan = 0, t_rounds = 0;
+  unsigned long long t_fin[3] = {0, 0, 0};
   uint32_t n_rounds = 0, n_flushes = 0;
   if (dbg) t_entry = __builtin_amdgcn_s_memrealtime();
   // all of the kernel's LDS is dynamic, the filter first: its word offsets are then LDS
@@ -473,6 +479,11 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   FusedLds& W = s_wave[wave];
   RangeLds& S = W.R;
   uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_wave + n_waves);   // 6 * n_waves + 2 words (finish_rows)
+  // shared rounds (fs_ranges.h): the slices the waves post for each other, behind s_cnt
+  CoopLds& C = *reinterpret_cast<CoopLds*>(s_cnt + ((6 * n_waves + 2 + 3) & ~3u));
+  // ... when the launch puts the records into place itself (FS_DIAG & 256: every wave does all
+  // the rounds of its range by itself, as before)
+  const bool coop = !STR && !sy.rinfo && out.xstage && !(diag & 256) && n_waves <= kCoopWaves;
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   // Sub-tiles dealt out evenly over the workgroups (the first n_sub % gridDim.x take one
   // more), and inside a workgroup of sixteen waves by how fast its SIMD serves each wave: the
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     auto cut = [&](uint32_t w) -> uint32_t {             // first sub-tile of wave w (w <= n_waves)
       if (n_waves != 16 || (diag & 16)) return (uint32_t)(((uint64_t)len * w) / n_waves);
       const uint32_t g = w >> 2, r = w & 3;
-      const uint32_t share[5] = {0, 305, 579, 830, 1024};          // cumulative, in 1/1024 of a quarter
+      const uint32_t share[5] = {0, shares.x, shares.y, shares.z, 1024};   // cumulative, in 1/1024 of a quarter
       const uint32_t at = 4 * share[g] + r * (share[g + 1] - share[g]);
       return (uint32_t)(((uint64_t)len * at) >> 12);
     };
@@ -539,6 +550,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   for (uint32_t e = threadIdx.x; e < disp_lds / 16; e += blockDim.x)     // (a multiple of 16 bytes)
     reinterpret_cast<uint4*>(s_dyn + (1u << lw))[e] = reinterpret_cast<const uint4*>(g.disp8)[e];
   copy_filter_to_lds(K ? g.sfilter : g.filter, s_filter, lw);
+  for (uint32_t e = threadIdx.x; e < kCoopSlots + kCoopWaves; e += blockDim.x) C.ring[e] = 0;
+  if (threadIdx.x < n_waves) s_cnt[threadIdx.x] = 0;        // records per wave: LDS atomics add to them
+  if (threadIdx.x == 0) { C.head = 0; C.tail = 0; C.posted = 0; C.pool = 0; }
   // FS_DIAG & 128: instruction priority by SIMD slot age (the youngest wave of a SIMD first)
   if (diag & 128) {
     const uint32_t age = wave >> 2;
@@ -558,6 +572,28 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   clk.on = !STR && dbg != nullptr;
   clk.t0 = clk.t1 = clk.t2 = clk.t3 = clk.t4 = clk.t5 = 0; clk.last = 0;
   uint32_t cacc = 0;                           // per lane: candidates seen
+  uint32_t my_slices = 0;                      // slices posted by this wave
+  // a round over the records [r0, r1) of a queue (all of them fit it), behind `hn` windows in
+  // front of `hbase + hn` that are verified whatever the filter said; the lanes of the
+  // records write the window positions into cand[]
+  auto make_round = [&](const uint32_t* qrec, uint32_t qa, uint32_t r0, uint32_t r1, uint32_t hn, uint32_t hbase) {
+    const uint32_t rec = r0 + (uint32_t)lane < r1 ? qrec[r0 + lane] : 0u;
+    uint32_t fb = rec & 0xFFu;
+    const uint32_t cn = __popc(fb);
+    const uint32_t inc = wave_incl_scan_dpp(cn);
+    if (cn) {
+      uint32_t at = hn + inc - cn;
+      const uint32_t pb = qa + ((rec >> 8) << 3) - 1u;
+      do {
+        W.cand[at++] = pb + (uint32_t)__ffs(fb);
+        fb &= fb - 1;
+      } while (fb);
+    }
+    if ((uint32_t)lane < hn) W.cand[lane] = hbase + (uint32_t)lane;
+    const uint32_t total = hn + (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    wave_sync();
+    return (uint32_t)lane < total ? W.cand[lane] : FS_NONE;
+  };
   if (s1 > s0) {
     const uint32_t a = s0 * SUB, bnd = s1 * SUB;
     R.E = a;
@@ -610,51 +646,81 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
     // the candidate counts says which records fit and where their candidates go, and the
     // lanes of those records write the window positions into cand[] -- three LDS round
     // trips (records, positions, positions back), no search.
-    auto flush = [&](uint32_t F_end) {
+    auto flush = [&](uint32_t F_end, bool final) {
       if (clk.on) clk.last = (uint32_t)__builtin_amdgcn_s_memrealtime();
       wave_sync();
       uint32_t rt = 0;                             // records taken so far
+      uint32_t rec_end = rec_cnt;                  // ... of those this wave works off itself
       do {
         const uint32_t take = R.hc ? 64u - R.hc : 63u;
         const uint32_t hn = halo_n;
-        const uint32_t rec = rt + (uint32_t)lane < rec_cnt ? W.rec[rt + lane] : 0u;
-        uint32_t fb = rec & 0xFFu;
-        const uint32_t cn = __popc(fb);
-        const uint32_t inc = wave_incl_scan_dpp(cn);
-        const bool fits = cn != 0 && hn + inc <= take;
-        const uint64_t fit = __ballot(fits);       // (a prefix of the lanes)
-        const uint32_t m = (uint32_t)__popcll(fit);
-        if (fits) {
-          uint32_t at = hn + inc - cn;
-          const uint32_t pb = a + ((rec >> 8) << 3) - 1u;
-          do {
-            W.cand[at++] = pb + (uint32_t)__ffs(fb);
-            fb &= fb - 1;
-          } while (fb);
+        // the records that fit this round: a prefix sum of their candidate counts
+        uint32_t m;
+        {
+          const uint32_t rec = rt + (uint32_t)lane < rec_end ? W.rec[rt + lane] : 0u;
+          const uint32_t cn = __popc(rec & 0xFFu);
+          const uint32_t inc = wave_incl_scan_dpp(cn);
+          m = (uint32_t)__popcll(__ballot(cn != 0 && hn + inc <= take));      // (a prefix of the lanes)
         }
-        if ((uint32_t)lane < hn) W.cand[lane] = a - hn + (uint32_t)lane;
-        const uint32_t total = hn + (m ? (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)(m - 1)) : 0u);
         // the first position whose hit status is not known after this round: the first
         // candidate left behind, or the scan front
         uint32_t F = F_end;
-        if (rt + m < rec_cnt) {
+        if (rt + m < rec_end) {
           const uint32_t r2 = W.rec[rt + m];       // (the same word for every lane)
           const uint32_t nx = a + ((r2 >> 8) << 3) + (uint32_t)__ffs(r2 & 0xFFu) - 1u;
           if (nx < F) F = nx;
+          // End of the range, more candidates than this round takes: what is left is cut
+          // into slices of one round each and posted for the waves that are through with their
+          // own ranges (fs_ranges.h, shared rounds) -- all of it or, with more than
+          // kCoopPerWave slices, none of it (this wave then goes on by itself)
+          if (final && coop && my_slices == 0) {
+            const uint32_t slot0 = wave * kCoopPerWave;
+            uint32_t q = rt + m, ns = 0;
+            bool ok = true;
+            while (q < rec_end) {
+              if (ns == kCoopPerWave) { ok = false; break; }
+              const uint32_t rq = q + (uint32_t)lane < rec_end ? W.rec[q + lane] : 0u;
+              const uint32_t cq = __popc(rq & 0xFFu);
+              const uint32_t iq = wave_incl_scan_dpp(cq);
+              const uint32_t mm = (uint32_t)__popcll(__ballot(cq != 0 && HALO + iq <= 63u));
+              const uint32_t r1st = (uint32_t)__builtin_amdgcn_readfirstlane((int)rq);
+              const uint32_t P = a + ((r1st >> 8) << 3) + (uint32_t)__ffs(r1st & 0xFFu) - 1u;
+              if (lane == 0) {
+                CoopSlice& d = C.slice[slot0 + ns];
+                d.r0 = q; d.r1 = q + mm; d.P = P; d.F = F_end; d.a = a;
+                d.base = 0; d.rows = 0; d.hits = 0; d.pairs = 0;
+                if (ns) C.slice[slot0 + ns - 1].F = P;
+              }
+              q += mm;
+              ++ns;
+            }
+            if (ok) {
+              if (lane == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                const uint32_t t0 = __hip_atomic_fetch_add(&C.tail, ns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (uint32_t k = 0; k < ns; ++k)
+                  __hip_atomic_store(&C.ring[t0 + k], slot0 + k + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+              }
+              my_slices = ns;
+              rec_end = rt + m;                    // this round is the wave's last of the range
+            }
+          }
         }
-        wave_sync();
-        const uint32_t p = (uint32_t)lane < total ? W.cand[lane] : FS_NONE;
+        const uint32_t p = make_round(W.rec, a, rt, rt + m, hn, a - hn);
         if (!(diag & 1))
           range_round<N, STR>(c, g, disp_off, S, p, F, a, range_id, out, R,
                               &strf, reinterpret_cast<uint32_t*>(fin.host_st + 1), keep_regs, clk);
         rt += m;
         halo_n = 0;
         ++n_rounds;
-      } while (rt < rec_cnt);
+      } while (rt < rec_end);
       rec_cnt = 0;
       ++n_flushes;
     };
-    const uint32_t flush_at = (diag >> 8) ? (diag >> 8) : kRecFlush;
+    // (shared rounds: what a range queues is best kept for its end, where the waves share the
+    // rounds; a wave that has to empty its queue in mid-range does so by itself)
+    const uint32_t flush_req = (diag >> 12) ? (diag >> 12) : coop ? kRecQueue - 128 : kRecFlush;
+    const uint32_t flush_at = flush_req < kRecQueue - 128 ? flush_req : kRecQueue - 128;
     Pair nx = request(s0);
     for (uint32_t j = s0; j < s1; j += 2) {
       const Pair v = arrive(nx);
@@ -663,28 +729,78 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       uint32_t halo[8];
       // A's halo: the first ids of the lane behind, lane 63: lane 0's first ids of B -- one
       // DPP rotation of the wave per id (no LDS), lane 0 offering its B ids
+      if (diag & 1024) {                         // (A/B: the same through ds_bpermute)
+#pragma unroll
+        for (int h = 0; h < (int)HALO; ++h) halo[h] = (uint32_t)__shfl((int)(lane == 0 ? mb.v[h] : ma.v[h]), (lane + 1) & 63);
+      } else
 #pragma unroll
       for (int h = 0; h < (int)HALO; ++h)
         halo[h] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(lane == 0 ? mb.v[h] : ma.v[h]), 0x134, 0xF, 0xF, false);   // wave_rol:1
       scan(ma, halo, j);
-      // (a queue of kRecQueue records: at most 64 more come from one sub-tile)
-      const bool odd_end = j + 1 == s1;
-      if (dbg && odd_end) t_scan = __builtin_amdgcn_s_memrealtime();
-      if (odd_end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt > kRecQueue - 64)
-        flush(odd_end ? bnd : j * SUB + SUB);
-      if (odd_end) break;
-      // B's halo: lane 63 takes the ids behind B (the same in every lane): a DPP shift of
-      // the wave, the lane without a source keeps `old`
-      {
+      const bool odd_end = j + 1 == s1;            // the range ends behind A
+      if (!odd_end) {
+        // B's halo: lane 63 takes the ids behind B (the same in every lane): a DPP shift of
+        // the wave, the lane without a source keeps `old`
         const uint32_t hv[8] = {v.h0.x, v.h0.y, v.h0.z, v.h0.w, v.h1.x, v.h1.y, v.h1.z, v.h1.w};
+        if (diag & 1024) {
+#pragma unroll
+          for (int h = 0; h < (int)HALO; ++h) halo[h] = (uint32_t)__shfl((int)(lane == 0 ? fs_premix(hv[h]) : mb.v[h]), (lane + 1) & 63);
+        } else
 #pragma unroll
         for (int h = 0; h < (int)HALO; ++h)
           halo[h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(hv[h]), (int)mb.v[h], 0x130, 0xF, 0xF, false);   // wave_shl:1
+        scan(mb, halo, j + 1);
       }
-      scan(mb, halo, j + 1);
-      const bool end = j + 2 == s1;
+      // ONE place where the queue is worked off (the rounds are a lot of code: a second copy
+      // of them competes for the instruction cache): behind the pair.  The queue holds
+      // kRecQueue = 192 records, a pair adds at most 128, so a queue below 64 at the start of
+      // a pair cannot overflow.
+      const bool end = odd_end || j + 2 == s1;
       if (dbg && end) t_scan = __builtin_amdgcn_s_memrealtime();
-      if (end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt >= flush_at) flush(end ? bnd : j * SUB + 2 * SUB);
+      if (end ? (rec_cnt | halo_n | R.hc) != 0 : rec_cnt >= flush_at) flush(end ? bnd : j * SUB + 2 * SUB, end);
+    }
+  }
+  // Shared rounds: this wave is through with its range; it takes slices in posting order
+  // (a ticket each) until every wave is through and every posted slice has been taken.
+  if (coop) {
+    if (lane == 0) __hip_atomic_fetch_add(&C.posted, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const RangeOut xout{out.xstage + (size_t)blockIdx.x * out.xpool * pool_rec_bytes(out.wire), out.xpool, out.wire,
+                        nullptr, 0};
+    for (;;) {
+      uint32_t t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add(&C.head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+      uint32_t slot = 0;
+      for (;;) {
+        slot = __hip_atomic_load(&C.ring[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (slot) break;
+        // (every wave through: the count of posted slices is final, and a ticket below it
+        // will be served)
+        if (__hip_atomic_load(&C.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == n_waves &&
+            t >= __hip_atomic_load(&C.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+      if (!slot) break;
+      CoopSlice& d = C.slice[slot - 1];
+      const uint32_t d_r0 = d.r0, d_r1 = d.r1, d_P = d.P, d_F = d.F, d_a = d.a;
+      RangeState Rs;
+      Rs.E = d_P; Rs.hc = 0; Rs.rows_run = 0; Rs.hits_run = 0; Rs.match_acc = 0; Rs.pool_base = 0;
+      Rs.k0 = make_uint4(0, 0, 0, 0); Rs.k1 = make_uint4(0, 0, 0, 0);
+      wave_sync();
+      const uint32_t p = make_round(s_wave[(slot - 1) / kCoopPerWave].rec, d_a, d_r0, d_r1, HALO, d_P - HALO);
+      if (!(diag & 1))
+        range_round<N, STR>(c, g, disp_off, S, p, d_F, d_P, 0u, xout, Rs,
+                            &strf, reinterpret_cast<uint32_t*>(fin.host_st + 1), false, clk, &C.pool);
+      // its records count for the wave that posted it, its hits and pairs for this one
+      R.hits_run += Rs.hits_run;
+      R.match_acc += Rs.match_acc;
+      if (lane == 0) {
+        d.base = Rs.pool_base; d.rows = Rs.rows_run - Rs.pool_base;
+        __hip_atomic_fetch_add(&s_cnt[(slot - 1) / kCoopPerWave], Rs.rows_run - Rs.pool_base, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      ++n_rounds;
     }
   }
 #pragma unroll
@@ -694,13 +810,14 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   }
   if (dbg) t_rounds = __builtin_amdgcn_s_memrealtime();
   finish_rows(sy, fin, out, g.selfdist, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt,
-              keep_regs ? &R : nullptr);
+              keep_regs ? &R : nullptr, coop ? &C : nullptr, my_slices,
+              reinterpret_cast<uint32_t*>(fin.host_st + 1) + 1, C.stat, dbg ? t_fin : nullptr);
   if (dbg && lane == 0) {
-    unsigned long long* d = dbg + 16 * (size_t)range_id;
+    unsigned long long* d = dbg + 20 * (size_t)range_id;
     d[0] = t_entry; d[1] = t_ready; d[2] = t_scan; d[3] = t_rounds;
     d[4] = __builtin_amdgcn_s_memrealtime(); d[5] = n_rounds; d[6] = n_flushes; d[7] = R.rows_run;
     d[8] = clk.t0; d[9] = clk.t1; d[10] = clk.t2; d[11] = clk.t3; d[12] = clk.t4; d[13] = clk.t5;
-    d[14] = 0; d[15] = 0;
+    d[14] = t_fin[0]; d[15] = t_fin[1]; d[16] = t_fin[2]; d[17] = 0; d[18] = 0; d[19] = 0;
   }
 }
 
@@ -849,6 +966,18 @@ static uint32_t fs_scan_rows_disp_lds(const fs_index* ix) {
   return bytes <= 16 * 1024 && ix->sw.rows_disp_lds ? bytes : 0;
 }
 
+// Shares of a SIMD's four waves in their quarter of the workgroup's sub-tiles, oldest slot
+// first, cumulative in 1/1024 (FS_ROWS_SHARES=a,b,c,d).  The waves of a SIMD are served
+// oldest first; the shares make them finish their scans together.
+uint4 fs_scan_rows_shares(const fs_index* ix, bool coop);
+uint4 fs_scan_rows_shares(const fs_index* ix, bool coop) {
+  const int* sh = ix->sw.rows_shares;
+  if (sh[0] > 0 && sh[0] + sh[1] + sh[2] + sh[3] == 1024)
+    return make_uint4((uint32_t)sh[0], (uint32_t)(sh[0] + sh[1]), (uint32_t)(sh[0] + sh[1] + sh[2]), 1024u);
+  (void)coop;
+  return make_uint4(305u, 579u, 830u, 1024u);
+}
+
 namespace {
 
 // log2 words of the filter k_scan_rows holds in LDS: the sub-shingle filter's where it
@@ -864,13 +993,14 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
                      const fsdev::RowFinal& fin, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   unsigned long long* dbg = nullptr;
   if (ix->sw.diag & 2) {               // timeline stamps, read back by fs_debug_stamps
-    FS_TRY(ix->cur->w_dbg.reserve((size_t)blocks * waves * 16));
+    FS_TRY(ix->cur->w_dbg.reserve((size_t)blocks * waves * 20));
     dbg = ix->cur->w_dbg.p;
-    ix->cur->dbg_words = (size_t)blocks * waves * 16;
+    ix->cur->dbg_words = (size_t)blocks * waves * 20;
   }
   const uint32_t disp_lds = fs_scan_rows_disp_lds(ix);
   const int lw = rows_filter_log2(ix);
-  const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds) + (6 * waves + 2) * sizeof(uint32_t);
+  const size_t lds = ((size_t)4 << lw) + disp_lds + waves * sizeof(FusedLds) +
+                     ((6 * waves + 2 + 3) & ~3u) * sizeof(uint32_t) + (sy.rinfo ? 0 : sizeof(fsdev::CoopLds));
   // (non-temporal id loads only on request, FS_SCAN_FLAGS=n: they measured slower at every
   // batch size, 0.50 against 0.61 of peak on a 1 GB batch)
   const bool nt = ix->sw.scan_flags == 'n';
@@ -903,7 +1033,7 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   }
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(waves * 64), (uint32_t)lds, s, e0, e1,
                         0u, c->dev(), ix->gram_dev(), n_sub, out,
-                        sy, fin, disp_lds, (uint32_t)ix->sw.diag, dbg, strf);
+                        sy, fin, disp_lds, (uint32_t)ix->sw.diag, dbg, strf, fs_scan_rows_shares(ix, sy.rinfo == nullptr));
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -925,8 +1055,8 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
   // a switch that asks for one of the other scan kernels or paths
   const fs_switches& sw = ix->sw;
   if (sw.scan_simple || sw.scan_tpl == 4 || !sw.scan_direct || sw.scan_capw) return 0;
-  // (1 KB: the kernel's static LDS, s_cnt)
-  const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 1024;
+  // (1 KB: s_cnt; the slices of the shared rounds)
+  const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 1024 + sizeof(fsdev::CoopLds);
   const size_t cu_lds = 160 * 1024;
   // a hit's LDS record holds its window position relative to the wave range in
   // fsdev::kHitPosBits bits: the longest range of the shape must fit (a wave of sixteen
@@ -934,7 +1064,7 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
   auto fits = [&](uint32_t waves, uint32_t nblocks) {
     const uint64_t n_sub = (c->n_tok + 511) / 512;
     const uint64_t len = n_sub / nblocks + 1;
-    const uint64_t longest = (waves == 16 && !(sw.diag & 16) ? (len * 305 + 4095) / 4096 : (len + waves - 1) / waves) + 1;
+    const uint64_t longest = (waves == 16 && !(sw.diag & 16) ? (len * 512 + 4095) / 4096 : (len + waves - 1) / waves) + 1;   // (a share of at most a half of its quarter)
     return longest * 512 + 16 < (1ull << fsdev::kHitPosBits);
   };
   if (sw.rows_waves) {
@@ -962,14 +1092,23 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
   const int stage_bytes = wire == 8 ? 8 : 16;          // (fs_row records are staged as 16-byte wire records)
   const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
   FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * stage_bytes));
-  const fsdev::RangeOut out{ln.w_stage.p, caprow, wire};
   fsdev::RowSync sy;
   FS_TRY(fs_row_sync(ix, blocks, &sy));
+  // shared rounds (the launch puts the records into place itself): a pool of records per
+  // workgroup for the slices' output, grown when a search reports that it ran out
+  uint32_t xpool = 0;
+  if (!sy.rinfo && ix->sw.rows_coop) {
+    xpool = std::max<uint32_t>(ix->sw.rows_xpool > 0 ? (uint32_t)ix->sw.rows_xpool : 4096u, ln.xpool_hint);
+    FS_TRY(ln.w_xstage.reserve((size_t)blocks * xpool * 32));
+  }
+  ln.xpool = xpool;
+  const fsdev::RangeOut out{ln.w_stage.p, caprow, wire, xpool ? ln.w_xstage.p : nullptr, xpool};
   // `done` (the search's completion event) rides on the search's last dispatch when that
   // dispatch has a free stop-event slot: k_compact, or this kernel when it is not timed
   if (done_attached) *done_attached = false;
   if (done && !sy.rinfo && !e1) { e1 = done; if (done_attached) *done_attached = true; }
-  const fsdev::RowFinal fin{reinterpret_cast<uint8_t*>(d_rows), rcap, ln.d_status.p, host_st, count_out, true};
+  const fsdev::RowFinal fin{reinterpret_cast<uint8_t*>(d_rows), rcap, ln.d_status.p, host_st, count_out, true,
+                            (ix->sw.diag & 512) != 0};
   switch (ix->cfg.window_size) {
     case 2: FS_TRY(launch_scan_rows<2>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;
     case 3: FS_TRY(launch_scan_rows<3>(ix, c, n_sub, waves, blocks, out, sy, fin, s, e0, e1)); break;

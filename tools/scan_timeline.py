@@ -63,7 +63,7 @@ def main():
     out = np.zeros(n.value, dtype=np.uint64)
     _lib.check(L.fs_debug_stamps(ix._h, 0, out.ctypes.data_as(C.POINTER(C.c_uint64)), n.value, C.byref(n)),
                "fs_debug_stamps")
-    d = out.reshape(-1, 16).astype(np.int64)
+    d = out.reshape(-1, 20).astype(np.int64)
     if a.dump:
         np.save(a.dump, d)
     t0 = d[:, 0].min()
@@ -77,6 +77,12 @@ def main():
     res["scan_dur"] = [round(float(x), 2) for x in np.percentile(us[:, 2] - us[:, 1], pct)]
     res["rounds_dur"] = [round(float(x), 2) for x in np.percentile(us[:, 3] - us[:, 2], pct)]
     res["finish_dur"] = [round(float(x), 2) for x in np.percentile(us[:, 4] - us[:, 3], pct)]
+    if d[:, 14].max() > 0:
+        fz = (d[:, 14:17] - t0) / 100.0
+        res["workgroup_together"] = [round(float(x), 2) for x in np.percentile(fz[:, 0], pct)]
+        polling = (np.arange(len(d)) % 16) < 4          # the waves that ask for the counts in front
+        res["counts_known_to_wave"] = [round(float(x), 2) for x in np.percentile(fz[polling, 1], pct)]
+        res["counts_known_to_workgroup"] = [round(float(x), 2) for x in np.percentile(fz[:, 2], pct)]
     res["rounds_per_range"] = {int(k): int(v) for k, v in zip(*np.unique(d[:, 5], return_counts=True))}
     res["flushes_per_range"] = {int(k): int(v) for k, v in zip(*np.unique(d[:, 6], return_counts=True))}
     res["records_per_range"] = [int(x) for x in np.percentile(d[:, 7], [0, 50, 100])]
