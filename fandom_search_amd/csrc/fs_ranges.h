@@ -492,6 +492,12 @@ struct RowFinal {
   bool nt;                 // streaming stores for the records
 };
 
+// FS_DIAG & 2: stamps of the hand-off (workgroup together, counts known to the wave, to the workgroup)
+struct FinStamps {
+  bool on;
+  unsigned long long t0, t1, t2;
+};
+
 // All threads of the workgroup call this once every wave has staged its records.
 //   range_id   the wave's range (blockIdx.x * waves + wave)
 //   my_rows    (wave-uniform) records of the wave's range; stats of the wave: hits, pairs,
@@ -502,10 +508,9 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
                                             uint32_t range_id,
                                             uint32_t my_rows, uint32_t hits, uint32_t pairs,
                                             uint32_t cands, uint32_t* s_cnt,
-                                            const RangeState* kept = nullptr,
-                                            const CoopLds* coop = nullptr, uint32_t my_slices = 0,
-                                            uint32_t* pool_need = nullptr, uint32_t* s_stat = nullptr,
-                                            unsigned long long* stamps = nullptr) {
+                                            const RangeState* kept,
+                                            const CoopLds* coop, uint32_t my_slices,
+                                            uint32_t* pool_need, uint32_t* s_stat, FinStamps& stamps) {
   const int lane = threadIdx.x & 63;
   const uint32_t wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   const uint32_t L = blockIdx.x;
@@ -553,7 +558,7 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
     r1 = fetch_staged(out.stage, out.wire, selfdist, sbase + lane + 64, (uint32_t)lane + 64 < staged);
   }
   __syncthreads();
-  if (stamps) stamps[0] = __builtin_amdgcn_s_memrealtime();      // every wave of the workgroup is here
+  if (stamps.on) stamps.t0 = __builtin_amdgcn_s_memrealtime();      // every wave of the workgroup is here
   // the records of this wave's first slice, from the workgroup's pool: asked for now (two per
   // lane), stored once their place is known
   PoolRec p0, p1;
@@ -620,9 +625,9 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   }
   pre = wave_sum_lane63(pre);
   if (lane == 63) s_cnt[5 * n_waves + 2 + wave] = pre;
-  if (stamps) stamps[1] = __builtin_amdgcn_s_memrealtime();      // the counts in front are known to this wave
+  if (stamps.on) stamps.t1 = __builtin_amdgcn_s_memrealtime();      // the counts in front are known to this wave
   __syncthreads();
-  if (stamps) stamps[2] = __builtin_amdgcn_s_memrealtime();      // ... and to every wave of the workgroup
+  if (stamps.on) stamps.t2 = __builtin_amdgcn_s_memrealtime();      // ... and to every wave of the workgroup
   // this wave's records: from the registers / the staging area to their place
   uint32_t before = 0;                                   // records of the workgroups in front
   for (uint32_t i = 0; i < n_waves; ++i) before += s_cnt[5 * n_waves + 2 + i];

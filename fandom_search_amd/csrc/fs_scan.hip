@@ -445,8 +445,10 @@ struct alignas(16) FusedLds {         // per wave
   uint32_t cand[64];                  // window positions of the round being made up
 };
 
-template <int N, int K, bool NT, bool LW14, bool STR = false>
-__global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
+// (the instance that leaves the hand-off to k_compact runs beside other searches' kernels:
+// five waves per SIMD -- 96 registers -- leave their waves a slot where four of 121 do not)
+template <int N, int K, bool NT, bool LW14, bool STR = false, bool INL = true>
+__global__ __launch_bounds__(1024, INL ? 4 : 5) void k_scan_rows(CorpusDev c, GramIndexDev g,
                                                     uint32_t n_sub, fsdev::RangeOut out,
                                                     fsdev::RowSync sy, fsdev::RowFinal fin,
                                                     uint32_t disp_lds, uint32_t diag,
@@ -460,7 +462,8 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   // of the hand-off (workgroup together, counts known to the wave, to the workgroup), -, -, -} in
   // ticks of the 100 MHz constant clock (tools/scan_timeline.py)
   unsigned long long t_entry = 0, t_ready = 0, t_scan = 0, t_rounds = 0;
-  unsigned long long t_fin[3] = {0, 0, 0};
+  FinStamps t_fin;
+  t_fin.on = dbg != nullptr; t_fin.t0 = 0; t_fin.t1 = 0; t_fin.t2 = 0;
   uint32_t n_rounds = 0, n_flushes = 0;
   if (dbg) t_entry = __builtin_amdgcn_s_memrealtime();
   // all of the kernel's LDS is dynamic, the filter first: its word offsets are then LDS
@@ -483,7 +486,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   CoopLds& C = *reinterpret_cast<CoopLds*>(s_cnt + ((6 * n_waves + 2 + 3) & ~3u));
   // ... when the launch puts the records into place itself (FS_DIAG & 256: every wave does all
   // the rounds of its range by itself, as before)
-  const bool coop = !STR && !sy.rinfo && out.xstage && !(diag & 256) && n_waves <= kCoopWaves;
+  // (INL: the launch puts the records into place itself; the other instance leaves that to
+  // k_compact and is compiled without the registers and the code of what follows from it)
+  const bool coop = INL && !STR && !sy.rinfo && out.xstage && !(diag & 256) && n_waves <= kCoopWaves;
   const uint32_t range_id = blockIdx.x * n_waves + wave;
   // Sub-tiles dealt out evenly over the workgroups (the first n_sub % gridDim.x take one
   // more), and inside a workgroup of sixteen waves by how fast its SIMD serves each wave: the
@@ -567,9 +572,9 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   R.k0 = make_uint4(0, 0, 0, 0); R.k1 = make_uint4(0, 0, 0, 0);
   // the launch puts the records into place itself: a range's first 128 stay in registers
   // (FS_DIAG & 32: all of them through the staging area)
-  const bool keep_regs = !STR && !sy.rinfo && !(diag & 32);   // (STR: the per-hit Levenshtein needs the registers)
+  const bool keep_regs = INL && !STR && !sy.rinfo && !(diag & 32);   // (STR: the per-hit Levenshtein needs the registers)
   RoundClock clk;
-  clk.on = !STR && dbg != nullptr;
+  clk.on = !STR && dbg != nullptr && (diag & 4);      // FS_DIAG & 4: the phase sums too (they drain the loads at the phase ends)
   clk.t0 = clk.t1 = clk.t2 = clk.t3 = clk.t4 = clk.t5 = 0; clk.last = 0;
   uint32_t cacc = 0;                           // per lane: candidates seen
   uint32_t my_slices = 0;                      // slices posted by this wave
@@ -729,10 +734,6 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       uint32_t halo[8];
       // A's halo: the first ids of the lane behind, lane 63: lane 0's first ids of B -- one
       // DPP rotation of the wave per id (no LDS), lane 0 offering its B ids
-      if (diag & 1024) {                         // (A/B: the same through ds_bpermute)
-#pragma unroll
-        for (int h = 0; h < (int)HALO; ++h) halo[h] = (uint32_t)__shfl((int)(lane == 0 ? mb.v[h] : ma.v[h]), (lane + 1) & 63);
-      } else
 #pragma unroll
       for (int h = 0; h < (int)HALO; ++h)
         halo[h] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(lane == 0 ? mb.v[h] : ma.v[h]), 0x134, 0xF, 0xF, false);   // wave_rol:1
@@ -741,14 +742,13 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
       if (!odd_end) {
         // B's halo: lane 63 takes the ids behind B (the same in every lane): a DPP shift of
         // the wave, the lane without a source keeps `old`
-        const uint32_t hv[8] = {v.h0.x, v.h0.y, v.h0.z, v.h0.w, v.h1.x, v.h1.y, v.h1.z, v.h1.w};
-        if (diag & 1024) {
-#pragma unroll
-          for (int h = 0; h < (int)HALO; ++h) halo[h] = (uint32_t)__shfl((int)(lane == 0 ? fs_premix(hv[h]) : mb.v[h]), (lane + 1) & 63);
-        } else
+        auto hv = [&](int h) {
+          return h == 0 ? v.h0.x : h == 1 ? v.h0.y : h == 2 ? v.h0.z : h == 3 ? v.h0.w
+               : h == 4 ? v.h1.x : h == 5 ? v.h1.y : h == 6 ? v.h1.z : v.h1.w;
+        };
 #pragma unroll
         for (int h = 0; h < (int)HALO; ++h)
-          halo[h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(hv[h]), (int)mb.v[h], 0x130, 0xF, 0xF, false);   // wave_shl:1
+          halo[h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(hv(h)), (int)mb.v[h], 0x130, 0xF, 0xF, false);   // wave_shl:1
         scan(mb, halo, j + 1);
       }
       // ONE place where the queue is worked off (the rounds are a lot of code: a second copy
@@ -811,13 +811,13 @@ __global__ __launch_bounds__(1024) void k_scan_rows(CorpusDev c, GramIndexDev g,
   if (dbg) t_rounds = __builtin_amdgcn_s_memrealtime();
   finish_rows(sy, fin, out, g.selfdist, range_id, R.rows_run, R.hits_run, R.match_acc, cacc, s_cnt,
               keep_regs ? &R : nullptr, coop ? &C : nullptr, my_slices,
-              reinterpret_cast<uint32_t*>(fin.host_st + 1) + 1, C.stat, dbg ? t_fin : nullptr);
+              reinterpret_cast<uint32_t*>(fin.host_st + 1) + 1, C.stat, t_fin);
   if (dbg && lane == 0) {
     unsigned long long* d = dbg + 20 * (size_t)range_id;
     d[0] = t_entry; d[1] = t_ready; d[2] = t_scan; d[3] = t_rounds;
     d[4] = __builtin_amdgcn_s_memrealtime(); d[5] = n_rounds; d[6] = n_flushes; d[7] = R.rows_run;
     d[8] = clk.t0; d[9] = clk.t1; d[10] = clk.t2; d[11] = clk.t3; d[12] = clk.t4; d[13] = clk.t5;
-    d[14] = t_fin[0]; d[15] = t_fin[1]; d[16] = t_fin[2]; d[17] = 0; d[18] = 0; d[19] = 0;
+    d[14] = t_fin.t0; d[15] = t_fin.t1; d[16] = t_fin.t2; d[17] = 0; d[18] = 0; d[19] = 0;
   }
 }
 
@@ -1006,17 +1006,26 @@ int launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t n_sub, uint32_t waves,
   const bool nt = ix->sw.scan_flags == 'n';
   const bool lw14 = lw == 14;
   constexpr int K = fs_sub_k(N);
-  auto kern = nt ? (lw14 ? k_scan_rows<N, 0, true, true> : k_scan_rows<N, 0, true, false>)
-                 : (lw14 ? k_scan_rows<N, 0, false, true> : k_scan_rows<N, 0, false, false>);
+  // (the instances with non-temporal id loads, FS_SCAN_FLAGS=n, are gone: they measured slower at
+  // every batch size, 0.50 against 0.61 of peak on a 1 GB batch)
+  const bool inl = sy.rinfo == nullptr;
   const bool sub = K != 0 && ix->sw.scan_sub && ix->d_sfilter.p;
-  if (sub)
-    kern = nt ? (lw14 ? k_scan_rows<N, K, true, true> : k_scan_rows<N, K, true, false>)
-              : (lw14 ? k_scan_rows<N, K, false, true> : k_scan_rows<N, K, false, false>);
+  auto pick = [&](auto kn, auto kk) {           // kn: no sub-shingle filter, kk: with it
+    return sub ? kk : kn;
+  };
+  (void)nt;
+  auto kern = k_scan_rows<N, 0, false, false, false, true>;
+  if (!c->has_str) {
+    if (inl) kern = lw14 ? pick(k_scan_rows<N, 0, false, true, false, true>, k_scan_rows<N, K, false, true, false, true>)
+                         : pick(k_scan_rows<N, 0, false, false, false, true>, k_scan_rows<N, K, false, false, false, true>);
+    else kern = lw14 ? pick(k_scan_rows<N, 0, false, true, false, false>, k_scan_rows<N, K, false, true, false, false>)
+                     : pick(k_scan_rows<N, 0, false, false, false, false>, k_scan_rows<N, K, false, false, false, false>);
+  }
   StrFast strf{nullptr, nullptr, 0, 0, nullptr};
   if (c->has_str) {                    // (fs_scan_rows_shape has checked that the path applies)
     strf = StrFast{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, c->d_strrec.p};
-    if (sub) kern = lw14 ? k_scan_rows<N, K, false, true, true> : k_scan_rows<N, K, false, false, true>;
-    else kern = lw14 ? k_scan_rows<N, 0, false, true, true> : k_scan_rows<N, 0, false, false, true>;
+    kern = lw14 ? pick(k_scan_rows<N, 0, false, true, true, true>, k_scan_rows<N, K, false, true, true, true>)
+                : pick(k_scan_rows<N, 0, false, false, true, true>, k_scan_rows<N, K, false, false, true, true>);
   }
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   {
