@@ -376,12 +376,13 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
     ix.set_scan_timing(0)
     run(shards)
     samples = []
-    for _ in range(passes):                       # one pass = the whole corpus
+    per_region = 3                                # passes per timed region (one pass = the whole corpus)
+    for _ in range(passes):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(shards)
+        run(shards * per_region)
         torch.cuda.synchronize()
-        samples.append(time.perf_counter() - t0)
+        samples.append((time.perf_counter() - t0) / per_region)
     dt = float(np.median(samples))
     ix.set_scan_timing(1)
     alone = [ix.search_end(ix.search_begin(corpora[i % shards], bufs[0].data_ptr(), cap, header=True))[1].scan_ms
@@ -408,8 +409,8 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
                     "samples_ms": [round(x * 1e3, 4) for x in samples],
                     "roofline_step": total_bytes / dt / 1e9 / HBM_PEAK_GBS,
                     "corpus_s": round(t_gen, 1),
-                    "note": "configs[2] whole on one GPU: a step = the eight shards of an 8-GPU run searched "
-                            "one behind the other (the N = 1 point of the strong-scaling curve `--gpus N` "
+                    "note": "configs[2] whole on one GPU (timed: three passes per region, five regions, the median "
+                            "pass): a step = the eight shards of an 8-GPU run searched one behind the other (the N = 1 point of the strong-scaling curve `--gpus N` "
                             "measures; same works, same shards)"},
     }
     for c in corpora:
@@ -649,12 +650,20 @@ def main():
             ix1 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
             os.environ["FS_LANES"] = str(max(1, args.lanes))
             c1s = [ix1.corpus(t, o, chars, coff) for t, o in zip(toks, offs)]
-            ix1.set_scan_timing(1)
-            one = []
-            for i in range(12):
-                one.append(ix1.search_end(ix1.search_begin(c1s[i % rotate], gather.bufs[0].data_ptr(), cap,
-                                                           packed=packed, header=True))[1].scan_ms)
-            search_alone_ms = float(np.mean(one[2:]))
+            ix1.set_scan_timing(4)     # (every 4th launch carries the events: an event record costs stream time)
+            one, tk = [], []
+            # one lane = one stream: the searches run strictly one after the other, each with the
+            # GPU to itself; three are kept queued so that the GPU does not fall idle (and drop
+            # its clock) between them while the host collects the previous one
+            for i in range(80):
+                tk.append(ix1.search_begin(c1s[i % rotate], gather.bufs[i % len(gather.bufs)].data_ptr(), cap,
+                                           packed=packed, header=True))
+                if len(tk) >= min(3, len(gather.bufs)):
+                    one.append(ix1.search_end(tk.pop(0))[1].scan_ms)
+            while tk:
+                one.append(ix1.search_end(tk.pop(0))[1].scan_ms)
+            one = [x for x in one[8:] if x > 0]
+            search_alone_ms = float(np.mean(one))
             kernel1 = ix1.kernel_name(c1s[0])
             ix1.close()
         rows_step = float(np.mean(rows_per_corpus))
@@ -753,8 +762,9 @@ def main():
                          "step": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "step_bytes": step_bytes,
                          "note": "achieved / frac: a whole search by itself (search_ms_alone: an index with one "
-                                 "lane, the one launch of `kernel_alone` takes ids in and puts the records into "
-                                 "place, HIP events on its dispatch, nothing else on the GPU).  launch_ms_alone: "
+                                 "lane = one stream, the one launch of `kernel_alone` takes ids in and puts the "
+                                 "records into place, HIP events on its dispatch; the launches run one after the "
+                                 "other, three queued, nothing else on the GPU).  launch_ms_alone: "
                                  "the kernel in the shape the timed region launches it in (%d lanes: k_compact "
                                  "puts the records into place behind it), also by itself; overlapped_launch_ms: "
                                  "its dispatch-to-completion time inside the timed region, where %d searches "

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--inflight", type=int, default=2)
+    ap.add_argument("--rotate", type=int, default=1,
+                    help="distinct batches per variant (4: 320 MB of c2 ids, more than the Infinity Cache: from HBM)")
     a = ap.parse_args()
 
     import torch
@@ -46,7 +48,9 @@ def main():
     script = synth.script_tokens(conf["script_tokens"])
     swords = [words[int(t)] for t in script]
     chars, coff = vocab.pack_strings(words)
-    tok, off = synth.corpus_tokens(conf["n_works"], conf["tokens_per_work"], script)
+    batches = [synth.corpus_tokens_parallel(conf["n_works"], conf["tokens_per_work"], script,
+                                            first_work=r * conf["n_works"]) for r in range(max(1, a.rotate))]
+    tok, off = batches[0]
     cfg = abi.make_config(window_size=a.window)
 
     setups = []
@@ -60,13 +64,18 @@ def main():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = o
-        corpus = ix.corpus(tok, off, chars, coff)
+        corpora = [ix.corpus(t, o, chars, coff) for t, o in batches]
+        corpus = corpora[0]
         rows, st = ix.search(corpus)
+        for cc in corpora[1:]:
+            cap_r, _ = ix.search(cc)
+            rows = rows if len(rows) >= len(cap_r) else cap_r
         cap = len(rows) + 64
         bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda")
                 for _ in range(a.inflight + 1)]
         ix.set_scan_timing(4)
-        setups.append(dict(name=v, ix=ix, corpus=corpus, bufs=bufs, cap=cap, n_rows=len(rows),
+        rows, st = ix.search(corpus)
+        setups.append(dict(name=v, ix=ix, corpus=corpus, corpora=corpora, bufs=bufs, cap=cap, n_rows=len(rows),
                            crc=hash(rows.tobytes()), ms=[], scan=[]))
     if not any("FS_DIAG" in s["name"] for s in setups):
         assert len({s["crc"] for s in setups}) == 1, "variants disagree on the rows"
@@ -75,7 +84,7 @@ def main():
         ix, corpus, bufs, cap = s["ix"], s["corpus"], s["bufs"], s["cap"]
         tickets, scan = [], []
         for i in range(steps):
-            tickets.append(ix.search_begin(corpus, bufs[i % len(bufs)].data_ptr(), cap, header=True))
+            tickets.append(ix.search_begin(s["corpora"][i % len(s["corpora"])], bufs[i % len(bufs)].data_ptr(), cap, header=True))
             if len(tickets) >= a.inflight:
                 n, st = ix.search_end(tickets.pop(0))
                 s["last"] = (int(st.candidates), int(st.lsh_pending))
