@@ -101,6 +101,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->ranges_caprow = num("FS_RANGES_CAPROW");
   sw->diag = num("FS_DIAG");
   if (const char* e = getenv("FS_LSH_GRAMTAB")) sw->lsh_gramtab = atoi(e) != 0;
+  if (const char* e = getenv("FS_LSH_SYN")) sw->lsh_syn = atoi(e) != 0;
   if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e) != 0;
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");
@@ -698,6 +699,14 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
     c->ctab_ready = true;
     c->ctab_str = c->has_str;
   }
+  if (!c->has_oov && ix->info.path != FS_MODE_EXACT && ix->syn_ok) {
+    // tables with near-synonyms: the component id of every token, for the integer prefilters
+    FS_TRY(fs_launch_comp_map(ix, c, ix->stream));
+    FS_HIP(hipStreamSynchronize(ix->stream));
+    c->ctok_ready = true;
+  } else {
+    c->ctok_ready = false;
+  }
   if (!c->has_str && !c->has_oov && ix->info.path != FS_MODE_EXACT && !c->selflev_ready && ix->sw.lsh_selflev) {
     // LSH pipeline, string id == vector id: the Levenshtein distance of a match with the
     // same id in every slot, once per string table
@@ -876,7 +885,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
     // tables whose proof fails by one slot only: the integer prefilter flags the windows
     // that can have a neighbour at all, the LSH work runs on those
     if (fs_lsh_prefilter_ok(ix, c))
-      FS_TRY(fs_launch_scan_near(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+      FS_TRY(fs_launch_scan_near(ix, c, ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     else
       FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
     FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, s));

@@ -100,7 +100,73 @@ __global__ __launch_bounds__(256) void k_cmax(const float* __restrict__ emb,
   if ((threadIdx.x & 63) == 0 && best > 0.0f) atomicMax(out_bits, __float_as_int(best));
 }
 
+// Pairs (script vector u, table vector v) that are *near*: cos(u, v) > 1 - coef / (|u| |v|), with
+// coef = n * thr * a_max^2 / 2 (fs_lsh.hip, component ids): same tiling as k_cmax, the pairs
+// appended to a list (float32 cosines, 1e-4 of slack towards more pairs).
+__global__ __launch_bounds__(256) void k_near_pairs(const float* __restrict__ emb,
+                                                    const float* __restrict__ embT, uint32_t n_vec,
+                                                    int D, const double* __restrict__ q,
+                                                    const uint32_t* __restrict__ rows_u, uint32_t n_u,
+                                                    float coef, uint2* __restrict__ pairs, uint32_t cap,
+                                                    uint32_t* __restrict__ count) {
+  extern __shared__ float s_u[];   // [kCmaxU][D], unit-normalised
+  __shared__ float s_nu[kCmaxU];
+  const uint32_t u0 = blockIdx.y * kCmaxU;
+  for (uint32_t i = threadIdx.x; i < (uint32_t)kCmaxU * D; i += blockDim.x) {
+    const uint32_t ui = u0 + i / D;
+    float val = 0.0f;
+    if (ui < n_u) {
+      const uint32_t row = rows_u[ui];
+      const double qq = q[row];
+      const float rn = qq > 0.0 ? (float)(1.0 / sqrt(qq)) : 0.0f;
+      val = emb[(size_t)row * D + i % D] * rn;
+    }
+    s_u[i] = val;
+  }
+  if (threadIdx.x < kCmaxU) s_nu[threadIdx.x] = u0 + threadIdx.x < n_u ? (float)sqrt(q[rows_u[u0 + threadIdx.x]]) : 0.0f;
+  __syncthreads();
+  const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n_vec) return;
+  float acc[kCmaxU];
+#pragma unroll
+  for (int i = 0; i < kCmaxU; ++i) acc[i] = 0.0f;
+  for (int d = 0; d < D; ++d) {
+    const float x = embT[(size_t)d * n_vec + v];
+#pragma unroll
+    for (int i = 0; i < kCmaxU; ++i) acc[i] = fmaf(s_u[i * D + d], x, acc[i]);
+  }
+  const float nv = (float)sqrt(q[v]);
+#pragma unroll
+  for (int i = 0; i < kCmaxU; ++i) {
+    const uint32_t ui = u0 + i;
+    if (ui >= n_u || rows_u[ui] == v) continue;
+    const float nn = s_nu[i] * nv;
+    // (a vector of norm 0 is near everything: its slot adds nothing to a window's cosine)
+    const bool near = !(nn > 0.0f) || acc[i] > 1.0f - coef / nn - 1e-4f;
+    if (near) {
+      const uint32_t at = atomicAdd(count, 1u);
+      if (at < cap) pairs[at] = make_uint2(rows_u[ui], v);
+    }
+  }
+}
+
 }  // namespace
+
+int fs_launch_near_pairs(const float* emb, uint64_t n_vec, int D, const uint32_t* rows_u, uint32_t n_u,
+                         const double* q, float* embT_scratch, float coef, uint2* pairs, uint32_t cap,
+                         uint32_t* count, hipStream_t s) {
+  if (!n_vec || !n_u) return FS_OK;
+  hipLaunchKernelGGL(k_transpose, dim3((uint32_t)((n_vec + 255) / 256)), dim3(256), 0, s, emb,
+                     (uint32_t)n_vec, D, q, embT_scratch);
+  const size_t lds = (size_t)kCmaxU * D * sizeof(float);
+  FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_near_pairs),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  dim3 grid((uint32_t)((n_vec + 255) / 256), (n_u + kCmaxU - 1) / kCmaxU);
+  hipLaunchKernelGGL(k_near_pairs, grid, dim3(256), lds, s, emb, embT_scratch, (uint32_t)n_vec, D, q,
+                     rows_u, n_u, coef, pairs, cap, count);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
 
 int fs_launch_rownorms(const float* emb, uint64_t n_vec, int D, double* q, hipStream_t s) {
   if (!n_vec) return FS_OK;

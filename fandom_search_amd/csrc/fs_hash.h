@@ -127,12 +127,20 @@ FS_HD uint32_t fs_wild_key(uint32_t fold_all, uint32_t term_j, int j) {
   h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
-FS_HD uint32_t fs_wild_word(uint32_t h, int log2_words) { return h >> (32 - log2_words); }
+// The filter is *grouped*: the n slots fall into three groups (slot k: group 3k / n), and the key
+// that leaves out a slot of group X lies in the 16-byte block chosen by the ids of the other
+// two groups -- which the window shares with the script window whatever its slot of group X
+// holds.  A window therefore looks at three blocks (one 16-byte read each) for its n keys; a
+// key sets four of the block's 128 bits.
+FS_HD int fs_wild_group(int k, int n) { return 3 * k / n; }
+FS_HD uint32_t fs_wild_block(uint32_t fold_others, int group, int log2_blocks) {
+  uint32_t h = fold_others + 0x7F4A7C15u * (uint32_t)(group + 1);
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h >> (32 - log2_blocks);
+}
+// (bit positions of key h inside its block: four 7-bit fields of the hash)
+FS_HD uint32_t fs_wild_bit(uint32_t h, int i) { return (h >> (7 * i)) & 127u; }
 // The same keys in an exact map (buckets of four {key, script window + 1}, one entry per distinct
 // script n-gram and slot, a full bucket spills into the next): the script windows that equal a
 // fan window in all slots but one can be enumerated, not just shown to be possible.
 FS_HD uint32_t fs_wmap_slot(uint32_t h, int log2_slots) { return (h * 0x9E3779B1u) >> (32 - log2_slots); }
-FS_HD uint32_t fs_wild_mask(uint32_t h) {
-  const uint32_t b = h * 0x9E3779B1u;
-  return (1u << (b >> 27)) | (1u << ((b >> 22) & 31)) | (1u << ((b >> 17) & 31)) | (1u << ((b >> 12) & 31));
-}

@@ -184,6 +184,7 @@ struct fs_switches {
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
+  bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
   bool lsh_gramtab = true;        // FS_LSH_GRAMTAB=0: no per-n-gram records (k_lsh_gramtab): every window with a script n-gram's ids walks the buckets
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
@@ -239,6 +240,14 @@ struct fs_index {
   int log2_wild = 0;
   DBuf<uint32_t> d_wmap;     // the same keys as an exact map {key, first window of the n-gram + 1}
   int log2_wmap = 0;
+  // Tables with near-synonyms (the proof fails by more than one slot): the same two filters
+  // over *component ids* -- connected components of "near" pairs of table vectors, at most one
+  // slot of a neighbour within the threshold joins two components (fs_lsh.hip)
+  DBuf<uint32_t> d_comp;     // [V] component id of a table vector
+  DBuf<uint32_t> d_sfilter3c, d_wildc;
+  int log2_wildc = 0;
+  bool syn_ok = false;
+  uint32_t n_comp = 0, comp_largest = 0;
 
   // Lanes: a stream with its own workspaces (grown on demand) and status block.
   // Searches are spread over n_lanes of them (FS_LANES in the environment, default
@@ -332,6 +341,8 @@ struct fs_corpus {
   DBuf<unsigned long long> d_gramtab_best;   // LSH pipeline: per script n-gram, what a window with its ids and
   DBuf<uint32_t> d_gramtab_cnt;        //   their strings gets (fs_best; kept matches + 1), k_lsh_gramtab
   bool gramtab_ready = false;
+  DBuf<uint32_t> d_ctok;               // LSH pipeline, tables with near-synonyms: component id per token (+ the scan's pad)
+  bool ctok_ready = false;
   DBuf<uint32_t> d_selflev;            // LSH pipeline, string id == vector id: Levenshtein of script window w
   bool selflev_ready = false;          // against the strings of its own ids (k_selflev), FS_NONE: not known
   CorpusDev dev() const;
@@ -381,10 +392,16 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
                        hipEvent_t e1 = nullptr);
 int fs_launch_selflev(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_lsh_gramtab(fs_index* ix, fs_corpus* c, hipStream_t s);
+int fs_launch_near_pairs(const float* emb, uint64_t n_vec, int D, const uint32_t* rows_u, uint32_t n_u,
+                         const double* q, float* embT_scratch, float coef, uint2* pairs, uint32_t cap,
+                         uint32_t* count, hipStream_t s);
+int fs_launch_comp_map(fs_index* ix, fs_corpus* c, hipStream_t s);      // component ids of a batch's tokens
+int fs_lsh_prefilter_mode(const fs_index* ix, const fs_corpus* c);
+int fs_scan_near_k(int n);                                               // K of k_scan_near's K-gram tests      // 0 none, 1 vector ids, 2 component ids
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 // fs_scan.hip: the integer prefilter of the LSH pipeline ("all but one slot identical")
 bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c);
-int fs_launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+int fs_launch_scan_near(const fs_index* ix, const fs_corpus* c, uint64_t* qbm, uint32_t* qcnt,
                         uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
                            uint32_t* check, hipStream_t s);

@@ -77,6 +77,8 @@ struct LshDev {
                            // this batch's string table (FS_NONE: compute), or nullptr
   const uint32_t* wild;    // one-slot-wildcard keys of the script windows (fs_hash.h), or nullptr
   int log2_wild;
+  const uint32_t* wild_tok;// the ids the keys are made of: nullptr = the vector ids, else the
+                           // component ids of the batch's tokens (tables with near-synonyms)
   const uint2* wmap;       // the same keys as an exact map: 2^log2_wmap buckets of four {key, script window + 1}, or nullptr
   int log2_wmap;
   uint32_t V, W;
@@ -832,23 +834,44 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
      const uint64_t p = cpos[il];
      bool pass = true;
      if (p + L.n <= c.n_tok) {
-       load_ids(c.tok + p, L.n, &f);
+       // the ids the keys are made of (the vector ids themselves are needed by the one-slot map only)
+       Ids16 kf;
+       load_ids((L.wild_tok ? L.wild_tok : c.tok) + p, L.n, &kf);
+       if (WMAP) f = kf;
 #pragma unroll
        for (int k = 0; k < NW; ++k) {
          term[k] = 0;
          if (k < L.n) {
-           term[k] = fs_rotl(fs_premix(f.v[k]), fs_rot_of(L.n - 1 - k));
+           term[k] = fs_rotl(fs_premix(kf.v[k]), fs_rot_of(L.n - 1 - k));
            fold ^= term[k];
          }
        }
        pass = false;
        keyed = true;
+       // three 16-byte blocks (one per group of slots), requested together
+       uint32_t gfold[3] = {0, 0, 0};
+#pragma unroll
+       for (int k = 0; k < NW; ++k)
+         if (k < L.n) gfold[fs_wild_group(k, L.n)] ^= term[k];
+       const uint4* wb = reinterpret_cast<const uint4*>(L.wild);
+       uint4 blk[3];
+#pragma unroll
+       for (int X = 0; X < 3; ++X) blk[X] = wb[fs_wild_block(fold ^ gfold[X], X, L.log2_wild)];
 #pragma unroll
        for (int k = 0; k < NW; ++k)
          if (k < L.n) {
            const uint32_t h = fs_wild_key(fold, term[k], k);
-           const uint32_t m = fs_wild_mask(h);
-           pass = pass || (L.wild[fs_wild_word(h, L.log2_wild)] & m) == m;
+           const int X = fs_wild_group(k, L.n);
+           const uint4 q = X == 0 ? blk[0] : X == 1 ? blk[1] : blk[2];
+           bool all = true;
+#pragma unroll
+           for (int i = 0; i < 4; ++i) {
+             const uint32_t bit = fs_wild_bit(h, i);
+             const uint32_t wsel = bit >> 5;
+             const uint32_t word = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
+             all = all && ((word >> (bit & 31)) & 1u);
+           }
+           pass = pass || all;
          }
      }
      if (!pass) { cg[il] = FS_NONE; live = false; }
@@ -1177,7 +1200,7 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
-  L.wild = nullptr; L.log2_wild = 0; L.selflev = nullptr; L.wmap = nullptr; L.log2_wmap = 0;
+  L.wild = nullptr; L.log2_wild = 0; L.wild_tok = nullptr; L.selflev = nullptr; L.wmap = nullptr; L.log2_wmap = 0;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
   L.B = (int)ix->cfg.hash_dimensions; L.D = (int)ix->cfg.emb_dim; L.C = L.H * L.B;
@@ -1210,6 +1233,123 @@ static int lsh_m_min(const fs_index* ix) {
   return m > n ? n : m;          // n + 1 would mean "nothing can match": exact windows still do
 }
 
+// The grouped filter of one-slot-wildcard keys (fs_hash.h) over the id sequence `st` (vector ids,
+// or component ids): log2 of its 16-byte blocks and the blocks, about 24 filter bits per key.
+static int build_wild_filter(const std::vector<uint32_t>& st, uint64_t W, int n, std::vector<uint32_t>* out) {
+  int lb = 8;
+  while (lb < 26 && ((uint64_t)128 << lb) < W * n * 24) ++lb;
+  out->assign((size_t)4 << lb, 0u);
+  for (uint64_t w = 0; w < W; ++w) {
+    uint32_t term[FS_MAX_WINDOW], fold = 0, gfold[3] = {0, 0, 0};
+    for (int k = 0; k < n; ++k) {
+      term[k] = fs_rotl(fs_premix(st[w + k]), fs_rot_of(n - 1 - k));
+      fold ^= term[k];
+      gfold[fs_wild_group(k, n)] ^= term[k];
+    }
+    for (int k = 0; k < n; ++k) {
+      const uint32_t h = fs_wild_key(fold, term[k], k);
+      const int X = fs_wild_group(k, n);
+      uint32_t* blk = out->data() + 4 * (size_t)fs_wild_block(fold ^ gfold[X], X, lb);
+      for (int i = 0; i < 4; ++i) { const uint32_t bit = fs_wild_bit(h, i); blk[bit >> 5] |= 1u << (bit & 31); }
+    }
+  }
+  return lb;
+}
+
+// Tables with near-synonyms (every real embedding table): the proof that a neighbour within the
+// threshold shares n or n - 1 vector ids with the window fails, but a weaker one holds.  With
+// x_k = |f_k|, y_k = |s_k|, c_k = cos(f_k, s_k):
+//   cos(F, S) |x| |y| = sum x_k y_k c_k = sum x_k y_k - sum d_k <= |x| |y| - sum d_k,
+//   d_k = (1 - c_k) x_k y_k >= 0,
+// so a record (cos > 1 - thr) needs sum d_k < thr |x| |y| <= T = thr n a_max^2, and at most ONE
+// slot has d_k >= T / 2, i.e. cos(f_k, s_k) <= 1 - T / (2 |f_k| |s_k|).  Call a pair of a script
+// vector and a table vector above that line *near* (unit vectors, n = 6, thr = 0.1: cos > 0.7)
+// and give every table vector the id of its connected component in the graph of near pairs:
+// a window can have a neighbour within the threshold only if its component ids equal a
+// script window's in n - 1 slots or more.  That is the test the filters of the
+// one-slot case make on vector ids (k_scan_near, the wildcard keys), here made on component
+// ids; the windows that pass get the full LSH work (their per-n-gram record where their vector
+// ids are a script n-gram's).  Sound: a filter only removes windows that cannot have a
+// neighbour.  Not used when the components are too coarse to filter (one of them holding an
+// eighth of the table or more: zero rows, hubs of tiny norm) or a side holds OOV vectors.
+static int fs_build_components(fs_index* ix) {
+  ix->syn_ok = false;
+  const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
+  const uint64_t V = ix->n_vec, W = ix->n_windows;
+  if (!ix->sw.lsh_syn || ix->script_oov || !W || V > FS_MAX_EXACT_ID || n < 6 ||
+      !(n <= 10 || n == 12) || !(ix->info.norm_max > 0.0)) return FS_OK;
+  std::vector<uint32_t> st(ix->n_script);
+  FS_HIP(hipMemcpyAsync(st.data(), ix->d_stok.p, ix->n_script * sizeof(uint32_t), hipMemcpyDeviceToHost, ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  std::vector<uint32_t> rows_u;
+  {
+    std::vector<uint8_t> seen(V, 0);
+    for (uint32_t id : st)
+      if (!seen[id]) { seen[id] = 1; rows_u.push_back(id); }
+  }
+  // near pairs (script vector, table vector) from the device
+  const uint32_t cap = 1u << 23;
+  DBuf<float> embT;
+  DBuf<uint32_t> d_rows_u, d_cnt;
+  DBuf<uint2> d_pairs;
+  FS_TRY(embT.reserve((size_t)V * D));
+  FS_TRY(d_rows_u.upload(rows_u.data(), rows_u.size(), ix->stream));
+  FS_TRY(d_cnt.reserve(1));
+  FS_TRY(d_pairs.reserve(cap));
+  FS_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t), ix->stream));
+  const double T = ix->cfg.distance_threshold * n * ix->info.norm_max * ix->info.norm_max * (1.0 + 1e-6);
+  FS_TRY(fs_launch_near_pairs(ix->d_emb.p, V, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p, embT.p,
+                              (float)(T / 2.0), d_pairs.p, cap, d_cnt.p, ix->stream));
+  uint32_t n_pairs = 0;
+  FS_HIP(hipMemcpyAsync(&n_pairs, d_cnt.p, sizeof n_pairs, hipMemcpyDeviceToHost, ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  if (n_pairs > cap) return FS_OK;                 // (far too many near pairs: nothing to filter with)
+  std::vector<uint2> pairs(n_pairs);
+  if (n_pairs) FS_HIP(hipMemcpy(pairs.data(), d_pairs.p, (size_t)n_pairs * sizeof(uint2), hipMemcpyDeviceToHost));
+  // connected components (union-find), ids dense in order of the smallest member
+  std::vector<uint32_t> parent(V);
+  for (uint64_t v = 0; v < V; ++v) parent[v] = (uint32_t)v;
+  auto find = [&](uint32_t v) {
+    while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; }
+    return v;
+  };
+  for (const uint2& e : pairs) {
+    const uint32_t a = find(e.x), b = find(e.y);
+    if (a != b) parent[a > b ? a : b] = a > b ? b : a;
+  }
+  std::vector<uint32_t> comp(V), size;
+  {
+    std::vector<uint32_t> id_of(V, FS_NONE);
+    for (uint64_t v = 0; v < V; ++v) {
+      const uint32_t r = find((uint32_t)v);
+      if (id_of[r] == FS_NONE) { id_of[r] = (uint32_t)size.size(); size.push_back(0); }
+      comp[v] = id_of[r];
+      ++size[comp[v]];
+    }
+  }
+  ix->n_comp = (uint32_t)size.size();
+  ix->comp_largest = *std::max_element(size.begin(), size.end());
+  if ((uint64_t)ix->comp_largest * 8 > V && ix->comp_largest > 64) return FS_OK;
+  FS_TRY(ix->d_comp.upload(comp.data(), comp.size(), ix->stream));
+  // the two filters of the one-slot case, over the script's component ids
+  std::vector<uint32_t> sc(st.size());
+  for (size_t i = 0; i < st.size(); ++i) sc[i] = comp[st[i]];
+  std::vector<uint32_t> sub(1u << ix->log2_words, 0u);
+  const int K = fs_scan_near_k(n);
+  for (uint64_t i = 0; i + K <= sc.size(); ++i) {
+    const uint32_t h = fs_gram_hash(sc.data() + i, K);
+    sub[fs_bloom_word(h, ix->log2_words)] |= 1u << (h & 31);
+  }
+  FS_TRY(ix->d_sfilter3c.upload(sub.data(), sub.size(), ix->stream));
+  std::vector<uint32_t> wild;
+  const int lwild = build_wild_filter(sc, W, n, &wild);
+  FS_TRY(ix->d_wildc.upload(wild.data(), wild.size(), ix->stream));
+  ix->log2_wildc = lwild;
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  ix->syn_ok = true;
+  return FS_OK;
+}
+
 int fs_lsh_build(fs_index* ix) {
   if (ix->lsh_ready) return FS_OK;
   ix->lsh_m_min = lsh_m_min(ix);
@@ -1231,20 +1371,8 @@ int fs_lsh_build(fs_index* ix) {
     // per key (k_lsh_verify drops a window none of whose keys is present)
     const int n = (int)ix->cfg.window_size;
     const uint64_t W = ix->n_windows;
-    int lwild = 12;
-    while (lwild < 24 && ((uint64_t)32 << lwild) < W * n * 24) ++lwild;
-    std::vector<uint32_t> wild((size_t)1 << lwild, 0u);
-    for (uint64_t w = 0; w < W; ++w) {
-      uint32_t term[FS_MAX_WINDOW], fold = 0;
-      for (int k = 0; k < n; ++k) {
-        term[k] = fs_rotl(fs_premix(st[w + k]), fs_rot_of(n - 1 - k));
-        fold ^= term[k];
-      }
-      for (int k = 0; k < n; ++k) {
-        const uint32_t h = fs_wild_key(fold, term[k], k);
-        wild[fs_wild_word(h, lwild)] |= fs_wild_mask(h);
-      }
-    }
+    std::vector<uint32_t> wild;
+    const int lwild = build_wild_filter(st, W, n, &wild);
     FS_TRY(ix->d_wild.upload(wild.data(), wild.size(), ix->stream));
     ix->log2_wild = lwild;
     // ... and as an exact map, one entry per distinct n-gram (its first window) and slot
@@ -1289,6 +1417,7 @@ int fs_lsh_build(fs_index* ix) {
     }
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
+  if ((int)ix->cfg.window_size - ix->lsh_m_min > 1) FS_TRY(fs_build_components(ix));
   if (!ix->d_normals.p) { fs_set_error("normals are required for the LSH pipeline"); return FS_E_INVALID; }
   hipStream_t s = ix->stream;
   const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
@@ -1418,9 +1547,36 @@ int fs_launch_lsh_gramtab(fs_index* ix, fs_corpus* c, hipStream_t s) {
   return FS_OK;
 }
 
+namespace {
+__global__ void k_comp_map(const uint32_t* __restrict__ tok, uint32_t n, const uint32_t* __restrict__ comp,
+                           uint32_t n_vec, uint32_t* __restrict__ out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint32_t t = tok[i];
+    out[i] = t < n_vec ? comp[t] : 0u;
+  }
+}
+}  // namespace
+
+// component ids of a batch's tokens (tables with near-synonyms), the scan's pad included
+int fs_launch_comp_map(fs_index* ix, fs_corpus* c, hipStream_t s) {
+  const uint64_t n = c->n_tok + fs_scan_pad_tokens();
+  FS_TRY(c->d_ctok.reserve(n));
+  hipLaunchKernelGGL(k_comp_map, dim3(2048), dim3(256), 0, s, (const uint32_t*)c->d_tok.p, (uint32_t)n,
+                     (const uint32_t*)ix->d_comp.p, (uint32_t)ix->n_vec, c->d_ctok.p);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s) {
   LshDev L = lsh_dev(ix);
   if (c->selflev_ready && !c->has_str) L.selflev = c->d_selflev.p;
+  // tables with near-synonyms: the wildcard keys over component ids (no one-slot map: a
+  // neighbour may differ from the window in every vector id)
+  if (fs_lsh_prefilter_mode(ix, c) == 2 && ix->sw.lsh_wild) {
+    L.wild = ix->d_wildc.p;
+    L.log2_wild = ix->log2_wildc;
+    L.wild_tok = c->d_ctok.p;
+  }
   // at most one slot may differ and no OOV id anywhere: the wildcard-key filter applies
   if (ix->sw.lsh_wild && ix->d_wild.p && !c->has_oov && !ix->script_oov &&
       (int)ix->cfg.window_size - ix->lsh_m_min == 1) {

@@ -79,11 +79,15 @@ __device__ __forceinline__ void store_ballots(const uint64_t* b, int lane, uint3
 // scan rate; the LSH keys, buckets and distances are then computed for the flagged
 // windows alone (k_lsh_verify), instead of 5 KB of projection rows for every window.
 // Same bitmap as k_scan / k_lsh_scan: four ballot words + one count per 256 tokens.
+// (K = 3 also at n = 6, where the four tests pass any window whose first or last 3-gram is a
+// script 3-gram: 29 % of the windows of the Zipf-distributed benchmark text over component
+// ids.  2-grams measured worse -- 48 %: half of all fan 2-grams occur in the script.)
+constexpr int fs_near_k(int n) { return n <= 5 ? 2 : 3; }
 template <int N, bool TAIL>
 __device__ __forceinline__ void window_ballots_near(const uint32_t* m, const uint32_t* s_filter,
                                                     int word_shift, uint32_t p0, uint32_t n_tok,
                                                     uint64_t* b) {
-  constexpr int K = 3, T = N - K + 1;           // 3-gram tests per window
+  constexpr int K = fs_near_k(N), T = N - K + 1;  // K-gram tests per window
   constexpr int NB = kTokPerLane + N - K;       // 3-gram positions of the lane
   uint32_t x = 0;
 #pragma unroll
@@ -1140,16 +1144,24 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
 }
 
 // ---- k_scan_near (integer prefilter of the LSH pipeline) --------------------------------
-bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c) {
+// 0: none; 1: at most one slot of a neighbour may differ in its vector id (k_scan_near over
+// the vector ids); 2: tables with near-synonyms, the same over component ids (fs_lsh.hip)
+int fs_lsh_prefilter_mode(const fs_index* ix, const fs_corpus* c) {
   const int n = (int)ix->cfg.window_size;
-  if (!ix->sw.lsh_prefilter || !ix->d_sfilter3.p || c->has_oov || ix->script_oov) return false;
-  if (n - ix->lsh_m_min != 1) return false;
-  return n == 7 || n == 8 || n == 9 || n == 10 || n == 12;
+  if (!ix->sw.lsh_prefilter || c->has_oov || ix->script_oov) return 0;
+  if (n - ix->lsh_m_min == 1 && ix->d_sfilter3.p)
+    return n == 7 || n == 8 || n == 9 || n == 10 || n == 12 ? 1 : 0;
+  if (ix->syn_ok && c->ctok_ready && ix->sw.lsh_syn && ix->d_sfilter3c.p)
+    return n == 6 || n == 7 || n == 8 || n == 9 || n == 10 || n == 12 ? 2 : 0;
+  return 0;
 }
+bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c) { return fs_lsh_prefilter_mode(ix, c) != 0; }
+int fs_scan_near_k(int n) { return fs_near_k(n); }
 
 namespace {
 template <int N>
-int launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+int launch_scan_near(const fs_index* ix, const CorpusDev& c, const uint32_t* ids, const uint32_t* filter,
+                     uint64_t* qbm, uint32_t* qcnt,
                      uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const uint32_t tile_tok = kSubTile * 2;
   const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
@@ -1160,21 +1172,26 @@ int launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint
   const bool nt = (uint64_t)c.n_tok * 4 > (256ull << 20);
   auto kern = nt ? k_scan_near<N, true> : k_scan_near<N, false>;
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
-  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, c.tok, c.n_tok,
-                        (const uint32_t*)ix->d_sfilter3.p, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
+  hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, ids, c.n_tok,
+                        filter, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
 }  // namespace
 
-int fs_launch_scan_near(const fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t* qcnt,
+int fs_launch_scan_near(const fs_index* ix, const fs_corpus* fc, uint64_t* qbm, uint32_t* qcnt,
                         uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  const CorpusDev c = fc->dev();
+  const bool comp = fs_lsh_prefilter_mode(ix, fc) == 2;
+  const uint32_t* ids = comp ? (const uint32_t*)fc->d_ctok.p : c.tok;
+  const uint32_t* filter = comp ? (const uint32_t*)ix->d_sfilter3c.p : (const uint32_t*)ix->d_sfilter3.p;
   switch (ix->cfg.window_size) {
-    case 7: return launch_scan_near<7>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 8: return launch_scan_near<8>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 9: return launch_scan_near<9>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 10: return launch_scan_near<10>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 12: return launch_scan_near<12>(ix, c, qbm, qcnt, n_bm_words, s, e0, e1);
-    default: fs_set_error("k_scan_near covers n = 7..10, 12"); return FS_E_UNSUPPORTED;
+    case 6: return launch_scan_near<6>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 7: return launch_scan_near<7>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 8: return launch_scan_near<8>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 9: return launch_scan_near<9>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 10: return launch_scan_near<10>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 12: return launch_scan_near<12>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    default: fs_set_error("k_scan_near covers n = 6..10, 12"); return FS_E_UNSUPPORTED;
   }
 }
