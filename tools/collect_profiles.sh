@@ -1,12 +1,12 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the measurements behind DESIGN.md section 8, each into
-# gpurun_out/r03/ under the name it keeps in profiles/.  Usage: tools/collect_profiles.sh part1|part2
+# gpurun_out/r04/ under the name it keeps in profiles/.  Usage: tools/collect_profiles.sh part1|part2
 # Every artifact carries the hash of the sources it was measured on (fandom_search_amd._lib
 # .source_hash: git is not available on the box); a step that fails stops the script, its
 # stderr stays next to the artifact (.err).
 set -eu -o pipefail
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-R=r03
+R=r04
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -80,8 +80,12 @@ if [ "$part" = part1 ]; then
   run ${R}_c3_quarter_bench.json bench.py --workload c3 --works 25000 --steps 40 --warmup 4 $B
   run ${R}_c3_half_bench.json bench.py --workload c3 --works 50000 --steps 40 --warmup 4 $B
   echo "== lanes A/B in one process"
-  run ${R}_step_ab.log tools/step_bench.py --inflight 4 "FS_LANES=1" "FS_LANES=1 FS_DIAG=16" "FS_LANES=2" "FS_LANES=4" \
-      "FS_LANES=4 FS_ROWS_BLOCKS_PER_CU=1" "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=0 FS_LANES=4"
+  echo "== the same from HBM (four distinct batches): what round 4 added, switched off one at a time"
+  run ${R}_step_ab.log tools/step_bench.py --rotate 4 --inflight 3 "FS_LANES=1" "FS_LANES=1 FS_DIAG=256" "FS_LANES=1 FS_DIAG=32" \
+      "FS_LANES=1 FS_DIAG=128" "FS_LANES=1 FS_DIAG=16" "FS_LANES=2" "FS_LANES=4" "FS_SCAN_ROWS=0" "FS_SCAN_ROWS=0 FS_LANES=4"
+  FS_LIB_FILE=libfandomsearch_hip_r03.so run ${R}_step_ab_r03lib.log tools/step_bench.py --rotate 4 --inflight 3 "FS_LANES=1" "FS_LANES=2" "FS_LANES=4"
+  run ${R}_step_ab_resident.log tools/step_bench.py --inflight 4 "FS_LANES=1" "FS_LANES=1 FS_DIAG=256" "FS_LANES=2" "FS_LANES=4" "FS_LANES=4 FS_ROWS_BLOCKS_PER_CU=1"
+  run ${R}_c2_scan_rows_timeline_phases.json tools/scan_timeline.py --extra FS_DIAG=6
   ls -la $OUT
 fi
 
@@ -98,9 +102,12 @@ if [ "$part" = part2 ]; then
   run ${R}_gloo2_rehearsal.json bench.py --gpus 2 --steps 30 --warmup 5 --backend gloo $B
   echo "== LSH pipeline on the synonym-rich table: 5000 works, kernel stats, SQ counters"
   run ${R}_lsh_clustered.json tools/lsh_bench.py --works 5000 --reps 2
-  prof_stats ${R}_lsh_clustered $ROOTDIR/tools/lsh_bench.py --works 5000 --reps 2
-  KERNEL=k_lsh_scan tools/collect_pmc.sh $OUT/sq_lsh - tools/lsh_bench.py --works 5000 --reps 2 > $OUT/${R}_lsh_sq.log 2>&1
+  FS_LSH_SYN=0 run ${R}_lsh_clustered_nosyn.json tools/lsh_bench.py --works 5000 --reps 2
+  prof_stats ${R}_lsh_clustered $ROOTDIR/tools/lsh_bench.py --works 5000 --reps 4
+  FS_LSH_SYN=0 KERNEL=k_lsh_scan tools/collect_pmc.sh $OUT/sq_lsh - tools/lsh_bench.py --works 5000 --reps 2 > $OUT/${R}_lsh_sq.log 2>&1
   cp $OUT/sq_lsh/sq_counters.json $OUT/${R}_lsh_scan_pmc_sq.json
+  KERNEL=k_lsh_sift tools/collect_pmc.sh $OUT/sq_sift - tools/lsh_bench.py --works 5000 --reps 2 > $OUT/${R}_lsh_sift_sq.log 2>&1
+  cp $OUT/sq_sift/sq_counters.json $OUT/${R}_lsh_sift_pmc_sq.json
   echo "== mixed-case companion by itself, kernel stats"
   run ${R}_tokstr.json tools/tokstr_bench.py 30
   FS_LANES=1 run ${R}_tokstr_lanes1.json tools/tokstr_bench.py 30

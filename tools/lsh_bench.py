@@ -72,7 +72,7 @@ def main():
     out = {"table": a.table, "window": a.window, "works": a.works, "tokens": a.tokens, "roofline": roof,
            "c_max": ix.info["c_max"], "index_s": round(t_index, 2), "total_ms": best,
            "scan_ms": st.scan_ms, "rows": len(rows), "matches": int(st.matches),
-           "candidates": int(st.candidates), "kernel": ix.kernel_name(corpus),
+           "candidates": int(st.candidates), "lsh_pending": int(st.lsh_pending), "kernel": ix.kernel_name(corpus),
            "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()),
            "fanworks_per_s": a.works / (best * 1e-3),
            "windows_per_s": st.windows_processed / (best * 1e-3)}
