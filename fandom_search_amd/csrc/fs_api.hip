@@ -102,6 +102,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->diag = num("FS_DIAG");
   if (const char* e = getenv("FS_LSH_GRAMTAB")) sw->lsh_gramtab = atoi(e) != 0;
   if (const char* e = getenv("FS_LSH_SYN")) sw->lsh_syn = atoi(e) != 0;
+  if (const char* e = getenv("FS_LSH_KEYS6")) sw->lsh_keys6 = atoi(e) != 0;
   if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e) != 0;
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
   sw->rows_finish = num("FS_ROWS_FINISH");

@@ -140,6 +140,11 @@ FS_HD uint32_t fs_wild_block(uint32_t fold_others, int group, int log2_blocks) {
 }
 // (bit positions of key h inside its block: four 7-bit fields of the hash)
 FS_HD uint32_t fs_wild_bit(uint32_t h, int i) { return (h >> (7 * i)) & 127u; }
+// n = 6 over component ids: the keys of the two middle slots (2 and 3) of every script window in a
+// filter of their own that k_scan_near holds in LDS (2^14 words, three bits per key as the
+// Bloom filter above)
+#define FS_NEAR6_LOG2_WORDS 14
+
 // The same keys in an exact map (buckets of four {key, script window + 1}, one entry per distinct
 // script n-gram and slot, a full bucket spills into the next): the script windows that equal a
 // fan window in all slots but one can be enumerated, not just shown to be possible.

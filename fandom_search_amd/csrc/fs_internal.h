@@ -184,6 +184,7 @@ struct fs_switches {
   bool lsh_selflev = true;        // FS_LSH_SELFLEV=0: every Levenshtein distance of the LSH pipeline computed per match
   bool lsh_wild = true;           // FS_LSH_WILD=0: no wildcard-key filter in front of k_lsh_verify
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
+  bool lsh_keys6 = true;          // FS_LSH_KEYS6=0: n = 6 over component ids without the middle-slot key filter in k_scan_near
   bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
   bool lsh_gramtab = true;        // FS_LSH_GRAMTAB=0: no per-n-gram records (k_lsh_gramtab): every window with a script n-gram's ids walks the buckets
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
@@ -244,7 +245,7 @@ struct fs_index {
   // over *component ids* -- connected components of "near" pairs of table vectors, at most one
   // slot of a neighbour within the threshold joins two components (fs_lsh.hip)
   DBuf<uint32_t> d_comp;     // [V] component id of a table vector
-  DBuf<uint32_t> d_sfilter3c, d_wildc;
+  DBuf<uint32_t> d_sfilter3c, d_wildc, d_keys6c;   // (d_keys6c: n = 6, the wildcard keys of slots 2 and 3)
   int log2_wildc = 0;
   bool syn_ok = false;
   uint32_t n_comp = 0, comp_largest = 0;

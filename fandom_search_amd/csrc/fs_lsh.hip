@@ -1345,6 +1345,22 @@ static int fs_build_components(fs_index* ix) {
   const int lwild = build_wild_filter(sc, W, n, &wild);
   FS_TRY(ix->d_wildc.upload(wild.data(), wild.size(), ix->stream));
   ix->log2_wildc = lwild;
+  if (n == 6) {
+    // the keys of slots 2 and 3 in a filter of their own for k_scan_near (fs_scan.hip)
+    std::vector<uint32_t> keys((size_t)1 << FS_NEAR6_LOG2_WORDS, 0u);
+    for (uint64_t w = 0; w < W; ++w) {
+      uint32_t term[6], fold = 0;
+      for (int k = 0; k < 6; ++k) {
+        term[k] = fs_rotl(fs_premix(sc[w + k]), fs_rot_of(5 - k));
+        fold ^= term[k];
+      }
+      for (int k = 2; k <= 3; ++k) {
+        const uint32_t h = fs_wild_key(fold, term[k], k);
+        keys[fs_bloom_word(h, FS_NEAR6_LOG2_WORDS)] |= fs_bloom_mask(h);
+      }
+    }
+    FS_TRY(ix->d_keys6c.upload(keys.data(), keys.size(), ix->stream));
+  }
   FS_HIP(hipStreamSynchronize(ix->stream));
   ix->syn_ok = true;
   return FS_OK;

@@ -86,7 +86,7 @@ constexpr int fs_near_k(int n) { return n <= 5 ? 2 : 3; }
 template <int N, bool TAIL>
 __device__ __forceinline__ void window_ballots_near(const uint32_t* m, const uint32_t* s_filter,
                                                     int word_shift, uint32_t p0, uint32_t n_tok,
-                                                    uint64_t* b) {
+                                                    uint64_t* b, const uint32_t* s_keys = nullptr) {
   constexpr int K = fs_near_k(N), T = N - K + 1;  // K-gram tests per window
   constexpr int NB = kTokPerLane + N - K;       // 3-gram positions of the lane
   uint32_t x = 0;
@@ -106,7 +106,23 @@ __device__ __forceinline__ void window_ballots_near(const uint32_t* m, const uin
   for (int j = 0; j < kTokPerLane; ++j) {
     const uint32_t z = ~(bits >> j) & ((1u << T) - 1);       // failed tests of window j
     // none, or all within three consecutive positions
-    const bool hit = z == 0 || (31 - __clz((int)z)) - (__ffs((int)z) - 1) < K;
+    bool hit = z == 0 || (31 - __clz((int)z)) - (__ffs((int)z) - 1) < K;
+    if constexpr (N == 6) {
+      // n = 6: "only the last 3-gram is a script 3-gram" (or only the first) passes the rule
+      // above and is what most windows that pass look like.  It leaves ONE slot that may differ
+      // (2, or 3), so the window's wildcard key for that slot must be a script window's: a
+      // second filter in LDS, over those two keys of every script window (fs_hash.h).
+      if (s_keys) {
+        const bool only_last = z == 0x7u, only_first = z == 0xEu;
+        uint32_t fold = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) fold ^= fs_rotl(m[j + k], fs_rot_of(5 - k));
+        const uint32_t term = only_last ? fs_rotl(m[j + 2], fs_rot_of(3)) : fs_rotl(m[j + 3], fs_rot_of(2));
+        const uint32_t h = fs_wild_key(fold, term, only_last ? 2 : 3);
+        const uint32_t word = s_keys[fs_bloom_word(h, FS_NEAR6_LOG2_WORDS)];
+        if (only_last | only_first) hit = fs_bloom_test(word, h) != 0;
+      }
+    }
     flags |= (hit ? 1u : 0u) << j;
   }
   if (TAIL) {
@@ -123,9 +139,16 @@ __global__ __launch_bounds__(1024) void k_scan_near(const uint32_t* __restrict__
                                                     const uint32_t* __restrict__ filter,
                                                     int log2_words, uint64_t* __restrict__ qbm,
                                                     uint32_t* __restrict__ qcnt,
-                                                    uint32_t n_bm_words, uint32_t n_tiles) {
+                                                    uint32_t n_bm_words, uint32_t n_tiles,
+                                                    const uint32_t* __restrict__ keys6) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   copy_filter_to_lds(filter, s_filter, log2_words);
+  // (n = 6 over component ids: the filter of the middle slots' wildcard keys behind it)
+  const uint32_t* s_keys = nullptr;
+  if (N == 6 && keys6) {
+    copy_filter_to_lds(keys6, s_filter + (1u << log2_words), FS_NEAR6_LOG2_WORDS);
+    s_keys = s_filter + (1u << log2_words);
+  }
   __syncthreads();
   constexpr int U = 2;
   constexpr int HALO = N - 1;
@@ -174,8 +197,8 @@ __global__ __launch_bounds__(1024) void k_scan_near(const uint32_t* __restrict__
       const uint32_t p0 = base + u * kSubTile + 4 * lane;
       uint64_t b[4];
       const bool tail = base + (uint32_t)(kSubTile * U) + HALO > n_tok;   // wave-uniform
-      if (tail) window_ballots_near<N, true>(a[u], s_filter, word_shift, p0, n_tok, b);
-      else window_ballots_near<N, false>(a[u], s_filter, word_shift, p0, n_tok, b);
+      if (tail) window_ballots_near<N, true>(a[u], s_filter, word_shift, p0, n_tok, b, s_keys);
+      else window_ballots_near<N, false>(a[u], s_filter, word_shift, p0, n_tok, b, s_keys);
       store_ballots(b, lane, tile * U + u, n_bm_words, qbm, qcnt);
     }
   }
@@ -1161,19 +1184,19 @@ int fs_scan_near_k(int n) { return fs_near_k(n); }
 namespace {
 template <int N>
 int launch_scan_near(const fs_index* ix, const CorpusDev& c, const uint32_t* ids, const uint32_t* filter,
-                     uint64_t* qbm, uint32_t* qcnt,
+                     const uint32_t* keys6, uint64_t* qbm, uint32_t* qcnt,
                      uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
   const uint32_t tile_tok = kSubTile * 2;
   const uint32_t n_tiles = (uint32_t)(((uint64_t)c.n_tok + tile_tok - 1) / tile_tok);
   if (n_tiles == 0) return FS_OK;
-  const size_t lds = (size_t)4 << ix->log2_words;
+  const size_t lds = ((size_t)4 << ix->log2_words) + (N == 6 && keys6 ? (size_t)4 << FS_NEAR6_LOG2_WORDS : 0);
   const uint32_t max_blocks = ix->num_cu * (lds <= 64 * 1024 ? 2 : 1);
   const uint32_t blocks = std::min<uint32_t>((n_tiles + 15) / 16, max_blocks);
   const bool nt = (uint64_t)c.n_tok * 4 > (256ull << 20);
   auto kern = nt ? k_scan_near<N, true> : k_scan_near<N, false>;
   FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
   hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, ids, c.n_tok,
-                        filter, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles);
+                        filter, ix->log2_words, qbm, qcnt, n_bm_words, n_tiles, N == 6 ? keys6 : (const uint32_t*)nullptr);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
@@ -1185,13 +1208,14 @@ int fs_launch_scan_near(const fs_index* ix, const fs_corpus* fc, uint64_t* qbm, 
   const bool comp = fs_lsh_prefilter_mode(ix, fc) == 2;
   const uint32_t* ids = comp ? (const uint32_t*)fc->d_ctok.p : c.tok;
   const uint32_t* filter = comp ? (const uint32_t*)ix->d_sfilter3c.p : (const uint32_t*)ix->d_sfilter3.p;
+  const uint32_t* keys6 = comp && ix->sw.lsh_keys6 ? (const uint32_t*)ix->d_keys6c.p : (const uint32_t*)nullptr;
   switch (ix->cfg.window_size) {
-    case 6: return launch_scan_near<6>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 7: return launch_scan_near<7>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 8: return launch_scan_near<8>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 9: return launch_scan_near<9>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 10: return launch_scan_near<10>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
-    case 12: return launch_scan_near<12>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 6: return launch_scan_near<6>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 7: return launch_scan_near<7>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 8: return launch_scan_near<8>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 9: return launch_scan_near<9>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 10: return launch_scan_near<10>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
+    case 12: return launch_scan_near<12>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
     default: fs_set_error("k_scan_near covers n = 6..10, 12"); return FS_E_UNSUPPORTED;
   }
 }
