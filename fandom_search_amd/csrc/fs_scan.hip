@@ -808,7 +808,7 @@ __global__ __launch_bounds__(1024, INL ? 4 : 5) void k_scan_rows(CorpusDev c, Gr
         // will be served)
         if (__hip_atomic_load(&C.posted, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == n_waves &&
             t >= __hip_atomic_load(&C.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(8);     // (a wave that waits for a ticket leaves the issue slots to the others)
       }
       slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
       if (!slot) break;

@@ -89,6 +89,27 @@ if [ "$part" = part1 ]; then
   ls -la $OUT
 fi
 
+if [ "$part" = traffic ]; then
+  echo "== (again, after a change of the sources) HBM traffic of k_scan_rows, one lane and four, and the kernel stats"
+  run ${R}_c2_bench_steps20.json bench.py --steps 20 --warmup 5 $B
+  run ${R}_c2_bench_lanes1.json bench.py --lanes 1 --inflight 2 $B
+  prof_stats ${R}_c2 $ROOTDIR/bench.py $B
+  prof_stats ${R}_c2_lanes1 $ROOTDIR/bench.py --lanes 1 --inflight 2 $B
+  pmc ${R}_c2_lanes1 FETCH_SIZE --steps 8 --warmup 2 --lanes 1 --inflight 1 $B
+  pmc ${R}_c2_lanes1 WRITE_SIZE --steps 8 --warmup 2 --lanes 1 --inflight 1 $B
+  run ${R}_c2_bench_lanes1_steps8.json bench.py --steps 8 --warmup 2 --lanes 1 --inflight 1 $B
+  python3 tools/pmc_to_traffic.py $OUT/${R}_c2_lanes1_pmc_FETCH_SIZE.csv $OUT/${R}_c2_lanes1_pmc_WRITE_SIZE.csv \
+      $OUT/${R}_c2_bench_lanes1_steps8.json --also k_compact --out $OUT/scan_traffic_lanes1.json > /dev/null
+  pmc ${R}_c2 FETCH_SIZE --steps 8 --warmup 2 --inflight 1 $B
+  pmc ${R}_c2 WRITE_SIZE --steps 8 --warmup 2 --inflight 1 $B
+  python3 tools/pmc_to_traffic.py $OUT/${R}_c2_pmc_FETCH_SIZE.csv $OUT/${R}_c2_pmc_WRITE_SIZE.csv \
+      $OUT/${R}_c2_bench_steps20.json --out $OUT/scan_traffic.json > /dev/null
+  tools/collect_pmc.sh $OUT/sq 6 > $OUT/${R}_c2_scan_rows_sq.log 2>&1
+  cp $OUT/sq/sq_counters.json $OUT/${R}_c2_scan_rows_pmc_sq.json
+  run ${R}_c2_scan_rows_timeline.json tools/scan_timeline.py
+  ls -la $OUT
+fi
+
 if [ "$part" = part2 ]; then
   echo "== configs[3]: n = 4, 8, 10 on the 10k-work corpus"
   for n in 4 8 10; do
