@@ -638,7 +638,8 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
     script K-grams (FS_SCAN_SUB=0), with the launch shape of an index that overlaps searches
     (FS_LANES=4: two workgroups of eight wave ranges per CU), with a sub-shingle filter far
     too small (many false candidates), with the displacement seeds read from memory instead
-    of LDS (as for scripts with more than 16 K buckets), with works that quote long stretches of the script (several rounds
+    of LDS (as for scripts with more than 16 K buckets), with the shared rounds of round 4 switched off or starved
+    of pool space (the dense work below posts slices from every wave range it covers), with works that quote long stretches of the script (several rounds
     of candidates per flush, hits carried from round to round), hits at range and work
     boundaries, ragged and empty works.  n = 7, 8 need a table the exact-n-gram proof
     accepts: 256 one-hot vectors."""
@@ -666,16 +667,31 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
     for k in range(9, 30):                                      # hits straddling 512-token borders
         at = (int(off[k]) // 512 + 1) * 512 - (k % (n + 3))
         tok[at:at + n + 2] = script[700 + k:700 + k + n + 2]
+    # quotes of 90, 150 and 300 tokens: more candidates than one round takes, few enough
+    # slices for the shared rounds (one, two, five per wave range); one across a 512-token border
+    for k, (ln, where) in enumerate(((90, 200), (150, 300), (300, 100), (150, 450))):
+        at = (int(off[31 + k]) // 512 + 1) * 512 + where
+        tok[at:at + ln] = script[2000 + 400 * k:2000 + 400 * k + ln]
     normals = synth.lsh_normals(n)
     cfg = abi.make_config(window_size=n)
     results = []
     envs = ({}, {"FS_SCAN_ROWS": "0"}, {"FS_RANGES_CAPROW": "2"}, {"FS_WAIT_SPINS": "0"},
             {"FS_ROWS_FINISH": "2"}, {"FS_ROWS_FINISH": "2", "FS_RANGES_CAPROW": "2"},
             {"FS_SCAN_SUB": "0"}, {"FS_LANES": "4"}, {"FS_LANES": "4", "FS_RANGES_CAPROW": "2"},
-            {"FS_SFILTER_LOG2_WORDS": "10"}, {"FS_ROWS_DISP_LDS": "0"})
+            {"FS_SFILTER_LOG2_WORDS": "10"}, {"FS_ROWS_DISP_LDS": "0"},
+            # round 4: without the shared rounds (every wave works its own queue off), with a
+            # pool for the slices' records that is far too small (the search reports what it
+            # needs and is repeated), with the pool AND the staging area too small, with all
+            # records through the staging area (none kept in registers), without the scanners'
+            # priority, with equal and with lopsided shares of the waves of a SIMD, with the
+            # phase clocks of the timeline running (FS_DIAG 6)
+            {"FS_ROWS_COOP": "0"}, {"FS_ROWS_XPOOL": "8"}, {"FS_ROWS_XPOOL": "8", "FS_RANGES_CAPROW": "2"},
+            {"FS_DIAG": "32"}, {"FS_DIAG": "128"}, {"FS_DIAG": "16"}, {"FS_ROWS_SHARES": "400,300,200,124"},
+            {"FS_DIAG": "6"}, {"FS_ROWS_FINISH": "1", "FS_LANES": "2"})
     for env in envs:
         for k in ("FS_SCAN_ROWS", "FS_RANGES_CAPROW", "FS_WAIT_SPINS", "FS_ROWS_FINISH", "FS_SCAN_SUB",
-                  "FS_LANES", "FS_SFILTER_LOG2_WORDS", "FS_ROWS_DISP_LDS"):
+                  "FS_LANES", "FS_SFILTER_LOG2_WORDS", "FS_ROWS_DISP_LDS", "FS_ROWS_COOP", "FS_ROWS_XPOOL",
+                  "FS_DIAG", "FS_ROWS_SHARES"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
