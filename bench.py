@@ -381,7 +381,7 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
     ix.set_scan_timing(0)
     run(shards)
     samples = []
-    per_region = 3                                # passes per timed region (one pass = the whole corpus)
+    per_region = 6                                # passes per timed region (one pass = the whole corpus)
     for _ in range(passes):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -414,7 +414,7 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
                     "samples_ms": [round(x * 1e3, 4) for x in samples],
                     "roofline_step": total_bytes / dt / 1e9 / HBM_PEAK_GBS,
                     "corpus_s": round(t_gen, 1),
-                    "note": "configs[2] whole on one GPU (timed: three passes per region, five regions, the median "
+                    "note": "configs[2] whole on one GPU (timed: six passes per region, five regions, the median "
                             "pass): a step = the eight shards of an 8-GPU run searched one behind the other (the N = 1 point of the strong-scaling curve `--gpus N` "
                             "measures; same works, same shards)"},
     }

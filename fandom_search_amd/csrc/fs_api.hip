@@ -1,6 +1,7 @@
 // fs_api.hip -- C ABI of libfandomsearch_hip.so (include/fandom_search.h): host
 // side index build and the orchestration of the device pipeline.
 #include "fs_internal.h"
+#include <sched.h>
 
 #include <math.h>
 #include <stdarg.h>
@@ -1086,7 +1087,14 @@ static void fs_expand_rows8_host(fs_index* ix, const uint32_t* rec, uint64_t n, 
   };
   if (n < 32768) { slice(0, n); return; }
   if (!ix->host_pool) {
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    // threads for the expansion: this process's share of the cores it may run on (its
+    // affinity mask, divided by the ranks of the node: every rank has such a pool, next to
+    // its tokeniser processes), at most 12
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) hw = std::max(1, CPU_COUNT(&set));
+    if (const char* e = getenv("LOCAL_WORLD_SIZE")) hw = std::max(1u, hw / (unsigned)std::max(1, atoi(e)));
+    else if (const char* e2 = getenv("WORLD_SIZE")) hw = std::max(1u, hw / (unsigned)std::max(1, atoi(e2)));
     ix->host_pool = new fs_host_pool;
     ix->host_pool->start(std::min(12u, hw) - 1);
   }

@@ -275,6 +275,7 @@ class TokenPool(object):
         self.processes = int(processes)
         self.pool = multiprocessing.get_context("fork").Pool(self.processes) if self.processes > 1 else None
         self.pending = {}
+        self._pids = sorted(p.pid for p in self.pool._pool) if self.pool is not None else None
 
     def start(self, filenames):
         key = tuple(filenames)
@@ -285,7 +286,32 @@ class TokenPool(object):
 
     def get(self, filenames):
         job = self.pending.pop(tuple(filenames), None)
-        return job.get() if job is not None else [tokenize_files(list(filenames))]
+        # (jobs queued for a list that was never asked for -- share() and the split of a batch
+        # disagreeing -- are dropped, not kept for the life of the pool: only the next cluster's
+        # job is ever ahead of the one asked for)
+        while len(self.pending) > 2:
+            self.pending.pop(next(iter(self.pending)))
+        if job is not None and self._workers_alive():
+            return job.get()
+        return [tokenize_files(list(filenames))]
+
+    def _workers_alive(self):
+        """multiprocessing.Pool re-forks a worker that died (out of memory, a signal) -- from
+        a parent that holds the HIP runtime and its threads by then, and with a vocabulary
+        newer than the replacement's protocol assumes.  A pool that has lost a worker is shut
+        down instead and the text work done in the parent from there on."""
+        if self.pool is None:
+            return False
+        pids = sorted(p.pid for p in self.pool._pool)
+        if self._pids is None:
+            self._pids = pids
+        if pids != self._pids or any(not p.is_alive() for p in self.pool._pool):
+            import sys
+            print("warning: a tokeniser process was lost; tokenising in the parent from here on",
+                  file=sys.stderr)
+            self.close()
+            return False
+        return True
 
     def close(self):
         if self.pool is not None:
