@@ -808,6 +808,56 @@ __device__ __forceinline__ bool one_slot_within(const LshDev& L, uint32_t s, int
 // lists and the Levenshtein code, which these steps do not need; consecutive candidates sit
 // in consecutive lanes, so the per-candidate arrays move in whole cache lines.
 constexpr uint32_t FS_PENDING = 0xFFFFFFFEu;
+// The one-slot-wildcard keys of the window at `p` (made of the vector ids, or of the
+// component ids: L.wild_tok): terms and fold for the caller, true when one of the n keys is in
+// the grouped filter (three 16-byte blocks, requested together).
+template <int NW>
+__device__ __forceinline__ bool sift_keys(const CorpusDev& c, const LshDev& L, uint64_t p,
+                                          uint32_t* term, uint32_t* fold_out, bool probe) {
+  Ids16 kf;
+  load_ids((L.wild_tok ? L.wild_tok : c.tok) + p, L.n, &kf);
+  uint32_t fold = 0, gfold[3] = {0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    term[k] = 0;
+    if (k < L.n) {
+      term[k] = fs_rotl(fs_premix(kf.v[k]), fs_rot_of(L.n - 1 - k));
+      fold ^= term[k];
+      gfold[fs_wild_group(k, L.n)] ^= term[k];
+    }
+  }
+  *fold_out = fold;
+  if (!probe) return true;
+  const uint4* wb = reinterpret_cast<const uint4*>(L.wild);
+  uint4 blk[3];
+#pragma unroll
+  for (int X = 0; X < 3; ++X) blk[X] = wb[fs_wild_block(fold ^ gfold[X], X, L.log2_wild)];
+  bool pass = false;
+#pragma unroll
+  for (int k = 0; k < NW; ++k)
+    if (k < L.n) {
+      const uint32_t h = fs_wild_key(fold, term[k], k);
+      const int X = fs_wild_group(k, L.n);
+      const uint4 q = X == 0 ? blk[0] : X == 1 ? blk[1] : blk[2];
+      bool all = true;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t bit = fs_wild_bit(h, i);
+        const uint32_t wsel = bit >> 5;
+        const uint32_t word = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
+        all = all && ((word >> (bit & 31)) & 1u);
+      }
+      pass = pass || all;
+    }
+  return pass;
+}
+
+// One lane per candidate, in two stages.  Stage 1, every candidate: the wildcard-key filter
+// (one level of loads behind the candidate's position and ids).  Most candidates end there --
+// 88 % at n = 8, 84 % over component ids -- and the deeper steps (exact table, one-slot map:
+// five to eight more levels of dependent loads) ran at a tenth of the lanes while every wave
+// had a survivor to wait for.  So the survivors queue up in LDS and stage 2 takes them 256 at
+// a time, a full lane each (round 4: 90 -> 40 us per C2 batch at n = 8).
 template <int NW, bool WMAP>
 __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramIndexDev g,
                                                   const uint32_t* __restrict__ cpos, NSrc nc,
@@ -819,130 +869,127 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
                                                   uint32_t* __restrict__ pend,
                                                   uint32_t* __restrict__ pend_cnt) {
   __shared__ uint32_t s_w32[4];
+  __shared__ uint32_t s_q[512];          // survivors of stage 1 (candidate numbers)
+  __shared__ uint32_t s_qn;
   const uint32_t total = nc.get();
+  const int lane = threadIdx.x & 63;
   uint32_t matches = 0;
+  if (threadIdx.x == 0) s_qn = 0;
+  __syncthreads();
+  // stage 2 for one queued candidate (FS_NONE: none)
+  auto stage2 = [&](uint32_t il) {
+    bool live = il != FS_NONE;
+    // 2. A window with the ids of a script n-gram (and the strings of those ids) takes the
+    //    n-gram's record of this string table (k_lsh_gramtab): no bucket is walked for it.
+    uint32_t gram = FS_NONE;
+    const uint64_t p = live ? cpos[il] : 0;
+    if (tab_cnt && live) {
+      uint32_t w = 0, kept = 0;
+      gram = verify_window(c, g, p, &w, &kept);
+      if (gram != FS_NONE) {
+        const uint32_t have = tab_cnt[gram];
+        if (have == 1) {
+          cg[il] = FS_NONE;                             // (no neighbour within the threshold)
+        } else {
+          const uint4* m = reinterpret_cast<const uint4*>(tab_best + 4 * (size_t)gram);
+          uint4* dst = reinterpret_cast<uint4*>(&cbest[il]);
+          dst[0] = m[0]; dst[1] = m[1];
+          cg[il] = 0;
+          cw[il] = w;
+          matches += have - 1;
+        }
+        live = false;
+      }
+    }
+    // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
+    //    slots but one (every neighbour within the threshold is one of them: m_min = n - 1) and
+    //    take their canonical distances.  None within the threshold: whatever the buckets hold,
+    //    nothing survives the threshold, and the window needs no LSH work.  One 32-byte bucket
+    //    of the map per slot, all n requested together; a window with more than two such
+    //    n-grams, or a full bucket in its way, is left to k_lsh_verify.
+    if (WMAP && live && L.wild && p + L.n <= c.n_tok) {
+      uint32_t term[NW], fold = 0;
+      sift_keys<NW>(c, L, p, term, &fold, false);
+      Ids16 f;
+      load_ids(c.tok + p, L.n, &f);
+      uint32_t s0 = 0, s1 = 0, nh = 0;
+      int k0 = 0, k1 = 0;
+      bool possible = false;
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+        if (k < L.n) {
+          const uint32_t h = fs_wild_key(fold, term[k], k);
+          const uint4* bp = reinterpret_cast<const uint4*>(L.wmap + 4 * (size_t)fs_wmap_slot(h, L.log2_wmap));
+          const uint4 a = bp[0], b = bp[1];
+          const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (val[e] && key[e] == h) {
+              if (nh == 0) { s0 = val[e] - 1; k0 = k; }
+              else if (nh == 1) { s1 = val[e] - 1; k1 = k; }
+              ++nh;
+            }
+          possible = possible || val[3] != 0;       // (filled in order: the bucket is full)
+        }
+      possible = possible || nh > 2;
+      if (!possible && nh > 0) possible = one_slot_within<NW>(L, s0, k0, f);
+      if (!possible && nh > 1) possible = one_slot_within<NW>(L, s1, k1, f);
+      if (!possible) { cg[il] = FS_NONE; live = false; }
+    }
+    // what is left: onto the list k_lsh_verify deals out window by window (pending windows
+    // come in runs, the boundary windows of one quoted passage, so dealing out blocks of
+    // candidates leaves a few waves with most of the work)
+    const uint64_t pb = __ballot(live);
+    if (pb) {
+      const int leader = __ffsll((unsigned long long)pb) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(pend_cnt, (uint32_t)__popcll(pb));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+      if (live) {
+        cg[il] = FS_PENDING;
+        pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
+      }
+    }
+  };
   for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < total; i0 += (uint64_t)gridDim.x * 256) {
-   const uint64_t il = i0 + threadIdx.x;
-   bool live = il < total;
-   // -- one lane per candidate --
-   // 1. (no OOV anywhere, at most one slot may differ) a window none of whose n one-slot-
-   //    wildcard keys is a script window's key has no neighbour within the threshold
-   Ids16 f;
-   uint32_t term[NW], fold = 0;
-   bool keyed = false;
-   if (L.wild && live) {
-     const uint64_t p = cpos[il];
-     bool pass = true;
-     if (p + L.n <= c.n_tok) {
-       // the ids the keys are made of (the vector ids themselves are needed by the one-slot map only)
-       Ids16 kf;
-       load_ids((L.wild_tok ? L.wild_tok : c.tok) + p, L.n, &kf);
-       if (WMAP) f = kf;
-#pragma unroll
-       for (int k = 0; k < NW; ++k) {
-         term[k] = 0;
-         if (k < L.n) {
-           term[k] = fs_rotl(fs_premix(kf.v[k]), fs_rot_of(L.n - 1 - k));
-           fold ^= term[k];
-         }
-       }
-       pass = false;
-       keyed = true;
-       // three 16-byte blocks (one per group of slots), requested together
-       uint32_t gfold[3] = {0, 0, 0};
-#pragma unroll
-       for (int k = 0; k < NW; ++k)
-         if (k < L.n) gfold[fs_wild_group(k, L.n)] ^= term[k];
-       const uint4* wb = reinterpret_cast<const uint4*>(L.wild);
-       uint4 blk[3];
-#pragma unroll
-       for (int X = 0; X < 3; ++X) blk[X] = wb[fs_wild_block(fold ^ gfold[X], X, L.log2_wild)];
-#pragma unroll
-       for (int k = 0; k < NW; ++k)
-         if (k < L.n) {
-           const uint32_t h = fs_wild_key(fold, term[k], k);
-           const int X = fs_wild_group(k, L.n);
-           const uint4 q = X == 0 ? blk[0] : X == 1 ? blk[1] : blk[2];
-           bool all = true;
-#pragma unroll
-           for (int i = 0; i < 4; ++i) {
-             const uint32_t bit = fs_wild_bit(h, i);
-             const uint32_t wsel = bit >> 5;
-             const uint32_t word = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
-             all = all && ((word >> (bit & 31)) & 1u);
-           }
-           pass = pass || all;
-         }
-     }
-     if (!pass) { cg[il] = FS_NONE; live = false; }
-   }
-   // 2. A window with the ids of a script n-gram (and the strings of those ids) takes the
-   //    n-gram's record of this string table (k_lsh_gramtab): no bucket is walked for it.
-   uint32_t gram = FS_NONE;
-   if (tab_cnt && live) {
-     uint32_t w = 0, kept = 0;
-     gram = verify_window(c, g, cpos[il], &w, &kept);
-     if (gram != FS_NONE) {
-       const uint32_t have = tab_cnt[gram];
-       if (have == 1) {
-         cg[il] = FS_NONE;                             // (no neighbour within the threshold)
-       } else {
-         const uint4* m = reinterpret_cast<const uint4*>(tab_best + 4 * (size_t)gram);
-         uint4* dst = reinterpret_cast<uint4*>(&cbest[il]);
-         dst[0] = m[0]; dst[1] = m[1];
-         cg[il] = 0;
-         cw[il] = w;
-         matches += have - 1;
-       }
-       live = false;
-     }
-   }
-   // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
-   //    slots but one (every neighbour within the threshold is one of them: m_min = n - 1) and
-   //    take their canonical distances.  None within the threshold: whatever the buckets hold,
-   //    nothing survives the threshold, and the window needs no LSH work.  One 32-byte bucket
-   //    of the map per slot, all n requested together; a window with more than two such
-   //    n-grams, or a full bucket in its way, is left to k_lsh_verify.
-   if (WMAP && live && keyed && gram == FS_NONE) {
-     uint32_t s0 = 0, s1 = 0, nh = 0;
-     int k0 = 0, k1 = 0;
-     bool possible = false;
-#pragma unroll
-     for (int k = 0; k < NW; ++k)
-       if (k < L.n) {
-         const uint32_t h = fs_wild_key(fold, term[k], k);
-         const uint4* bp = reinterpret_cast<const uint4*>(L.wmap + 4 * (size_t)fs_wmap_slot(h, L.log2_wmap));
-         const uint4 a = bp[0], b = bp[1];
-         const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
-#pragma unroll
-         for (int e = 0; e < 4; ++e)
-           if (val[e] && key[e] == h) {
-             if (nh == 0) { s0 = val[e] - 1; k0 = k; }
-             else if (nh == 1) { s1 = val[e] - 1; k1 = k; }
-             ++nh;
-           }
-         possible = possible || val[3] != 0;       // (filled in order: the bucket is full)
-       }
-     possible = possible || nh > 2;
-     if (!possible && nh > 0) possible = one_slot_within<NW>(L, s0, k0, f);
-     if (!possible && nh > 1) possible = one_slot_within<NW>(L, s1, k1, f);
-     if (!possible) { cg[il] = FS_NONE; live = false; }
-   }
-   // what is left: onto the list k_lsh_verify deals out window by window (pending windows
-   // come in runs, the boundary windows of one quoted passage, so dealing out blocks of
-   // candidates leaves a few waves with most of the work)
-   const uint64_t pb = __ballot(live);
-   if (pb) {
-     const int lane = threadIdx.x & 63;
-     const int leader = __ffsll((unsigned long long)pb) - 1;
-     uint32_t base = 0;
-     if (lane == leader) base = atomicAdd(pend_cnt, (uint32_t)__popcll(pb));
-     base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-     if (live) {
-       cg[il] = FS_PENDING;
-       pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
-     }
-   }
+    const uint64_t il = i0 + threadIdx.x;
+    bool live = il < total;
+    // 1. (no OOV anywhere, at most one slot may differ) a window none of whose n one-slot-
+    //    wildcard keys is a script window's key has no neighbour within the threshold
+    if (L.wild && live) {
+      const uint64_t p = cpos[il];
+      bool pass = true;
+      if (p + L.n <= c.n_tok) {
+        uint32_t term[NW], fold;
+        pass = sift_keys<NW>(c, L, p, term, &fold, true);
+      }
+      if (!pass) { cg[il] = FS_NONE; live = false; }
+    }
+    // the survivors onto the queue (a slot per wave's worth of them)
+    {
+      const uint64_t sb = __ballot(live);
+      uint32_t base = 0;
+      if (sb) {
+        const int leader = __ffsll((unsigned long long)sb) - 1;
+        if (lane == leader) base = atomicAdd(&s_qn, (uint32_t)__popcll(sb));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
+        if (live)
+          s_q[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)il;
+      }
+    }
+    __syncthreads();
+    // stage 2 once 256 are queued (the queue holds at most 255 + 256), all of them at the end
+    const bool last = i0 + (uint64_t)gridDim.x * 256 >= total;
+    uint32_t qn = s_qn;
+    while (qn >= 256 || (last && qn > 0)) {
+      const uint32_t take = qn < 256 ? qn : 256u;
+      const uint32_t mine = threadIdx.x < take ? s_q[qn - take + threadIdx.x] : FS_NONE;
+      __syncthreads();
+      if (threadIdx.x == 0) s_qn = qn - take;
+      stage2(mine);
+      __syncthreads();
+      qn = s_qn;
+    }
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
