@@ -278,13 +278,16 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     cs = ix.corpus(toks[0], offs[0], schars, scoff, tok_str=tok_str)
     rows, st = ix.search(cs)
     cap = len(rows) + 64
-    bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(3)]
-    reps, tickets = 30, []
+    n_fl = max(2, int(os.environ.get("FS_LANES", "1")))          # searches in flight, as in the timed region
+    bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(n_fl + 1)]
+    reps, tickets = 48, []
+    for i in range(8):                                           # (primed pipeline)
+        ix.search_end(ix.search_begin(cs, bufs[0].data_ptr(), cap, header=True))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(reps):
-        tickets.append(ix.search_begin(cs, bufs[i % 3].data_ptr(), cap, header=True))
-        if len(tickets) >= 2:
+        tickets.append(ix.search_begin(cs, bufs[i % len(bufs)].data_ptr(), cap, header=True))
+        if len(tickets) >= n_fl:
             ix.search_end(tickets.pop(0))
     while tickets:
         ix.search_end(tickets.pop(0))
@@ -294,7 +297,7 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
                       "rows_per_step": int(len(rows)), "kernel": ix.kernel_name(cs),
                       "note": "8 % of the fan tokens capitalised: string ids next to vector ids; a hit "
                               "whose tokens are not all written as their vector row's word takes its "
-                              "Levenshtein distances inside the same kernel (`kernel`), two searches in flight"}
+                              "Levenshtein distances inside the same kernel (`kernel`), as many searches in flight as the timed region keeps"}
     cs.close()
     # (4) the LSH pipeline on a table with near-synonyms (c_max ~ 1: the exact-n-gram proof
     # fails, every real embedding table is of this kind)
