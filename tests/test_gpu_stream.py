@@ -111,3 +111,57 @@ def test_update_of_a_corpus_with_a_search_in_flight_is_refused(synth_base):
     want2, _ = oi.search(tok2, off2, synth_base["chars"], synth_base["off"])
     util.assert_rows_equal(got2, want2)
     ix.close()
+
+
+@pytest.mark.timeout(1500)
+def test_configs4_at_full_size(synth_base):
+    """BASELINE.json configs[4] in full: 1 000 000 works x 1 000 tokens (4 GB of ids) streamed
+    from pinned host memory in ten batches through two device corpora.  Too large for the
+    oracle: the records are checked through size-independent properties (one record per
+    word, ascending, the matched script word carries the fan word's vector id, the window
+    count), two of the ten batches against the numpy n-gram join, and the first batch's
+    first 300 works against the oracle."""
+    from fandom_search_amd.engine import PinnedBuffer, ScriptIndex, search_stream
+    from tests.test_gpu_fullsize import _check_rows, _covered_words
+    conf = synth.CONFIGS["c5"]
+    n_works, tpw, n_batches, n = conf["n_works"], conf["tokens_per_work"], 10, 6
+    per = n_works // n_batches
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(conf["script_tokens"])
+    normals = synth.lsh_normals(n)
+    ix = ScriptIndex(script, [words[int(t)] for t in script], emb, normals, cfg=abi.make_config())
+    stage_tok = [PinnedBuffer(per * tpw, np.uint32) for _ in range(2)]
+    stage_off = [PinnedBuffer(per + 1, np.uint64) for _ in range(2)]
+    off = np.arange(per + 1, dtype=np.uint64) * np.uint64(tpw)
+    kept = {}
+
+    def batches():
+        for b in range(n_batches):
+            tok, _ = synth.corpus_tokens_parallel(per, tpw, script, first_work=b * per)
+            if b in (0, 7):
+                kept[b] = tok.copy()
+            stage_tok[b & 1].array[:] = tok
+            stage_off[b & 1].array[:] = off
+            yield stage_tok[b & 1].array, stage_off[b & 1].array
+
+    total_rows, windows = 0, 0
+    for b, (rows, st) in enumerate(search_stream(ix, batches(), synth_base["chars"], synth_base["off"])):
+        assert st.path == abi.FS_MODE_EXACT and st.scan_launches == 1
+        assert st.windows_processed == per * (tpw - n + 1)
+        windows += st.windows_processed
+        total_rows += len(rows)
+        pos = off[rows["work"]].astype(np.int64) + rows["fan_ix"].astype(np.int64)
+        assert np.all(np.diff(pos) > 0)                       # one record per word, ascending
+        assert np.all(rows["lev"] == n + 1) and np.all(np.abs(rows["dist"]) < 1e-15)
+        if b in kept:
+            got_pos = _check_rows(rows, kept[b], off, script, n)
+            want_pos, _ = _covered_words(kept[b], off, script, n)
+            assert np.array_equal(got_pos, want_pos)          # completeness, no extras
+        if b == 0:
+            oi = util.oracle_index(abi.make_config(), script, words, emb, normals)
+            want, _ = oi.search(kept[0][:300 * tpw], off[:301], synth_base["chars"], synth_base["off"])
+            util.assert_rows_equal(rows[rows["work"] < 300], want)
+    assert windows == n_works * (tpw - n + 1) == 995_000_000
+    assert total_rows > 10_000_000
+    for pb in stage_tok + stage_off:
+        pb.close()
