@@ -223,6 +223,7 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     from fandom_search_amd import abi, synth, vocab
     from fandom_search_amd.engine import PinnedBuffer, ScriptIndex, search_stream
     out = {}
+    ix.set_scan_timing(1 << 20)       # (no timing events on the companions' launches)
     # (1) records copied to the host after every search (FS_ROWS_HOST, synchronous)
     reps = 10
     ix.search(corpora[0], reuse=True)
@@ -381,7 +382,7 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
         while tickets:
             ix.search_end(tickets.pop(0))
 
-    ix.set_scan_timing(0)
+    ix.set_scan_timing(1 << 20)                   # (no events on these launches: an event record costs stream time)
     run(shards)
     samples = []
     per_region = 6                                # passes per timed region (one pass = the whole corpus)
