@@ -1182,7 +1182,10 @@ __global__ __launch_bounds__(256, 4) void k_lsh_gramtab(CorpusDev c, LshDev L, G
   }
 }
 
-__global__ __launch_bounds__(256, 4) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
+// (five waves per SIMD: 94 registers with two spilt; 97 at four.  A wave per window and about ten
+// levels of dependent loads: the windows in flight are what counts -- n = 10: 0.268 -> 0.249 ms per
+// C2 batch; six waves, 80 registers, eight spilt, measured slower again)
+__global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
                                                     const uint32_t* __restrict__ cpos, NSrc nc,
                                                     uint32_t* __restrict__ cg,
                                                     uint32_t* __restrict__ cw,
