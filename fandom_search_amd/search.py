@@ -309,12 +309,39 @@ class TokenPool(object):
             import sys
             print("warning: a tokeniser process was lost; tokenising in the parent from here on",
                   file=sys.stderr)
-            self.close()
+            self._abandon()
             return False
         return True
 
+    def _abandon(self):
+        """Give a pool up that has lost a worker: Pool.terminate() can wait for ever for a
+        queue lock the dead worker held, so the remaining workers are killed and the pool's
+        own finaliser is cancelled (its helper threads are daemons)."""
+        pool, self.pool = self.pool, None
+        self.pending.clear()
+        if pool is None:
+            return
+        try:
+            pool._terminate.cancel()
+            # (its maintenance thread stops forking replacements: it looks at its own state)
+            pool._state = "TERMINATE"
+            pool._worker_handler._state = "TERMINATE"
+            pool._change_notifier.put(None)
+        except Exception:
+            pass
+        import time
+        time.sleep(0.05)                       # (the thread has seen its state before the workers go)
+        for p in list(pool._pool):
+            try:
+                p.kill()
+            except Exception:
+                pass
+
     def close(self):
         if self.pool is not None:
+            if any(not p.is_alive() for p in self.pool._pool):
+                self._abandon()
+                return
             self.pool.terminate()
             self.pool.join()
             self.pool = None

@@ -232,3 +232,39 @@ def test_batch_csv_from_a_pool_worker_equals_the_inline_form(tmp_path, monkeypat
         forked = tmp_path / "forked.csv"
         assert pool.apply(search._write_batch, (str(spath), str(forked), filenames, rows.tobytes(), fan_words)) == n
     assert inline.read_bytes() == direct.read_bytes() == forked.read_bytes() and inline.stat().st_size > 0
+
+
+def test_token_pool_survives_a_lost_worker_and_drops_stale_jobs(tmp_path):
+    """a tokeniser process that dies must not be replaced by a fork of the (by then
+    GPU-holding) parent: the pool is shut down and the text work done inline; jobs queued for a
+    list nobody asks for are dropped.  The results are the same either way."""
+    import os
+    import signal
+    import time
+    from fandom_search_amd import search
+    files = []
+    for i in range(6):
+        p = tmp_path / ("w%d.txt" % i)
+        p.write_text(" ".join("tok%d" % ((i * 7 + j) % 11) for j in range(40 + i)))
+        files.append(str(p))
+    want = [search.tokenize_files(files[:3])]
+    pool = search.TokenPool(2)
+    try:
+        pool.start(files[:3])
+        got = pool.get(files[:3])
+        assert len(got) == 1 or sum(len(g[0]) for g in got) == 3
+        assert np.concatenate([g[1] for g in got]).tolist() == want[0][1].tolist()
+        # stale jobs: three lists queued, the first never asked for
+        pool.start(files[3:4]); pool.start(files[4:5]); pool.start(files[5:6])
+        pool.get(files[5:6])
+        assert len(pool.pending) <= 2
+        # a worker dies: the next get() notices, closes the pool and works inline
+        os.kill(pool.pool._pool[0].pid, signal.SIGKILL)
+        time.sleep(0.3)
+        pool.start(files[:3])
+        got = pool.get(files[:3])
+        assert pool.pool is None
+        assert np.concatenate([g[1] for g in got]).tolist() == want[0][1].tolist()
+        assert pool.get(files[3:5])[0][0].tolist() == search.tokenize_files(files[3:5])[0].tolist()
+    finally:
+        pool.close()
