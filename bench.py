@@ -594,7 +594,11 @@ def main():
             step(it)
             it += 1
         drain()
+        if trace is not None:
+            trace.append(("drain", 0, time.perf_counter(), 0.0))
         torch.cuda.synchronize()
+        if trace is not None:
+            trace.append(("sync", 0, time.perf_counter(), 0.0))
         if world > 1:
             dist.barrier()
         samples.append(time.perf_counter() - t0)

@@ -174,6 +174,7 @@ struct fs_switches {
   double lsh_f32_slack = 1.0;     // FS_LSH_F32_SLACK: factor on the float32 key bound (tests force the fallback)
   bool lsh_f32 = true;            // FS_LSH_F32=0: float64 keys only
   int lsh_diag = 0;               // FS_LSH_DIAG
+  bool end_query = true;          // FS_END_QUERY=0: fs_search_corpus_end does not poll its lane's stream
   bool lsh_no_gtab = false;       // FS_LSH_NO_GTAB
   bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
   bool lsh_prefilter = true;      // FS_LSH_PREFILTER=0: always the full key scan
@@ -269,6 +270,7 @@ struct fs_index {
     DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup, then four statistics granules each
     DBuf<uint4> w_rinfo, w_csum;   // k_compact: {records, hits, pairs, candidates} per range / per workgroup
     uint32_t sync_epoch = 0;
+    uint64_t enqueued = 0;         // searches put on this lane so far
     DBuf<fs_best> w_cbest;
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)
     DBuf<fs_row> w_rows;
@@ -286,6 +288,7 @@ struct fs_index {
     hipEvent_t ev_begin = nullptr, ev_scan0 = nullptr, ev_scan1 = nullptr, ev_end = nullptr;
     fs_status* h_status = nullptr;    // pinned
     bool busy = false;
+    uint64_t lane_seq = 0;            // Lane::enqueued when this search went in
     fs_corpus* c = nullptr;
     fs_row* rows = nullptr;
     uint64_t cap = 0, ccap = 0, rcap = 0;

@@ -77,7 +77,7 @@ def main():
         rows, st = ix.search(corpus)
         setups.append(dict(name=v, ix=ix, corpus=corpus, corpora=corpora, bufs=bufs, cap=cap, n_rows=len(rows),
                            crc=hash(rows.tobytes()), ms=[], scan=[]))
-    if not any("FS_DIAG" in s["name"] for s in setups):
+    if not any("DIAG" in s["name"] for s in setups):
         assert len({s["crc"] for s in setups}) == 1, "variants disagree on the rows"
 
     def run(s, steps):
