@@ -118,6 +118,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);
   if (const char* e = getenv("FS_LSH_F32")) sw->lsh_f32 = e[0] != '0';
   sw->lsh_diag = num("FS_LSH_DIAG");
+  sw->scan_near8 = !getenv("FS_SCAN_NEAR8") || num("FS_SCAN_NEAR8") != 0;
   sw->end_query = !getenv("FS_END_QUERY") || num("FS_END_QUERY") != 0;
   sw->lsh_no_gtab = getenv("FS_LSH_NO_GTAB") != nullptr;
   sw->lsh_serial = getenv("FS_LSH_SERIAL") != nullptr;
@@ -533,7 +534,7 @@ extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   const int n = (int)ix->cfg.window_size;
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   if (!exact) {
-    snprintf(name, sizeof name, fs_lsh_prefilter_ok(ix, c) ? "k_scan_near<%d>" : "k_lsh_scan", n);
+    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? "k_lsh_scan" : fs_scan_near8(ix) ? "k_scan_near8<%d>" : "k_scan_near<%d>", n);
   } else if (uint32_t blocks = 0; fs_scan_rows_shape(ix, c, &blocks)) {
     const int k = ix->sw.scan_sub && ix->d_sfilter.p ? fs_sub_k(n) : 0;
     snprintf(name, sizeof name, "k_scan_rows<%d,%d>", n, k);
@@ -887,11 +888,13 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   } else {
     // tables whose proof fails by one slot only: the integer prefilter flags the windows
     // that can have a neighbour at all, the LSH work runs on those
+    fs_scan_extra ex;
+    ex.bsum = ln.w_bsum.p; ex.zero = ln.d_status.p;
     if (fs_lsh_prefilter_ok(ix, c))
-      FS_TRY(fs_launch_scan_near(ix, c, ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+      FS_TRY(fs_launch_scan_near(ix, c, ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
     else
       FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
-    FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, 4, s));
+    FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, sl.tpl, s, ex.counted));
     FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
     FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, 0, sl.h_status, s, count_out));
   }
@@ -944,7 +947,9 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
   sl.exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   static const bool host8 = !getenv("FS_HOST_WIRE8") || atoi(getenv("FS_HOST_WIRE8")) != 0;
   sl.host_wire8 = rows_mode == FS_ROWS_HOST && sl.exact && ix->n_script < (1ull << 18) && host8;
-  sl.tpl = sl.exact ? fs_scan_tpl(ix, T) : 4;
+  // (bitmap layout of the chained kernels: the LSH pipeline's scans write four tokens per lane,
+  // k_scan_near8 eight)
+  sl.tpl = sl.exact ? fs_scan_tpl(ix, T) : (fs_scan_near8(ix) && fs_lsh_prefilter_ok(ix, c)) ? 8 : 4;
   sl.n_bm = (uint32_t)((T + 64 * sl.tpl - 1) / (64 * sl.tpl));
   if (rows_mode == FS_ROWS_DEVICE_PACKED8 && (!sl.exact || ix->n_script >= (1ull << 18))) {
     fs_set_error("8-byte rows exist for the exact n-gram pipeline and scripts below 2^18 tokens");

@@ -174,6 +174,7 @@ struct fs_switches {
   double lsh_f32_slack = 1.0;     // FS_LSH_F32_SLACK: factor on the float32 key bound (tests force the fallback)
   bool lsh_f32 = true;            // FS_LSH_F32=0: float64 keys only
   int lsh_diag = 0;               // FS_LSH_DIAG
+  bool scan_near8 = true;         // FS_SCAN_NEAR8=0: k_scan_near (four tokens per lane) also for n >= 7; read when the index is built
   bool end_query = true;          // FS_END_QUERY=0: fs_search_corpus_end does not poll its lane's stream
   bool lsh_no_gtab = false;       // FS_LSH_NO_GTAB
   bool lsh_serial = false;        // FS_LSH_SERIAL: neighbour lists on one lane (cross-check of the wave form)
@@ -238,6 +239,7 @@ struct fs_index {
   bool script_oov = false;   // the script holds out-of-vocabulary (3-hot) vectors
   int lsh_m_min = 0;         // fewer id-identical slots than this cannot reach the threshold
   DBuf<uint32_t> d_sfilter3; // one bit per script 3-gram: the <= 1 mismatch prefilter (fs_scan.hip)
+  bool near8 = false;        // ... in the form k_scan_near8 reads (fs_scan_near_bit)
   DBuf<uint32_t> d_wild;     // one-slot-wildcard keys of the script windows (fs_hash.h; k_lsh_verify)
   int log2_wild = 0;
   DBuf<uint32_t> d_wmap;     // the same keys as an exact map {key, first window of the n-gram + 1}
@@ -405,8 +407,13 @@ int fs_scan_near_k(int n);                                               // K of
 int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
 // fs_scan.hip: the integer prefilter of the LSH pipeline ("all but one slot identical")
 bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c);
+bool fs_scan_near8_wanted(const fs_index* ix);
+bool fs_scan_near8(const fs_index* ix);
+int fs_scan_near_log2(const fs_index* ix);
+void fs_scan_near_bit(const fs_index* ix, const uint32_t* t, uint32_t* word, uint32_t* bit);
 int fs_launch_scan_near(const fs_index* ix, const fs_corpus* c, uint64_t* qbm, uint32_t* qcnt,
-                        uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+                        uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                        fs_scan_extra* ex);
 int fs_launch_corpus_check(const uint32_t* tok, const uint32_t* str, uint32_t n_tok,
                            uint32_t* check, hipStream_t s);
 int fs_launch_histogram(const uint32_t* d_orig, const double* d_comb, const fs_row* d_rows,

@@ -1384,11 +1384,12 @@ static int fs_build_components(fs_index* ix) {
   // the two filters of the one-slot case, over the script's component ids
   std::vector<uint32_t> sc(st.size());
   for (size_t i = 0; i < st.size(); ++i) sc[i] = comp[st[i]];
-  std::vector<uint32_t> sub(1u << ix->log2_words, 0u);
+  std::vector<uint32_t> sub(1u << fs_scan_near_log2(ix), 0u);
   const int K = fs_scan_near_k(n);
   for (uint64_t i = 0; i + K <= sc.size(); ++i) {
-    const uint32_t h = fs_gram_hash(sc.data() + i, K);
-    sub[fs_bloom_word(h, ix->log2_words)] |= 1u << (h & 31);
+    uint32_t word, bit;
+    fs_scan_near_bit(ix, sc.data() + i, &word, &bit);
+    sub[word] |= 1u << bit;
   }
   FS_TRY(ix->d_sfilter3c.upload(sub.data(), sub.size(), ix->stream));
   std::vector<uint32_t> wild;
@@ -1419,6 +1420,7 @@ static int fs_build_components(fs_index* ix) {
 int fs_lsh_build(fs_index* ix) {
   if (ix->lsh_ready) return FS_OK;
   ix->lsh_m_min = lsh_m_min(ix);
+  ix->near8 = fs_scan_near8_wanted(ix);
   if ((int)ix->cfg.window_size - ix->lsh_m_min == 1 && !ix->script_oov && ix->cfg.window_size >= 4 &&
       ix->n_vec <= FS_MAX_EXACT_ID) {
     // a neighbour differs from the window in at most one slot: one bit per script 3-gram
@@ -1427,10 +1429,11 @@ int fs_lsh_build(fs_index* ix) {
     FS_HIP(hipMemcpyAsync(st.data(), ix->d_stok.p, ix->n_script * sizeof(uint32_t), hipMemcpyDeviceToHost,
                           ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
-    std::vector<uint32_t> sub(1u << ix->log2_words, 0u);
+    std::vector<uint32_t> sub(1u << fs_scan_near_log2(ix), 0u);
     for (uint64_t i = 0; i + 3 <= ix->n_script; ++i) {
-      const uint32_t h = fs_gram_hash(st.data() + i, 3);
-      sub[fs_bloom_word(h, ix->log2_words)] |= 1u << (h & 31);
+      uint32_t word, bit;
+      fs_scan_near_bit(ix, st.data() + i, &word, &bit);
+      sub[word] |= 1u << bit;
     }
     FS_TRY(ix->d_sfilter3.upload(sub.data(), sub.size(), ix->stream));
     // ... and the n one-slot-wildcard keys of every script window, about 24 filter bits

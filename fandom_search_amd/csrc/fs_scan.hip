@@ -444,6 +444,129 @@ __global__ __launch_bounds__(1024) void k_scan8(const uint32_t* __restrict__ tok
   }
 }
 
+// ---- the integer prefilter, eight tokens per lane (n >= 7) ---------------------------
+// k_scan_near's rule in k_scan8's shape: lane L owns tokens [8L, 8L+8) of a 512-token sub-tile,
+// the n - 1 tokens behind them come from the next lane (and the one after it, n > 9) through
+// two DPP wave shifts instead of shuffles through the LDS crossbar, the 3-gram hash is the
+// polynomial one of fs_hash.h (one instruction per position), and the rule "every failed
+// test within three consecutive positions" is worked out for the lane's eight windows at once:
+// with R = T - 3 tests that must hold, window j passes iff for some a in 0..R its first a tests
+// and its last R - a tests hold -- runs of set bits, R - 1 shift-ands, and one and-or per a.
+// Bitmap and counts as k_scan8 writes them (64 bytes per sub-tile, chunk sums for k_expand).
+constexpr int kNearK = 3;
+template <int N, bool TAIL>
+__device__ __forceinline__ uint32_t window_flags_near8(const uint32_t* m, uint32_t mask_words,
+                                                       uint32_t p0, uint32_t n_tok) {
+  constexpr int K = kNearK, S = fs_sub_shift(K);
+  constexpr int NB = 8 + N - K;                 // 3-gram positions of the lane
+  constexpr int T = N - K + 1, R = T - K;       // tests per window, tests that must hold
+  static_assert(NB <= 32 && R >= 1, "window size");
+  uint32_t x[NB], w[NB];
+  x[0] = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) x[0] = (x[0] << S) + m[k];
+#pragma unroll
+  for (int j = 1; j < NB; ++j) x[j] = (x[j - 1] << S) + m[j - 1 + K];
+  // (the filter sits at LDS address 0: the kernel has no static LDS)
+  typedef const __attribute__((address_space(3))) uint32_t lds_word;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = fs_sub_word_offset(x[j], mask_words);
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = *reinterpret_cast<lds_word*>((uintptr_t)w[j]);
+  asm volatile("" : "+v"(w[0]), "+v"(w[NB - 1]));
+#pragma unroll
+  for (int j = 0; j < NB; ++j) w[j] = fs_shr_by_byte1(w[j], x[j]);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int j = 0; j < NB; ++j) bits = __builtin_amdgcn_alignbit(w[j], bits, 1);
+  bits >>= 32 - NB;                             // 3-gram j at bit j
+  uint32_t run[R + 1];                          // run[r]: bit i = tests i .. i + r - 1 hold
+  run[0] = 0xFFFFFFFFu;
+  run[1] = bits;
+#pragma unroll
+  for (int r = 2; r <= R; ++r) run[r] = run[r - 1] & (bits >> (r - 1));
+  uint32_t flags = 0;
+#pragma unroll
+  for (int a = 0; a <= R; ++a) flags |= run[a] & (run[R - a] >> (a + K));
+  flags &= 0xFFu;
+  if (TAIL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if ((uint64_t)p0 + j + N > n_tok) flags &= ~(1u << j);
+  }
+  return flags;
+}
+
+template <int N>
+__global__ __launch_bounds__(1024) void k_scan_near8(const uint32_t* __restrict__ tok, uint32_t n_tok,
+                                                     const uint32_t* __restrict__ filter,
+                                                     int log2_words, uint64_t* __restrict__ qbm,
+                                                     uint32_t* __restrict__ qcnt, uint32_t n_sub,
+                                                     uint32_t chunk, uint32_t* __restrict__ bsum,
+                                                     fs_status* __restrict__ zero) {
+  static_assert(N >= 7 && N <= 16, "halo of at most two lanes");
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
+  uint32_t* s_csum = s_filter + (1u << log2_words);           // [kChunksPerBlock]
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
+    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->max_rows = 0;
+    zero->lsh_pending = 0;
+  }
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t kc = wave >> 2, q = wave & 3;                 // chunk of the workgroup, quarter
+  const uint32_t per = (chunk + 3) >> 2;                       // sub-tiles per wave range
+  const uint64_t chunk_first = ((uint64_t)blockIdx.x * kChunksPerBlock + kc) * chunk;
+  uint32_t j0 = q * per, j1 = j0 + per;
+  if (j1 > chunk) j1 = chunk;
+  if (j0 > j1) j0 = j1;
+  if (chunk_first + j1 > n_sub) j1 = chunk_first + j0 < n_sub ? (uint32_t)(n_sub - chunk_first) : j0;
+  if ((uint64_t)blockIdx.x * kChunksPerBlock * chunk >= n_sub) {   // nothing to scan: empty chunks
+    if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = 0;
+    return;
+  }
+  if (threadIdx.x < kChunksPerBlock) s_csum[threadIdx.x] = 0;
+  copy_filter_to_lds(filter, s_filter, log2_words);
+  __syncthreads();
+  constexpr int HALO = N - 1;
+  constexpr int H1 = HALO < 8 ? HALO : 8, H2 = HALO - H1;     // from the next lane, from the one after
+  uint32_t mask_words = ((1u << log2_words) - 1u) << 2;
+  asm volatile("" : "+v"(mask_words));          // keep the SDWA operand in a register
+  uint8_t* bm_bytes = reinterpret_cast<uint8_t*>(qbm);
+  uint32_t cand_run = 0;
+  for (uint32_t j = j0; j < j1; ++j) {
+    const uint32_t sub = (uint32_t)chunk_first + j;
+    const uint32_t base = sub * 512u;
+    const uint4* p = reinterpret_cast<const uint4*>(tok + base + 8 * lane);
+    const uint4 a0 = p[0], a1 = p[1];
+    // the first tokens of the next sub-tile, for the last two lanes (the buffer is padded)
+    const uint4* nx = reinterpret_cast<const uint4*>(tok + base + 512);
+    const uint4 n0 = nx[0], n1 = nx[1], n2 = nx[2];
+    uint32_t m[8 + HALO];
+    m[0] = fs_premix(a0.x); m[1] = fs_premix(a0.y); m[2] = fs_premix(a0.z); m[3] = fs_premix(a0.w);
+    m[4] = fs_premix(a1.x); m[5] = fs_premix(a1.y); m[6] = fs_premix(a1.z); m[7] = fs_premix(a1.w);
+    const uint32_t nv[12] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+    // wave_shl:1 -- lane L takes lane L + 1's value, lane 63 keeps `old`
+#pragma unroll
+    for (int h = 0; h < H1; ++h)
+      m[8 + h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(nv[h]), (int)m[h], 0x130, 0xF, 0xF, false);
+#pragma unroll
+    for (int h = 0; h < H2; ++h)
+      m[16 + h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(nv[8 + h]), (int)m[8 + h], 0x130, 0xF, 0xF, false);
+    const uint32_t p0 = base + 8 * lane;
+    uint32_t flags;
+    if (base + 512u + HALO > n_tok) flags = window_flags_near8<N, true>(m, mask_words, p0, n_tok);
+    else flags = window_flags_near8<N, false>(m, mask_words, p0, n_tok);
+    bm_bytes[(size_t)sub * 64 + lane] = (uint8_t)flags;
+    const uint32_t cnt = fsdev::wave_sum_lane63(__popc(flags));
+    if (lane == 63) qcnt[sub] = cnt;
+    cand_run += (uint32_t)__builtin_amdgcn_readlane((int)cnt, 63);
+  }
+  if (lane == 0 && cand_run) atomicAdd(&s_csum[kc], cand_run);    // LDS
+  __syncthreads();
+  if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = s_csum[threadIdx.x];
+}
+
 // ---- scan and records in one kernel -------------------------------------------------
 // k_scan_rows: the scan loop of k_scan8 with the post-scan work of fs_ranges.hip inside
 // the same wave.  Tokens in, output records (staged per wave range) out; nothing else
@@ -1180,6 +1303,30 @@ int fs_lsh_prefilter_mode(const fs_index* ix, const fs_corpus* c) {
 }
 bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c) { return fs_lsh_prefilter_mode(ix, c) != 0; }
 int fs_scan_near_k(int n) { return fs_near_k(n); }
+// n >= 7: the eight-tokens-per-lane form (k_scan_near8: polynomial 3-gram hash, at most 2^14
+// filter words, k_scan8's bitmap); n = 6 keeps k_scan_near with its second filter
+// (decided when the filters are built, fs_lsh_build: the hash has to match)
+bool fs_scan_near8_wanted(const fs_index* ix) {
+  const int n = (int)ix->cfg.window_size;
+  return ix->sw.scan_near8 && n >= 7 && (n <= 10 || n == 12);
+}
+bool fs_scan_near8(const fs_index* ix) { return ix->near8; }
+int fs_scan_near_log2(const fs_index* ix) {
+  return fs_scan_near8(ix) ? std::min(ix->log2_words, FS_SUB_MAX_LOG2_WORDS) : ix->log2_words;
+}
+// bit of the 3-gram t[0..3) in the filter k_scan_near / k_scan_near8 hold in LDS
+void fs_scan_near_bit(const fs_index* ix, const uint32_t* t, uint32_t* word, uint32_t* bit) {
+  const int K = fs_near_k((int)ix->cfg.window_size);
+  if (fs_scan_near8(ix)) {
+    const uint32_t h = fs_sub_hash(t, K);
+    *word = fs_sub_word(h, fs_scan_near_log2(ix));
+    *bit = fs_sub_bit(h);
+  } else {
+    const uint32_t h = fs_gram_hash(t, K);
+    *word = fs_bloom_word(h, ix->log2_words);
+    *bit = h & 31;
+  }
+}
 
 namespace {
 template <int N>
@@ -1200,15 +1347,46 @@ int launch_scan_near(const fs_index* ix, const CorpusDev& c, const uint32_t* ids
   FS_HIP(hipGetLastError());
   return FS_OK;
 }
+
+template <int N>
+int launch_scan_near8(const fs_index* ix, const CorpusDev& c, const uint32_t* ids, const uint32_t* filter,
+                      uint64_t* qbm, uint32_t* qcnt, uint32_t n_sub, hipStream_t s, hipEvent_t e0,
+                      hipEvent_t e1, fs_scan_extra* ex) {
+  const int lw = fs_scan_near_log2(ix);
+  const size_t lds = ((size_t)4 << lw) + 16 * sizeof(uint32_t);
+  // the chained kernels' chunking (chunk_of_block): kNB chunks of `chunk` sub-tiles
+  const uint32_t chunk = std::max<uint32_t>(1, (n_sub + fsdev::kNB - 1) / fsdev::kNB);
+  auto kern = k_scan_near8<N>;
+  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
+  hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, ids, c.n_tok,
+                        filter, lw, qbm, qcnt, n_sub, chunk, ex->bsum, ex->zero);
+  FS_HIP(hipGetLastError());
+  ex->counted = true;
+  return FS_OK;
+}
 }  // namespace
 
+// ex: chunk sums and status block for the eight-tokens-per-lane form (ex->counted on return:
+// k_expand needs no k_reduce in front)
 int fs_launch_scan_near(const fs_index* ix, const fs_corpus* fc, uint64_t* qbm, uint32_t* qcnt,
-                        uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+                        uint32_t n_bm_words, hipStream_t s, hipEvent_t e0, hipEvent_t e1,
+                        fs_scan_extra* ex) {
   const CorpusDev c = fc->dev();
   const bool comp = fs_lsh_prefilter_mode(ix, fc) == 2;
   const uint32_t* ids = comp ? (const uint32_t*)fc->d_ctok.p : c.tok;
   const uint32_t* filter = comp ? (const uint32_t*)ix->d_sfilter3c.p : (const uint32_t*)ix->d_sfilter3.p;
   const uint32_t* keys6 = comp && ix->sw.lsh_keys6 ? (const uint32_t*)ix->d_keys6c.p : (const uint32_t*)nullptr;
+  ex->counted = false;
+  if (fs_scan_near8(ix)) {
+    switch (ix->cfg.window_size) {
+      case 7: return launch_scan_near8<7>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
+      case 8: return launch_scan_near8<8>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
+      case 9: return launch_scan_near8<9>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
+      case 10: return launch_scan_near8<10>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
+      case 12: return launch_scan_near8<12>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
+      default: break;
+    }
+  }
   switch (ix->cfg.window_size) {
     case 6: return launch_scan_near<6>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);
     case 7: return launch_scan_near<7>(ix, c, ids, filter, keys6, qbm, qcnt, n_bm_words, s, e0, e1);

@@ -83,7 +83,7 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
     ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
                        synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL
-    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near<%d>" % n
+    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near8<%d>" % n
     # (what k_lsh_sift leaves to the wave-per-window kernel: the windows one slot away from a
     # script n-gram that may be within the threshold, a small share of the candidates)
     assert 0 < st.lsh_pending < st.candidates
@@ -100,9 +100,10 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
     # wildcard-key filter in front of k_lsh_verify, with every Levenshtein distance
     # computed per match, without the per-n-gram records, without the exact one-slot map: the
     # same bytes
-    for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near<%d>" % n),
-                        ("FS_LSH_SELFLEV", "k_scan_near<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near<%d>" % n),
-                        ("FS_LSH_WMAP", "k_scan_near<%d>" % n)):
+    # ... and with the four-tokens-per-lane form of the prefilter scan (its own 3-gram hash)
+    for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near8<%d>" % n),
+                        ("FS_LSH_SELFLEV", "k_scan_near8<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near8<%d>" % n),
+                        ("FS_LSH_WMAP", "k_scan_near8<%d>" % n), ("FS_SCAN_NEAR8", "k_scan_near<%d>" % n)):
         monkeypatch.setenv(env, "0")
         full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
         c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
