@@ -47,6 +47,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <vector>
 
 using namespace fsdev;
@@ -993,7 +994,11 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
   }
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
-  if (threadIdx.x == 0) bmatch[blockIdx.x] = tot;
+  if (threadIdx.x == 0) {
+    bmatch[blockIdx.x] = tot;
+    // (the sums are read kNB at a time: the workgroups that were not launched have none)
+    for (uint32_t b = blockIdx.x + gridDim.x; b < (uint32_t)kNB; b += gridDim.x) bmatch[b] = 0;
+  }
 }
 
 // The LDS a wave needs for one window (private to the wave).
@@ -1672,11 +1677,32 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   FS_TRY(ix->cur->w_pend.reserve(ccap));
   auto sift = L.n <= 8 ? (L.wmap ? k_lsh_sift<8, true> : k_lsh_sift<8, false>)
                        : (L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true> : k_lsh_sift<FS_MAX_WINDOW, false>);
-  hipLaunchKernelGGL(sift, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+  // one resident set of workgroups each (both kernels loop over their work and are bound by the
+  // latency of dependent loads: a second, partial round of workgroups costs a whole round's time)
+  auto resident = [&](const void* kern) {
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> seen;      // workgroups per CU, asked once per kernel
+    int per_cu = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      for (const auto& e : seen)
+        if (e.first == kern) per_cu = e.second;
+      if (!per_cu) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess || per_cu < 1)
+          per_cu = -1;
+        seen.push_back({kern, per_cu});
+      }
+    }
+    return per_cu < 1 ? (uint32_t)kNB : std::min<uint32_t>(kNB, ix->num_cu * (uint32_t)per_cu);
+  };
+  static const bool full_grid = getenv("FS_LSH_FULL_GRID") && atoi(getenv("FS_LSH_FULL_GRID")) != 0;
+  const uint32_t sift_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(sift));
+  const uint32_t verify_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(k_lsh_verify));
+  hipLaunchKernelGGL(sift, dim3(sift_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p,
                      ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, tab_best, tab_cnt, ix->cur->w_pend.p,
                      &st->lsh_pending);
-  hipLaunchKernelGGL(k_lsh_verify, dim3(kNB), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+  hipLaunchKernelGGL(k_lsh_verify, dim3(verify_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
                      ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p);
   FS_HIP(hipGetLastError());
