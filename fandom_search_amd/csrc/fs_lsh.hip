@@ -860,7 +860,7 @@ __device__ __forceinline__ bool sift_keys(const CorpusDev& c, const LshDev& L, u
 // had a survivor to wait for.  So the survivors queue up in LDS and stage 2 takes them 256 at
 // a time, a full lane each (round 4: 90 -> 40 us per C2 batch at n = 8).
 template <int NW, bool WMAP>
-__global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramIndexDev g,
+__global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, GramIndexDev g,
                                                   const uint32_t* __restrict__ cpos, NSrc nc,
                                                   uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
                                                   fs_best* __restrict__ cbest,
@@ -870,21 +870,25 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
                                                   uint32_t* __restrict__ pend,
                                                   uint32_t* __restrict__ pend_cnt) {
   __shared__ uint32_t s_w32[4];
-  __shared__ uint32_t s_q[512];          // survivors of stage 1 (candidate numbers)
-  __shared__ uint32_t s_qn;
+  __shared__ uint32_t s_q[1024];         // survivors of stage 1 (candidate numbers): at most 255 + 3 * 256
+  __shared__ uint32_t s_qn, s_pn, s_pbase;
   const uint32_t total = nc.get();
   const int lane = threadIdx.x & 63;
   uint32_t matches = 0;
-  if (threadIdx.x == 0) s_qn = 0;
+  if (L.diag & 8192) {                         // diagnostics: the launch by itself
+    if (threadIdx.x == 0) bmatch[blockIdx.x] = 0;
+    return;
+  }
+  if (threadIdx.x == 0) { s_qn = 0; s_pn = 0; }
   __syncthreads();
-  // stage 2 for one queued candidate (FS_NONE: none)
+  // stage 2 for one queued candidate (FS_NONE: none); every thread of the workgroup calls it
   auto stage2 = [&](uint32_t il) {
     bool live = il != FS_NONE;
     // 2. A window with the ids of a script n-gram (and the strings of those ids) takes the
     //    n-gram's record of this string table (k_lsh_gramtab): no bucket is walked for it.
     uint32_t gram = FS_NONE;
     const uint64_t p = live ? cpos[il] : 0;
-    if (tab_cnt && live) {
+    if (tab_cnt && live && !(L.diag & 128)) {
       uint32_t w = 0, kept = 0;
       gram = verify_window(c, g, p, &w, &kept);
       if (gram != FS_NONE) {
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
     //    nothing survives the threshold, and the window needs no LSH work.  One 32-byte bucket
     //    of the map per slot, all n requested together; a window with more than two such
     //    n-grams, or a full bucket in its way, is left to k_lsh_verify.
-    if (WMAP && live && L.wild && p + L.n <= c.n_tok) {
+    if (WMAP && live && L.wild && p + L.n <= c.n_tok && !(L.diag & 256)) {
       uint32_t term[NW], fold = 0;
       sift_keys<NW>(c, L, p, term, &fold, false);
       Ids16 f;
@@ -933,6 +937,7 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
           possible = possible || val[3] != 0;       // (filled in order: the bucket is full)
         }
       possible = possible || nh > 2;
+      if (L.diag & 512) possible = possible || nh > 0;                 // diagnostics: no distances here
       if (!possible && nh > 0) possible = one_slot_within<NW>(L, s0, k0, f);
       if (!possible && nh > 1) possible = one_slot_within<NW>(L, s1, k1, f);
       if (!possible) { cg[il] = FS_NONE; live = false; }
@@ -940,47 +945,117 @@ __global__ __launch_bounds__(256) void k_lsh_sift(CorpusDev c, LshDev L, GramInd
     // what is left: onto the list k_lsh_verify deals out window by window (pending windows
     // come in runs, the boundary windows of one quoted passage, so dealing out blocks of
     // candidates leaves a few waves with most of the work)
+    // (one addition to the list's counter per workgroup: five thousand waves adding to the one
+    // address took 5 ns each, a third of the kernel)
     const uint64_t pb = __ballot(live);
-    if (pb) {
-      const int leader = __ffsll((unsigned long long)pb) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(pend_cnt, (uint32_t)__popcll(pb));
-      base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-      if (live) {
-        cg[il] = FS_PENDING;
-        pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
-      }
+    uint32_t wbase = 0;
+    if (pb && lane == 0) wbase = atomicAdd(&s_pn, (uint32_t)__popcll(pb));      // LDS
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t n_p = s_pn;
+      s_pbase = n_p ? atomicAdd(pend_cnt, n_p) : 0u;
+      s_pn = 0;
+    }
+    __syncthreads();
+    if (live) {
+      const uint32_t base = s_pbase + (uint32_t)__builtin_amdgcn_readlane((int)wbase, 0);
+      cg[il] = FS_PENDING;
+      pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
     }
   };
-  for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < total; i0 += (uint64_t)gridDim.x * 256) {
-    const uint64_t il = i0 + threadIdx.x;
-    bool live = il < total;
+  // U candidates per lane and pass, their loads level by level: positions, ids, filter blocks
+  constexpr int U = NW <= 8 ? 3 : 2;
+  const uint64_t pass = (uint64_t)gridDim.x * 256;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < total; i0 += pass * U) {
+    uint64_t il[U], p[U];
+    bool live[U], probe[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      il[u] = i0 + (uint64_t)u * pass + threadIdx.x;
+      live[u] = il[u] < total;
+      p[u] = (L.wild && live[u]) ? cpos[il[u]] : 0;
+    }
     // 1. (no OOV anywhere, at most one slot may differ) a window none of whose n one-slot-
     //    wildcard keys is a script window's key has no neighbour within the threshold
-    if (L.wild && live) {
-      const uint64_t p = cpos[il];
-      bool pass = true;
-      if (p + L.n <= c.n_tok) {
-        uint32_t term[NW], fold;
-        pass = sift_keys<NW>(c, L, p, term, &fold, true);
+    if (L.wild) {
+      uint32_t kf[U][NW];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        probe[u] = live[u] && p[u] + L.n <= c.n_tok;
+        if (L.diag & 4096) { if (live[u]) cg[il[u]] = FS_NONE; live[u] = false; probe[u] = false; }   // diagnostics
+        // (the window start is only 4-byte aligned; the buffers are padded: fs_device.h, load_ids)
+        const uint4* src = reinterpret_cast<const uint4*>((L.wild_tok ? L.wild_tok : c.tok) + (probe[u] ? p[u] : 0));
+#pragma unroll
+        for (int q4 = 0; q4 < NW / 4; ++q4) {
+          uint4 t = make_uint4(0, 0, 0, 0);
+          if (q4 < 2 || L.n > 8) t = src[q4];
+          kf[u][4 * q4] = t.x; kf[u][4 * q4 + 1] = t.y; kf[u][4 * q4 + 2] = t.z; kf[u][4 * q4 + 3] = t.w;
+        }
       }
-      if (!pass) { cg[il] = FS_NONE; live = false; }
+      const uint4* wb = reinterpret_cast<const uint4*>(L.wild);
+      uint4 blk0[U], blk1[U], blk2[U];
+      uint32_t fold[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        uint32_t g0 = 0, g1 = 0, g2 = 0;
+        fold[u] = 0;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+          if (k < L.n) {
+            const uint32_t t = fs_rotl(fs_premix(kf[u][k]), fs_rot_of(L.n - 1 - k));
+            const int X = fs_wild_group(k, L.n);
+            fold[u] ^= t;
+            g0 ^= X == 0 ? t : 0u; g1 ^= X == 1 ? t : 0u; g2 ^= X == 2 ? t : 0u;
+          }
+        if (L.diag & 2048) { g0 = g1 = g2 = fold[u] ^ (uint32_t)threadIdx.x; }    // diagnostics: the same blocks for every wave
+        blk0[u] = wb[fs_wild_block(fold[u] ^ g0, 0, L.log2_wild)];
+        blk1[u] = wb[fs_wild_block(fold[u] ^ g1, 1, L.log2_wild)];
+        blk2[u] = wb[fs_wild_block(fold[u] ^ g2, 2, L.log2_wild)];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        bool pass1 = false;
+#pragma unroll
+        for (int k = 0; k < NW; ++k)
+          if (k < L.n) {
+            const uint32_t t = fs_rotl(fs_premix(kf[u][k]), fs_rot_of(L.n - 1 - k));
+            const uint32_t h = fs_wild_key(fold[u], t, k);
+            const int X = fs_wild_group(k, L.n);
+            uint4 q;
+            q.x = X == 0 ? blk0[u].x : X == 1 ? blk1[u].x : blk2[u].x;
+            q.y = X == 0 ? blk0[u].y : X == 1 ? blk1[u].y : blk2[u].y;
+            q.z = X == 0 ? blk0[u].z : X == 1 ? blk1[u].z : blk2[u].z;
+            q.w = X == 0 ? blk0[u].w : X == 1 ? blk1[u].w : blk2[u].w;
+            bool all = true;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t bit = fs_wild_bit(h, i);
+              const uint32_t wsel = bit >> 5;
+              const uint32_t word = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
+              all = all && ((word >> (bit & 31)) & 1u);
+            }
+            pass1 = pass1 || all;
+          }
+        if (L.diag & 1024) pass1 = false;                                          // diagnostics: nothing survives
+        if (probe[u] && !pass1) { cg[il[u]] = FS_NONE; live[u] = false; }
+      }
     }
     // the survivors onto the queue (a slot per wave's worth of them)
-    {
-      const uint64_t sb = __ballot(live);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint64_t sb = __ballot(live[u]);
       uint32_t base = 0;
       if (sb) {
         const int leader = __ffsll((unsigned long long)sb) - 1;
         if (lane == leader) base = atomicAdd(&s_qn, (uint32_t)__popcll(sb));
         base = (uint32_t)__builtin_amdgcn_readlane((int)base, leader);
-        if (live)
-          s_q[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)il;
+        if (live[u])
+          s_q[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u))] = (uint32_t)il[u];
       }
     }
     __syncthreads();
-    // stage 2 once 256 are queued (the queue holds at most 255 + 256), all of them at the end
-    const bool last = i0 + (uint64_t)gridDim.x * 256 >= total;
+    // stage 2 once 256 are queued, all of them at the end
+    const bool last = i0 + pass * U >= total;
     uint32_t qn = s_qn;
     while (qn >= 256 || (last && qn > 0)) {
       const uint32_t take = qn < 256 ? qn : 256u;
