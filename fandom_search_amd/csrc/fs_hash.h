@@ -43,6 +43,19 @@ FS_HD uint32_t fs_premix(uint32_t tok) {
 #endif
 }
 
+// full-rate mixing for filters whose hashes are made many at a time (k_lsh_sift)
+FS_HD uint32_t fs_mul24(uint32_t a, uint32_t m) {        // low 32 bits of (a mod 2^24) * m, m < 2^24
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __umul24(a, m);
+#else
+  return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * m);
+#endif
+}
+FS_HD uint32_t fs_mix24(uint32_t x) {
+  x ^= x >> 16;
+  return fs_mul24(x, 0x9E3779u) ^ fs_rotl(fs_mul24(x >> 8, 0x85EBCBu), 16);
+}
+
 // rotation applied to the token that is j places before the end of the window
 FS_HD int fs_rot_of(int j) { return (7 * j) & 31; }
 
@@ -134,12 +147,18 @@ FS_HD uint32_t fs_wild_key(uint32_t fold_all, uint32_t term_j, int j) {
 // key sets four of the block's 128 bits.
 FS_HD int fs_wild_group(int k, int n) { return 3 * k / n; }
 FS_HD uint32_t fs_wild_block(uint32_t fold_others, int group, int log2_blocks) {
-  uint32_t h = fold_others + 0x7F4A7C15u * (uint32_t)(group + 1);
-  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  const uint32_t h = fs_mix24(fold_others + 0x7F4A7C15u * (uint32_t)(group + 1));
   return h >> (32 - log2_blocks);
 }
-// (bit positions of key h inside its block: four 7-bit fields of the hash)
-FS_HD uint32_t fs_wild_bit(uint32_t h, int i) { return (h >> (7 * i)) & 127u; }
+// The filter's own hash of a key (fs_wild_key is the exact map's): full-rate instructions only --
+// k_lsh_sift makes n of them per candidate and is bound by its VALU work -- and the four bits of a
+// key one to each dword of the block, at bits 0-4 of the hash's four bytes, so that a test is
+// four shifts with an SDWA byte select as the amount and two ands.  (A hash only selects: what
+// the filter lets through is decided exactly behind it.)
+FS_HD uint32_t fs_wild_fkey(uint32_t fold_all, uint32_t term_j, int j) {
+  return fs_mix24((fold_all ^ term_j) + 0x9E3779B9u * (uint32_t)(j + 1));
+}
+FS_HD uint32_t fs_wild_fbit(uint32_t h, int i) { return (h >> (8 * i)) & 31u; }   // its bit in dword i
 // n = 6 over component ids: the keys of the two middle slots (2 and 3) of every script window in a
 // filter of their own that k_scan_near holds in LDS (2^14 words, three bits per key as the
 // Bloom filter above)

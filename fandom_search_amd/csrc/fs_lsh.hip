@@ -837,18 +837,11 @@ __device__ __forceinline__ bool sift_keys(const CorpusDev& c, const LshDev& L, u
 #pragma unroll
   for (int k = 0; k < NW; ++k)
     if (k < L.n) {
-      const uint32_t h = fs_wild_key(fold, term[k], k);
+      const uint32_t h = fs_wild_fkey(fold, term[k], k);
       const int X = fs_wild_group(k, L.n);
       const uint4 q = X == 0 ? blk[0] : X == 1 ? blk[1] : blk[2];
-      bool all = true;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t bit = fs_wild_bit(h, i);
-        const uint32_t wsel = bit >> 5;
-        const uint32_t word = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
-        all = all && ((word >> (bit & 31)) & 1u);
-      }
-      pass = pass || all;
+      pass = pass || ((q.x >> fs_wild_fbit(h, 0)) & (q.y >> fs_wild_fbit(h, 1)) &
+                      (q.z >> fs_wild_fbit(h, 2)) & (q.w >> fs_wild_fbit(h, 3)) & 1u);
     }
   return pass;
 }
@@ -859,7 +852,22 @@ __device__ __forceinline__ bool sift_keys(const CorpusDev& c, const LshDev& L, u
 // five to eight more levels of dependent loads) ran at a tenth of the lanes while every wave
 // had a survivor to wait for.  So the survivors queue up in LDS and stage 2 takes them 256 at
 // a time, a full lane each (round 4: 90 -> 40 us per C2 batch at n = 8).
-template <int NW, bool WMAP>
+// word >> (bits 8B .. 8B+4 of h): the shift takes the low five bits of the selected byte
+template <int B>
+__device__ __forceinline__ uint32_t shr_by_byte(uint32_t word, uint32_t h) {
+  uint32_t r;
+  if constexpr (B == 0)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  else if constexpr (B == 1)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  else if constexpr (B == 2)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  else
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  return r;
+}
+
+template <int NW, bool WMAP, int NN>
 __global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, GramIndexDev g,
                                                   const uint32_t* __restrict__ cpos, NSrc nc,
                                                   uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
@@ -995,15 +1003,16 @@ __global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, Gram
       const uint4* wb = reinterpret_cast<const uint4*>(L.wild);
       uint4 blk0[U], blk1[U], blk2[U];
       uint32_t fold[U];
+      const int n = NN ? NN : L.n;              // (NN: the window size at compile time -- groups and rotations are constants then)
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         uint32_t g0 = 0, g1 = 0, g2 = 0;
         fold[u] = 0;
 #pragma unroll
         for (int k = 0; k < NW; ++k)
-          if (k < L.n) {
-            const uint32_t t = fs_rotl(fs_premix(kf[u][k]), fs_rot_of(L.n - 1 - k));
-            const int X = fs_wild_group(k, L.n);
+          if (k < n) {
+            const uint32_t t = fs_rotl(fs_premix(kf[u][k]), fs_rot_of(n - 1 - k));
+            const int X = fs_wild_group(k, n);
             fold[u] ^= t;
             g0 ^= X == 0 ? t : 0u; g1 ^= X == 1 ? t : 0u; g2 ^= X == 2 ? t : 0u;
           }
@@ -1014,28 +1023,21 @@ __global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, Gram
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        bool pass1 = false;
+        uint32_t any = 0;                       // bit 0: one of the keys is in the filter
 #pragma unroll
         for (int k = 0; k < NW; ++k)
-          if (k < L.n) {
-            const uint32_t t = fs_rotl(fs_premix(kf[u][k]), fs_rot_of(L.n - 1 - k));
-            const uint32_t h = fs_wild_key(fold[u], t, k);
-            const int X = fs_wild_group(k, L.n);
+          if (k < n) {
+            const uint32_t t = fs_rotl(fs_premix(kf[u][k]), fs_rot_of(n - 1 - k));
+            const uint32_t h = fs_wild_fkey(fold[u], t, k);
+            const int X = fs_wild_group(k, n);
             uint4 q;
             q.x = X == 0 ? blk0[u].x : X == 1 ? blk1[u].x : blk2[u].x;
             q.y = X == 0 ? blk0[u].y : X == 1 ? blk1[u].y : blk2[u].y;
             q.z = X == 0 ? blk0[u].z : X == 1 ? blk1[u].z : blk2[u].z;
             q.w = X == 0 ? blk0[u].w : X == 1 ? blk1[u].w : blk2[u].w;
-            bool all = true;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const uint32_t bit = fs_wild_bit(h, i);
-              const uint32_t wsel = bit >> 5;
-              const uint32_t word = wsel == 0 ? q.x : wsel == 1 ? q.y : wsel == 2 ? q.z : q.w;
-              all = all && ((word >> (bit & 31)) & 1u);
-            }
-            pass1 = pass1 || all;
+            any |= shr_by_byte<0>(q.x, h) & shr_by_byte<1>(q.y, h) & shr_by_byte<2>(q.z, h) & shr_by_byte<3>(q.w, h);
           }
+        bool pass1 = (any & 1u) != 0;
         if (L.diag & 1024) pass1 = false;                                          // diagnostics: nothing survives
         if (probe[u] && !pass1) { cg[il[u]] = FS_NONE; live[u] = false; }
       }
@@ -1377,10 +1379,10 @@ static int build_wild_filter(const std::vector<uint32_t>& st, uint64_t W, int n,
       gfold[fs_wild_group(k, n)] ^= term[k];
     }
     for (int k = 0; k < n; ++k) {
-      const uint32_t h = fs_wild_key(fold, term[k], k);
+      const uint32_t h = fs_wild_fkey(fold, term[k], k);
       const int X = fs_wild_group(k, n);
       uint32_t* blk = out->data() + 4 * (size_t)fs_wild_block(fold ^ gfold[X], X, lb);
-      for (int i = 0; i < 4; ++i) { const uint32_t bit = fs_wild_bit(h, i); blk[bit >> 5] |= 1u << (bit & 31); }
+      for (int i = 0; i < 4; ++i) blk[i] |= 1u << fs_wild_fbit(h, i);
     }
   }
   return lb;
@@ -1750,8 +1752,14 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
     tab_cnt = c->d_gramtab_cnt.p;
   }
   FS_TRY(ix->cur->w_pend.reserve(ccap));
-  auto sift = L.n <= 8 ? (L.wmap ? k_lsh_sift<8, true> : k_lsh_sift<8, false>)
-                       : (L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true> : k_lsh_sift<FS_MAX_WINDOW, false>);
+  auto sift = L.n <= 8 ? (L.wmap ? k_lsh_sift<8, true, 0> : k_lsh_sift<8, false, 0>)
+                       : (L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true, 0> : k_lsh_sift<FS_MAX_WINDOW, false, 0>);
+  switch (L.n) {            // the common window sizes with their size at compile time
+    case 6: sift = L.wmap ? k_lsh_sift<8, true, 6> : k_lsh_sift<8, false, 6>; break;
+    case 8: sift = L.wmap ? k_lsh_sift<8, true, 8> : k_lsh_sift<8, false, 8>; break;
+    case 10: sift = L.wmap ? k_lsh_sift<FS_MAX_WINDOW, true, 10> : k_lsh_sift<FS_MAX_WINDOW, false, 10>; break;
+    default: break;
+  }
   // one resident set of workgroups each (both kernels loop over their work and are bound by the
   // latency of dependent loads: a second, partial round of workgroups costs a whole round's time)
   auto resident = [&](const void* kern) {
