@@ -324,19 +324,25 @@ __device__ inline uint32_t lev_wave(const GramIndexDev& g, uint32_t s, const uin
   const uint64_t last = 1ull << (m - 1);
   uint64_t pv = ~0ull, mv = 0;
   uint32_t score = m;
-  for (uint32_t i = 0; i < t; ++i) {
-    const uint32_t c = txt[i];
-    const uint64_t eq = __ballot(pc == c);
-    const uint64_t xv = eq | mv;
-    const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
-    uint64_t ph = mv | ~(xh | pv);
-    uint64_t mh = pv & xh;
-    if (ph & last) ++score;
-    if (mh & last) --score;
-    ph = (ph << 1) | 1ull;
-    mh <<= 1;
-    pv = mh | ~(xv | ph);
-    mv = ph & xv;
+  // (the text 64 code points at a time in a register, a lane each, and read out lane by lane:
+  // an LDS read per column was most of a column's time)
+  for (uint32_t base = 0; base < t; base += 64) {
+    const uint32_t tv = base + (uint32_t)lane < t ? txt[base + lane] : 0u;
+    const uint32_t cnt = t - base < 64u ? t - base : 64u;
+    for (uint32_t i = 0; i < cnt; ++i) {
+      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)tv, (int)i);
+      const uint64_t eq = __ballot(pc == c);
+      const uint64_t xv = eq | mv;
+      const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
+      uint64_t ph = mv | ~(xh | pv);
+      uint64_t mh = pv & xh;
+      if (ph & last) ++score;
+      if (mh & last) --score;
+      ph = (ph << 1) | 1ull;
+      mh <<= 1;
+      pv = mh | ~(xv | ph);
+      mv = ph & xv;
+    }
   }
   return score;
 }
