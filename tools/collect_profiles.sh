@@ -119,6 +119,13 @@ if [ "$part" = part2 ]; then
   echo "== the same without the per-n-gram records and the one-slot map (round 2's k_lsh_verify work)"
   run ${R}_c4_ab.log tools/step_bench.py --window 8 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=4 FS_LSH_WMAP=0" "FS_LANES=4 FS_LSH_GRAMTAB=0 FS_LSH_WMAP=0"
   run ${R}_c4_n10_ab.log tools/step_bench.py --window 10 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=4 FS_LSH_WMAP=0" "FS_LANES=4 FS_LSH_GRAMTAB=0 FS_LSH_WMAP=0"
+  echo "== round 4, second half: the prefilter scan with four tokens per lane, kNB workgroups for k_lsh_sift / k_lsh_verify; one lane, kernel by kernel"
+  run ${R}_c4_near_ab.log tools/step_bench.py --window 8 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=4 FS_SCAN_NEAR8=0" "FS_LANES=1" "FS_LANES=1 FS_SCAN_NEAR8=0"
+  run ${R}_c4_n10_near_ab.log tools/step_bench.py --window 10 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=4 FS_SCAN_NEAR8=0" "FS_LANES=1" "FS_LANES=1 FS_SCAN_NEAR8=0"
+  FS_LSH_FULL_GRID=1 run ${R}_c4_fullgrid.log tools/step_bench.py --window 8 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=1"
+  FS_LSH_FULL_GRID=1 run ${R}_c4_n10_fullgrid.log tools/step_bench.py --window 10 --steps 100 --inflight 4 "FS_LANES=4" "FS_LANES=1"
+  prof_stats ${R}_c4_n8_lanes1 $ROOTDIR/tools/step_bench.py --window 8 --steps 60 --rounds 2 --inflight 1 "FS_LANES=1"
+  prof_stats ${R}_c4_n10_lanes1 $ROOTDIR/tools/step_bench.py --window 10 --steps 60 --rounds 2 --inflight 1 "FS_LANES=1"
   echo "== N = 2 rehearsal: bench.py --gpus 2 typed as is (both ranks on this GPU, gloo)"
   run ${R}_gloo2_rehearsal.json bench.py --gpus 2 --steps 30 --warmup 5 --backend gloo $B
   echo "== LSH pipeline on the synonym-rich table: 5000 works, kernel stats, SQ counters"
