@@ -114,6 +114,50 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
         monkeypatch.delenv(env)
 
 
+@pytest.mark.parametrize("n", [8, 9, 10, 12])
+def test_prefilter_scan_at_sub_tile_boundaries(synth_base, monkeypatch, n):
+    """k_scan_near8 takes a lane's halo from the next lane and the one after it, and the last
+    two lanes of a 512-token sub-tile from the next sub-tile: script spans (verbatim, and with one
+    token replaced by its nearest table vector) straddle the sub-tile boundaries in every
+    way, and one ends with the corpus' last token.  Records as the
+    oracle's, and as the four-tokens-per-lane scan's."""
+    from fandom_search_amd.engine import ScriptIndex
+    words, emb = synth_base["words"], synth_base["emb"]
+    script = synth.script_tokens(3000)
+    tok, off = util.ragged_corpus([5000, 3, 4100, 2600], script)
+    tok = tok.copy()
+    cos = emb[script[:2900]] @ emb.T
+    cos[np.arange(2900), script[:2900]] = -1.0
+    best = cos.argmax(axis=1)
+    starts = []
+    for j, boundary in enumerate(range(512, len(tok) - 2 * n, 512)):
+        at = boundary + 1 - (j % (n + 2))              # the span's first token 1 behind ... n before the boundary
+        src = 40 + 31 * j
+        w = int(np.searchsorted(off, at, side="right")) - 1
+        if at + n > int(off[w + 1]) or at < int(off[w]):   # stays inside its work
+            continue
+        tok[at:at + n] = script[src:src + n]
+        if j % 3 == 1:
+            tok[at + j % n] = best[src + j % n]
+        starts.append(at % 512)
+    assert len(set(starts)) >= n                       # every way of straddling a boundary
+    tok[len(tok) - n:] = script[700:700 + n]           # the corpus' last window
+    cfg = abi.make_config(window_size=n)
+    normals = synth.lsh_normals(n)
+    swords = [words[int(t)] for t in script]
+    ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
+                       synth_base["chars"], synth_base["off"])
+    assert st.path == abi.FS_MODE_GENERAL and len(got) > 100
+    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near8<%d>" % n
+    assert int(got["fan_ix"][got["work"] == 3].max()) == 2600 - 1      # the last token is in a record
+    monkeypatch.setenv("FS_SCAN_NEAR8", "0")
+    old = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    c = old.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    assert old.kernel_name(c) == "k_scan_near<%d>" % n
+    got2, st2 = old.search(c)
+    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+
+
 def test_general_mode_equals_exact_mode(synth_base):
     """Forcing the LSH pipeline where the proof holds must not change a byte."""
     from fandom_search_amd.engine import ScriptIndex
