@@ -212,7 +212,10 @@ def corpus_tokens_parallel(n_works, tokens_per_work, script, first_work=0,
     import subprocess
     import sys
     import tempfile
-    procs = procs or min(16, len(os.sched_getaffinity(0)))
+    if not procs:
+        # (the ranks of one node share its cores)
+        ranks = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+        procs = min(16, max(1, len(os.sched_getaffinity(0)) // max(1, ranks)))
     if procs <= 1 or n_works < 4096:
         return corpus_tokens(n_works, tokens_per_work, script, first_work, vocab_size)
     per = -(-n_works // procs)
