@@ -311,10 +311,15 @@ __device__ inline uint32_t lev_wave(const GramIndexDev& g, uint32_t s, const uin
     s_b[j] = in_word ? chars[at] : ch;
   }
   __builtin_amdgcn_wave_barrier();
-  const uint32_t* pat = la <= lb ? s_a : s_b;
-  const uint32_t* txt = la <= lb ? s_b : s_a;
-  const uint32_t m = la <= lb ? la : lb, t = la <= lb ? lb : la;
+  // the pattern sits in the lanes (at most 64 code points), the text is walked column by column
+  // -- a column is ~25 scalar instructions, and a CU has one scalar unit for all its waves: with
+  // both operands within 64 the LONGER one is the pattern (the distance is symmetric)
+  const bool a_pat = (la <= 64 && lb <= 64) ? la >= lb : la <= lb;
+  const uint32_t* pat = a_pat ? s_a : s_b;
+  const uint32_t* txt = a_pat ? s_b : s_a;
+  const uint32_t m = a_pat ? la : lb, t = a_pat ? lb : la;
   if (m == 0) return t;
+  if (t == 0) return m;
   if (m > 64) {
     uint32_t r = 0;
     if (lane == 0) r = lev_device(g, s, fan_sid, chars, coff, n_str, st);

@@ -165,17 +165,26 @@ __device__ __forceinline__ uint32_t assemble_key(const uint64_t* bal, int h, int
 
 // CosineDistance of fan window f[] to script window s (canonical), with the
 // sound skips described in the file header.  Returns false when skipped or NaN.
-__device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, double ff,
-                                double rff, double* out) {
+// qf: q of the fan window's slots (LDS; lsh_neighbours_wave), or nullptr.  With it, where the
+// ids were compared (stage 0), a slot that holds the same id on both sides needs no load at
+// all (its q is the fan side's) and only the slots that differ fetch the script side: its id,
+// q and the pair-table entry -- at n = 10 two levels of loads for the one slot instead of two
+// per slot.
+__device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, const double* qf,
+                                double ff, double rff, double* out) {
   // stage 0: integer only.  With all table norms in [sqrt(q_min), sqrt(q_max)] and
   // no OOV vector involved, m identical slots bound the cosine by
   // (m q_max + (n-m) c_max q_max) / (n q_min); m_min is the smallest m for which that
   // reaches 1 - threshold (host side, lsh_dev).
   int same = -1;
+  uint32_t diff = 0xFFFFFFFFu;                  // bit k: slot k holds different ids (all: not compared)
+  // (the window's record requested with its ids: one level for the two)
+  fs_swin sw = L.sw[s];
   if (L.m_min > 0) {
     // (the window's ids requested together: stok is padded by a window)
     const uint4* sp = reinterpret_cast<const uint4*>(L.stok + s);
     same = 0;
+    diff = 0;
     uint32_t anyoov = 0;
 #pragma unroll
     for (int q4 = 0; q4 < FS_MAX_WINDOW / 4; ++q4) {
@@ -185,12 +194,15 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (4 * q4 + k < L.n) {
-          same += u4[k] == f[4 * q4 + k];
+          const bool eq = u4[k] == f[4 * q4 + k];
+          same += eq;
+          diff |= eq ? 0u : 1u << (4 * q4 + k);
           anyoov |= u4[k] | f[4 * q4 + k];
         }
     }
-    if (anyoov & FS_OOV_FLAG) same = -1;
-    else if (same < L.m_min) return false;
+    asm volatile("" : "+v"(sw.ss), "+v"(sw.rss), "+v"(sw.qu0), "+v"(sw.u0), "+v"(sw.r0));
+    if (anyoov & FS_OOV_FLAG) { same = -1; diff = 0xFFFFFFFFu; }
+    else if (L.m_min > 0 && same < L.m_min) return false;
   }
   // stage 1: the canonical sum SF slot by slot, leaving as soon as the slots still to
   // come cannot lift it to the threshold.  By Cauchy-Schwarz the remaining slots add
@@ -199,7 +211,6 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
   // distance > thr + 1e-6, far outside the rounding of the canonical expression.  A
   // bucket collision between unrelated windows leaves after its first slot, which
   // costs one 32-byte record of the script window and one pair-table entry.
-  const fs_swin sw = L.sw[s];
   const double norm = __dmul_rn(sw.rss, rff);
   if (same == L.n) {
     // identical ids in every slot: the canonical sum adds q(u_k) in slot order from 0.0,
@@ -212,16 +223,23 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
   const double need = (1.0 - L.thr - 1e-6) * norm * (1.0 - 1e-9);
   double sf = 0.0, ssr = sw.ss, ffr = ff;
   for (int k = 0; k < L.n; ++k) {
-    const uint32_t u = k ? L.stok[s + k] : sw.u0, v = f[k];
-    const double qu = k ? q_of(L, u) : sw.qu0;
-    double g;
-    if (u == v) g = qu;
-    else if (k == 0 && sw.r0 >= 0 && !(v & FS_OOV_FLAG)) g = L.gtab[(size_t)sw.r0 * L.V + v];
-    else g = g_of(L, u, v);
+    double g, qu, qv;
+    if (qf && !(diff >> k & 1u)) {
+      // the same id on both sides: g = q(u) = q(v), the fan side's (the same bits: q is a
+      // function of the id)
+      qu = qv = g = qf[k];
+    } else {
+      const uint32_t u = k ? L.stok[s + k] : sw.u0, v = f[k];
+      qu = k ? q_of(L, u) : sw.qu0;
+      if (u == v) g = qu;
+      else if (k == 0 && sw.r0 >= 0 && !(v & FS_OOV_FLAG)) g = L.gtab[(size_t)sw.r0 * L.V + v];
+      else g = g_of(L, u, v);
+      qv = u == v ? qu : qf ? qf[k] : q_of(L, v);
+    }
     sf = __dadd_rn(sf, g);
     if (k + 1 < L.n) {
       ssr -= qu;
-      ffr -= u == v ? qu : q_of(L, v);
+      ffr -= qv;
       const double t = need - sf;
       const double rem = fmax(ssr, 0.0) * fmax(ffr, 0.0) * (1.0 + 1e-9);
       if (t > 0.0 && t * t > rem) return false;
@@ -256,7 +274,7 @@ __device__ int lsh_neighbours(const LshDev& L, const uint32_t* keys, const uint3
       }
       double d;
       if (L.diag == 3) { cnt += s == 0xFFFFFFFFu; continue; }          // diagnostics: bucket walk only
-      if (!window_distance(L, s, f, ff, rff, &d)) continue;
+      if (!window_distance(L, s, f, nullptr, ff, rff, &d)) continue;
       if (!(d < L.thr)) continue;
       if (ANY) return 1;
       // stable insertion: behind every entry with distance <= d
@@ -283,10 +301,14 @@ __device__ int lsh_neighbours(const LshDev& L, const uint32_t* keys, const uint3
 // (distance, then arrival) below nn.  Equal to lsh_neighbours<false> entry for entry.
 __device__ int lsh_neighbours_wave(const LshDev& L, const uint32_t* keys, const uint32_t* f,
                                    uint32_t* top_s, double* top_d, uint32_t* s_pre,
-                                   uint32_t* s_e0) {
+                                   uint32_t* s_e0, double* qf) {
   const int lane = threadIdx.x & 63;
+  if (lane < L.n) qf[lane] = q_of(L, f[lane]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   double ff = 0.0;
-  for (int k = 0; k < L.n; ++k) ff = __dadd_rn(ff, q_of(L, f[k]));
+  for (int k = 0; k < L.n; ++k) ff = __dadd_rn(ff, qf[k]);
   const double rff = __dsqrt_rn(ff);
   const uint32_t nb1 = (1u << L.B) + 1;
   uint32_t e0 = 0, cnt_h = 0;
@@ -319,7 +341,7 @@ __device__ int lsh_neighbours_wave(const LshDev& L, const uint32_t* keys, const 
       for (uint32_t step = 32; step > 0; step >>= 1)
         if (h + step < (uint32_t)L.H && s_pre[h + step] <= j) h += step;
       s = L.bids[(size_t)h * L.W + s_e0[h] + (j - s_pre[h])];
-      if (L.diag != 3) valid = window_distance(L, s, f, ff, rff, &d) && d < L.thr;
+      if (L.diag != 3) valid = window_distance(L, s, f, qf, ff, rff, &d) && d < L.thr;
     }
     if (L.unique) {
       // not the window of a kept entry or of an earlier lane of this round
@@ -748,7 +770,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
         if (L.diag == 3) continue;               // diagnostics: bucket walk only
         const double pff = s_ff[pw];
         double d;
-        if (window_distance(L, sidx, s_tok + pw, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_flag[pw] = 1;
+        if (window_distance(L, sidx, s_tok + pw, nullptr, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_flag[pw] = 1;
       }
       __syncthreads();
     }
@@ -1090,6 +1112,7 @@ struct LshWaveLds {
   uint32_t* fs;       // [FS_MAX_WINDOW] string ids of the window
   int* n;             // [1]
   uint32_t *pre, *e0; // [64]
+  double* qf;         // [FS_MAX_WINDOW] q of the window's slots
 };
 
 // What the reference returns for one fan window, worked out by a whole wave (all 64 lanes
@@ -1176,8 +1199,7 @@ __device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, c
   if (L.diag & 32) {
     cnt = 0;
   } else if (L.nn <= 48 && L.H <= 64 && !L.serial_neighbours) {
-    cnt = lsh_neighbours_wave(L, S.key, S.f, S.top_s, S.top_d, S.pre,
-                              S.e0);
+    cnt = lsh_neighbours_wave(L, S.key, S.f, S.top_s, S.top_d, S.pre, S.e0, S.qf);
   } else {                                    // NearestFilter(N > 48): one lane walks the buckets
     if (lane == 0)
       S.n[0] = lsh_neighbours<false>(L, S.key, S.f, S.top_s, S.top_d);
@@ -1226,10 +1248,11 @@ __device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, c
   __shared__ uint32_t s_fs[4][FS_MAX_WINDOW];                                                 \
   __shared__ int s_n[4];                                                                      \
   __shared__ uint32_t s_pre[4][64], s_e0[4][64];                                              \
+  __shared__ double s_qf[4][FS_MAX_WINDOW];                                                   \
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));                   \
   const LshWaveLds S{s_bal[wave], s_key[wave], s_top_s[wave], s_top_d[wave], s_lev[wave],     \
                      s_la[wave], s_lb[wave], s_f[wave], s_fs[wave], &s_n[wave], s_pre[wave],   \
-                     s_e0[wave]}
+                     s_e0[wave], s_qf[wave]}
 
 // Per script n-gram, once per string table (fs_corpus_update_end, like the exact path's
 // ctab): what a fan window with the n-gram's ids and the strings of those ids gets.  The
