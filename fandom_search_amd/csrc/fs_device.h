@@ -1,6 +1,7 @@
 // fs_device.h -- device helpers shared by fs_post.hip and fs_lsh.hip.
 #pragma once
 #include "fs_internal.h"
+#include <type_traits>
 
 namespace fsdev {
 
@@ -326,29 +327,44 @@ __device__ inline uint32_t lev_wave(const GramIndexDev& g, uint32_t s, const uin
     return __shfl(r, 0);
   }
   const uint32_t pc = lane < (int)m ? pat[lane] : 0xFFFFFFFFu;    // never equal to a code point
-  const uint64_t last = 1ull << (m - 1);
   uint64_t pv = ~0ull, mv = 0;
   uint32_t score = m;
-  // (the text 64 code points at a time in a register, a lane each, and read out lane by lane:
-  // an LDS read per column was most of a column's time)
-  for (uint32_t base = 0; base < t; base += 64) {
-    const uint32_t tv = base + (uint32_t)lane < t ? txt[base + lane] : 0u;
-    const uint32_t cnt = t - base < 64u ? t - base : 64u;
-    for (uint32_t i = 0; i < cnt; ++i) {
-      const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)tv, (int)i);
-      const uint64_t eq = __ballot(pc == c);
-      const uint64_t xv = eq | mv;
-      const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
-      uint64_t ph = mv | ~(xh | pv);
-      uint64_t mh = pv & xh;
-      if (ph & last) ++score;
-      if (mh & last) --score;
-      ph = (ph << 1) | 1ull;
-      mh <<= 1;
-      pv = mh | ~(xv | ph);
-      mv = ph & xv;
+  // (the text 64 code points at a time in a register, a lane each, and read out lane by lane: an
+  // LDS read per column was most of a column's time.  The column's +1 / -1 -- bit m - 1 of ph and
+  // of mh -- is not counted column by column: the word that holds the bit goes into lane i of a
+  // register, two vector instructions where the test, the select and the add were eight scalar
+  // ones, and the lanes are counted once per 64 columns)
+  const uint32_t bit = (m - 1) & 31u;
+  auto columns = [&](auto hi_word) {
+    constexpr bool HI = decltype(hi_word)::value;
+    for (uint32_t base = 0; base < t; base += 64) {
+      const uint32_t tv = base + (uint32_t)lane < t ? txt[base + lane] : 0u;
+      const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t - base < 64u ? t - base : 64u));
+      uint32_t accp = 0, accm = 0;
+      for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)tv, (int)i);
+        const uint64_t eq = __ballot(pc == c);
+        const uint64_t xv = eq | mv;
+        const uint64_t xh = (((eq & pv) + pv) ^ pv) | eq;
+        uint64_t ph = mv | ~(xh | pv);
+        uint64_t mh = pv & xh;
+        // (gfx9: one SGPR per vector instruction, so the lane number travels in m0, which is
+        // put back: the compiler does not track it through an asm statement)
+        uint32_t m0_keep;
+        asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+            : "+v"(accp), "+v"(accm), "=&s"(m0_keep)
+            : "s"((uint32_t)(HI ? ph >> 32 : ph)), "s"((uint32_t)(HI ? mh >> 32 : mh)), "s"(i));
+        ph = (ph << 1) | 1ull;
+        mh <<= 1;
+        pv = mh | ~(xv | ph);
+        mv = ph & xv;
+      }
+      const bool in = (uint32_t)lane < cnt;
+      score += (uint32_t)__popcll(__ballot(in && ((accp >> bit) & 1u)));
+      score -= (uint32_t)__popcll(__ballot(in && ((accm >> bit) & 1u)));
     }
-  }
+  };
+  if (m > 32) columns(std::true_type{}); else columns(std::false_type{});
   return score;
 }
 
