@@ -118,6 +118,7 @@ void fs_read_switches(fs_switches* sw) {
   if (const char* e = getenv("FS_LSH_F32_SLACK")) sw->lsh_f32_slack = atof(e);
   if (const char* e = getenv("FS_LSH_F32")) sw->lsh_f32 = e[0] != '0';
   sw->lsh_diag = num("FS_LSH_DIAG");
+  sw->lsh_lev_lane = getenv("FS_LSH_LEV_LANE") ? num("FS_LSH_LEV_LANE") : 1;
   sw->scan_near8 = !getenv("FS_SCAN_NEAR8") || num("FS_SCAN_NEAR8") != 0;
   sw->end_query = !getenv("FS_END_QUERY") || num("FS_END_QUERY") != 0;
   sw->lsh_no_gtab = getenv("FS_LSH_NO_GTAB") != nullptr;
@@ -681,8 +682,10 @@ extern "C" int fs_corpus_update_end(fs_corpus* c) {
     }
     c->levtab_ready = true;
   }
-  if (c->has_str && !c->has_oov && ix->info.path == FS_MODE_EXACT && ix->strfast_ok && ix->sw.str_fast &&
-      !c->strrec_ready) {
+  // (the LSH pipeline's k_lsh_lev reads them too, with or without string ids of the batch's own)
+  const bool lsh_path = ix->info.path != FS_MODE_EXACT || c->has_oov;
+  if (((c->has_str && !c->has_oov && ix->info.path == FS_MODE_EXACT) || (lsh_path && ix->sw.lsh_lev_lane)) &&
+      ix->strfast_ok && ix->sw.str_fast && !c->strrec_ready) {
     // the string table as character classes of the script's alphabet, once per string table
     FS_TRY(fs_launch_strrec(ix, c, ix->stream));
     FS_HIP(hipStreamSynchronize(ix->stream));
@@ -1205,6 +1208,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     st->scan_launches = sl.launches;
     st->lsh_pending = sl.exact ? 0 : hs.lsh_pending;
   }
+  if (!sl.exact) ix->lanes[sl.lane].pend_hint = hs.lsh_pending;
   if (hs.n_rows > sl.cap) return FS_E_CAPACITY;
   if (sl.mode == FS_ROWS_HOST && hs.n_rows) {
     fs_index::Lane& ln = ix->lanes[sl.lane];

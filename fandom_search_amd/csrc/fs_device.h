@@ -443,4 +443,72 @@ __device__ inline uint32_t lev_lane(const GramIndexDev& g, const CorpusDev& c, c
   return score;
 }
 
+// lev_lane with the window's string ids in registers and every word's string record requested
+// up front, together with the script window's bit planes: one level of loads where lev_lane
+// walks id -> record word by word (k_lsh_lev: a lane per kept match, nothing else to hide a
+// chain of 2n loads behind).
+__device__ inline uint32_t lev_lane_ids(const GramIndexDev& g, const CorpusDev& c, const StrFast& F,
+                                        uint32_t s, const Ids16& sid, fs_status* st) {
+  const uint4* P4 = reinterpret_cast<const uint4*>(F.pat + 8 * (size_t)s);
+  const uint4 t0 = P4[0], t1 = P4[1], t2 = P4[2], t3 = P4[3];
+  uint4 rec[FS_MAX_WINDOW];
+#pragma unroll
+  for (int k = 0; k < FS_MAX_WINDOW; ++k)
+    if (k < g.n) rec[k] = F.strrec[sid.v[k]];
+  const uint32_t la = t3.z;
+  if (la > 64) return lev_device(g, s, sid.v, c.chars, c.coff, c.n_str, st);
+  const uint32_t plo[7] = {t0.x, t0.z, t1.x, t1.z, t2.x, t2.z, t3.x};
+  const uint32_t phi[7] = {t0.y, t0.w, t1.y, t1.w, t2.y, t2.w, t3.y};
+  const unsigned long long last = 1ull << (la - 1);
+  unsigned long long pv = ~0ull, mv = 0ull;
+  uint32_t score = la;
+  auto step = [&](uint32_t cl) {
+    uint32_t elo = 0xFFFFFFFFu, ehi = 0xFFFFFFFFu;
+#pragma unroll
+    for (int b = 0; b < 7; ++b) {
+      const uint32_t m = 0u - ((cl >> b) & 1u);
+      elo &= ~(plo[b] ^ m);
+      ehi &= ~(phi[b] ^ m);
+    }
+    const unsigned long long eq = (unsigned long long)elo | ((unsigned long long)ehi << 32);
+    const unsigned long long xv = eq | mv;
+    const unsigned long long xh = (((eq & pv) + pv) ^ pv) | eq;
+    unsigned long long ph = mv | ~(xh | pv);
+    unsigned long long mh = pv & xh;
+    score += (ph & last) ? 1u : 0u;
+    score -= (mh & last) ? 1u : 0u;
+    ph = (ph << 1) | 1ull;
+    mh <<= 1;
+    pv = mh | ~(xv | ph);
+    mv = ph & xv;
+  };
+  step(F.punct & 0xFFu);                                   // '['
+  // (one word: `cur` its record; the loop over the words below is written out so that the
+  // records stay in registers)
+  auto word = [&](uint4 cur, uint32_t id, bool first) {
+    if (!first) { step((F.punct >> 8) & 0xFFu); step((F.punct >> 16) & 0xFFu); }   // ', '
+    const uint32_t len = cur.x & 0xFFu;
+    if (len <= 15) {
+      for (uint32_t j = 0; j < len; ++j) {
+        cur.x = __builtin_amdgcn_alignbit(cur.y, cur.x, 8);
+        cur.y = __builtin_amdgcn_alignbit(cur.z, cur.y, 8);
+        cur.z = __builtin_amdgcn_alignbit(cur.w, cur.z, 8);
+        cur.w >>= 8;
+        step(cur.x & 0xFFu);
+      }
+    } else {
+      for (uint64_t a = c.coff[id]; a < c.coff[id + 1]; ++a) step(cls_of(F, c.chars[a]));
+    }
+  };
+#define FS_LEV_WORD(K) if (K < g.n) word(rec[K], sid.v[K], K == 0)
+  FS_LEV_WORD(0); FS_LEV_WORD(1); FS_LEV_WORD(2); FS_LEV_WORD(3); FS_LEV_WORD(4); FS_LEV_WORD(5);
+  FS_LEV_WORD(6); FS_LEV_WORD(7); FS_LEV_WORD(8); FS_LEV_WORD(9); FS_LEV_WORD(10); FS_LEV_WORD(11);
+  FS_LEV_WORD(12); FS_LEV_WORD(13); FS_LEV_WORD(14); FS_LEV_WORD(15);
+#undef FS_LEV_WORD
+  static_assert(FS_MAX_WINDOW == 16, "the words are written out");
+  step(F.punct >> 24);                                     // ']'
+  if (score > 1023u) st->lev_overflow = 1;
+  return score;
+}
+
 }  // namespace fsdev

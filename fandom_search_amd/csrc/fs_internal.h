@@ -174,6 +174,7 @@ struct fs_switches {
   double lsh_f32_slack = 1.0;     // FS_LSH_F32_SLACK: factor on the float32 key bound (tests force the fallback)
   bool lsh_f32 = true;            // FS_LSH_F32=0: float64 keys only
   int lsh_diag = 0;               // FS_LSH_DIAG
+  int lsh_lev_lane = 1;           // FS_LSH_LEV_LANE=0: the kept matches' Levenshtein distances a wave per match inside k_lsh_verify; 2: a lane per match (k_lsh_lev) however few windows are pending
   bool scan_near8 = true;         // FS_SCAN_NEAR8=0: k_scan_near (four tokens per lane) also for n >= 7; read when the index is built
   bool end_query = true;          // FS_END_QUERY=0: fs_search_corpus_end does not poll its lane's stream
   bool lsh_no_gtab = false;       // FS_LSH_NO_GTAB
@@ -263,6 +264,8 @@ struct fs_index {
     hipStream_t stream = nullptr;
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum, w_pend;
+    DBuf<uint32_t> w_mcnt, w_mtop_s;   // k_lsh_verify -> k_lsh_lev: kept matches per pending window
+    DBuf<double> w_mtop_d;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range
@@ -272,6 +275,7 @@ struct fs_index {
     DBuf<unsigned long long> w_gran;   // finish_rows: {epoch, records} per workgroup, then four statistics granules each
     DBuf<uint4> w_rinfo, w_csum;   // k_compact: {records, hits, pairs, candidates} per range / per workgroup
     uint32_t sync_epoch = 0;
+    uint32_t pend_hint = 0xFFFFFFFFu;   // LSH pipeline: windows the lane's last search left to k_lsh_verify (none yet: many)
     uint64_t enqueued = 0;         // searches put on this lane so far
     DBuf<fs_best> w_cbest;
     DBuf<double> w_hcomb;          // per candidate: combined distance of its best rank (+inf: no hit)

@@ -1121,8 +1121,10 @@ struct LshWaveLds {
 // Levenshtein distance of every kept match (search.py:189-190) and the first minimum of
 // dist * lev in rank order.  S.f / S.fs hold the window's vector and string ids.  Returns the
 // number of kept matches; *b (lane 0) is the record when that is not 0.
+// `defer`: stop behind the neighbour list (S.top_s / S.top_d hold it): the Levenshtein distances and
+// the first minimum are then k_lsh_lev's, a lane per kept match.
 __device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, const GramIndexDev& g,
-                                          const LshWaveLds& S, fs_status* st, fs_best* b) {
+                                          const LshWaveLds& S, fs_status* st, fs_best* b, bool defer = false) {
   const int lane = threadIdx.x & 63;
   const int NW = (L.C + 63) >> 6;
   // keys.  Fast path as in k_lsh_scan: lane l holds projection columns 4l .. 4l+3, one
@@ -1206,7 +1208,7 @@ __device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, c
     __builtin_amdgcn_wave_barrier();
     cnt = S.n[0];
   }
-  if (cnt == 0) return 0;
+  if (cnt == 0 || defer) return cnt;
   // Levenshtein of every kept match (search.py:189-190), the wave working on one
   // match at a time
   for (int r = 0; r < cnt; ++r) {
@@ -1290,13 +1292,17 @@ __global__ __launch_bounds__(256, 4) void k_lsh_gramtab(CorpusDev c, LshDev L, G
 // (five waves per SIMD: 94 registers with two spilt; 97 at four.  A wave per window and about ten
 // levels of dependent loads: the windows in flight are what counts -- n = 10: 0.268 -> 0.249 ms per
 // C2 batch; six waves, 80 registers, eight spilt, measured slower again)
+template <bool DEFER>
 __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, GramIndexDev g,
                                                     const uint32_t* __restrict__ cpos, NSrc nc,
                                                     uint32_t* __restrict__ cg,
                                                     uint32_t* __restrict__ cw,
                                                     fs_best* __restrict__ cbest,
                                                     uint32_t* __restrict__ bmatch, fs_status* st,
-                                                    const uint32_t* __restrict__ pend) {
+                                                    const uint32_t* __restrict__ pend,
+                                                    uint32_t* __restrict__ mcnt,
+                                                    uint32_t* __restrict__ mtop_s,
+                                                    double* __restrict__ mtop_d) {
   FS_LSH_WAVE_LDS;
   __shared__ uint32_t s_w32[4];
   const int lane = threadIdx.x & 63;
@@ -1317,7 +1323,7 @@ __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, Gr
         ok = p + L.n <= work_end;                 // a window never crosses a work boundary
       }
       if (!ok) {                                  // wave-uniform
-        if (lane == 0) cg[i] = FS_NONE;
+        if (lane == 0) { cg[i] = FS_NONE; if (DEFER) mcnt[j] = 0; }
         continue;
       }
       if (lane < L.n) {
@@ -1326,8 +1332,20 @@ __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, Gr
       }
       __builtin_amdgcn_wave_barrier();
       fs_best b;
-      const int cnt = lsh_window(c, L, g, S, st, &b);
-      if (lane == 0) {
+      const int cnt = lsh_window(c, L, g, S, st, &b, DEFER);
+      if (DEFER) {
+        // the kept matches in NearestFilter order for k_lsh_lev (a lane per match there)
+        if (lane < cnt) {
+          mtop_s[(size_t)j * L.nn + lane] = S.top_s[lane];
+          mtop_d[(size_t)j * L.nn + lane] = S.top_d[lane];
+        }
+        if (lane == 0) {
+          mcnt[j] = (uint32_t)cnt;
+          cg[i] = cnt ? FS_PENDING : FS_NONE;
+          cw[i] = w;
+          matches += (uint32_t)cnt;
+        }
+      } else if (lane == 0) {
         if (cnt) {
           cbest[i] = b;
           cg[i] = 0;
@@ -1343,6 +1361,96 @@ __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, Gr
   uint32_t tot;
   block_excl_scan(matches, s_w32, &tot);
   if (threadIdx.x == 0) bmatch[blockIdx.x] += tot;       // (on top of k_lsh_sift's)
+}
+
+// The Levenshtein distances of the matches k_lsh_verify<true> kept, and the record of every
+// pending window: a lane per (window, rank) pair -- lev_lane, Myers' recurrence on one lane's
+// registers against the script window's bit planes, where k_lsh_verify ran it as a wave per
+// pair on the scalar unit (a ballot per column and ~20 scalar instructions: the CU's one
+// scalar unit was busy more than half of that kernel's time).  A workgroup takes 128 windows at
+// a time (a pair is ~4 us of one lane's time whatever else runs: the fewer rounds of pairs a
+// workgroup has to make, the better -- 128 windows are one round of its 256 lanes unless they
+// keep two matches each): prefix sum of their match counts, the pairs dealt out evenly over
+// the threads (the window of a pair by binary search in LDS), the distances through LDS, then a
+// lane per window takes the first minimum of dist * lev in rank order (search.py:224-225).
+constexpr int kLevMaxN = 16;            // NearestFilter sizes this form serves (the default is 10)
+constexpr uint32_t kLevWin = 128;       // windows per workgroup and step
+__global__ __launch_bounds__(256) void k_lsh_lev(CorpusDev c, LshDev L, GramIndexDev g, StrFast F,
+                                                 const uint32_t* __restrict__ cpos, uint32_t cap,
+                                                 const uint32_t* __restrict__ pend,
+                                                 const uint32_t* __restrict__ mcnt,
+                                                 const uint32_t* __restrict__ mtop_s,
+                                                 const double* __restrict__ mtop_d,
+                                                 uint32_t* __restrict__ cg, fs_best* __restrict__ cbest,
+                                                 fs_status* st) {
+  __shared__ uint32_t s_w32[4];
+  __shared__ uint32_t s_pref[257];
+  __shared__ uint32_t s_lev[kLevWin * kLevMaxN];
+  const uint32_t n_pend = min(st->lsh_pending, cap);
+  const uint32_t nn = (uint32_t)L.nn;
+  for (uint32_t j0 = blockIdx.x * kLevWin; j0 < n_pend; j0 += gridDim.x * kLevWin) {
+    const uint32_t j = j0 + threadIdx.x;
+    const uint32_t cnt = (threadIdx.x < kLevWin && j < n_pend) ? mcnt[j] : 0u;
+    uint32_t total;
+    const uint32_t base = block_excl_scan(cnt, s_w32, &total);
+    s_pref[threadIdx.x] = base;
+    if (threadIdx.x == 255) s_pref[256] = total;
+    __syncthreads();
+    for (uint32_t q0 = 0; q0 < total; q0 += 256) {
+      const uint32_t q = q0 + threadIdx.x;
+      if (q < total) {
+        uint32_t lo = 0, hi = 256;               // s_pref[lo] <= q < s_pref[hi]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_pref[mid] <= q) lo = mid; else hi = mid;
+        }
+        const uint32_t r = q - s_pref[lo], jj = j0 + lo;
+        const uint32_t s = mtop_s[(size_t)jj * nn + r];
+        const uint64_t p = cpos[pend[jj]];
+        uint32_t lv = FS_NONE;
+        if (L.selflev) {
+          // a match with the same id in every slot has the strings of the script window's own
+          // ids: its distance was computed once per string table (k_selflev)
+          Ids16 u, f;
+          load_ids(L.stok + s, L.n, &u);
+          load_ids(c.tok + p, L.n, &f);
+          bool same = true;
+#pragma unroll
+          for (int k = 0; k < FS_MAX_WINDOW; ++k)
+            if (k < L.n) same = same && u.v[k] == f.v[k];
+          if (same) lv = L.selflev[s];
+        }
+        if (lv == FS_NONE) {
+          Ids16 sid;
+          load_ids((c.str ? c.str : c.tok) + p, L.n, &sid);
+          bool bad = false;
+#pragma unroll
+          for (int k = 0; k < FS_MAX_WINDOW; ++k)
+            if (k < L.n) bad = bad || sid.v[k] >= c.n_str;
+          if (bad) { st->bad_string = 1; lv = 0; }
+          else lv = lev_lane_ids(g, c, F, s, sid, st);
+        }
+        s_lev[lo * nn + r] = lv;
+      }
+    }
+    __syncthreads();
+    if (cnt) {
+      fs_best b;
+      b.pad = 0.0;
+      for (uint32_t r = 0; r < cnt; ++r) {          // first minimum of dist * lev in rank order
+        const double d = mtop_d[(size_t)j * nn + r];
+        const uint32_t lv = s_lev[threadIdx.x * nn + r];
+        const double comb = __dmul_rn(d, (double)lv);
+        if (r == 0 || comb < b.comb) {
+          b.s = mtop_s[(size_t)j * nn + r]; b.lev = lv; b.dist = d; b.comb = comb;
+        }
+      }
+      const uint32_t i = pend[j];
+      cbest[i] = b;
+      cg[i] = 0;
+    }
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -1803,14 +1911,36 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   };
   static const bool full_grid = getenv("FS_LSH_FULL_GRID") && atoi(getenv("FS_LSH_FULL_GRID")) != 0;
   const uint32_t sift_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(sift));
-  const uint32_t verify_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(k_lsh_verify));
   hipLaunchKernelGGL(sift, dim3(sift_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p,
                      ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, tab_best, tab_cnt, ix->cur->w_pend.p,
                      &st->lsh_pending);
-  hipLaunchKernelGGL(k_lsh_verify, dim3(verify_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+  // the kept matches' Levenshtein distances a lane per match (k_lsh_lev) where the script
+  // windows' bit planes and the string table's records exist; else a wave per match inside
+  // k_lsh_verify
+  // (a launch of its own costs ~20 us whatever it finds to do -- the chain of loads in front of a
+  // pair and the pair itself, 4 us of one lane's time: worth it from some thousands of pending
+  // windows on, which the lane's last search tells; FS_LSH_LEV_LANE=2: always)
+  const bool defer = ix->sw.lsh_lev_lane && ix->sw.str_fast && ix->strfast_ok && c->strrec_ready &&
+                     L.nn <= kLevMaxN && (ix->cur->pend_hint >= 8192u || ix->sw.lsh_lev_lane == 2);
+  if (defer) {
+    FS_TRY(ix->cur->w_mcnt.reserve(ccap));
+    FS_TRY(ix->cur->w_mtop_s.reserve((size_t)ccap * L.nn));
+    FS_TRY(ix->cur->w_mtop_d.reserve((size_t)ccap * L.nn));
+  }
+  auto verify = defer ? k_lsh_verify<true> : k_lsh_verify<false>;
+  const uint32_t verify_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(verify));
+  hipLaunchKernelGGL(verify, dim3(verify_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
-                     ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p);
+                     ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p, ix->cur->w_mcnt.p,
+                     ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p);
+  if (defer) {
+    const StrFast F{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, c->d_strrec.p};
+    const uint32_t lev_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(k_lsh_lev));
+    hipLaunchKernelGGL(k_lsh_lev, dim3(lev_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(), F,
+                       ix->cur->w_cpos.p, ccap, ix->cur->w_pend.p, ix->cur->w_mcnt.p,
+                       ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p, ix->cur->w_cg.p, ix->cur->w_cbest.p, st);
+  }
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

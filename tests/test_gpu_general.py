@@ -103,7 +103,8 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
     # ... and with the four-tokens-per-lane form of the prefilter scan (its own 3-gram hash)
     for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near8<%d>" % n),
                         ("FS_LSH_SELFLEV", "k_scan_near8<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near8<%d>" % n),
-                        ("FS_LSH_WMAP", "k_scan_near8<%d>" % n), ("FS_SCAN_NEAR8", "k_scan_near<%d>" % n)):
+                        ("FS_LSH_WMAP", "k_scan_near8<%d>" % n), ("FS_SCAN_NEAR8", "k_scan_near<%d>" % n),
+                        ("FS_LSH_LEV_LANE", "k_scan_near8<%d>" % n)):
         monkeypatch.setenv(env, "0")
         full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
         c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
