@@ -344,8 +344,11 @@ __device__ int lsh_neighbours_wave(const LshDev& L, const uint32_t* keys, const 
       if (L.diag != 3) valid = window_distance(L, s, f, qf, ff, rff, &d) && d < L.thr;
     }
     if (L.unique) {
-      // not the window of a kept entry or of an earlier lane of this round
-      uint64_t live = __ballot(s != FS_NONE);
+      // not the window of a kept entry or of an earlier lane of this round.  Only lanes within
+      // the threshold are looked at: a second entry of a window that is not has the same
+      // distance and is dropped like the first (two or three lanes instead of every bucket
+      // entry: the loop is scalar work, which this kernel is short of)
+      uint64_t live = __ballot(valid);
       bool dup = false;
       while (live) {
         const int l = __ffsll((unsigned long long)live) - 1;
