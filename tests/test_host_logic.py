@@ -268,3 +268,37 @@ def test_token_pool_survives_a_lost_worker_and_drops_stale_jobs(tmp_path):
         assert pool.get(files[3:5])[0][0].tolist() == search.tokenize_files(files[3:5])[0].tolist()
     finally:
         pool.close()
+
+
+def test_prefilter_rule_for_eight_windows_at_once():
+    """k_scan_near8 (fs_scan.hip: window_flags_near8) decides a lane's eight windows with runs of
+    set bits instead of a loop over the windows: with T = n - 2 three-gram tests per window and
+    R = T - 3 that must hold, window j passes iff for some a in 0..R its first a and its last
+    R - a tests hold.  The same answer as the rule as stated -- every failed test within three
+    consecutive positions -- for random test outcomes at every supported window size."""
+    import random
+    K = 3
+    rng = random.Random(7)
+
+    def stated(z):
+        if z == 0:
+            return True
+        hi = z.bit_length() - 1
+        lo = (z & -z).bit_length() - 1
+        return hi - lo < K
+
+    for n in (7, 8, 9, 10, 12):
+        T, NB = n - K + 1, 8 + n - K
+        R = T - K
+        for _ in range(4000):
+            bits = rng.getrandbits(NB)
+            run = [0xFFFFFFFF, bits]
+            for r in range(2, R + 1):
+                run.append(run[-1] & (bits >> (r - 1)))
+            flags = 0
+            for a in range(R + 1):
+                flags |= run[a] & (run[R - a] >> (a + K))
+            flags &= 0xFF
+            for j in range(8):
+                z = ~(bits >> j) & ((1 << T) - 1)
+                assert stated(z) == bool(flags >> j & 1), (n, bits, j)
