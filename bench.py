@@ -317,10 +317,28 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
         rows, st = ixl.search(cl)
         if st.total_ms > 0:           # (0: the search was repeated to grow a workspace)
             best = st.total_ms if best is None else min(best, st.total_ms)
+    # ... and as the timed region measures the headline: as many searches in flight as it keeps
+    capl = len(rows) + 64
+    bufl = [torch.zeros(32 + capl * 32, dtype=torch.uint8, device="cuda") for _ in range(n_fl + 1)]
+    for i in range(2 * n_fl):                                    # (every lane's workspaces grown)
+        ixl.search_end(ixl.search_begin(cl, bufl[0].data_ptr(), capl, header=True))
+    repl, tickets = 24, []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(repl):
+        tickets.append(ixl.search_begin(cl, bufl[i % len(bufl)].data_ptr(), capl, header=True))
+        if len(tickets) >= n_fl:
+            ixl.search_end(tickets.pop(0))
+    while tickets:
+        ixl.search_end(tickets.pop(0))
+    torch.cuda.synchronize()
+    dt_l = (time.perf_counter() - t0) / repl
+    del bufl
     cp = (15 * 14 + 3) & ~3
     lsh_bytes = float(st.windows_processed) * window * cp * 4
     out["lsh_clustered_table"] = {
-        "value": n_l / (best * 1e-3), "unit": "fanworks/s", "ms_per_step": best,
+        "value": n_l / dt_l, "unit": "fanworks/s", "ms_per_step": dt_l * 1e3,
+        "ms_per_search_alone": best, "value_alone": n_l / (best * 1e-3),
         "kernel": ixl.kernel_name(cl),
         "roofline": None if not ixl.kernel_name(cl).startswith("k_lsh_scan") else
                     {"bound": "infinity-cache gather", "kernel": ixl.kernel_name(cl),
@@ -336,7 +354,9 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
         "candidates": int(st.candidates), "lsh_pending": int(st.lsh_pending),
         "note": "synth.clustered_table (1024 groups of 8 near-synonyms), 10 % of the fan tokens swapped "
                 "for a synonym; the LSH pipeline behind the component-id prefilters (`kernel`: the "
-                "first kernel of the search; k_lsh_scan when they do not apply), device time of one search"}
+                "first kernel of the search; k_lsh_scan when they do not apply); value: as many searches "
+                "in flight as the timed region keeps, like the headline; *_alone: device time of one search "
+                "by itself (what rounds 2 and 3 reported)"}
     cl.close()
     ixl.close()
     return out
