@@ -1067,7 +1067,10 @@ __global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, Gram
         if (probe[u] && !pass1) { cg[il[u]] = FS_NONE; live[u] = false; }
       }
     }
-    // the survivors onto the queue (a slot per wave's worth of them)
+    // the survivors onto the queue (a slot per wave's worth of them).  The barrier keeps a
+    // fast wave's additions to s_qn behind every wave's read of it at the end of the round
+    // before (the read decides a workgroup-uniform branch around barriers)
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const uint64_t sb = __ballot(live[u]);

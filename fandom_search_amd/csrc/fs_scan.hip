@@ -504,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_scan_near8(const uint32_t* __restrict_
                                                      uint32_t* __restrict__ qcnt, uint32_t n_sub,
                                                      uint32_t chunk, uint32_t* __restrict__ bsum,
                                                      fs_status* __restrict__ zero) {
-  static_assert(N >= 7 && N <= 16, "halo of at most two lanes");
+  static_assert(N >= 7 && N <= 12, "twelve halo tokens are loaded (nv[12])");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   uint32_t* s_csum = s_filter + (1u << log2_words);           // [kChunksPerBlock]
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(1024) void k_scan_simple(const uint32_t* __restrict
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is set once per kernel and size (per
 // device: the attribute belongs to the loaded code object), not on every launch
+static constexpr size_t kCuLdsBytes = 160 * 1024;  // gfx950: LDS per CU = the most one workgroup may ask for
 static int ensure_dynamic_lds(const void* kern, int device, size_t lds) {
   struct Seen { const void* k; int dev; size_t lds; };
   static std::vector<Seen> seen;                  // a handful of entries
@@ -1219,7 +1220,7 @@ uint32_t fs_scan_rows_shape(const fs_index* ix, const fs_corpus* c, uint32_t* bl
   if (sw.scan_simple || sw.scan_tpl == 4 || !sw.scan_direct || sw.scan_capw) return 0;
   // (1 KB: s_cnt; the slices of the shared rounds)
   const size_t fixed = ((size_t)4 << rows_filter_log2(ix)) + fs_scan_rows_disp_lds(ix) + 1024 + sizeof(fsdev::CoopLds);
-  const size_t cu_lds = 160 * 1024;
+  const size_t cu_lds = kCuLdsBytes;
   // a hit's LDS record holds its window position relative to the wave range in
   // fsdev::kHitPosBits bits: the longest range of the shape must fit (a wave of sixteen
   // takes at most 305/4096 of its workgroup's sub-tiles, else an equal share)
@@ -1376,6 +1377,9 @@ int fs_launch_scan_near(const fs_index* ix, const fs_corpus* fc, uint64_t* qbm, 
   const uint32_t* ids = comp ? (const uint32_t*)fc->d_ctok.p : c.tok;
   const uint32_t* filter = comp ? (const uint32_t*)ix->d_sfilter3c.p : (const uint32_t*)ix->d_sfilter3.p;
   const uint32_t* keys6 = comp && ix->sw.lsh_keys6 ? (const uint32_t*)ix->d_keys6c.p : (const uint32_t*)nullptr;
+  // the second filter of k_scan_near<6> is optional (a superset test in front of a superset
+  // test): with a 3-gram filter of 2^15 words the two together exceed the CU's LDS
+  if (((size_t)4 << ix->log2_words) + ((size_t)4 << FS_NEAR6_LOG2_WORDS) > kCuLdsBytes) keys6 = nullptr;
   ex->counted = false;
   if (fs_scan_near8(ix)) {
     switch (ix->cfg.window_size) {

@@ -275,6 +275,7 @@ class TokenPool(object):
         self.processes = int(processes)
         self.pool = multiprocessing.get_context("fork").Pool(self.processes) if self.processes > 1 else None
         self.pending = {}
+        self.writes = []                       # [job or None, function, arguments] of queued writes
         self._pids = sorted(p.pid for p in self.pool._pool) if self.pool is not None else None
 
     def start(self, filenames):
@@ -294,6 +295,32 @@ class TokenPool(object):
         if job is not None and self._workers_alive():
             return job.get()
         return [tokenize_files(list(filenames))]
+
+    def write_async(self, fn, args):
+        """Queue fn(*args) -- a batch file to be written -- on a worker.  The arguments are
+        kept until finish_writes() has seen the job complete: a pool that loses a worker is
+        given up, and its queued jobs would never be done."""
+        job = self.pool.apply_async(fn, args) if self.pool is not None and self._workers_alive() else None
+        self.writes.append([job, fn, args])
+
+    def finish_writes(self):
+        """Wait for every queued write (raises what a writer raised).  No unbounded wait: a job
+        is polled with the workers' liveness checked in between, and what a lost pool left
+        undone -- including a file a killed writer left half written -- is redone here."""
+        import multiprocessing
+        writes, self.writes = self.writes, []
+        for job, fn, args in writes:
+            while job is not None and not job.ready() and self.pool is not None and self._workers_alive():
+                try:
+                    job.get(timeout=0.25)
+                except multiprocessing.TimeoutError:
+                    pass
+                except Exception:
+                    break                       # (ready now: raised again below)
+            if job is not None and job.ready():
+                job.get()
+            else:
+                fn(*args)
 
     def _workers_alive(self):
         """multiprocessing.Pool re-forks a worker that died (out of memory, a signal) -- from
@@ -698,7 +725,6 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
 
     lap("index")
     _startup_lap("script index on the GPU (library load, HIP start-up, fs_index_create)")
-    writes = []
     failure = None
     t_start = time.time()
     for i, fan_cluster in enumerate(fan_clusters):
@@ -733,9 +759,9 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
                 # parse the script's columns themselves) while this process searches the next
                 # cluster; the reference writes every batch file before the next pool.map
                 # (search.py:386-388), the bytes are the same
-                writes.append(pool.pool.apply_async(
+                pool.write_async(
                     _write_batch, (args.script, batch_filename.format(i), list(fan_cluster),
-                                   np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).tobytes(), words)))
+                                   np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).tobytes(), words))
                 lap("hand batch to a writer")
                 continue
             records = join_records(fan_cluster, rows, words,
@@ -751,8 +777,8 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
                 raise
             failure = e
     try:
-        for job in writes:
-            job.get()                               # (raises what the writer raised)
+        if pool is not None:
+            pool.finish_writes()                    # (raises what a writer raised)
     except Exception as e:                          # told to the other ranks below, then raised
         failure = failure or e
     lap("wait for the writers")

@@ -231,10 +231,16 @@ def corpus_tokens_parallel(n_works, tokens_per_work, script, first_work=0,
             cmd = [sys.executable, "-m", "fandom_search_amd.synth", spath, out, str(n),
                    str(tokens_per_work), str(first_work + lo), str(vocab_size)]
             jobs.append((lo, n, out, subprocess.Popen(cmd, cwd=root)))
-        for lo, n, out, p in jobs:
-            if p.wait() != 0:
-                raise RuntimeError("corpus worker failed (exit code %d)" % p.returncode)
-            tok[lo * tokens_per_work:(lo + n) * tokens_per_work] = np.fromfile(out, dtype=np.uint32)
+        try:
+            for lo, n, out, p in jobs:
+                if p.wait() != 0:
+                    raise RuntimeError("corpus worker failed (exit code %d)" % p.returncode)
+                tok[lo * tokens_per_work:(lo + n) * tokens_per_work] = np.fromfile(out, dtype=np.uint32)
+        finally:
+            for _, _, _, p in jobs:             # (a failure leaves no child behind)
+                if p.poll() is None:
+                    p.kill()
+                    p.wait()
     off = np.arange(n_works + 1, dtype=np.uint64) * np.uint64(tokens_per_work)
     return tok, off
 

@@ -126,3 +126,25 @@ def test_coarse_components_fall_back(synth_base):
         tok, off, synth_base["chars"], synth_base["off"])
     util.assert_rows_equal(got, want)
     assert st.matches == ost.matches
+
+
+def test_largest_filter_at_n6_leaves_the_second_filter_out(synth_base, monkeypatch):
+    """A 3-gram filter of 2^15 words (scripts with more than ~22k distinct 6-grams) and the
+    64 KiB middle-slot filter of k_scan_near<6> together exceed the CU's 160 KiB of LDS: the
+    launch must leave the optional second filter out, not fail."""
+    from oracle import c_oracle
+    monkeypatch.setenv("FS_FILTER_LOG2_WORDS", "15")
+    emb, perm, inv = _clustered()
+    words = synth_base["words"]
+    script = synth.script_tokens(3000)
+    swords = [words[int(t)] for t in script]
+    tok, off = _swapped_corpus(script, perm, inv, 8, 16, 700)
+    cfg = abi.make_config()
+    normals = synth.lsh_normals(6)
+    ix, c, got, st = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
+    assert ix.kernel_name(c) == "k_scan_near<6>"
+    sch, so = pack_strings(swords)
+    want, ost = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8).search(
+        tok, off, synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and len(got) > 0

@@ -270,6 +270,62 @@ def test_token_pool_survives_a_lost_worker_and_drops_stale_jobs(tmp_path):
         pool.close()
 
 
+def _slow_write(path, text, delay, parent=0):
+    import time
+    with open(path, "w", newline="") as f:
+        f.write(text[:3])                      # a partial file, should the writer die here
+        f.flush()
+        if os.getpid() != parent:              # (slow in a worker only)
+            time.sleep(delay)
+        f.write(text[3:])
+    return len(text)
+
+
+def test_queued_batch_writes_survive_a_lost_worker(tmp_path):
+    """a pool that is given up never completes the writes queued on it; waiting for
+    them without a limit hung the command (and, with more ranks, everybody else in the next
+    collective).  finish_writes() polls, notices the loss and redoes the writes inline; a file
+    a killed writer left half written is written again."""
+    import os
+    import signal
+    import time
+    from fandom_search_amd import search
+    pool = search.TokenPool(2)
+    try:
+        done = tmp_path / "done.csv"
+        pool.write_async(_slow_write, (str(done), "finished\r\n", 0.0))
+        time.sleep(0.3)
+        a, b = tmp_path / "a.csv", tmp_path / "b.csv"
+        pool.write_async(_slow_write, (str(a), "first batch\r\n", 30.0, os.getpid()))
+        pool.write_async(_slow_write, (str(b), "second batch\r\n", 30.0, os.getpid()))
+        time.sleep(0.3)
+        for p in pool.pool._pool:
+            os.kill(p.pid, signal.SIGKILL)
+        t0 = time.time()
+        pool.finish_writes()
+        assert time.time() - t0 < 10 and pool.pool is None and not pool.writes
+        assert done.read_bytes() == b"finished\r\n"
+        assert a.read_bytes() == b"first batch\r\n" and b.read_bytes() == b"second batch\r\n"
+        # with the pool gone a write is done at finish_writes() at the latest
+        c = tmp_path / "c.csv"
+        pool.write_async(_slow_write, (str(c), "third\r\n", 0.0))
+        pool.finish_writes()
+        assert c.read_bytes() == b"third\r\n"
+    finally:
+        pool.close()
+
+
+def test_a_failing_batch_write_is_raised_by_finish_writes(tmp_path):
+    from fandom_search_amd import search
+    pool = search.TokenPool(2)
+    try:
+        pool.write_async(_slow_write, (str(tmp_path / "no" / "such" / "dir.csv"), "x", 0.0))
+        with pytest.raises(FileNotFoundError):
+            pool.finish_writes()
+    finally:
+        pool.close()
+
+
 def test_prefilter_rule_for_eight_windows_at_once():
     """k_scan_near8 (fs_scan.hip: window_flags_near8) decides a lane's eight windows with runs of
     set bits instead of a loop over the windows: with T = n - 2 three-gram tests per window and
