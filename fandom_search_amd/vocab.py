@@ -99,7 +99,13 @@ def tokenize(text):
 def chunk_text(txt, size=100000):
     """Chunking of sp_parse_chunks (search.py:47-63): pieces of at most
     100000 characters cut at a space; the `size` argument is ignored by the
-    reference too (100000 is hard-coded at :51,:56)."""
+    reference too (100000 is hard-coded at :51,:56).  Held to the reference's own
+    function by tests/golden/make_search_golden.py, its two oddities included: a rest
+    of exactly 100000 characters indexes one past the end (IndexError, as the reference),
+    and where no space lies within 100000 characters the reference's index walks back
+    below the chunk's start -- past 0 it wraps round to the end of the text -- and it
+    either raises IndexError (no space anywhere) or yields chunks for ever; the endless
+    case is an error here."""
     if len(txt) < 100000:
         yield txt
         return
@@ -111,6 +117,14 @@ def chunk_text(txt, size=100000):
         else:
             while txt[end] != ' ':
                 end -= 1
+                if end < start:
+                    if ' ' not in txt:
+                        raise IndexError('string index out of range')
+                    raise ValueError('no space within 100000 characters at offset %d: the '
+                                     'reference (search.py:57-58) does not terminate on this text'
+                                     % start)
+            if end < start:                    # (a space at start - 1 ... cannot happen: start = end + 1)
+                raise ValueError('no space within 100000 characters at offset %d' % start)
         yield txt[start:end]
         start = end + 1
 
