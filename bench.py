@@ -183,7 +183,7 @@ def cpu_reference_shaped(window):
     works of configs[0] (c1: 50 works x 1000 tokens, 5000-token script).  Runs before
     anything touches the GPU (the pool forks)."""
     import multiprocessing as mp
-    from fandom_search_amd import synth, vocab
+    from fandom_search_amd import abi, synth, vocab
     from oracle import nearpy_restated as nr
     from oracle import search_restated as sr
     conf = synth.CONFIGS["c1"]
@@ -200,7 +200,7 @@ def cpu_reference_shaped(window):
     rows = [[words[t], voc.orth(t), int(scene[i]), char[i]] for i, t in enumerate(script)]
     t0 = time.perf_counter()
     _REF["idx"] = sr.AnnIndexSearch(rows, toks(script), window, 15, 14, 0.1, normals,
-                                    arith=nr.LiteralArith(), unique_filter=True)
+                                    arith=nr.LiteralArith(), unique_filter=abi.default_unique_filter())
     t_index = time.perf_counter() - t0
     _REF["toks"] = toks
     _REF["works"] = [tok[int(off[w]):int(off[w + 1])] for w in range(conf["n_works"])]
@@ -452,6 +452,11 @@ def main():
     cmd = launcher_command(args, sys.argv[1:], os.environ)
     if cmd is not None:
         import subprocess
+        if args.backend == "nccl":
+            # (device_count() does not initialise the GPU on this image: the parent stays clean)
+            import torch
+            from fandom_search_amd.dist import check_device_count
+            check_device_count(0, args.gpus, torch.cuda.device_count())
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         sys.exit(subprocess.call(cmd, env=env))
     os.environ["FS_LANES"] = str(max(1, args.lanes))
@@ -474,12 +479,16 @@ def main():
 
     rehearsal = args.backend == "gloo"
     dev_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(dev_index)
-    if world > 1:
-        if rehearsal:
+    if world > 1 and not rehearsal:
+        # one process per GPU over RCCL: refuse up front when two ranks would share a device
+        # (fandom_search_amd.dist.init_nccl_checked: device count, then identities through the
+        # rendezvous store, then the first collective)
+        from fandom_search_amd.dist import init_nccl_checked
+        init_nccl_checked(local_rank, world)
+    else:
+        torch.cuda.set_device(dev_index)
+        if world > 1:
             dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- workload -------------------------------------------------------------------
     scaling = args.scaling or ("strong" if world > 1 else "weak")

@@ -53,7 +53,7 @@ class FsStats(C.Structure):
                 ("path", C.c_uint32),
                 ("scan_launches", C.c_uint32),
                 ("lsh_pending", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("handoff_fallbacks", C.c_uint32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -82,11 +82,28 @@ ROW_DTYPE = np.dtype([("work", np.uint32), ("fan_ix", np.uint32),
 assert ROW_DTYPE.itemsize == 32
 
 
+def default_unique_filter():
+    """Whether a query's bucket contents go through NearPy's UniqueFilter before the
+    distances are taken.  OFF by default: the reference calls `engine.neighbours(row)`
+    with no arguments (/root/reference/search.py:178), and NearPy 1.0.0 -- the release pip
+    installed when the reference was written; requirements.txt pins none -- applies fetch
+    filters only when they are passed to neighbours() itself (`if fetch_vector_filters:`
+    on the ARGUMENT; the engine's own default [UniqueFilter()] is never consulted there),
+    so a script window found under k of the 15 hashes comes back k times and takes k of
+    NearestFilter(10)'s places.  NearPy 0.2.x applied the engine's filter:
+    FANDOM_SEARCH_UNIQUE_FILTER=1 (or `ao3.py search --unique-filter 1`) gives that."""
+    import os
+    return os.environ.get("FANDOM_SEARCH_UNIQUE_FILTER", "0").strip() not in ("", "0", "false", "no", "off")
+
+
 def make_config(window_size=6, number_of_hashes=15, hash_dimensions=14,
                 distance_threshold=0.1, emb_dim=300, nearest_n=10,
-                unique_filter=True, mode=FS_MODE_AUTO, device=0):
+                unique_filter=None, mode=FS_MODE_AUTO, device=0):
     """Defaults are the keyword defaults of the reference's analyze()
-    (/root/reference/search.py:336-341) and NearPy's Engine defaults."""
+    (/root/reference/search.py:336-341) and what NearPy's Engine does with the defaults
+    the reference leaves it (unique_filter: default_unique_filter())."""
+    if unique_filter is None:
+        unique_filter = default_unique_filter()
     cfg = FsConfig()
     cfg.struct_size = C.sizeof(FsConfig)
     cfg.window_size = window_size

@@ -41,6 +41,10 @@ def build_parser():
     search_parser.add_argument('--synthetic-vocab', action='store_true',
                                help='use the synthetic benchmark vocabulary (8192 pseudo-words '
                                     'with random vectors: no semantic similarity)')
+    search_parser.add_argument('--unique-filter', default=None, type=int, choices=(0, 1),
+                               help="NearPy's UniqueFilter on a query's bucket contents: 0 = what "
+                                    "NearPy 1.0.0 does for the reference's call (default), 1 = "
+                                    "NearPy 0.2.x; also FANDOM_SEARCH_UNIQUE_FILTER")
     search_parser.set_defaults(func=_search)
 
     data_parser = subparsers.add_parser(
@@ -80,6 +84,8 @@ def _search(args):
         os.environ['FANDOM_SEARCH_VECTORS'] = args.vectors
     if getattr(args, 'synthetic_vocab', False):
         os.environ['FANDOM_SEARCH_SYNTHETIC_VOCAB'] = '1'
+    if getattr(args, 'unique_filter', None) is not None:
+        os.environ['FANDOM_SEARCH_UNIQUE_FILTER'] = str(args.unique_filter)
     return search.analyze(args)
 
 

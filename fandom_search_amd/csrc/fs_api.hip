@@ -943,7 +943,7 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
         return FS_E_INVALID;
       }
   const uint64_t T = c->n_tok;
-  sl.c = c; sl.rows = rows; sl.cap = cap; sl.mode = rows_mode; sl.launches = 0;
+  sl.c = c; sl.rows = rows; sl.cap = cap; sl.mode = rows_mode; sl.launches = 0; sl.fallbacks = 0;
   sl.header = header;
   sl.lane = (int)(id % (uint32_t)ix->n_lanes);
   const fs_index::Lane& ln = ix->lanes[sl.lane];
@@ -1163,6 +1163,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
       sl.capw = fs_scan_direct_ok(ix, T) ? std::max<uint32_t>(64, ix->lanes[sl.lane].capw_hint) : 0;
       sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ix->lanes[sl.lane].w_cpos.n);
       ix->wait_fallbacks++;
+      sl.fallbacks++;
       FS_TRY(search_enqueue(ix, sl));
       continue;
     }
@@ -1207,6 +1208,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     st->path = sl.exact ? FS_MODE_EXACT : FS_MODE_GENERAL;
     st->scan_launches = sl.launches;
     st->lsh_pending = sl.exact ? 0 : hs.lsh_pending;
+    st->handoff_fallbacks = sl.fallbacks;
   }
   if (!sl.exact) ix->lanes[sl.lane].pend_hint = hs.lsh_pending;
   if (hs.n_rows > sl.cap) return FS_E_CAPACITY;

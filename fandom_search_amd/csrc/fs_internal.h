@@ -303,7 +303,7 @@ struct fs_index {
     bool host_wire8 = false;          // FS_ROWS_HOST: 8-byte records cross PCIe, fs_row made on the host
     bool host_direct = false;         //   ... stored into pinned host memory by the search's last kernel
     bool exact = false;
-    uint32_t n_bm = 0, launches = 0;
+    uint32_t n_bm = 0, launches = 0, fallbacks = 0;
     bool timed = false;               // this search's scan carries timing events
     bool whole_timed = false;         // ... and ev_begin / ev_end bracket the whole search
     int tpl = 4;                      // tokens per lane of the bitmap layout
@@ -434,7 +434,7 @@ int fs_launch_strrec(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_ctab(fs_index* ix, fs_corpus* c, hipStream_t s);
 // fs_scan.hip: scan + records in one kernel (k_scan_rows)
 namespace fsdev { struct RowSync; }
-int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy);   // fs_ranges.hip
+int fs_row_sync(fs_index* ix, uint32_t n_blocks, uint64_t n_tok, fsdev::RowSync* sy);   // fs_ranges.hip
 int fs_launch_compact_after_scan_rows(fs_index* ix, uint32_t n_ranges, uint32_t waves, uint32_t caprow,
                                       int wire, uint32_t rcap, fs_row* d_rows,
                                       fs_status* host_st, hipStream_t s, uint64_t* count_out,

@@ -473,7 +473,9 @@ struct RowSync {
   unsigned long long* sgran; // [n_blocks][4] {epoch << 32 | hits, pairs, candidates, max records of a range}
   uint32_t epoch;            // >= 1
   uint32_t n_blocks;
-  uint32_t spin_limit;       // polls of one batch of granules before the wait gives up
+  uint32_t spin_limit;       // polls of one batch of granules before the wait gives up (FS_WAIT_SPINS; tests: 0)
+  uint32_t wait_ticks;       // ... and the time it may take, in ticks of the 100 MHz constant clock: a few
+                             // times what the launch needs for its scan (fs_row_sync), not "about a second"
   // the other finish (searches overlapped on several lanes: a waiting workgroup would hold
   // its CU): per-range and per-workgroup counts go to memory and k_compact, the next
   // kernel, puts the records into place
@@ -609,6 +611,7 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
   // epoch.  Wave w takes the granules [64 w, 64 w + 64), and so on in steps of the
   // workgroup: the waves poll side by side, one round trip when everybody is done.
   uint32_t pre = 0;
+  const uint64_t t_wait0 = __builtin_amdgcn_s_memrealtime();
   for (uint32_t i0 = wave * 64; i0 < L; i0 += n_waves * 64) {
     const uint32_t i = i0 + lane;
     unsigned long long v = 0;
@@ -619,7 +622,10 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
         ok = (uint32_t)(v >> 32) == sy.epoch;
       }
       if (spins > 16) __builtin_amdgcn_s_sleep(1);
-      if (spins >= sy.spin_limit) { gave_up = true; break; }   // default: about a second
+      if (spins >= sy.spin_limit) { gave_up = true; break; }
+      // (the clock every 32nd poll: the workgroups in front are co-resident and publish when
+      // their scan is through; a wait of several scans' length means one of them is not running)
+      if ((spins & 31) == 31 && __builtin_amdgcn_s_memrealtime() - t_wait0 > sy.wait_ticks) { gave_up = true; break; }
     }
     pre += (i < L && ok) ? (uint32_t)v : 0u;
   }
@@ -687,6 +693,7 @@ __device__ __forceinline__ void finish_rows(const RowSync& sy, const RowFinal& f
               (uint32_t)(c2 >> 32) == sy.epoch && (uint32_t)(d2 >> 32) == sy.epoch) break;
           if (spins > 16) __builtin_amdgcn_s_sleep(8);
           if (spins >= sy.spin_limit) { gave_up = true; break; }
+          if ((spins & 31) == 31 && __builtin_amdgcn_s_memrealtime() - t_wait0 > sy.wait_ticks) { gave_up = true; break; }
         }
         h += (uint32_t)a; pr += (uint32_t)b; cd += (uint32_t)c2;
         mx = (uint32_t)d2 > mx ? (uint32_t)d2 : mx;

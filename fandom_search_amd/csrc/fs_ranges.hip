@@ -208,7 +208,7 @@ static int launch_compact(fs_index* ix, uint32_t n_ranges, uint32_t csum_per, ui
 
 // The lane's hand-off words for one launch of `n_blocks` workgroups that end in
 // finish_rows: granules and statistics per workgroup, next epoch.
-int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy) {
+int fs_row_sync(fs_index* ix, uint32_t n_blocks, uint64_t n_tok, fsdev::RowSync* sy) {
   fs_index::Lane& ln = *ix->cur;
   if (n_blocks > FS_SYNC_BLOCKS) { fs_set_error("%u workgroups in a records kernel", n_blocks); return FS_E_INVALID; }
   if (!ln.w_gran.p) {
@@ -221,7 +221,17 @@ int fs_row_sync(fs_index* ix, uint32_t n_blocks, fsdev::RowSync* sy) {
   sy->sgran = ln.w_gran.p + FS_SYNC_BLOCKS;
   sy->epoch = ln.sync_epoch;
   sy->n_blocks = n_blocks;
-  sy->spin_limit = ix->sw.wait_spins >= 0 ? (uint32_t)ix->sw.wait_spins : (1u << 22);
+  sy->spin_limit = ix->sw.wait_spins >= 0 ? (uint32_t)ix->sw.wait_spins : 0xffffffffu;
+  // time limit of the in-launch hand-off: 500 us + eight times what the scan of this corpus
+  // takes at 1 TB/s (a C2 batch: 80 us -> 1.1 ms; a 2 GB corpus: 16.5 ms).  A launch whose
+  // workgroups are all resident hands off within microseconds of its last scanner; what this
+  // guards against is a workgroup that is not running (co-residency lost), and then the
+  // search is repeated through the chained kernels (fs_stats.handoff_fallbacks)
+  {
+    const double scan_us = (double)n_tok * 4.0 / 1.0e6;           // bytes / (1 TB/s) in us
+    const double lim_us = 500.0 + 8.0 * scan_us;
+    sy->wait_ticks = (uint32_t)std::min<double>(4.0e9, lim_us * 100.0);
+  }
   sy->rinfo = nullptr; sy->csum = nullptr; sy->cmax = nullptr;
   // several lanes (searches overlapped on the GPU): a workgroup waiting inside the launch
   // would hold its CU; the counts go to memory instead and k_compact finishes

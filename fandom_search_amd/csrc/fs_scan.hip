@@ -1256,7 +1256,7 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
   const uint32_t n_sub = (uint32_t)((c->n_tok + 511) / 512);
   FS_TRY(ln.w_stage.reserve((size_t)n_ranges * caprow * stage_bytes));
   fsdev::RowSync sy;
-  FS_TRY(fs_row_sync(ix, blocks, &sy));
+  FS_TRY(fs_row_sync(ix, blocks, c->n_tok, &sy));
   // shared rounds (the launch puts the records into place itself): a pool of records per
   // workgroup for the slices' output, grown when a search reports that it ran out
   uint32_t xpool = 0;

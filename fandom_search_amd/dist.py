@@ -32,6 +32,75 @@ def env_world():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+class DeviceMapError(RuntimeError):
+    """Two ranks of an RCCL run would use the same GPU."""
+
+
+def check_device_count(local_rank, local_world, visible):
+    """Before anything else of a one-GPU-per-rank run: `visible` devices must cover the
+    node's ranks.  RCCL refuses a communicator with two ranks on one device only after
+    its bootstrap, with a message about duplicate GPUs from inside the first collective
+    (or a hang, when only some of the ranks get that far); this says it up front."""
+    if visible < local_world or local_rank >= visible:
+        raise DeviceMapError(
+            "%d ranks on this node but %d GPU(s) visible (LOCAL_RANK %d): two ranks would share a "
+            "device and the RCCL communicator cannot be formed.  Run with --gpus <= %d, or, to "
+            "rehearse the multi-rank code on one GPU, with the gloo backend (bench.py --backend "
+            "gloo / FANDOM_SEARCH_DIST_BACKEND=gloo)" % (local_world, visible, local_rank, max(1, visible)))
+
+
+def verify_distinct_devices(store, rank, world, ident, timeout_s=60.0):
+    """Every rank publishes what tells its GPU apart on its node (host name + PCI bus id, or
+    the device's UUID) in the rendezvous store -- plain TCP, no collective -- and reads the
+    others': the same identity on two ranks raises DeviceMapError on both, naming them."""
+    import datetime
+    store.set("fs_device/%d" % rank, ident)
+    keys = ["fs_device/%d" % r for r in range(world)]
+    store.wait(keys, datetime.timedelta(seconds=timeout_s))
+    seen = {}
+    for r, k in enumerate(keys):
+        v = store.get(k)
+        v = v.decode("utf-8", "replace") if isinstance(v, bytes) else str(v)
+        if v in seen:
+            raise DeviceMapError("ranks %d and %d both map to device %s: one process per GPU is "
+                                 "required (check LOCAL_RANK and the *_VISIBLE_DEVICES variables)"
+                                 % (seen[v], r, v))
+        seen[v] = r
+
+
+def device_identity(index):
+    """Host name + what identifies device `index` physically."""
+    import socket
+    import torch
+    p = torch.cuda.get_device_properties(index)
+    uuid = getattr(p, "uuid", None)
+    bus = "%s:%s:%s" % (getattr(p, "pci_domain_id", "?"), getattr(p, "pci_bus_id", "?"),
+                        getattr(p, "pci_device_id", "?"))
+    return "%s/%s/%s" % (socket.gethostname(), bus, uuid)
+
+
+def init_nccl_checked(local_rank, world):
+    """init_process_group("nccl") for one process per GPU, failing fast and clearly when two
+    ranks map to one device (the first real RCCL run must not end in a hang): device count
+    first, then the process group WITHOUT a bound device (no communicator is formed yet),
+    the identities compared through the store, and only then the first collective."""
+    import torch
+    import torch.distributed as dist
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE") or world)
+    check_device_count(local_rank, local_world, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl")
+    try:
+        from torch.distributed.distributed_c10d import _get_default_store
+        verify_distinct_devices(_get_default_store(), dist.get_rank(), world, device_identity(local_rank))
+    except DeviceMapError:
+        raise
+    except Exception as e:              # (a store without wait/get, a torch without the accessor: not fatal)
+        import sys
+        print("warning: device map not verified (%r)" % (e,), file=sys.stderr)
+    dist.barrier(device_ids=[local_rank])       # the communicator, here and now
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* when
     WORLD_SIZE > 1.  Returns (rank, local_rank, world)."""
@@ -45,8 +114,7 @@ def init_from_env(backend=None):
                 backend = os.environ.get("FANDOM_SEARCH_DIST_BACKEND") or \
                     ("nccl" if torch.cuda.is_available() else "gloo")
             if backend == "nccl":
-                torch.cuda.set_device(local_rank)
-                dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
+                init_nccl_checked(local_rank, world)
             else:
                 dist.init_process_group(backend)
     return rank, local_rank, world

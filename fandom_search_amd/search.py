@@ -392,7 +392,7 @@ class AnnIndexSearch(object):
     def __init__(self, original_script_filename, window_size,
                  number_of_hashes, hash_dimensions, distance_threshold,
                  vocab=None, normals=None, device=0, mode=abi.FS_MODE_AUTO,
-                 unique_filter=True):
+                 unique_filter=None):
         from .engine import ScriptIndex   # needs the HIP library: fail loudly
 
         orig_csv = load_markup_script(original_script_filename)[1:]

@@ -70,7 +70,7 @@ typedef struct fs_config {
   uint32_t hash_dimensions;    /* B <= 24      search.py:339  default 14      */
   uint32_t emb_dim;            /* D            300 for en_core_web_md         */
   uint32_t nearest_n;          /* NearPy NearestFilter(N) default 10          */
-  uint32_t unique_filter;      /* NearPy UniqueFilter on fetch, default 1     */
+  uint32_t unique_filter;      /* NearPy UniqueFilter on fetch: 0 = NearPy 1.0.0 for the reference's call (host default), 1 = NearPy 0.2.x */
   uint32_t mode;               /* FS_MODE_*                                   */
   int32_t  device;             /* HIP device ordinal                          */
   uint32_t reserved;
@@ -103,7 +103,10 @@ typedef struct fs_stats {
   uint32_t lsh_pending;        /* general pipeline: candidate windows that took the full LSH
                                   path (keys, buckets, distances), a wave each; the others
                                   ended in the lane-per-candidate steps                  */
-  uint32_t reserved;
+  uint32_t handoff_fallbacks;  /* times this call ran its search again through the chained
+                                  kernels because the in-launch hand-off of k_scan_rows gave
+                                  up (a workgroup waited longer than a few scan times for
+                                  the ones in front: co-residency lost); 0 in normal running */
 } fs_stats;
 
 typedef struct fs_index_info {

@@ -190,7 +190,13 @@ class NearestFilter(object):
 
 
 class Engine(object):
-    def __init__(self, lshashes, arith, unique_filter=True, nearest=10):
+    def __init__(self, lshashes, arith, unique_filter=False, nearest=10):
+        """unique_filter: whether neighbours() sends the bucket contents through UniqueFilter.
+        NearPy 1.0.0's neighbours(v, distance=None, fetch_vector_filters=None,
+        vector_filters=None) tests the ARGUMENT (`if fetch_vector_filters:`) and never falls
+        back to the engine's own [UniqueFilter()], unlike vector_filters and distance; the
+        reference passes nothing (search.py:178): OFF.  NearPy 0.2.x applied
+        self.fetch_vector_filters: ON gives that behaviour."""
         self.lshashes = lshashes
         self.arith = arith
         self.storage = MemoryStorage()

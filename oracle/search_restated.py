@@ -100,7 +100,7 @@ def _windows(vectors, window_size):
 
 
 def build_lsh_engine(orig, window_size, number_of_hashes, hash_dimensions,
-                     normals, oov_hash, arith, unique_filter=True):
+                     normals, oov_hash, arith, unique_filter=False):
     """search.py:86-124.  `orig` is the list of lower-cased script tokens
     (the reference's Doc(vocab, word_lowercase), search.py:151);
     normals[h] is the (hash_dimensions, D*n) matrix of hash h."""
@@ -132,7 +132,7 @@ class AnnIndexSearch(object):
 
     def __init__(self, script_rows, script_toks, window_size,
                  number_of_hashes, hash_dimensions, distance_threshold,
-                 normals, oov_hash=None, arith=None, unique_filter=True):
+                 normals, oov_hash=None, arith=None, unique_filter=False):
         orig_csv = [[i] + list(r) for i, r in enumerate(script_rows)]
         (self.word_index,
          self.word_lowercase,

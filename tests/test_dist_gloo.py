@@ -99,6 +99,15 @@ WORKER = textwrap.dedent('''
 ''')
 
 
+def _free_port():
+    """A rendezvous port nobody holds right now (two test runs on one box must not collide
+    on a hard-coded one)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def _run(tmp_path, outdir, fandir, script, world, check=True, **extra):
     worker = tmp_path / "worker.py"
     worker.write_text(WORKER % dict(root=ROOT))
@@ -109,7 +118,7 @@ def _run(tmp_path, outdir, fandir, script, world, check=True, **extra):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", "29533", str(worker), outdir, fandir, script]
+               "--master-port", str(_free_port()), str(worker), outdir, fandir, script]
     r = subprocess.run(cmd, check=check, env=env, timeout=600, cwd=ROOT,
                        stdout=None if check else subprocess.PIPE, stderr=None if check else subprocess.STDOUT, text=True)
     if not check:
@@ -254,7 +263,7 @@ def test_ranks_with_different_record_formats_and_an_empty_shard(tmp_path):
     worker = tmp_path / "mixed.py"
     worker.write_text(MIXED_WORKER % dict(root=ROOT))
     for world in (2, 3):
-        r = _torchrun(worker, world, 29541 + world, "mixed")
+        r = _torchrun(worker, world, _free_port(), "mixed")
         assert r.returncode == 0, r.stdout[-3000:]
         assert "MIXED_OK" in r.stdout
 
@@ -267,7 +276,7 @@ def test_a_failing_rank_stops_every_rank(tmp_path):
     worker = tmp_path / "mixed.py"
     worker.write_text(MIXED_WORKER % dict(root=ROOT))
     t0 = time.time()
-    r = _torchrun(worker, 2, 29547, "fail")
+    r = _torchrun(worker, 2, _free_port(), "fail")
     assert r.returncode != 0
     assert time.time() - t0 < 120, "the surviving rank waited for the failed one"
     assert "boom on rank 1" in r.stdout
@@ -317,10 +326,61 @@ def test_two_ranks_with_the_hip_searcher(tmp_path):
         else:
             cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                    "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-                   "--master-port", "29534", str(worker), outdir, fandir, spath]
+                   "--master-port", str(_free_port()), str(worker), outdir, fandir, spath]
         subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
         outs[world] = {f: open(os.path.join(outdir, f), "rb").read() for f in sorted(os.listdir(outdir))}
     assert list(outs[1]) == list(outs[2]) and len(outs[1]) == 4
     for name in outs[1]:
         assert outs[1][name] == outs[2][name], name
     assert sum(len(v) for v in outs[1].values()) > 1000
+
+
+def test_two_ranks_on_one_device_are_refused_up_front():
+    """The first RCCL run must not end in a hang inside a collective: fewer visible devices
+    than ranks, or two ranks with the same device identity, raise DeviceMapError before any
+    communicator is formed (dist.init_nccl_checked; the identities travel through the
+    rendezvous store, here an in-process one driven from two threads)."""
+    import threading
+    import torch.distributed as tdist
+    from fandom_search_amd import dist as fdist
+    fdist.check_device_count(1, 2, 2)
+    fdist.check_device_count(7, 8, 8)
+    with pytest.raises(fdist.DeviceMapError, match="2 ranks on this node but 1 GPU"):
+        fdist.check_device_count(1, 2, 1)
+    with pytest.raises(fdist.DeviceMapError):
+        fdist.check_device_count(0, 8, 4)
+
+    def run(idents):
+        store = tdist.HashStore()
+        errs = [None] * len(idents)
+
+        def rank(r):
+            try:
+                fdist.verify_distinct_devices(store, r, len(idents), idents[r], timeout_s=20)
+            except Exception as e:
+                errs[r] = e
+
+        ts = [threading.Thread(target=rank, args=(r,)) for r in range(len(idents))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(30)
+        return errs
+
+    assert run(["box/0:1:0/a", "box/0:2:0/b", "box/0:3:0/c"]) == [None, None, None]
+    errs = run(["box/0:1:0/a", "box/0:1:0/a"])
+    assert all(isinstance(e, fdist.DeviceMapError) for e in errs)
+    assert "ranks 0 and 1 both map to device box/0:1:0/a" in str(errs[0])
+
+
+def test_bench_refuses_an_nccl_run_with_fewer_devices_than_ranks():
+    """`bench.py --gpus 2 --backend nccl` on a box with fewer than two GPUs (this container:
+    none) ends at once with the reason, in the parent, before any rank is started."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "nccl",
+                        "--steps", "1", "--warmup", "0"], cwd=ROOT, timeout=300, text=True,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")})
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices here: the run itself is the driver's to make")
+    assert r.returncode != 0 and "GPU(s) visible" in r.stdout and "gloo" in r.stdout

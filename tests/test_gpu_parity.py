@@ -701,6 +701,10 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
         rows, st = ix.search(c)
         rows2, _ = ix.search(c)
         assert rows.tobytes() == rows2.tobytes()
+        # the hand-off's give-up is counted per call (and nowhere else does one happen)
+        if n <= 8 and "FS_SCAN_ROWS" not in env:
+            fell_back = env.get("FS_WAIT_SPINS") == "0" and "FS_LANES" not in env
+            assert (st.handoff_fallbacks > 0) == fell_back, (env, st.handoff_fallbacks)
         wires = []
         cap = len(rows) + 3
         for packed, size in ((True, 16), (8, 8)):
