@@ -156,6 +156,11 @@ def load():
     if hasattr(L, "fs_debug_stamps"):      # (absent from older builds loaded through FS_LIB_FILE)
         L.fs_debug_stamps.restype = C.c_int
         L.fs_debug_stamps.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_uint64, u64p]
+    if hasattr(L, "fs_search_profile"):    # (absent from older builds loaded through FS_LIB_FILE)
+        L.fs_search_profile.restype = C.c_int
+        L.fs_search_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,
+                                        C.c_char_p, C.c_uint64, C.POINTER(C.c_double), C.c_uint32,
+                                        C.POINTER(C.c_uint32)]
     L.fs_scan_benchmark.restype = C.c_int
     L.fs_scan_benchmark.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32,
                                     C.POINTER(C.c_double)]

@@ -75,6 +75,7 @@ fs_index::~fs_index() {
   if (h_status) (void)hipHostFree(h_status);
   if (h_stage) (void)hipHostFree(h_stage);
   if (host_pool) fs_host_pool_free(host_pool);
+  for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
   for (int l = 0; l < FS_LANES; ++l)
     if (lanes[l].stream) (void)hipStreamDestroy(lanes[l].stream);
   for (int i = 0; i < FS_SEARCH_SLOTS; ++i) {
@@ -120,6 +121,7 @@ void fs_read_switches(fs_switches* sw) {
   sw->lsh_diag = num("FS_LSH_DIAG");
   sw->lsh_lev_lane = getenv("FS_LSH_LEV_LANE") ? num("FS_LSH_LEV_LANE") : 1;
   sw->scan_near8 = !getenv("FS_SCAN_NEAR8") || num("FS_SCAN_NEAR8") != 0;
+  sw->near_fused = !getenv("FS_NEAR_FUSED") || num("FS_NEAR_FUSED") != 0;
   sw->end_query = !getenv("FS_END_QUERY") || num("FS_END_QUERY") != 0;
   sw->lsh_no_gtab = getenv("FS_LSH_NO_GTAB") != nullptr;
   sw->lsh_serial = getenv("FS_LSH_SERIAL") != nullptr;
@@ -535,7 +537,8 @@ extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   const int n = (int)ix->cfg.window_size;
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   if (!exact) {
-    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? "k_lsh_scan" : fs_scan_near8(ix) ? "k_scan_near8<%d>" : "k_scan_near<%d>", n);
+    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? "k_lsh_scan" : fs_near_fused(ix, c) ? "k_near_sift<%d>" :
+                                fs_scan_near8(ix) ? "k_scan_near8<%d>" : "k_scan_near<%d>", n);
   } else if (uint32_t blocks = 0; fs_scan_rows_shape(ix, c, &blocks)) {
     const int k = ix->sw.scan_sub && ix->d_sfilter.p ? fs_sub_k(n) : 0;
     snprintf(name, sizeof name, "k_scan_rows<%d,%d>", n, k);
@@ -874,6 +877,7 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   const bool whole = sl.timed && ix->scan_timing_period <= 1 && ix->sync_call;
   if (whole) FS_HIP(hipEventRecord(sl.ev_begin, s));
   sl.whole_timed = whole;
+  if (ix->prof.on) fs_prof_mark(ix, s, "<begin>");
   hipEvent_t e0 = sl.timed ? sl.ev_scan0 : nullptr, e1 = sl.timed ? sl.ev_scan1 : nullptr;
   const uint32_t ccap32 = (uint32_t)std::min<uint64_t>(sl.ccap, 0xFFFFFFFFull);
   const uint32_t rcap32 = (uint32_t)std::min<uint64_t>(sl.rcap, 0xFFFFFFFFull);
@@ -881,30 +885,101 @@ static int search_enqueue(fs_index* ix, fs_index::Slot& sl) {
   if (sl.exact && sl.fused_waves) {
     // (the whole-search timing of the synchronous call keeps its own end marker)
     FS_TRY(fs_launch_scan_rows(ix, c, sl.fused_waves, sl.fused_blocks, rcap32, d_rows, wire, sl.caprow, sl.h_status, s,
-                               e0, e1, count_out, whole ? nullptr : sl.ev_end, &end_attached));
+                               e0, e1, count_out, whole || ix->prof.on ? nullptr : sl.ev_end, &end_attached));
+    if (ix->prof.on) fs_prof_mark(ix, s, ix->n_lanes > 1 ? "k_scan_rows+k_compact" : fs_search_kernel_name(ix, c));
   } else if (sl.exact) {
     fs_scan_extra ex;
     ex.bsum = ln.w_bsum.p; ex.zero = ln.d_status.p;
     if (sl.capw) { ex.recs = ln.w_recs.p; ex.info = ln.w_info.p; ex.capw = sl.capw; }
     FS_TRY(fs_launch_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
+    if (ix->prof.on) fs_prof_mark(ix, s, fs_search_kernel_name(ix, c));
     FS_TRY(fs_launch_post(ix, c, n_bm, sl.tpl, ccap32, rcap32, d_rows, wire, sl.h_status, s, ex, count_out));
+    if (ix->prof.on) fs_prof_mark(ix, s, "verify .. k_rows");
   } else {
     // tables whose proof fails by one slot only: the integer prefilter flags the windows
     // that can have a neighbour at all, the LSH work runs on those
     fs_scan_extra ex;
     ex.bsum = ln.w_bsum.p; ex.zero = ln.d_status.p;
-    if (fs_lsh_prefilter_ok(ix, c))
-      FS_TRY(fs_launch_scan_near(ix, c, ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
-    else
-      FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
-    FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, sl.tpl, s, ex.counted));
-    FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
+    if (sl.caps) {
+      // the prefilter and the wildcard filter in one kernel, the survivors in lists per wave
+      // range: no bitmap, no k_expand, an eighth of the entries for everything behind
+      FS_TRY(ln.w_slist.reserve((size_t)fs_near_ranges() * sl.caps));
+      FS_TRY(ln.w_scount.reserve(fs_near_ranges()));
+      FS_TRY(fs_launch_near_sift(ix, c, ln.w_slist.p, sl.caps, ln.w_scount.p, ln.w_bsum.p, ln.d_status.p, s, e0, e1));
+      if (ix->prof.on) fs_prof_mark(ix, s, fs_search_kernel_name(ix, c));
+      const fs_near_lists near{ln.w_slist.p, ln.w_scount.p, sl.caps};
+      FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s, &near));
+    } else {
+      if (fs_lsh_prefilter_ok(ix, c))
+        FS_TRY(fs_launch_scan_near(ix, c, ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1, &ex));
+      else
+        FS_TRY(fs_launch_lsh_scan(ix, c->dev(), ln.w_qbm.p, ln.w_qcnt.p, n_bm, s, e0, e1));
+      if (ix->prof.on) fs_prof_mark(ix, s, fs_search_kernel_name(ix, c));
+      FS_TRY(fs_launch_expand(ix, c, n_bm, ccap32, sl.tpl, s, ex.counted));
+      if (ix->prof.on) fs_prof_mark(ix, s, ex.counted ? "k_expand" : "k_reduce+k_expand");
+      FS_TRY(fs_launch_lsh_verify(ix, c, ccap32, s));
+    }
     FS_TRY(fs_launch_rows(ix, c, ln.w_cbest.p, 1, ccap32, rcap32, d_rows, 0, sl.h_status, s, count_out));
+    if (ix->prof.on) fs_prof_mark(ix, s, "k_hitrows+k_rows");
   }
   ++sl.launches;
   sl.lane_seq = ++ln.enqueued;
   if (!end_attached) FS_HIP(hipEventRecord(sl.ev_end, s));
   ix->cur = &ix->lanes[0];
+  return FS_OK;
+}
+
+// ---- per-kernel times of one search (diagnostics) ----------------------------------------
+int fs_prof_mark(fs_index* ix, hipStream_t s, const char* name) {
+  fs_index::Prof& pf = ix->prof;
+  if (pf.used == pf.ev.size()) {
+    hipEvent_t e;
+    FS_HIP(hipEventCreate(&e));
+    pf.ev.push_back(e);
+  }
+  FS_HIP(hipEventRecord(pf.ev[pf.used++], s));
+  pf.names.push_back(name);
+  return FS_OK;
+}
+
+extern "C" int fs_search_corpus(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap, int rows_on_device,
+                                uint64_t* n_rows, fs_stats* st);
+
+extern "C" int fs_search_profile(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap, int rows_on_device,
+                                 char* names, uint64_t names_cap, double* ms, uint32_t ms_cap, uint32_t* n_out) {
+  if (!ix || !c || !names || !ms || !n_out) { fs_set_error("null argument"); return FS_E_INVALID; }
+  *n_out = 0;
+  if (names_cap) names[0] = 0;
+  for (int i = 0; i < FS_SEARCH_SLOTS; ++i)
+    if (ix->slots[i].busy) { fs_set_error("fs_search_profile needs the index to itself"); return FS_E_INVALID; }
+  FS_ENTER(ix->device);
+  fs_index::Prof& pf = ix->prof;
+  uint64_t n_rows = 0;
+  // (a search that grows a workspace runs its kernels again: the marks of the last run count)
+  pf.on = true; pf.used = 0; pf.names.clear();
+  const int rc = fs_search_corpus(ix, c, rows, cap, rows_on_device, &n_rows, nullptr);
+  pf.on = false;
+  if (rc != FS_OK) return rc;
+  // marks of the last enqueue: from the last "begin" mark on
+  size_t first = 0;
+  for (size_t i = 0; i < pf.used; ++i)
+    if (pf.names[i][0] == '<') first = i;
+  uint32_t n = 0;
+  size_t at = 0;
+  for (size_t i = first + 1; i < pf.used; ++i) {
+    float t = 0;
+    FS_HIP(hipEventElapsedTime(&t, pf.ev[i - 1], pf.ev[i]));
+    if (n < ms_cap) ms[n] = t;
+    const size_t len = strlen(pf.names[i]);
+    if (at + len + 2 <= names_cap) {
+      memcpy(names + at, pf.names[i], len);
+      at += len;
+      names[at++] = '\n';
+      names[at] = 0;
+    }
+    ++n;
+  }
+  *n_out = n;
   return FS_OK;
 }
 
@@ -982,6 +1057,15 @@ extern "C" int fs_search_corpus_begin(fs_index* ix, fs_corpus* c, fs_row* rows, 
     if (ix->sw.ranges_caprow > 0) sl.caprow = (uint32_t)ix->sw.ranges_caprow;
   }
   if (sl.fused_waves) { sl.capw = 0; sl.tpl = 8; sl.n_bm = (uint32_t)((T + 511) / 512); }
+  // k_near_sift: list entries per wave range -- an eighth of its tokens to start with (a C2
+  // batch uses 17 of 305 on average at n = 8, 112 over component ids at n = 6), more once a
+  // search has asked for it
+  sl.caps = 0;
+  if (!sl.exact && fs_near_fused(ix, c)) {
+    sl.caps = std::max<uint32_t>((uint32_t)std::min<uint64_t>(std::max<uint64_t>(64, T / fs_near_ranges() / 8), 1u << 20),
+                                 ln.caps_hint);
+    if (ix->sw.scan_capw > 0) sl.caps = (uint32_t)ix->sw.scan_capw;   // tests: force the growth path
+  }
   // capacities: grown from the device totals when a stage overflows
   sl.ccap = std::max<uint64_t>(std::max<uint64_t>(4096, T / 16), ln.w_cpos.n);
   sl.rcap = rows_mode != FS_ROWS_HOST
@@ -1179,6 +1263,11 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     if (sl.caprow && hs.max_rows > sl.caprow) {
       sl.caprow = (hs.max_rows + hs.max_rows / 4 + 7) & ~7u;
       ix->lanes[sl.lane].caprow_hint = sl.caprow;
+      again = true;
+    }
+    if (sl.caps && hs.max_recs > sl.caps) {
+      sl.caps = (hs.max_recs + hs.max_recs / 4 + 7) & ~7u;
+      ix->lanes[sl.lane].caps_hint = sl.caps;
       again = true;
     }
     if (sl.capw && hs.max_recs > sl.capw) {

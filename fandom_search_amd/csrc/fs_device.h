@@ -45,6 +45,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan_dpp(uint32_t x) {
   return x;
 }
 
+// word >> (bits 8B .. 8B+4 of h): the shift takes the low five bits of the selected byte
+template <int B>
+__device__ __forceinline__ uint32_t shr_by_byte(uint32_t word, uint32_t h) {
+  uint32_t r;
+  if constexpr (B == 0)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  else if constexpr (B == 1)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  else if constexpr (B == 2)
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  else
+    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
+  return r;
+}
+
+
 // ---- block-wide helpers ----------------------------------------------------
 
 template <class V>

@@ -189,6 +189,7 @@ struct fs_switches {
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
   bool lsh_keys6 = true;          // FS_LSH_KEYS6=0: n = 6 over component ids without the middle-slot key filter in k_scan_near
   bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
+  bool near_fused = true;         // FS_NEAR_FUSED=0: k_scan_near8 + k_expand + k_lsh_sift (round 4's chain) instead of k_near_sift + k_lsh_sift2; read when the index is built (n = 6: which prefilter kernel the 3-gram filter is laid out for)
   bool lsh_gramtab = true;        // FS_LSH_GRAMTAB=0: no per-n-gram records (k_lsh_gramtab): every window with a script n-gram's ids walks the buckets
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)
   int rows_blocks_per_cu = 0;     // FS_ROWS_BLOCKS_PER_CU: workgroups of k_scan_rows per CU (experiments)
@@ -267,6 +268,8 @@ struct fs_index {
     DBuf<uint32_t> w_mcnt, w_mtop_s;   // k_lsh_verify -> k_lsh_lev: kept matches per pending window
     DBuf<double> w_mtop_d;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
+    DBuf<uint32_t> w_slist, w_scount;   // k_near_sift: survivors of the wildcard filter per wave range (caps each), their counts
+    uint32_t caps_hint = 0;        //   entries per wave range the last searches needed
     uint32_t capw_hint = 0;        // records per wave range that the last searches needed
     DBuf<uint8_t> w_stage;         // k_scan_rows: staged records, caprow per wave range
     uint32_t caprow_hint = 0;      //   staged records per wave range the last searches needed
@@ -309,6 +312,7 @@ struct fs_index {
     int tpl = 4;                      // tokens per lane of the bitmap layout
     int lane = 0;                     // the lane (stream + workspaces) it was queued on
     uint32_t capw = 0;                // direct path: record capacity per wave range (0: bitmap path)
+    uint32_t caps = 0;                // k_near_sift: list entries per wave range (0: the chained prefilter)
     uint32_t caprow = 0;              // k_scan_rows: staged records per wave range
     uint32_t fused_waves = 0;         // k_scan_rows: waves per workgroup (0: separate kernels)
     uint32_t fused_blocks = 0;        //              workgroups
@@ -319,6 +323,9 @@ struct fs_index {
   uint32_t scan_timing_period = 1;    // attach timing events to every k-th scan
   uint64_t searches = 0;
   uint64_t wait_fallbacks = 0;        // searches repeated through the chained kernels (finish_rows gave up)
+  // fs_search_profile: an event behind every kernel of one search (diagnostics; bench.py's
+  // per-kernel shares come from here)
+  struct Prof { bool on = false; std::vector<hipEvent_t> ev; std::vector<const char*> names; size_t used = 0; } prof;
 
   // corpora created on this index and still alive: fs_index_destroy detaches them, so that
   // a corpus destroyed after its index does not touch freed memory
@@ -408,7 +415,15 @@ int fs_launch_near_pairs(const float* emb, uint64_t n_vec, int D, const uint32_t
 int fs_launch_comp_map(fs_index* ix, fs_corpus* c, hipStream_t s);      // component ids of a batch's tokens
 int fs_lsh_prefilter_mode(const fs_index* ix, const fs_corpus* c);
 int fs_scan_near_k(int n);                                               // K of k_scan_near's K-gram tests      // 0 none, 1 vector ids, 2 component ids
-int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s);
+struct fs_near_lists { const uint32_t* slist; const uint32_t* scount; uint32_t caps; };
+int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s, const fs_near_lists* near = nullptr);
+int fs_prof_mark(fs_index* ix, hipStream_t s, const char* name);      // fs_api.hip
+void fs_lsh_wild_of(const fs_index* ix, const fs_corpus* c, const uint32_t** wild, int* log2_wild,
+                    const uint32_t** wild_tok);                        // fs_lsh.hip
+bool fs_near_fused(const fs_index* ix, const fs_corpus* c);            // fs_scan.hip: k_near_sift takes this search's prefilter
+uint32_t fs_near_ranges();                                              // wave ranges of k_near_sift
+int fs_launch_near_sift(const fs_index* ix, const fs_corpus* c, uint32_t* slist, uint32_t caps, uint32_t* scount,
+                        uint32_t* bsum, fs_status* zero, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 // fs_scan.hip: the integer prefilter of the LSH pipeline ("all but one slot identical")
 bool fs_lsh_prefilter_ok(const fs_index* ix, const fs_corpus* c);
 bool fs_scan_near8_wanted(const fs_index* ix);

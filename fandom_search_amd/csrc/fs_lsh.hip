@@ -877,19 +877,103 @@ __device__ __forceinline__ bool sift_keys(const CorpusDev& c, const LshDev& L, u
 // five to eight more levels of dependent loads) ran at a tenth of the lanes while every wave
 // had a survivor to wait for.  So the survivors queue up in LDS and stage 2 takes them 256 at
 // a time, a full lane each (round 4: 90 -> 40 us per C2 batch at n = 8).
-// word >> (bits 8B .. 8B+4 of h): the shift takes the low five bits of the selected byte
-template <int B>
-__device__ __forceinline__ uint32_t shr_by_byte(uint32_t word, uint32_t h) {
-  uint32_t r;
-  if constexpr (B == 0)
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
-  else if constexpr (B == 1)
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
-  else if constexpr (B == 2)
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
-  else
-    asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(h), "v"(word));
-  return r;
+// k_lsh_sift's second stage for one candidate per thread (il = FS_NONE: none; every thread of
+// the workgroup calls it: it holds barriers): the per-n-gram record, the exact one-slot map, or
+// onto the pending list.  Shared by k_lsh_sift and k_lsh_sift2.
+struct SiftOut {
+  uint32_t* cg; uint32_t* cw; fs_best* cbest;
+  const unsigned long long* tab_best; const uint32_t* tab_cnt;
+  uint32_t* pend; uint32_t* pend_cnt;
+  uint32_t* s_pn; uint32_t* s_pbase;          // LDS words of the workgroup
+};
+template <int NW, bool WMAP>
+__device__ __forceinline__ void sift_stage2(const CorpusDev& c, const LshDev& L, const GramIndexDev& g,
+                                            const SiftOut& o, uint32_t il, uint64_t p_in, uint32_t* matches_io) {
+  const int lane = threadIdx.x & 63;
+  uint32_t* const cg = o.cg; uint32_t* const cw = o.cw; fs_best* const cbest = o.cbest;
+  const unsigned long long* const tab_best = o.tab_best; const uint32_t* const tab_cnt = o.tab_cnt;
+  uint32_t* const pend = o.pend; uint32_t* const pend_cnt = o.pend_cnt;
+  uint32_t& s_pn = *o.s_pn; uint32_t& s_pbase = *o.s_pbase;
+  uint32_t& matches = *matches_io;
+  bool live = il != FS_NONE;
+  // 2. A window with the ids of a script n-gram (and the strings of those ids) takes the
+  //    n-gram's record of this string table (k_lsh_gramtab): no bucket is walked for it.
+  uint32_t gram = FS_NONE;
+  const uint64_t p = live ? p_in : 0;
+  if (tab_cnt && live && !(L.diag & 128)) {
+    uint32_t w = 0, kept = 0;
+    gram = verify_window(c, g, p, &w, &kept);
+    if (gram != FS_NONE) {
+      const uint32_t have = tab_cnt[gram];
+      if (have == 1) {
+        cg[il] = FS_NONE;                             // (no neighbour within the threshold)
+      } else {
+        const uint4* m = reinterpret_cast<const uint4*>(tab_best + 4 * (size_t)gram);
+        uint4* dst = reinterpret_cast<uint4*>(&cbest[il]);
+        dst[0] = m[0]; dst[1] = m[1];
+        cg[il] = 0;
+        cw[il] = w;
+        matches += have - 1;
+      }
+      live = false;
+    }
+  }
+  // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
+  //    slots but one (every neighbour within the threshold is one of them: m_min = n - 1) and
+  //    take their canonical distances.  None within the threshold: whatever the buckets hold,
+  //    nothing survives the threshold, and the window needs no LSH work.  One 32-byte bucket
+  //    of the map per slot, all n requested together; a window with more than two such
+  //    n-grams, or a full bucket in its way, is left to k_lsh_verify.
+  if (WMAP && live && L.wild && p + L.n <= c.n_tok && !(L.diag & 256)) {
+    uint32_t term[NW], fold = 0;
+    sift_keys<NW>(c, L, p, term, &fold, false);
+    Ids16 f;
+    load_ids(c.tok + p, L.n, &f);
+    uint32_t s0 = 0, s1 = 0, nh = 0;
+    int k0 = 0, k1 = 0;
+    bool possible = false;
+#pragma unroll
+    for (int k = 0; k < NW; ++k)
+      if (k < L.n) {
+        const uint32_t h = fs_wild_key(fold, term[k], k);
+        const uint4* bp = reinterpret_cast<const uint4*>(L.wmap + 4 * (size_t)fs_wmap_slot(h, L.log2_wmap));
+        const uint4 a = bp[0], b = bp[1];
+        const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (val[e] && key[e] == h) {
+            if (nh == 0) { s0 = val[e] - 1; k0 = k; }
+            else if (nh == 1) { s1 = val[e] - 1; k1 = k; }
+            ++nh;
+          }
+        possible = possible || val[3] != 0;       // (filled in order: the bucket is full)
+      }
+    possible = possible || nh > 2;
+    if (L.diag & 512) possible = possible || nh > 0;                 // diagnostics: no distances here
+    if (!possible && nh > 0) possible = one_slot_within<NW>(L, s0, k0, f);
+    if (!possible && nh > 1) possible = one_slot_within<NW>(L, s1, k1, f);
+    if (!possible) { cg[il] = FS_NONE; live = false; }
+  }
+  // what is left: onto the list k_lsh_verify deals out window by window (pending windows
+  // come in runs, the boundary windows of one quoted passage, so dealing out blocks of
+  // candidates leaves a few waves with most of the work)
+  // (one addition to the list's counter per workgroup: five thousand waves adding to the one
+  // address took 5 ns each, a third of the kernel)
+  const uint64_t pb = __ballot(live);
+  uint32_t wbase = 0;
+  if (pb && lane == 0) wbase = atomicAdd(&s_pn, (uint32_t)__popcll(pb));      // LDS
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t n_p = s_pn;
+    s_pbase = n_p ? atomicAdd(pend_cnt, n_p) : 0u;
+    s_pn = 0;
+  }
+  __syncthreads();
+  if (live) {
+    const uint32_t base = s_pbase + (uint32_t)__builtin_amdgcn_readlane((int)wbase, 0);
+    cg[il] = FS_PENDING;
+    pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
+  }
 }
 
 template <int NW, bool WMAP, int NN>
@@ -915,86 +999,9 @@ __global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, Gram
   if (threadIdx.x == 0) { s_qn = 0; s_pn = 0; }
   __syncthreads();
   // stage 2 for one queued candidate (FS_NONE: none); every thread of the workgroup calls it
+  const SiftOut so{cg, cw, cbest, tab_best, tab_cnt, pend, pend_cnt, &s_pn, &s_pbase};
   auto stage2 = [&](uint32_t il) {
-    bool live = il != FS_NONE;
-    // 2. A window with the ids of a script n-gram (and the strings of those ids) takes the
-    //    n-gram's record of this string table (k_lsh_gramtab): no bucket is walked for it.
-    uint32_t gram = FS_NONE;
-    const uint64_t p = live ? cpos[il] : 0;
-    if (tab_cnt && live && !(L.diag & 128)) {
-      uint32_t w = 0, kept = 0;
-      gram = verify_window(c, g, p, &w, &kept);
-      if (gram != FS_NONE) {
-        const uint32_t have = tab_cnt[gram];
-        if (have == 1) {
-          cg[il] = FS_NONE;                             // (no neighbour within the threshold)
-        } else {
-          const uint4* m = reinterpret_cast<const uint4*>(tab_best + 4 * (size_t)gram);
-          uint4* dst = reinterpret_cast<uint4*>(&cbest[il]);
-          dst[0] = m[0]; dst[1] = m[1];
-          cg[il] = 0;
-          cw[il] = w;
-          matches += have - 1;
-        }
-        live = false;
-      }
-    }
-    // 3. Not a script n-gram itself: enumerate the script n-grams that equal the window in all
-    //    slots but one (every neighbour within the threshold is one of them: m_min = n - 1) and
-    //    take their canonical distances.  None within the threshold: whatever the buckets hold,
-    //    nothing survives the threshold, and the window needs no LSH work.  One 32-byte bucket
-    //    of the map per slot, all n requested together; a window with more than two such
-    //    n-grams, or a full bucket in its way, is left to k_lsh_verify.
-    if (WMAP && live && L.wild && p + L.n <= c.n_tok && !(L.diag & 256)) {
-      uint32_t term[NW], fold = 0;
-      sift_keys<NW>(c, L, p, term, &fold, false);
-      Ids16 f;
-      load_ids(c.tok + p, L.n, &f);
-      uint32_t s0 = 0, s1 = 0, nh = 0;
-      int k0 = 0, k1 = 0;
-      bool possible = false;
-#pragma unroll
-      for (int k = 0; k < NW; ++k)
-        if (k < L.n) {
-          const uint32_t h = fs_wild_key(fold, term[k], k);
-          const uint4* bp = reinterpret_cast<const uint4*>(L.wmap + 4 * (size_t)fs_wmap_slot(h, L.log2_wmap));
-          const uint4 a = bp[0], b = bp[1];
-          const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (val[e] && key[e] == h) {
-              if (nh == 0) { s0 = val[e] - 1; k0 = k; }
-              else if (nh == 1) { s1 = val[e] - 1; k1 = k; }
-              ++nh;
-            }
-          possible = possible || val[3] != 0;       // (filled in order: the bucket is full)
-        }
-      possible = possible || nh > 2;
-      if (L.diag & 512) possible = possible || nh > 0;                 // diagnostics: no distances here
-      if (!possible && nh > 0) possible = one_slot_within<NW>(L, s0, k0, f);
-      if (!possible && nh > 1) possible = one_slot_within<NW>(L, s1, k1, f);
-      if (!possible) { cg[il] = FS_NONE; live = false; }
-    }
-    // what is left: onto the list k_lsh_verify deals out window by window (pending windows
-    // come in runs, the boundary windows of one quoted passage, so dealing out blocks of
-    // candidates leaves a few waves with most of the work)
-    // (one addition to the list's counter per workgroup: five thousand waves adding to the one
-    // address took 5 ns each, a third of the kernel)
-    const uint64_t pb = __ballot(live);
-    uint32_t wbase = 0;
-    if (pb && lane == 0) wbase = atomicAdd(&s_pn, (uint32_t)__popcll(pb));      // LDS
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t n_p = s_pn;
-      s_pbase = n_p ? atomicAdd(pend_cnt, n_p) : 0u;
-      s_pn = 0;
-    }
-    __syncthreads();
-    if (live) {
-      const uint32_t base = s_pbase + (uint32_t)__builtin_amdgcn_readlane((int)wbase, 0);
-      cg[il] = FS_PENDING;
-      pend[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(pb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pb, 0u))] = (uint32_t)il;
-    }
+    sift_stage2<NW, WMAP>(c, L, g, so, il, il != FS_NONE ? (uint64_t)cpos[il] : 0ull, &matches);
   };
   // U candidates per lane and pass, their loads level by level: positions, ids, filter blocks
   constexpr int U = NW <= 8 ? 3 : 2;
@@ -1102,6 +1109,87 @@ __global__ __launch_bounds__(256, 5) void k_lsh_sift(CorpusDev c, LshDev L, Gram
   if (threadIdx.x == 0) {
     bmatch[blockIdx.x] = tot;
     // (the sums are read kNB at a time: the workgroups that were not launched have none)
+    for (uint32_t b = blockIdx.x + gridDim.x; b < (uint32_t)kNB; b += gridDim.x) bmatch[b] = 0;
+  }
+}
+
+// k_lsh_sift2 (round 5): behind k_near_sift, which has put the candidates that pass the wildcard
+// filter into one list per wave range.  Numbers them across the ranges (chunk sums: four ranges
+// a chunk), writes the flat arrays the kernels behind expect -- an eighth of the entries
+// k_expand used to make -- and takes k_lsh_sift's second stage for each.  Every workgroup takes
+// an equal share of the numbered survivors (its place among the chunks by a search in the
+// chunk sums' prefix, which each workgroup makes for itself in LDS): one pass of full waves.
+// (A workgroup per chunk measured 45 us at n = 8 and 67 at n = 10: a C2 batch leaves 70 to 100
+// survivors per chunk, so the deep steps ran at a third of the lanes, twice over.)
+template <int NW, bool WMAP>
+__global__ __launch_bounds__(256, 5) void k_lsh_sift2(CorpusDev c, LshDev L, GramIndexDev g,
+                                                   const uint32_t* __restrict__ slist, uint32_t caps,
+                                                   const uint32_t* __restrict__ scount,
+                                                   const uint32_t* __restrict__ bsum,
+                                                   uint32_t* __restrict__ cpos, uint32_t ccap,
+                                                   uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
+                                                   fs_best* __restrict__ cbest,
+                                                   uint32_t* __restrict__ bmatch,
+                                                   const unsigned long long* __restrict__ tab_best,
+                                                   const uint32_t* __restrict__ tab_cnt,
+                                                   uint32_t* __restrict__ pend, fs_status* st) {
+  static_assert(kNB == 8 * 256, "eight chunk sums per thread");
+  __shared__ uint32_t s_w32[4];
+  __shared__ uint32_t s_pn, s_pbase;
+  __shared__ uint32_t s_pre[kNB + 1];                 // survivors in front of chunk i
+  uint32_t matches = 0;
+  if (threadIdx.x == 0) s_pn = 0;
+  {
+    uint32_t v[8], sum = 0;
+    const uint4* src = reinterpret_cast<const uint4*>(bsum + 8 * threadIdx.x);
+    const uint4 a = src[0], b = src[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sum += v[k];
+    uint32_t tot_all;
+    uint32_t run = block_excl_scan(sum, s_w32, &tot_all);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s_pre[8 * threadIdx.x + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) s_pre[kNB] = tot_all;
+  }
+  __syncthreads();
+  const uint32_t total = s_pre[kNB];
+  const SiftOut so{cg, cw, cbest, tab_best, tab_cnt, pend, &st->lsh_pending, &s_pn, &s_pbase};
+  // this workgroup's share, in whole steps of 256
+  const uint32_t steps = (total + 255) / 256;
+  const uint32_t per = (steps + gridDim.x - 1) / gridDim.x;
+  const uint32_t lo = (uint32_t)min((uint64_t)blockIdx.x * per * 256, (uint64_t)total);
+  const uint32_t hi = (uint32_t)min((uint64_t)(blockIdx.x + 1) * per * 256, (uint64_t)total);
+  for (uint32_t t0 = lo; t0 < hi; t0 += 256) {        // (workgroup-uniform)
+    const uint32_t il = t0 + threadIdx.x;
+    bool live = il < hi && il < ccap;                 // (beyond the arrays: n_cands says so, the search is repeated)
+    uint32_t p = 0;
+    if (live) {
+      uint32_t a = 0, b = kNB;                        // the last chunk with s_pre[chunk] <= il
+      while (b - a > 1) {
+        const uint32_t mid = (a + b) >> 1;
+        if (s_pre[mid] <= il) a = mid; else b = mid;
+      }
+      uint32_t off = il - s_pre[a];
+      const uint4 cn = *reinterpret_cast<const uint4*>(scount + 4 * a);
+      const uint32_t c0 = min(cn.x, caps), c1 = min(cn.y, caps), c2 = min(cn.z, caps);
+      uint32_t r = 0;
+      if (off >= c0) { off -= c0; r = 1; if (off >= c1) { off -= c1; r = 2; if (off >= c2) { off -= c2; r = 3; } } }
+      p = slist[(size_t)(4 * a + r) * caps + off];
+      cpos[il] = p;
+    }
+    sift_stage2<NW, WMAP>(c, L, g, so, live ? il : FS_NONE, p, &matches);
+  }
+  if (blockIdx.x == 0) {                              // for the kernels behind and the host
+    uint32_t over = 0;
+    for (uint32_t i = threadIdx.x; i < 4u * kNB; i += 256) over = max(over, scount[i]);
+    if (threadIdx.x == 0) st->n_cands = total;
+    if (over > caps) atomicMax(&st->max_recs, over);  // a range's list was too short (rare: the search is repeated)
+  }
+  uint32_t tot;
+  block_excl_scan(matches, s_w32, &tot);
+  if (threadIdx.x == 0) {
+    bmatch[blockIdx.x] = tot;
     for (uint32_t b = blockIdx.x + gridDim.x; b < (uint32_t)kNB; b += gridDim.x) bmatch[b] = 0;
   }
 }
@@ -1855,21 +1943,35 @@ int fs_launch_comp_map(fs_index* ix, fs_corpus* c, hipStream_t s) {
   return FS_OK;
 }
 
-int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s) {
-  LshDev L = lsh_dev(ix);
-  if (c->selflev_ready && !c->has_str) L.selflev = c->d_selflev.p;
+// The wildcard-key filter that stands in front of the LSH work of a search of `c` (nullptr: none),
+// and the ids its keys are made of (nullptr: the vector ids).
+void fs_lsh_wild_of(const fs_index* ix, const fs_corpus* c, const uint32_t** wild, int* log2_wild,
+                    const uint32_t** wild_tok) {
+  *wild = nullptr; *log2_wild = 0; *wild_tok = nullptr;
   // tables with near-synonyms: the wildcard keys over component ids (no one-slot map: a
   // neighbour may differ from the window in every vector id)
   if (fs_lsh_prefilter_mode(ix, c) == 2 && ix->sw.lsh_wild) {
-    L.wild = ix->d_wildc.p;
-    L.log2_wild = ix->log2_wildc;
-    L.wild_tok = c->d_ctok.p;
+    *wild = ix->d_wildc.p;
+    *log2_wild = ix->log2_wildc;
+    *wild_tok = c->d_ctok.p;
   }
   // at most one slot may differ and no OOV id anywhere: the wildcard-key filter applies
   if (ix->sw.lsh_wild && ix->d_wild.p && !c->has_oov && !ix->script_oov &&
       (int)ix->cfg.window_size - ix->lsh_m_min == 1) {
-    L.wild = ix->d_wild.p;
-    L.log2_wild = ix->log2_wild;
+    *wild = ix->d_wild.p;
+    *log2_wild = ix->log2_wild;
+    *wild_tok = nullptr;
+  }
+}
+
+// near: the candidates come from k_near_sift's lists (the wildcard filter applied):
+// k_lsh_sift2 numbers them and takes the second stage, instead of k_lsh_sift over k_expand's list
+int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t s, const fs_near_lists* near) {
+  LshDev L = lsh_dev(ix);
+  if (c->selflev_ready && !c->has_str) L.selflev = c->d_selflev.p;
+  // the wildcard-key filter of this search, if any (fs_lsh_wild_of)
+  fs_lsh_wild_of(ix, c, &L.wild, &L.log2_wild, &L.wild_tok);
+  if (L.wild && !L.wild_tok) {
     // A one-slot neighbour has cosine (n - 1 + c) / n with c the cosine of the two differing
     // vectors: within the threshold iff c > 1 - n * thr.  At n = 8 (c > 0.2) nearly every such
     // window ends in k_lsh_sift; at n = 10 (c > 0) half of them are real neighbours and stay
@@ -1916,11 +2018,23 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
     return per_cu < 1 ? (uint32_t)kNB : std::min<uint32_t>(kNB, ix->num_cu * (uint32_t)per_cu);
   };
   static const bool full_grid = getenv("FS_LSH_FULL_GRID") && atoi(getenv("FS_LSH_FULL_GRID")) != 0;
+  if (near) {
+    auto sift2 = L.n <= 8 ? (L.wmap ? k_lsh_sift2<8, true> : k_lsh_sift2<8, false>)
+                          : (L.wmap ? k_lsh_sift2<FS_MAX_WINDOW, true> : k_lsh_sift2<FS_MAX_WINDOW, false>);
+    const uint32_t blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(sift2));
+    hipLaunchKernelGGL(sift2, dim3(blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+                       near->slist, near->caps, near->scount, ix->cur->w_bsum.p,
+                       ix->cur->w_cpos.p, ccap, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
+                       ix->cur->w_bsum.p + kNB, tab_best, tab_cnt, ix->cur->w_pend.p, st);
+    if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_sift2");
+  } else {
   const uint32_t sift_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(sift));
   hipLaunchKernelGGL(sift, dim3(sift_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p,
                      ix->cur->w_cbest.p, ix->cur->w_bsum.p + kNB, tab_best, tab_cnt, ix->cur->w_pend.p,
                      &st->lsh_pending);
+    if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_sift");
+  }
   // the kept matches' Levenshtein distances a lane per match (k_lsh_lev) where the script
   // windows' bit planes and the string table's records exist; else a wave per match inside
   // k_lsh_verify
@@ -1940,12 +2054,14 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
                      ix->cur->w_cpos.p, nc, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_cbest.p,
                      ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p, ix->cur->w_mcnt.p,
                      ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p);
+  if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_verify");
   if (defer) {
     const StrFast F{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, c->d_strrec.p};
     const uint32_t lev_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(k_lsh_lev));
     hipLaunchKernelGGL(k_lsh_lev, dim3(lev_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(), F,
                        ix->cur->w_cpos.p, ccap, ix->cur->w_pend.p, ix->cur->w_mcnt.p,
                        ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p, ix->cur->w_cg.p, ix->cur->w_cbest.p, st);
+    if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_lev");
   }
   FS_HIP(hipGetLastError());
   return FS_OK;

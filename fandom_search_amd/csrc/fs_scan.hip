@@ -504,7 +504,7 @@ __global__ __launch_bounds__(1024) void k_scan_near8(const uint32_t* __restrict_
                                                      uint32_t* __restrict__ qcnt, uint32_t n_sub,
                                                      uint32_t chunk, uint32_t* __restrict__ bsum,
                                                      fs_status* __restrict__ zero) {
-  static_assert(N >= 7 && N <= 12, "twelve halo tokens are loaded (nv[12])");
+  static_assert(N >= 6 && N <= 12, "twelve halo tokens are loaded (nv[12])");
   extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
   uint32_t* s_csum = s_filter + (1u << log2_words);           // [kChunksPerBlock]
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -563,6 +563,189 @@ __global__ __launch_bounds__(1024) void k_scan_near8(const uint32_t* __restrict_
     cand_run += (uint32_t)__builtin_amdgcn_readlane((int)cnt, 63);
   }
   if (lane == 0 && cand_run) atomicAdd(&s_csum[kc], cand_run);    // LDS
+  __syncthreads();
+  if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = s_csum[threadIdx.x];
+}
+
+// ---- prefilter scan and wildcard-key filter in one kernel (round 5) ---------------------
+// k_near_sift: k_scan_near8's loop with the first stage of k_lsh_sift behind it in the same
+// wave.  Round 4 wrote a bitmap of the windows that pass the 3-gram rule (1.18 M of the 20 M of
+// a C2 batch at n = 8), k_expand turned it into a list of positions, and k_lsh_sift read every
+// one of them again -- position, ids, three filter blocks -- in two passes of its resident
+// workgroups, to keep an eighth; k_hitrows and k_rows then walked the same 1.18 M entries.
+// Here a lane whose eight windows hold candidates appends {(position - range start) / 8, flag
+// byte} to its wave's queue in LDS (k_scan_rows' record), and whenever 64 candidates are queued
+// the wave takes one each: the n ids (the stream it has just read: L2), the grouped wildcard
+// filter's three 16-byte blocks, requested together, the n key tests.  The survivors go to the
+// wave range's own list in memory, in position order; k_lsh_sift2 (fs_lsh.hip) numbers them
+// across the ranges and takes the deeper steps.  No bitmap, no k_expand, no global atomics, and
+// everything behind this kernel runs over an eighth of the entries.
+constexpr uint32_t kSiftQueue = 128;            // queued records per wave: < 64 left over + <= 64 of a sub-tile
+struct alignas(16) SiftLds {                    // per wave
+  uint32_t rec[kSiftQueue];                     // {(position - range start) / 8 << 8 | flag byte}
+  uint32_t cand[64];                            // window positions of the round being made up
+};
+
+// Does the window at `ids` (vector ids, or component ids on tables with near-synonyms) have one
+// of its N one-slot-wildcard keys in the grouped filter `wb` (fs_hash.h)?  k_lsh_sift's stage 1
+// for one candidate per lane, the window size at compile time.
+template <int N>
+__device__ __forceinline__ bool wild_stage1(const uint32_t* __restrict__ ids, const uint4* __restrict__ wb,
+                                            int log2_wild) {
+  constexpr int Q = (N + 3) / 4;
+  uint32_t kf[4 * Q];
+  // (the window start is only 4-byte aligned; the buffers are padded: fs_device.h, load_ids)
+  const uint4* src = reinterpret_cast<const uint4*>(ids);
+#pragma unroll
+  for (int q4 = 0; q4 < Q; ++q4) {
+    const uint4 t = src[q4];
+    kf[4 * q4] = t.x; kf[4 * q4 + 1] = t.y; kf[4 * q4 + 2] = t.z; kf[4 * q4 + 3] = t.w;
+  }
+  uint32_t fold = 0, g0 = 0, g1 = 0, g2 = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint32_t t = fs_rotl(fs_premix(kf[k]), fs_rot_of(N - 1 - k));
+    const int X = fs_wild_group(k, N);
+    fold ^= t;
+    g0 ^= X == 0 ? t : 0u; g1 ^= X == 1 ? t : 0u; g2 ^= X == 2 ? t : 0u;
+  }
+  const uint4 blk0 = wb[fs_wild_block(fold ^ g0, 0, log2_wild)];
+  const uint4 blk1 = wb[fs_wild_block(fold ^ g1, 1, log2_wild)];
+  const uint4 blk2 = wb[fs_wild_block(fold ^ g2, 2, log2_wild)];
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const uint32_t t = fs_rotl(fs_premix(kf[k]), fs_rot_of(N - 1 - k));
+    const uint32_t h = fs_wild_fkey(fold, t, k);
+    const int X = fs_wild_group(k, N);
+    const uint4 q = X == 0 ? blk0 : X == 1 ? blk1 : blk2;
+    any |= fsdev::shr_by_byte<0>(q.x, h) & fsdev::shr_by_byte<1>(q.y, h) & fsdev::shr_by_byte<2>(q.z, h) &
+           fsdev::shr_by_byte<3>(q.w, h);
+  }
+  return (any & 1u) != 0;
+}
+
+template <int N>
+__global__ __launch_bounds__(1024) void k_near_sift(const uint32_t* __restrict__ tok, uint32_t n_tok,
+                                                    const uint32_t* __restrict__ filter, int log2_words,
+                                                    const uint32_t* __restrict__ wild, int log2_wild,
+                                                    uint32_t n_sub, uint32_t chunk,
+                                                    uint32_t* __restrict__ slist, uint32_t caps,
+                                                    uint32_t* __restrict__ scount,
+                                                    uint32_t* __restrict__ bsum,
+                                                    fs_status* __restrict__ zero) {
+  static_assert(N >= 6 && N <= 12, "twelve halo tokens are loaded (nv[12])");
+  extern __shared__ __attribute__((aligned(16))) uint32_t s_filter[];
+  uint32_t* s_csum = s_filter + (1u << log2_words);           // [kChunksPerBlock]
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    zero->n_cands = 0; zero->n_hits = 0; zero->n_matches = 0; zero->n_rows = 0;
+    zero->max_recs = 0; zero->lev_overflow = 0; zero->bad_string = 0; zero->max_rows = 0;
+    zero->lsh_pending = 0;
+  }
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6;
+  SiftLds& Q = reinterpret_cast<SiftLds*>(s_csum + 4)[wave];
+  const uint32_t kc = wave >> 2, q = wave & 3;                 // chunk of the workgroup, quarter
+  const uint32_t range_id = (blockIdx.x * kChunksPerBlock + kc) * 4 + q;
+  const uint32_t per = (chunk + 3) >> 2;                       // sub-tiles per wave range
+  const uint64_t chunk_first = ((uint64_t)blockIdx.x * kChunksPerBlock + kc) * chunk;
+  uint32_t j0 = q * per, j1 = j0 + per;
+  if (j1 > chunk) j1 = chunk;
+  if (j0 > j1) j0 = j1;
+  if (chunk_first + j1 > n_sub) j1 = chunk_first + j0 < n_sub ? (uint32_t)(n_sub - chunk_first) : j0;
+  if ((uint64_t)blockIdx.x * kChunksPerBlock * chunk >= n_sub) {   // nothing to scan: empty chunks
+    if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = 0;
+    if (lane == 0) scount[range_id] = 0;
+    return;
+  }
+  if (threadIdx.x < kChunksPerBlock) s_csum[threadIdx.x] = 0;
+  copy_filter_to_lds(filter, s_filter, log2_words);
+  __syncthreads();
+  constexpr int HALO = N - 1;
+  constexpr int H1 = HALO < 8 ? HALO : 8, H2 = HALO - H1;     // from the next lane, from the one after
+  uint32_t mask_words = ((1u << log2_words) - 1u) << 2;
+  asm volatile("" : "+v"(mask_words));          // keep the SDWA operand in a register
+  const uint4* wb = reinterpret_cast<const uint4*>(wild);
+  const uint32_t range_base = ((uint32_t)chunk_first + j0) * 512u;
+  uint32_t* my_list = slist + (size_t)range_id * caps;
+  uint32_t qn = 0, qc = 0, out_n = 0;           // queued records, queued candidates, survivors so far (wave-uniform)
+
+  // one round: the longest run of queued records that holds 64 candidates or fewer, a lane per candidate
+  auto round = [&]() {
+    const uint32_t r = (uint32_t)lane < qn ? Q.rec[lane] : 0u;
+    const uint32_t cnt = __popc(r & 0xFFu);
+    const uint32_t inc = fsdev::wave_incl_scan_dpp(cnt);
+    const bool fits = (uint32_t)lane < qn && inc <= 64u;
+    const uint32_t nfit = (uint32_t)__popcll(__ballot(fits));            // >= 1: a record holds at most eight
+    const uint32_t ncand = (uint32_t)__builtin_amdgcn_readlane((int)inc, (int)nfit - 1);
+    if (fits) {
+      uint32_t f = r & 0xFFu, k = inc - cnt;
+      const uint32_t rel = (r >> 8) << 3;
+      while (f) {
+        Q.cand[k++] = rel + (uint32_t)(__ffs((int)f) - 1);
+        f &= f - 1;
+      }
+    }
+    // the records behind them move to the front of the queue
+    const uint32_t i0 = (uint32_t)lane + nfit, i1 = i0 + 64u;
+    const uint32_t r0 = i0 < qn ? Q.rec[i0] : 0u, r1 = i1 < qn ? Q.rec[i1] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    Q.rec[lane] = r0;
+    Q.rec[lane + 64] = r1;
+    qn -= nfit; qc -= ncand;
+    __builtin_amdgcn_wave_barrier();
+    const bool live = (uint32_t)lane < ncand;
+    const uint32_t p = range_base + (live ? Q.cand[lane] : 0u);
+    bool pass = live;
+    if (wb) pass = wild_stage1<N>(tok + p, wb, log2_wild) && live;
+    const uint64_t sb = __ballot(pass);
+    if (pass) {
+      const uint32_t slot = out_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(sb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)sb, 0u));
+      if (slot < caps) my_list[slot] = p;
+    }
+    out_n += (uint32_t)__popcll(sb);
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  for (uint32_t j = j0; j < j1; ++j) {
+    const uint32_t sub = (uint32_t)chunk_first + j;
+    const uint32_t base = sub * 512u;
+    const uint4* p = reinterpret_cast<const uint4*>(tok + base + 8 * lane);
+    const uint4 a0 = p[0], a1 = p[1];
+    // the first tokens of the next sub-tile, for the last two lanes (the buffer is padded)
+    const uint4* nx = reinterpret_cast<const uint4*>(tok + base + 512);
+    const uint4 n0 = nx[0], n1 = nx[1], n2 = nx[2];
+    uint32_t m[8 + HALO];
+    m[0] = fs_premix(a0.x); m[1] = fs_premix(a0.y); m[2] = fs_premix(a0.z); m[3] = fs_premix(a0.w);
+    m[4] = fs_premix(a1.x); m[5] = fs_premix(a1.y); m[6] = fs_premix(a1.z); m[7] = fs_premix(a1.w);
+    const uint32_t nv[12] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w};
+    // wave_shl:1 -- lane L takes lane L + 1's value, lane 63 keeps `old`
+#pragma unroll
+    for (int h = 0; h < H1; ++h)
+      m[8 + h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(nv[h]), (int)m[h], 0x130, 0xF, 0xF, false);
+#pragma unroll
+    for (int h = 0; h < H2; ++h)
+      m[16 + h] = (uint32_t)__builtin_amdgcn_update_dpp((int)fs_premix(nv[8 + h]), (int)m[8 + h], 0x130, 0xF, 0xF, false);
+    const uint32_t p0 = base + 8 * lane;
+    uint32_t flags;
+    if (base + 512u + HALO > n_tok) flags = window_flags_near8<N, true>(m, mask_words, p0, n_tok);
+    else flags = window_flags_near8<N, false>(m, mask_words, p0, n_tok);
+    const uint64_t has = __ballot(flags != 0);
+    if (flags != 0) {
+      const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(has >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)has, 0u));
+      Q.rec[slot] = (((p0 - range_base) >> 3) << 8) | flags;
+    }
+    qn += (uint32_t)__popcll(has);
+    qc += (uint32_t)__builtin_amdgcn_readlane((int)fsdev::wave_sum_lane63(__popc(flags)), 63);
+    __builtin_amdgcn_wave_barrier();
+    while (qc >= 64u) round();
+  }
+  while (qn) round();
+  if (lane == 0) {
+    scount[range_id] = out_n;                   // (beyond caps: k_lsh_sift2 reports it, the search is repeated)
+    const uint32_t kept = out_n < caps ? out_n : caps;
+    if (kept) atomicAdd(&s_csum[kc], kept);     // LDS
+  }
   __syncthreads();
   if (threadIdx.x < kChunksPerBlock) bsum[blockIdx.x * kChunksPerBlock + threadIdx.x] = s_csum[threadIdx.x];
 }
@@ -1309,8 +1492,15 @@ int fs_scan_near_k(int n) { return fs_near_k(n); }
 // (decided when the filters are built, fs_lsh_build: the hash has to match)
 bool fs_scan_near8_wanted(const fs_index* ix) {
   const int n = (int)ix->cfg.window_size;
-  return ix->sw.scan_near8 && n >= 7 && (n <= 10 || n == 12);
+  // (n = 6 in this form only for k_near_sift: by itself k_scan_near<6> with its second filter is
+  // the better prefilter there)
+  return ix->sw.scan_near8 && (n >= 7 || (n == 6 && ix->sw.near_fused)) && (n <= 10 || n == 12);
 }
+// k_near_sift (prefilter + wildcard filter in one kernel, lists per wave range) takes the search
+bool fs_near_fused(const fs_index* ix, const fs_corpus* c) {
+  return ix->sw.near_fused && fs_scan_near8(ix) && fs_lsh_prefilter_ok(ix, c);
+}
+uint32_t fs_near_ranges() { return (uint32_t)fsdev::kNB * 4u; }
 bool fs_scan_near8(const fs_index* ix) { return ix->near8; }
 int fs_scan_near_log2(const fs_index* ix) {
   return fs_scan_near8(ix) ? std::min(ix->log2_words, FS_SUB_MAX_LOG2_WORDS) : ix->log2_words;
@@ -1365,7 +1555,40 @@ int launch_scan_near8(const fs_index* ix, const CorpusDev& c, const uint32_t* id
   ex->counted = true;
   return FS_OK;
 }
+template <int N>
+int launch_near_sift(const fs_index* ix, const CorpusDev& c, const uint32_t* ids, const uint32_t* filter,
+                     const uint32_t* wild, int log2_wild, uint32_t* slist, uint32_t caps, uint32_t* scount,
+                     uint32_t* bsum, fs_status* zero, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  const int lw = fs_scan_near_log2(ix);
+  const uint32_t n_sub = (uint32_t)(((uint64_t)c.n_tok + 511) / 512);
+  const size_t lds = ((size_t)4 << lw) + 16 + 16 * sizeof(SiftLds);
+  const uint32_t chunk = std::max<uint32_t>(1, (n_sub + fsdev::kNB - 1) / fsdev::kNB);
+  auto kern = k_near_sift<N>;
+  FS_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(kern), ix->device, lds));
+  hipExtLaunchKernelGGL(kern, dim3(kScanBlocks), dim3(1024), (uint32_t)lds, s, e0, e1, 0u, ids, c.n_tok,
+                        filter, lw, wild, log2_wild, n_sub, chunk, slist, caps, scount, bsum, zero);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
 }  // namespace
+
+int fs_launch_near_sift(const fs_index* ix, const fs_corpus* fc, uint32_t* slist, uint32_t caps, uint32_t* scount,
+                        uint32_t* bsum, fs_status* zero, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+  const CorpusDev c = fc->dev();
+  const bool comp = fs_lsh_prefilter_mode(ix, fc) == 2;
+  const uint32_t* ids = comp ? (const uint32_t*)fc->d_ctok.p : c.tok;
+  const uint32_t* filter = comp ? (const uint32_t*)ix->d_sfilter3c.p : (const uint32_t*)ix->d_sfilter3.p;
+  const uint32_t *wild = nullptr, *wild_tok = nullptr;
+  int log2_wild = 0;
+  fs_lsh_wild_of(ix, fc, &wild, &log2_wild, &wild_tok);
+  if (wild && (wild_tok ? wild_tok != ids : comp)) { fs_set_error("k_near_sift: the keys' ids are not the scanned ids"); return FS_E_DEVICE; }
+  switch (ix->cfg.window_size) {
+#define FS_NS(N) case N: return launch_near_sift<N>(ix, c, ids, filter, wild, log2_wild, slist, caps, scount, bsum, zero, s, e0, e1)
+    FS_NS(6); FS_NS(7); FS_NS(8); FS_NS(9); FS_NS(10); FS_NS(12);
+#undef FS_NS
+    default: fs_set_error("k_near_sift covers n = 6..10, 12"); return FS_E_UNSUPPORTED;
+  }
+}
 
 // ex: chunk sums and status block for the eight-tokens-per-lane form (ex->counted on return:
 // k_expand needs no k_reduce in front)
@@ -1383,6 +1606,7 @@ int fs_launch_scan_near(const fs_index* ix, const fs_corpus* fc, uint64_t* qbm, 
   ex->counted = false;
   if (fs_scan_near8(ix)) {
     switch (ix->cfg.window_size) {
+      case 6: return launch_scan_near8<6>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
       case 7: return launch_scan_near8<7>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
       case 8: return launch_scan_near8<8>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);
       case 9: return launch_scan_near8<9>(ix, c, ids, filter, qbm, qcnt, n_bm_words, s, e0, e1, ex);

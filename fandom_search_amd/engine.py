@@ -243,6 +243,19 @@ class ScriptIndex(object):
         """Diagnostics: the kernel that dominates a search of `corpus` (profile name)."""
         return _lib.load().fs_search_kernel_name(self._h, corpus._h).decode()
 
+    def profile(self, corpus, rows_ptr, cap):
+        """Diagnostics: one search of `corpus` (records to the device buffer at `rows_ptr`)
+        with a HIP event behind each of its kernels; returns [(kernel name, ms), ...] in
+        launch order.  The GPU should be idle otherwise (fs_search_profile)."""
+        names = C.create_string_buffer(2048)
+        ms = (C.c_double * 32)()
+        n = C.c_uint32()
+        _lib.check(_lib.load().fs_search_profile(self._h, corpus._h, C.c_void_p(rows_ptr), cap, 1,
+                                                 names, len(names), ms, 32, C.byref(n)),
+                   "fs_search_profile")
+        labels = names.value.decode().split("\n")
+        return [(labels[i], float(ms[i])) for i in range(min(n.value, 32, len(labels) - 1))]
+
     def reload_switches(self):
         """Diagnostics: re-read the FS_* environment switches (read at creation)."""
         _lib.check(_lib.load().fs_index_reload_switches(self._h), "fs_index_reload_switches")

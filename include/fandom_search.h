@@ -262,6 +262,15 @@ int fs_index_set_scan_timing(fs_index* ix, uint32_t period);
  * of the search lists first.  Static storage, valid until the next call on this thread. */
 const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c);
 
+/* Diagnostics: one synchronous search of `c` (arguments as fs_search_corpus) with a HIP event
+ * behind every kernel of it.  names: the kernels' names in launch order, '\n'-separated;
+ * ms[i]: time from the previous mark to the one behind kernel i (its duration when nothing else
+ * runs on the GPU); *n = number of entries (also when the buffers hold fewer).  What bench.py
+ * names as the dominant kernel of a search that is more than one launch comes from here.
+ * Not part of the search path. */
+int fs_search_profile(fs_index* ix, fs_corpus* c, fs_row* rows, uint64_t cap, int rows_on_device,
+                      char* names, uint64_t names_cap, double* ms, uint32_t ms_cap, uint32_t* n);
+
 /* Diagnostics: the FS_* environment switches (kernel variants, forced capacities) are
  * read once at fs_index_create; a test or sweep that changes them on a live index
  * calls this to have them read again.  Not part of the search path. */

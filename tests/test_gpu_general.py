@@ -83,7 +83,7 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
     ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
                        synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL
-    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near8<%d>" % n
+    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_near_sift<%d>" % n
     # (what k_lsh_sift leaves to the wave-per-window kernel: the windows one slot away from a
     # script n-gram that may be within the threshold, a small share of the candidates)
     assert 0 < st.lsh_pending < st.candidates
@@ -101,18 +101,32 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
     # computed per match, without the per-n-gram records, without the exact one-slot map: the
     # same bytes
     # ... and with the four-tokens-per-lane form of the prefilter scan (its own 3-gram hash)
-    for env, kernel in (("FS_LSH_PREFILTER", "k_lsh_scan"), ("FS_LSH_WILD", "k_scan_near8<%d>" % n),
-                        ("FS_LSH_SELFLEV", "k_scan_near8<%d>" % n), ("FS_LSH_GRAMTAB", "k_scan_near8<%d>" % n),
-                        ("FS_LSH_WMAP", "k_scan_near8<%d>" % n), ("FS_SCAN_NEAR8", "k_scan_near<%d>" % n),
-                        ("FS_LSH_LEV_LANE", "k_scan_near8<%d>" % n)):
-        monkeypatch.setenv(env, "0")
+    # ... with round 4's chain behind the prefilter scan (bitmap, k_expand, k_lsh_sift over every
+    # candidate) instead of k_near_sift + k_lsh_sift2, the same switches under it, and with
+    # k_near_sift's lists starting at two entries per wave range (the search reports what it
+    # needs and is repeated)
+    fused = "k_near_sift<%d>" % n
+    chain = "k_scan_near8<%d>" % n
+    for env, kernel in (({"FS_LSH_PREFILTER": "0"}, "k_lsh_scan"), ({"FS_LSH_WILD": "0"}, fused),
+                        ({"FS_LSH_SELFLEV": "0"}, fused), ({"FS_LSH_GRAMTAB": "0"}, fused),
+                        ({"FS_LSH_WMAP": "0"}, fused), ({"FS_SCAN_NEAR8": "0"}, "k_scan_near<%d>" % n),
+                        ({"FS_LSH_LEV_LANE": "0"}, fused), ({"FS_NEAR_FUSED": "0"}, chain),
+                        ({"FS_NEAR_FUSED": "0", "FS_LSH_WILD": "0"}, chain),
+                        ({"FS_NEAR_FUSED": "0", "FS_LSH_WMAP": "0"}, chain),
+                        ({"FS_NEAR_FUSED": "0", "FS_LSH_GRAMTAB": "0"}, chain),
+                        ({"FS_SCAN_CAPW": "2"}, fused), ({"FS_LANES": "4"}, fused)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
         c = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
         assert full.kernel_name(c) == kernel
         got2, st2 = full.search(c)
-        assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+        assert got.tobytes() == got2.tobytes() and st.matches == st2.matches, env
+        got3, _ = full.search(c)
+        assert got.tobytes() == got3.tobytes(), env
         full.close()
-        monkeypatch.delenv(env)
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 @pytest.mark.parametrize("n", [8, 9, 10, 12])
@@ -149,14 +163,17 @@ def test_prefilter_scan_at_sub_tile_boundaries(synth_base, monkeypatch, n):
     ix, got, st = _run(cfg, script, swords, emb, normals, tok, off,
                        synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL and len(got) > 100
-    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_scan_near8<%d>" % n
+    assert ix.kernel_name(ix.corpus(tok, off, synth_base["chars"], synth_base["off"])) == "k_near_sift<%d>" % n
     assert int(got["fan_ix"][got["work"] == 3].max()) == 2600 - 1      # the last token is in a record
-    monkeypatch.setenv("FS_SCAN_NEAR8", "0")
-    old = ScriptIndex(script, swords, emb, normals, cfg=cfg)
-    c = old.corpus(tok, off, synth_base["chars"], synth_base["off"])
-    assert old.kernel_name(c) == "k_scan_near<%d>" % n
-    got2, st2 = old.search(c)
-    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+    for env, kernel in (("FS_SCAN_NEAR8", "k_scan_near<%d>" % n), ("FS_NEAR_FUSED", "k_scan_near8<%d>" % n)):
+        monkeypatch.setenv(env, "0")
+        old = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+        c = old.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        assert old.kernel_name(c) == kernel
+        got2, st2 = old.search(c)
+        assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+        old.close()
+        monkeypatch.delenv(env)
 
 
 def test_general_mode_equals_exact_mode(synth_base):

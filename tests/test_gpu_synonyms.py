@@ -69,7 +69,7 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     normals = synth.lsh_normals(n)
     ix, c, got, st = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL and ix.info["c_max"] > 0.9
-    assert ix.kernel_name(c) == ("k_scan_near<6>" if n == 6 else "k_scan_near8<%d>" % n)   # the component prefilter ran
+    assert ix.kernel_name(c) == "k_near_sift<%d>" % n                  # the component prefilter ran
     assert 0 < st.candidates < st.windows_processed // 2
     sch, so = pack_strings(swords)
     oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
@@ -82,6 +82,12 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     ix2, c2, got2, st2 = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
     assert ix2.kernel_name(c2) == "k_lsh_scan"
     assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+    monkeypatch.delenv("FS_LSH_SYN")
+    # round 4's chain (prefilter bitmap, k_expand, k_lsh_sift over every candidate): the same bytes
+    monkeypatch.setenv("FS_NEAR_FUSED", "0")
+    ix3, c3, got3, st3 = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
+    assert ix3.kernel_name(c3) == ("k_scan_near<6>" if n == 6 else "k_scan_near8<%d>" % n)
+    assert got.tobytes() == got3.tobytes() and st.matches == st3.matches
 
 
 def test_vectors_of_different_length(synth_base, monkeypatch):
@@ -96,7 +102,7 @@ def test_vectors_of_different_length(synth_base, monkeypatch):
     cfg = abi.make_config()
     normals = synth.lsh_normals(6)
     ix, c, got, st = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
-    assert ix.kernel_name(c) == "k_scan_near<6>"
+    assert ix.kernel_name(c) == "k_near_sift<6>"
     sch, so = pack_strings(swords)
     want, ost = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8).search(
         tok, off, synth_base["chars"], synth_base["off"])
@@ -134,6 +140,7 @@ def test_largest_filter_at_n6_leaves_the_second_filter_out(synth_base, monkeypat
     launch must leave the optional second filter out, not fail."""
     from oracle import c_oracle
     monkeypatch.setenv("FS_FILTER_LOG2_WORDS", "15")
+    monkeypatch.setenv("FS_NEAR_FUSED", "0")            # (k_near_sift's filter has 2^14 words at most)
     emb, perm, inv = _clustered()
     words = synth_base["words"]
     script = synth.script_tokens(3000)
