@@ -122,6 +122,8 @@ void fs_read_switches(fs_switches* sw) {
   sw->lsh_lev_lane = getenv("FS_LSH_LEV_LANE") ? num("FS_LSH_LEV_LANE") : 1;
   sw->scan_near8 = !getenv("FS_SCAN_NEAR8") || num("FS_SCAN_NEAR8") != 0;
   sw->near_fused = !getenv("FS_NEAR_FUSED") || num("FS_NEAR_FUSED") != 0;
+  sw->lsh_batch = !getenv("FS_LSH_BATCH") || num("FS_LSH_BATCH") != 0;
+  if (getenv("FS_LSH_DEFER_MIN")) sw->lsh_defer_min = num("FS_LSH_DEFER_MIN");
   sw->end_query = !getenv("FS_END_QUERY") || num("FS_END_QUERY") != 0;
   sw->lsh_no_gtab = getenv("FS_LSH_NO_GTAB") != nullptr;
   sw->lsh_serial = getenv("FS_LSH_SERIAL") != nullptr;

@@ -189,6 +189,8 @@ struct fs_switches {
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
   bool lsh_keys6 = true;          // FS_LSH_KEYS6=0: n = 6 over component ids without the middle-slot key filter in k_scan_near
   bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
+  bool lsh_batch = true;          // FS_LSH_BATCH=0: the pending windows a wave each (k_lsh_verify) instead of eight per wave level by level (k_lsh_batch)
+  int lsh_defer_min = 8192;       // FS_LSH_DEFER_MIN: pending windows of the lane's last search from which on the kept matches' Levenshtein distances go to k_lsh_lev (and the windows to k_lsh_batch)
   bool near_fused = true;         // FS_NEAR_FUSED=0: k_scan_near8 + k_expand + k_lsh_sift (round 4's chain) instead of k_near_sift + k_lsh_sift2; read when the index is built (n = 6: which prefilter kernel the 3-gram filter is laid out for)
   bool lsh_gramtab = true;        // FS_LSH_GRAMTAB=0: no per-n-gram records (k_lsh_gramtab): every window with a script n-gram's ids walks the buckets
   int rows_waves = 0;             // FS_ROWS_WAVES: waves per workgroup of k_scan_rows (experiments)

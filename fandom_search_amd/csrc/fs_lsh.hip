@@ -1457,6 +1457,321 @@ __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, Gr
   if (threadIdx.x == 0) bmatch[blockIdx.x] += tot;       // (on top of k_lsh_sift's)
 }
 
+// ---- the pending windows eight at a time (round 5) ----------------------------------------
+// k_lsh_verify works a window off with a whole wave: keys, bucket ranges, bucket members,
+// distances, NearestFilter -- about ten levels of dependent loads for one window, during most
+// of which most lanes wait (71 % of the wave cycles waiting, r04_lsh_verify_pmc_sq_after.json),
+// and on a table with near-synonyms a C2 batch leaves 280 k such windows: 0.85 of the search's
+// 1.05 ms.  k_lsh_batch takes EIGHT windows of the pending list per wave and walks the same
+// steps level by level for all of them at once:
+//   A  ids, q and bounds of the eight windows, lane per (window, slot); float32 projection rows
+//      summed in slot order, four columns a lane (float64 redo per window where a sign is not
+//      certain, as lsh_window)
+//   B  the 8 x H bucket ranges, lane per (window, table)
+//   C  the bucket members of all eight windows numbered in (window, table, entry) order and
+//      dealt to the lanes 64 at a time: script window, canonical distance (window_distance);
+//      those within the threshold go to the window's list in LDS in arrival order
+//   D  UniqueFilter and NearestFilter per window, eight lanes a window: an entry's rank in the
+//      stable order (distance, then arrival) among the entries that are not repeats
+// What it keeps equals lsh_neighbours_wave's list entry for entry (NearPy: UniqueFilter keeps a
+// window's first arrival, NearestFilter is a stable sort).  A window with more than kBatchCap
+// members within the threshold (crowded buckets) is worked off by lsh_window behind the batch.
+// The Levenshtein distances are k_lsh_lev's (a lane per kept match).
+constexpr int kBatchW = 8;                // windows per wave and step
+constexpr int kBatchCap = 40;             // members within the threshold kept per window
+constexpr int kBatchH = 16;               // tables (number_of_hashes) this form serves
+struct alignas(16) BatchLds {             // per wave
+  uint64_t bal[kBatchW][6];               // sign bits of the projection columns (C <= 256), + a zero word
+  double qf[kBatchW][FS_MAX_WINDOW];      // q of the windows' slots
+  double ff[kBatchW], rff[kBatchW];
+  double vd[kBatchW][kBatchCap];          // members within the threshold, arrival order: distance ...
+  uint32_t vs[kBatchW][kBatchCap];        // ... and script window (bit 31: a repeat)
+  uint32_t f[kBatchW][FS_MAX_WINDOW];     // vector ids
+  uint32_t key[kBatchW][kBatchH];
+  uint32_t e0[kBatchW][kBatchH];          // first entry of the window's bucket in table h
+  uint32_t pre[kBatchW][kBatchH];         // entries of the window in the tables before h
+  uint32_t wbase[kBatchW + 1];            // entries of the windows before w
+  uint32_t vn[kBatchW];                   // members within the threshold so far (may exceed kBatchCap)
+  uint32_t ci[kBatchW];                   // candidate number
+  uint32_t work[kBatchW];
+  uint32_t ok[kBatchW];                   // 1: a window of one work; 2: its keys need float64
+  float bnd[kBatchW];
+};
+static_assert(sizeof(double) * kBatchW * kBatchCap + sizeof(uint32_t) * kBatchW * kBatchCap >= 2400,
+              "lsh_window's scratch is laid over vd / vs");
+
+template <int N>
+__global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, GramIndexDev g,
+                                                   const uint32_t* __restrict__ cpos, uint32_t cap,
+                                                   uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
+                                                   uint32_t* __restrict__ bmatch, fs_status* st,
+                                                   const uint32_t* __restrict__ pend,
+                                                   uint32_t* __restrict__ mcnt,
+                                                   uint32_t* __restrict__ mtop_s,
+                                                   double* __restrict__ mtop_d) {
+  __shared__ BatchLds s_b[4];
+  __shared__ uint32_t s_w32[4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  BatchLds& S = s_b[wave];
+  uint32_t matches = 0;
+  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
+  const uint32_t n_pend = min(st->lsh_pending, cap);
+  const uint32_t nn = (uint32_t)L.nn;
+  const uint32_t nb1 = (1u << L.B) + 1;
+  auto sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (uint32_t j0 = gw * kBatchW; j0 < n_pend; j0 += NWAVES * kBatchW) {
+    const uint32_t nw = min((uint32_t)kBatchW, n_pend - j0);
+    // ---- A: the windows ------------------------------------------------------------------
+    if (lane < kBatchW) {
+      uint32_t ok = 0, w = 0, i = 0;
+      uint64_t p = 0;
+      if ((uint32_t)lane < nw) {
+        i = pend[j0 + lane];
+        p = cpos[i];
+        if (p + N <= c.n_tok) {
+          uint64_t work_end;
+          w = work_of_token(c, p, &work_end);
+          ok = p + N <= work_end ? 1u : 0u;       // a window never crosses a work boundary
+        }
+      }
+      S.ci[lane] = i; S.work[lane] = w; S.ok[lane] = ok; S.vn[lane] = 0;
+      S.wbase[lane] = (uint32_t)p;                // (the position, until B overwrites it)
+      S.bal[lane][(L.C + 63) >> 6] = 0;
+    }
+    sync();
+#pragma unroll
+    for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t) {      // lane per (window, slot)
+      const int w = (t * 64 + lane) / FS_MAX_WINDOW, k = (t * 64 + lane) % FS_MAX_WINDOW;
+      float am = 0.0f;
+      uint32_t oov = 0;
+      if (k < N && S.ok[w]) {
+        const uint32_t id = c.tok[(uint64_t)S.wbase[w] + k];
+        S.f[w][k] = id;
+        S.qf[w][k] = q_of(L, id);
+        oov = id & FS_OOV_FLAG;
+        if (!oov && L.atab32) am = L.amax[(size_t)k * L.V + id];
+      }
+      // sum / or over the window's FS_MAX_WINDOW lanes
+      static_assert(FS_MAX_WINDOW == 16, "a window's slots are one row of sixteen lanes");
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) { am += __shfl_xor(am, d); oov |= (uint32_t)__shfl_xor((int)oov, d); }
+      if (k == 0 && S.ok[w]) {
+        S.bnd[w] = L.bound_scale * am;
+        if (oov || !L.atab32 || L.C > 256) S.ok[w] = 2u;
+      }
+    }
+    sync();
+    if (lane < kBatchW && S.ok[lane]) {
+      double ff = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, S.qf[lane][k]);
+      S.ff[lane] = ff;
+      S.rff[lane] = __dsqrt_rn(ff);
+    }
+    // keys, float32: lane l holds projection columns 4l .. 4l+3; the N rows of a window
+    // requested together, summed in slot order (as lsh_window)
+    {
+      const int col = 4 * lane;
+      const int left = L.C - col;
+      const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
+      const int colc = left > 0 ? col : 0;
+      for (uint32_t w = 0; w < nw; ++w) {
+        if (S.ok[w] != 1u) continue;              // (wave-uniform)
+        float4 r[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          r[k] = *reinterpret_cast<const float4*>(L.atab32 + ((size_t)k * L.V + S.f[w][k]) * L.Cp + colc);
+        float4 acc = r[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) {
+          acc.x = __fadd_rn(acc.x, r[k].x); acc.y = __fadd_rn(acc.y, r[k].y);
+          acc.z = __fadd_rn(acc.z, r[k].z); acc.w = __fadd_rn(acc.w, r[k].w);
+        }
+        const float bnd = S.bnd[w];
+        const uint32_t sure = (fabsf(acc.x) > bnd ? 1u : 0u) | (fabsf(acc.y) > bnd ? 2u : 0u) |
+                              (fabsf(acc.z) > bnd ? 4u : 0u) | (fabsf(acc.w) > bnd ? 8u : 0u);
+        if (__any((~sure & cmask) != 0u)) {
+          if (lane == 0) S.ok[w] = 2u;            // a sign is not certain: float64 below
+          continue;
+        }
+        uint32_t x = ((acc.x > 0.0f ? 1u : 0u) | (acc.y > 0.0f ? 2u : 0u) |
+                      (acc.z > 0.0f ? 4u : 0u) | (acc.w > 0.0f ? 8u : 0u)) & cmask;
+        // eight lanes -> one 32-bit piece of the column bit string
+        x |= (uint32_t)__shfl_down((int)x, 1) << 4;
+        x |= (uint32_t)__shfl_down((int)x, 2) << 8;
+        x |= (uint32_t)__shfl_down((int)x, 4) << 16;
+        uint32_t* pieces = reinterpret_cast<uint32_t*>(S.bal[w]);
+        if ((lane & 7) == 0) pieces[lane >> 3] = x;
+      }
+    }
+    sync();
+    for (uint32_t w = 0; w < nw; ++w) {           // float64 keys where needed (rare)
+      if (S.ok[w] != 2u) continue;
+      for (int ch = 0; ch < (L.C + 63) >> 6; ++ch) {
+        const int col = ch * 64 + lane;
+        bool bit = false;
+        if (col < L.C) {
+          double acc = a_value(L, 0, S.f[w][0], col);
+          for (int k = 1; k < N; ++k) acc = __dadd_rn(acc, a_value(L, k, S.f[w][k], col));
+          bit = acc > 0.0;
+        }
+        const uint64_t b = __ballot(bit);
+        if (lane == 0) S.bal[w][ch] = b;
+      }
+    }
+    sync();
+    // ---- B: bucket ranges, lane per (window, table) ----------------------------------------
+#pragma unroll
+    for (int t = 0; t < kBatchW * kBatchH / 64; ++t) {
+      const int w = (t * 64 + lane) / kBatchH, h = (t * 64 + lane) % kBatchH;
+      uint32_t e0 = 0, cnt_h = 0;
+      if (h < L.H && S.ok[w]) {
+        const uint32_t key = assemble_key(S.bal[w], h, L.B);
+        S.key[w][h] = key;
+        const uint32_t* o = L.boff + (size_t)h * nb1 + key;
+        e0 = o[0];
+        cnt_h = o[1] - e0;
+      }
+      // exclusive prefix inside the window's row of sixteen lanes
+      uint32_t incl = cnt_h;
+#pragma unroll
+      for (int d = 1; d < kBatchH; d <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+        if (h >= d) incl += up;
+      }
+      S.e0[w][h] = e0;
+      S.pre[w][h] = incl - cnt_h;
+      if (h == kBatchH - 1) S.vn[w] = incl;       // (the window's entries, until C needs vn)
+    }
+    sync();
+    if (lane == 0) {
+      uint32_t run = 0;
+#pragma unroll
+      for (int w = 0; w < kBatchW; ++w) { S.wbase[w] = run; run += S.vn[w]; S.vn[w] = 0; }
+      S.wbase[kBatchW] = run;
+    }
+    sync();
+    // ---- C: the members, 64 at a time -------------------------------------------------------
+    const uint32_t total = S.wbase[kBatchW];
+    for (uint32_t r0 = 0; r0 < total; r0 += 64) {
+      const uint32_t j = r0 + lane;
+      bool valid = false;
+      uint32_t w = 0, s = 0;
+      double d = 0.0;
+      if (j < total) {
+#pragma unroll
+        for (int i = 1; i < kBatchW; ++i) w += S.wbase[i] <= j ? 1u : 0u;
+        const uint32_t jw = j - S.wbase[w];
+        uint32_t h = 0;                           // last table with pre[w][h] <= jw
+#pragma unroll
+        for (uint32_t step = kBatchH / 2; step > 0; step >>= 1)
+          if (h + step < (uint32_t)L.H && S.pre[w][h + step] <= jw) h += step;
+        s = L.bids[(size_t)h * L.W + S.e0[w][h] + (jw - S.pre[w][h])];
+        valid = window_distance(L, s, S.f[w], S.qf[w], S.ff[w], S.rff[w], &d) && d < L.thr;
+      }
+      // to the window's list, arrival order: the lanes of one window are consecutive
+      const uint64_t vm = __ballot(valid);
+      if (vm) {
+        const uint32_t first = S.wbase[w] > r0 ? S.wbase[w] - r0 : 0u;        // the window's first lane of this round
+        const uint64_t below = ((1ull << lane) - 1) & ~((1ull << first) - 1);
+        const uint32_t slot = S.vn[w] + (uint32_t)__popcll(vm & below);
+        if (valid && slot < (uint32_t)kBatchCap) { S.vs[w][slot] = s; S.vd[w][slot] = d; }
+        sync();
+        // the counts: the window's last valid lane of the round adds the round's number
+        const uint32_t last_lane = min(63u, S.wbase[w + 1] - 1 - r0);
+        const uint64_t mine = vm & (~0ull >> (63 - last_lane)) & ~((1ull << first) - 1);
+        if (valid && (mine >> lane) == 1ull) S.vn[w] = slot + 1;
+      }
+      sync();
+    }
+    // ---- D: UniqueFilter, NearestFilter: eight lanes a window -----------------------------
+    {
+      const int w = lane >> 3, t = lane & 7;
+      const uint32_t V = min(S.vn[w], (uint32_t)kBatchCap);
+      const bool over = S.vn[w] > (uint32_t)kBatchCap;
+      if (L.unique && !over) {
+        for (uint32_t e = t; e < V; e += 8) {
+          const uint32_t se = S.vs[w][e] & 0x7FFFFFFFu;
+          bool dup = false;
+          for (uint32_t x = 0; x < e; ++x) dup = dup || (S.vs[w][x] & 0x7FFFFFFFu) == se;
+          if (dup) S.vs[w][e] = se | 0x80000000u;
+        }
+      }
+      sync();
+      uint32_t kept = 0;
+      if (!over && (uint32_t)w < nw) {
+        const uint32_t jj = j0 + w;
+        for (uint32_t e = t; e < V; e += 8) {
+          const uint32_t se = S.vs[w][e];
+          if (se & 0x80000000u) continue;
+          ++kept;
+          const double de = S.vd[w][e];
+          uint32_t rank = 0;
+          for (uint32_t x = 0; x < V; ++x) {
+            const double dx = S.vd[w][x];
+            rank += (!(S.vs[w][x] & 0x80000000u) && (dx < de || (dx == de && x < e))) ? 1u : 0u;
+          }
+          if (rank < nn) { mtop_s[(size_t)jj * nn + rank] = se; mtop_d[(size_t)jj * nn + rank] = de; }
+        }
+      }
+      kept += (uint32_t)__shfl_xor((int)kept, 1);
+      kept += (uint32_t)__shfl_xor((int)kept, 2);
+      kept += (uint32_t)__shfl_xor((int)kept, 4);
+      kept = min(kept, nn);
+      if (t == 0 && (uint32_t)w < nw && !over) {
+        const uint32_t i = S.ci[w];
+        mcnt[j0 + w] = kept;
+        cg[i] = kept ? FS_PENDING : FS_NONE;
+        cw[i] = S.work[w];
+        matches += kept;
+      }
+    }
+    sync();
+    // the crowded windows, a wave each (lsh_window with its scratch laid over the lists)
+    for (uint32_t w = 0; w < nw; ++w) {
+      if (S.vn[w] <= (uint32_t)kBatchCap) continue;             // (wave-uniform)
+      uint8_t* raw = reinterpret_cast<uint8_t*>(&S.vd[0][0]);
+      LshWaveLds X;
+      X.bal = reinterpret_cast<uint64_t*>(raw);                  // 32 x 8
+      X.top_d = reinterpret_cast<double*>(raw + 256);            // 64 x 8
+      X.qf = reinterpret_cast<double*>(raw + 768);               // 16 x 8
+      X.key = reinterpret_cast<uint32_t*>(raw + 896);            // 64 x 4
+      X.top_s = X.key + 64; X.pre = X.key + 128; X.e0 = X.key + 192;
+      X.f = X.key + 256; X.fs = X.key + 272;                     // 16 + 16
+      X.n = reinterpret_cast<int*>(X.key + 288);
+      X.lev = nullptr; X.la = nullptr; X.lb = nullptr;           // (deferred: no Levenshtein here)
+      static_assert(896 + 4 * 292 <= sizeof(double) * kBatchW * kBatchCap + sizeof(uint32_t) * kBatchW * kBatchCap, "scratch");
+      const uint32_t idv = lane < N ? S.f[w][lane] : 0u;
+      const uint32_t i = S.ci[w], wk = S.work[w];
+      sync();
+      if (lane < N) { X.f[lane] = idv; X.fs[lane] = idv; }
+      sync();
+      fs_best b;
+      const int cnt = lsh_window(c, L, g, X, st, &b, true);
+      const uint32_t jj = j0 + w;
+      if (lane < cnt) {
+        mtop_s[(size_t)jj * nn + lane] = X.top_s[lane];
+        mtop_d[(size_t)jj * nn + lane] = X.top_d[lane];
+      }
+      if (lane == 0) {
+        mcnt[jj] = (uint32_t)cnt;
+        cg[i] = cnt ? FS_PENDING : FS_NONE;
+        cw[i] = wk;
+        matches += (uint32_t)cnt;
+      }
+      sync();
+    }
+  }
+  uint32_t tot;
+  block_excl_scan(matches, s_w32, &tot);
+  if (threadIdx.x == 0) bmatch[blockIdx.x] += tot;       // (on top of k_lsh_sift's)
+}
+
 // The Levenshtein distances of the matches k_lsh_verify<true> kept, and the record of every
 // pending window: a lane per (window, rank) pair -- lev_lane, Myers' recurrence on one lane's
 // registers against the script window's bit planes, where k_lsh_verify ran it as a wave per
@@ -2042,12 +2357,33 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   // pair and the pair itself, 4 us of one lane's time: worth it from some thousands of pending
   // windows on, which the lane's last search tells; FS_LSH_LEV_LANE=2: always)
   const bool defer = ix->sw.lsh_lev_lane && ix->sw.str_fast && ix->strfast_ok && c->strrec_ready &&
-                     L.nn <= kLevMaxN && (ix->cur->pend_hint >= 8192u || ix->sw.lsh_lev_lane == 2);
+                     L.nn <= kLevMaxN && (ix->cur->pend_hint >= (uint32_t)ix->sw.lsh_defer_min || ix->sw.lsh_lev_lane == 2);
   if (defer) {
     FS_TRY(ix->cur->w_mcnt.reserve(ccap));
     FS_TRY(ix->cur->w_mtop_s.reserve((size_t)ccap * L.nn));
     FS_TRY(ix->cur->w_mtop_d.reserve((size_t)ccap * L.nn));
   }
+  // the pending windows eight at a time per wave (k_lsh_batch) where the kept matches' Levenshtein
+  // distances are k_lsh_lev's anyway; a wave per window (k_lsh_verify) otherwise
+  void (*batch)(CorpusDev, LshDev, GramIndexDev, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*,
+                fs_status*, const uint32_t*, uint32_t*, uint32_t*, double*) = nullptr;
+  if (defer && ix->sw.lsh_batch && L.H <= kBatchH && L.nn <= 48 && !L.serial_neighbours && !L.diag)
+    switch (L.n) {
+      case 6: batch = k_lsh_batch<6>; break;
+      case 7: batch = k_lsh_batch<7>; break;
+      case 8: batch = k_lsh_batch<8>; break;
+      case 9: batch = k_lsh_batch<9>; break;
+      case 10: batch = k_lsh_batch<10>; break;
+      case 12: batch = k_lsh_batch<12>; break;
+      default: break;
+    }
+  if (batch) {
+    const uint32_t blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(batch));
+    hipLaunchKernelGGL(batch, dim3(blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
+                       ix->cur->w_cpos.p, ccap, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_bsum.p + kNB, st,
+                       ix->cur->w_pend.p, ix->cur->w_mcnt.p, ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p);
+    if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_batch");
+  } else {
   auto verify = defer ? k_lsh_verify<true> : k_lsh_verify<false>;
   const uint32_t verify_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(verify));
   hipLaunchKernelGGL(verify, dim3(verify_blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
@@ -2055,6 +2391,7 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
                      ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p, ix->cur->w_mcnt.p,
                      ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p);
   if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_verify");
+  }
   if (defer) {
     const StrFast F{ix->d_pat.p, ix->d_clsmap.p, ix->n_cls, ix->str_punct, c->d_strrec.p};
     const uint32_t lev_blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(k_lsh_lev));

@@ -114,7 +114,12 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
                         ({"FS_NEAR_FUSED": "0", "FS_LSH_WILD": "0"}, chain),
                         ({"FS_NEAR_FUSED": "0", "FS_LSH_WMAP": "0"}, chain),
                         ({"FS_NEAR_FUSED": "0", "FS_LSH_GRAMTAB": "0"}, chain),
-                        ({"FS_SCAN_CAPW": "2"}, fused), ({"FS_LANES": "4"}, fused)):
+                        ({"FS_SCAN_CAPW": "2"}, fused), ({"FS_LANES": "4"}, fused),
+                        # the pending windows eight per wave (k_lsh_batch) on every search, however
+                        # few; a wave each (k_lsh_verify) with the Levenshtein distances deferred; and
+                        # inside k_lsh_verify
+                        ({"FS_LSH_DEFER_MIN": "0"}, fused), ({"FS_LSH_BATCH": "0", "FS_LSH_DEFER_MIN": "0"}, fused),
+                        ({"FS_LSH_BATCH": "0", "FS_LSH_DEFER_MIN": "1000000000"}, fused)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         full = ScriptIndex(script, swords, emb, normals, cfg=cfg)

@@ -83,6 +83,18 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     assert ix2.kernel_name(c2) == "k_lsh_scan"
     assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
     monkeypatch.delenv("FS_LSH_SYN")
+    # the pending windows a wave each (k_lsh_verify) instead of eight per wave (k_lsh_batch), and
+    # k_lsh_batch on every search of an index (the second search of a small batch would take
+    # k_lsh_verify: few windows pending): the same bytes
+    for env in ({"FS_LSH_BATCH": "0"}, {"FS_LSH_DEFER_MIN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ixb, cb, gotb, stb = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
+        againb, _ = ixb.search(cb)
+        assert got.tobytes() == gotb.tobytes() == againb.tobytes() and st.matches == stb.matches, env
+        ixb.close()
+        for k in env:
+            monkeypatch.delenv(k)
     # round 4's chain (prefilter bitmap, k_expand, k_lsh_sift over every candidate): the same bytes
     monkeypatch.setenv("FS_NEAR_FUSED", "0")
     ix3, c3, got3, st3 = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
