@@ -156,6 +156,13 @@ struct alignas(32) fs_swin {
   int32_t r0;      // its row in the pair table, -1: none
 };
 
+// what the canonical distance needs of one script token: a 16-byte read per slot
+struct alignas(16) fs_spos {
+  double q;        // q of the token's vector
+  int32_t row;     // its row in the pair table, -1: none
+  uint32_t id;     // its vector id
+};
+
 struct fs_corpus;
 
 // Diagnostic switches (FS_* environment variables), read once at fs_index_create and
@@ -189,6 +196,7 @@ struct fs_switches {
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
   bool lsh_keys6 = true;          // FS_LSH_KEYS6=0: n = 6 over component ids without the middle-slot key filter in k_scan_near
   bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
+  bool lsh_emap = true;           // FS_LSH_EMAP=0: k_lsh_batch walks the buckets of every pending window instead of enumerating the script n-grams one slot away
   bool lsh_batch = true;          // FS_LSH_BATCH=0: the pending windows a wave each (k_lsh_verify) instead of eight per wave level by level (k_lsh_batch)
   int lsh_defer_min = 8192;       // FS_LSH_DEFER_MIN: pending windows of the lane's last search from which on the kept matches' Levenshtein distances go to k_lsh_lev (and the windows to k_lsh_batch)
   bool near_fused = true;         // FS_NEAR_FUSED=0: k_scan_near8 + k_expand + k_lsh_sift (round 4's chain) instead of k_near_sift + k_lsh_sift2; read when the index is built (n = 6: which prefilter kernel the 3-gram filter is laid out for)
@@ -236,6 +244,10 @@ struct fs_index {
   DBuf<double> d_nt, d_atab, d_ss, d_gtab;
   DBuf<fs_swin> d_sw;            // per script window: what a bucket candidate's first slot needs
   DBuf<int32_t> d_sidx;
+  DBuf<fs_spos> d_spos;      // per script token (k_spos)
+  DBuf<uint32_t> d_skeys;    // [W][H] LSH keys of the script windows
+  DBuf<uint32_t> d_emap, d_emapc;   // wildcard keys -> distinct script n-gram, over vector ids / component ids (build_emap)
+  int log2_emap = 0, log2_emapc = 0;
   DBuf<float> d_atab32, d_amax;
   DBuf<uint32_t> d_boff, d_bids;
   bool lsh_ready = false;

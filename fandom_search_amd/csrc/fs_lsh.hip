@@ -74,6 +74,11 @@ struct LshDev {
   int serial_neighbours;   // FS_LSH_SERIAL=1: k_lsh_verify walks the buckets on one lane (cross-check)
   const double* gtab;      // [n_srow][V] g(script row, table row), or nullptr
   const int32_t* sidx;     // [V] row of gtab for a table id, -1 if not a script word
+  const uint2* emap;       // one-slot-wildcard keys (over the vector ids, or the component ids: emap_comp) -> distinct
+                           // script n-gram: 2^log2_emap buckets of four {key, gram + 1} (k_lsh_batch), or nullptr
+  int log2_emap, emap_comp;
+  const uint32_t* skeys;   // [W][H] LSH keys of the script windows
+  const fs_spos* spos;     // [n_script] {q, pair-table row, id} of every script token (k_spos), or nullptr
   const uint32_t* selflev; // [W] Levenshtein of script window w against the strings of its own ids for
                            // this batch's string table (FS_NONE: compute), or nullptr
   const uint32_t* wild;    // one-slot-wildcard keys of the script windows (fs_hash.h), or nullptr
@@ -170,6 +175,9 @@ __device__ __forceinline__ uint32_t assemble_key(const uint64_t* bal, int h, int
 // all (its q is the fan side's) and only the slots that differ fetch the script side: its id,
 // q and the pair-table entry -- at n = 10 two levels of loads for the one slot instead of two
 // per slot.
+__device__ __forceinline__ bool window_distance_rest(const LshDev& L, uint32_t s, const fs_swin& sw, int same,
+                                                     uint32_t diff, const uint32_t* f, const double* qf,
+                                                     double ff, double rff, double* out);
 __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, const double* qf,
                                 double ff, double rff, double* out) {
   // stage 0: integer only.  With all table norms in [sqrt(q_min), sqrt(q_max)] and
@@ -204,6 +212,13 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
     if (anyoov & FS_OOV_FLAG) { same = -1; diff = 0xFFFFFFFFu; }
     else if (L.m_min > 0 && same < L.m_min) return false;
   }
+  return window_distance_rest(L, s, sw, same, diff, f, qf, ff, rff, out);
+}
+
+// (stage 1 of window_distance, behind the window's record and the comparison of the ids)
+__device__ __forceinline__ bool window_distance_rest(const LshDev& L, uint32_t s, const fs_swin& sw, int same,
+                                                     uint32_t diff, const uint32_t* f, const double* qf,
+                                                     double ff, double rff, double* out) {
   // stage 1: the canonical sum SF slot by slot, leaving as soon as the slots still to
   // come cannot lift it to the threshold.  By Cauchy-Schwarz the remaining slots add
   // at most sqrt(SS_rem * FF_rem) (SS_rem, FF_rem = squared norms of the remaining
@@ -244,6 +259,78 @@ __device__ bool window_distance(const LshDev& L, uint32_t s, const uint32_t* f, 
       const double rem = fmax(ssr, 0.0) * fmax(ffr, 0.0) * (1.0 + 1e-9);
       if (t > 0.0 && t * t > rem) return false;
     }
+  }
+  const double d = __dsub_rn(1.0, __ddiv_rn(sf, norm));
+  if (d != d) return false;
+  *out = d;
+  return true;
+}
+
+// window_distance for k_lsh_batch, the window size at compile time.  The same first level of
+// loads (the window's record and ids); a window that differs from the fan window in three slots
+// or fewer -- every real neighbour -- then fetches what the canonical sum needs of those slots
+// together: their 16-byte {q, pair-table row, id} records (k_spos) in one level, the pair-table
+// entries in the next, where window_distance goes id -> q, id -> row -> entry slot after slot.
+// The same arithmetic in the same order; everything else (bucket collisions of unrelated
+// windows, which leave after a slot or two; OOV ids) takes window_distance's own loop.
+template <int N>
+__device__ __forceinline__ bool window_distance_flat(const LshDev& L, uint32_t s, const uint32_t* f,
+                                                     const double* qf, double ff, double rff, double* out) {
+  const fs_swin sw = L.sw[s];
+  const uint4* sp = reinterpret_cast<const uint4*>(L.stok + s);
+  uint32_t u[4 * ((N + 3) / 4)];
+#pragma unroll
+  for (int q4 = 0; q4 < (N + 3) / 4; ++q4) {
+    const uint4 t = sp[q4];
+    u[4 * q4] = t.x; u[4 * q4 + 1] = t.y; u[4 * q4 + 2] = t.z; u[4 * q4 + 3] = t.w;
+  }
+  uint32_t diff = 0, anyoov = 0;
+  int same = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    const bool eq = u[k] == f[k];
+    same += eq;
+    diff |= eq ? 0u : 1u << k;
+    anyoov |= u[k] | f[k];
+  }
+  if (anyoov & FS_OOV_FLAG) return window_distance_rest(L, s, sw, -1, 0xFFFFFFFFu, f, qf, ff, rff, out);
+  if (L.m_min > 0 && same < L.m_min) return false;
+  if (!L.spos || !L.gtab || N - same > 3)
+    return window_distance_rest(L, s, sw, L.m_min > 0 ? same : -1, L.m_min > 0 ? diff : 0xFFFFFFFFu, f, qf, ff, rff, out);
+  const double norm = __dmul_rn(sw.rss, rff);
+  if (same == N) {
+    const double d = __dsub_rn(1.0, __ddiv_rn(sw.ss, norm));
+    if (d != d) return false;
+    *out = d;
+    return true;
+  }
+  // the (at most three) slots that differ
+  int kd[3];
+  uint32_t rest = diff;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    kd[i] = rest ? __ffs((int)rest) - 1 : -1;
+    rest &= rest - 1;
+  }
+  uint4 rec[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (kd[i] >= 0) rec[i] = *reinterpret_cast<const uint4*>(L.spos + s + kd[i]);
+  double gd[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    gd[i] = 0.0;
+    if (kd[i] >= 0) {
+      const int32_t row = (int32_t)rec[i].z;
+      gd[i] = row >= 0 ? L.gtab[(size_t)row * L.V + f[kd[i]]] : g_of(L, rec[i].w, f[kd[i]]);
+    }
+  }
+  double sf = 0.0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double g = qf[k];
+    g = k == kd[0] ? gd[0] : g; g = k == kd[1] ? gd[1] : g; g = k == kd[2] ? gd[2] : g;
+    sf = __dadd_rn(sf, g);
   }
   const double d = __dsub_rn(1.0, __ddiv_rn(sf, norm));
   if (d != d) return false;
@@ -463,6 +550,17 @@ __global__ void k_ss(const uint32_t* __restrict__ stok, uint32_t W, LshDev L,
   r.qu0 = q_of(L, r.u0);
   r.r0 = (L.gtab && !(r.u0 & FS_OOV_FLAG)) ? L.sidx[r.u0] : -1;
   sw[w] = r;
+}
+
+// {q, pair-table row, id} of every script token: what window_distance_flat reads per slot
+__global__ void k_spos(const uint32_t* __restrict__ stok, uint32_t n_script, LshDev L, fs_spos* __restrict__ spos) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_script) return;
+  fs_spos r;
+  r.id = stok[i];
+  r.q = q_of(L, r.id);
+  r.row = (L.gtab && !(r.id & FS_OOV_FLAG)) ? L.sidx[r.id] : -1;
+  spos[i] = r;
 }
 
 // keys of the windows of a token stream; one wave per window
@@ -1478,8 +1576,9 @@ __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, Gr
 // members within the threshold (crowded buckets) is worked off by lsh_window behind the batch.
 // The Levenshtein distances are k_lsh_lev's (a lane per kept match).
 constexpr int kBatchW = 8;                // windows per wave and step
-constexpr int kBatchCap = 40;             // members within the threshold kept per window
+constexpr int kBatchCap = 32;             // members within the threshold kept per window
 constexpr int kBatchH = 16;               // tables (number_of_hashes) this form serves
+constexpr int kBatchG = 3;                // script n-grams one slot away from a window that the enumeration takes
 struct alignas(16) BatchLds {             // per wave
   uint64_t bal[kBatchW][6];               // sign bits of the projection columns (C <= 256), + a zero word
   double qf[kBatchW][FS_MAX_WINDOW];      // q of the windows' slots
@@ -1490,6 +1589,13 @@ struct alignas(16) BatchLds {             // per wave
   uint32_t key[kBatchW][kBatchH];
   uint32_t e0[kBatchW][kBatchH];          // first entry of the window's bucket in table h
   uint32_t pre[kBatchW][kBatchH];         // entries of the window in the tables before h
+  uint32_t dh[128];                       // C: (window, script window) -> a lane of the round that holds the pair
+  uint32_t fc[kBatchW][FS_MAX_WINDOW];    // E: the ids the wildcard keys are made of (component ids on tables with near-synonyms)
+  uint32_t va[kBatchW][kBatchCap];        // E: arrival order of a list entry (table * W + script window)
+  double gd[kBatchW][kBatchG];            // E: distance of the window to gram gi
+  uint32_t gg[kBatchW][kBatchG];          // E: the script n-grams one slot away (gram ids)
+  uint32_t gh[kBatchW][kBatchG];          // E: bit h: table h holds the window and the gram in one bucket
+  uint32_t gn[kBatchW];                   // E: number of such n-grams (> kBatchG: the window walks the buckets)
   uint32_t wbase[kBatchW + 1];            // entries of the windows before w
   uint32_t vn[kBatchW];                   // members within the threshold so far (may exceed kBatchCap)
   uint32_t ci[kBatchW];                   // candidate number
@@ -1501,7 +1607,7 @@ static_assert(sizeof(double) * kBatchW * kBatchCap + sizeof(uint32_t) * kBatchW 
               "lsh_window's scratch is laid over vd / vs");
 
 template <int N>
-__global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, GramIndexDev g,
+__global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, GramIndexDev g,
                                                    const uint32_t* __restrict__ cpos, uint32_t cap,
                                                    uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
                                                    uint32_t* __restrict__ bmatch, fs_status* st,
@@ -1552,6 +1658,7 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       if (k < N && S.ok[w]) {
         const uint32_t id = c.tok[(uint64_t)S.wbase[w] + k];
         S.f[w][k] = id;
+        S.fc[w][k] = L.emap_comp ? L.wild_tok[(uint64_t)S.wbase[w] + k] : id;
         S.qf[w][k] = q_of(L, id);
         oov = id & FS_OOV_FLAG;
         if (!oov && L.atab32) am = L.amax[(size_t)k * L.V + id];
@@ -1625,14 +1732,166 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       }
     }
     sync();
+    if (L.diag & 0x10000) {                       // diagnostics: the keys only
+      if (lane < kBatchW && (uint32_t)lane < nw) { mcnt[j0 + lane] = 0; cg[S.ci[lane]] = FS_NONE; }
+      continue;
+    }
+    // the keys
+#pragma unroll
+    for (int t = 0; t < kBatchW * kBatchH / 64; ++t) {
+      const int w = (t * 64 + lane) / kBatchH, h = (t * 64 + lane) % kBatchH;
+      if (h < L.H && S.ok[w]) S.key[w][h] = assemble_key(S.bal[w], h, L.B);
+    }
+    if (lane < kBatchW) S.gn[lane] = 0xFFFFu;     // (not enumerated)
+    sync();
+    // ---- E: the script n-grams one slot away, enumerated --------------------------------------
+    // Every script window within the threshold equals the fan window in all slots but one (by
+    // vector ids where the table's c_max proves it, by component ids on tables with near-
+    // synonyms), so its n-gram is found under one of the window's n one-slot-wildcard keys in
+    // the exact map.  What LSH finds of it: the tables in which its key is the window's
+    // (the script windows' keys are kept); all its occurrences share those buckets, in
+    // ascending order.  So the window's list is made without walking a bucket: per n-gram its
+    // first nn entries in arrival order (table, script window), then the stable order by
+    // distance as in D.  (Windows beyond the threshold never reach the list: NearestFilter
+    // sorts by distance and everything within the threshold is in front of them.)
+    if (L.emap && L.skeys && nn * kBatchG <= (uint32_t)kBatchCap) {
+      if (lane < kBatchW) S.gn[lane] = 0;
+      sync();
+      uint32_t hit[kBatchW * FS_MAX_WINDOW / 64][4];
+#pragma unroll
+      for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t) {
+        const int w = (t * 64 + lane) / FS_MAX_WINDOW, k = (t * 64 + lane) % FS_MAX_WINDOW;
+        const bool live = k < N && S.ok[w];
+        const uint32_t term = live ? fs_rotl(fs_premix(S.fc[w][k]), fs_rot_of(N - 1 - k)) : 0u;
+        uint32_t fold = term;
+#pragma unroll
+        for (int d = 8; d > 0; d >>= 1) fold ^= (uint32_t)__shfl_xor((int)fold, d);
+        hit[t][0] = hit[t][1] = hit[t][2] = hit[t][3] = 0;
+        if (live) {
+          const uint32_t h = fs_wild_key(fold, term, k);
+          const uint4* bp = reinterpret_cast<const uint4*>(L.emap + 4 * (size_t)fs_wmap_slot(h, L.log2_emap));
+          const uint4 a = bp[0], b = bp[1];
+          hit[t][0] = a.y && a.x == h ? a.y : 0u; hit[t][1] = a.w && a.z == h ? a.w : 0u;
+          hit[t][2] = b.y && b.x == h ? b.y : 0u; hit[t][3] = b.w && b.z == h ? b.w : 0u;
+          if (b.w) S.gn[w] = 0xFFFFu;             // a full bucket: entries may have spilt -- the bucket walk
+        }
+      }
+      sync();
+      // the distinct n-grams of a window, slot after slot (eight windows side by side)
+#pragma unroll
+      for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t)
+        for (int k = 0; k < N; ++k) {
+          const int w = (t * 64 + lane) / FS_MAX_WINDOW;
+          if ((t * 64 + lane) % FS_MAX_WINDOW == k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (hit[t][e]) {
+                const uint32_t gid = hit[t][e] - 1;
+                if (gid >= g.n_grams) { atomicMax(&st->max_rows, 0x70000001u); continue; }   // (cannot happen: the map holds gram ids)
+                uint32_t cn = S.gn[w];
+                bool seen = false;
+                for (uint32_t x = 0; x < cn && x < (uint32_t)kBatchG; ++x) seen = seen || S.gg[w][x] == gid;
+                if (!seen && cn != 0xFFFFu) {
+                  if (cn < (uint32_t)kBatchG) { S.gg[w][cn] = gid; S.gn[w] = cn + 1; }
+                  else S.gn[w] = 0xFFFFu;         // more n-grams than the lists hold: the bucket walk
+                }
+              }
+          }
+          sync();
+        }
+      // distance to each n-gram (its first window), lane per (window, n-gram)
+      {
+        const int w = lane / 4, gi = lane % 4;
+        if (lane < kBatchW * 4 && gi < kBatchG && S.ok[w] && S.gn[w] != 0xFFFFu && (uint32_t)gi < S.gn[w]) {
+          const uint32_t s0 = g.gpos[(size_t)S.gg[w][gi] * nn];
+          if (s0 >= L.W) atomicMax(&st->max_rows, 0x70000002u);               // (cannot happen)
+          double d = 0.0;
+          const bool v = s0 < L.W && window_distance_flat<N>(L, s0, S.f[w], S.qf[w], S.ff[w], S.rff[w], &d) && d < L.thr;
+          S.gd[w][gi] = v ? d : __longlong_as_double(0x7FF8000000000000ll);   // (NaN: beyond the threshold; a distance may be -2e-16)
+          S.gh[w][gi] = 0;
+        }
+      }
+      sync();
+      // the tables that hold window and n-gram in one bucket, lane per (window, n-gram, table)
+      for (int t0 = 0; t0 < kBatchW * kBatchG * kBatchH; t0 += 64) {
+        const int x = t0 + lane;
+        const int w = x / (kBatchG * kBatchH), gi = (x / kBatchH) % kBatchG, h = x % kBatchH;
+        if (w < kBatchW && h < L.H && S.ok[w] && S.gn[w] != 0xFFFFu && (uint32_t)gi < S.gn[w] && S.gd[w][gi] == S.gd[w][gi]) {
+          const uint32_t s0 = g.gpos[(size_t)S.gg[w][gi] * nn];
+          if (L.skeys[(size_t)s0 * L.H + h] == S.key[w][h]) atomicOr(&S.gh[w][gi], 1u << h);
+        }
+      }
+      sync();
+      // the lists: per n-gram its first nn entries in arrival order
+      {
+        const int w = lane / 4, gi = lane % 4;
+        if (lane < kBatchW * 4 && gi < kBatchG && S.gn[w] != 0xFFFFu) {
+          uint32_t made = 0;               // (a window that is none -- across a work boundary -- gets empty lists)
+          if (S.ok[w] && (uint32_t)gi < S.gn[w] && S.gd[w][gi] == S.gd[w][gi]) {
+            const uint32_t gid = S.gg[w][gi], occ = g.gcnt[gid];
+            uint32_t tables = S.gh[w][gi];
+            if (L.unique && tables) tables &= 0u - tables;         // a script window counts where it arrives first
+            const double d = S.gd[w][gi];
+            while (tables && made < nn) {
+              const uint32_t h = (uint32_t)__ffs((int)tables) - 1;
+              tables &= tables - 1;
+              for (uint32_t r = 0; r < occ && made < nn; ++r) {
+                const uint32_t sr = g.gpos[(size_t)gid * nn + r];
+                S.vs[w][gi * nn + made] = sr; S.vd[w][gi * nn + made] = d;
+                S.va[w][gi * nn + made] = h * L.W + sr;
+                ++made;
+              }
+            }
+          }
+          for (uint32_t e = made; e < nn; ++e) S.vs[w][gi * nn + e] = FS_NONE;
+        }
+      }
+      sync();
+      // NearestFilter: rank in (distance, arrival) order, eight lanes a window
+      {
+        const int w = lane >> 3, t = lane & 7;
+        const bool mine = (uint32_t)w < nw && S.gn[w] != 0xFFFFu;
+        const uint32_t V = mine ? (uint32_t)kBatchG * nn : 0u;
+        uint32_t kept = 0;
+        for (uint32_t e = t; e < V; e += 8) {
+          const uint32_t se = S.vs[w][e];
+          if (se == FS_NONE) continue;
+          ++kept;
+          const double de = S.vd[w][e];
+          const uint32_t ae = S.va[w][e];
+          uint32_t rank = 0;
+          for (uint32_t x = 0; x < V; ++x) {
+            const double dx = S.vd[w][x];
+            rank += (S.vs[w][x] != FS_NONE && (dx < de || (dx == de && S.va[w][x] < ae))) ? 1u : 0u;
+          }
+          if (rank < nn) { mtop_s[(size_t)(j0 + w) * nn + rank] = se; mtop_d[(size_t)(j0 + w) * nn + rank] = de; }
+        }
+        kept += (uint32_t)__shfl_xor((int)kept, 1);
+        kept += (uint32_t)__shfl_xor((int)kept, 2);
+        kept += (uint32_t)__shfl_xor((int)kept, 4);
+        kept = min(kept, nn);
+        if (t == 0 && mine) {
+          const uint32_t i = S.ci[w];
+          mcnt[j0 + w] = kept;
+          cg[i] = kept ? FS_PENDING : FS_NONE;
+          cw[i] = S.work[w];
+          matches += kept;
+        }
+      }
+      sync();
+      // (what is left for the bucket walk below: the windows whose map buckets were full or held
+      // more n-grams than the lists take)
+      if (lane < kBatchW && S.gn[lane] != 0xFFFFu) S.ok[lane] = 0;
+      sync();
+      if (!__any(lane < kBatchW && (uint32_t)lane < nw && S.ok[lane] != 0)) continue;
+    }
     // ---- B: bucket ranges, lane per (window, table) ----------------------------------------
 #pragma unroll
     for (int t = 0; t < kBatchW * kBatchH / 64; ++t) {
       const int w = (t * 64 + lane) / kBatchH, h = (t * 64 + lane) % kBatchH;
       uint32_t e0 = 0, cnt_h = 0;
       if (h < L.H && S.ok[w]) {
-        const uint32_t key = assemble_key(S.bal[w], h, L.B);
-        S.key[w][h] = key;
+        const uint32_t key = S.key[w][h];
         const uint32_t* o = L.boff + (size_t)h * nb1 + key;
         e0 = o[0];
         cnt_h = o[1] - e0;
@@ -1657,7 +1916,8 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     }
     sync();
     // ---- C: the members, 64 at a time -------------------------------------------------------
-    const uint32_t total = S.wbase[kBatchW];
+    const uint32_t total = (L.diag & 0x20000) ? 0u : S.wbase[kBatchW];      // (diagnostics: no members)
+    if (L.diag & 0x80000) { if (lane == 0) atomicAdd(&st->max_rows, S.wbase[kBatchW]); }   // diagnostics: count them (printed by fs_search_corpus_end)
     for (uint32_t r0 = 0; r0 < total; r0 += 64) {
       const uint32_t j = r0 + lane;
       bool valid = false;
@@ -1672,7 +1932,25 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
         for (uint32_t step = kBatchH / 2; step > 0; step >>= 1)
           if (h + step < (uint32_t)L.H && S.pre[w][h + step] <= jw) h += step;
         s = L.bids[(size_t)h * L.W + S.e0[w][h] + (jw - S.pre[w][h])];
-        valid = window_distance(L, s, S.f[w], S.qf[w], S.ff[w], S.rff[w], &d) && d < L.thr;
+      }
+      // A script window comes back once per table whose bucket it shares with the fan window --
+      // a dozen times for a real neighbour -- and its distance is the same every time: one lane
+      // of the round works it out for all that hold the same (window, script window) pair.  The
+      // lanes agree on it through a small table in LDS (a lane that finds another pair's lane
+      // in its slot works its own out).
+      const uint32_t pair = s * (uint32_t)kBatchW + w;
+      const uint32_t hslot = (pair * 0x9E3779B1u) >> 25;
+      if (j < total) S.dh[hslot] = (uint32_t)lane;
+      sync();
+      const int leader = j < total ? (int)S.dh[hslot] : lane;
+      const bool follow = (uint32_t)__shfl((int)pair, leader) == pair && leader != lane && j < total;
+      if (j < total && !follow && !(L.diag & 0x40000))                  // (diagnostics: no distances)
+        valid = window_distance_flat<N>(L, s, S.f[w], S.qf[w], S.ff[w], S.rff[w], &d) && d < L.thr;
+      {
+        const long long db = __double_as_longlong(d);
+        const int lo = __shfl((int)(uint32_t)db, leader), hi = __shfl((int)(uint32_t)(db >> 32), leader);
+        const int lv = __shfl((int)valid, leader);
+        if (follow) { d = __longlong_as_double(((long long)hi << 32) | (uint32_t)lo); valid = lv != 0; }
       }
       // to the window's list, arrival order: the lanes of one window are consecutive
       const uint64_t vm = __ballot(valid);
@@ -1693,7 +1971,7 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     {
       const int w = lane >> 3, t = lane & 7;
       const uint32_t V = min(S.vn[w], (uint32_t)kBatchCap);
-      const bool over = S.vn[w] > (uint32_t)kBatchCap;
+      const bool over = S.vn[w] > (uint32_t)kBatchCap || S.gn[w] != 0xFFFFu;    // (or enumerated above: done)
       if (L.unique && !over) {
         for (uint32_t e = t; e < V; e += 8) {
           const uint32_t se = S.vs[w][e] & 0x7FFFFFFFu;
@@ -1795,13 +2073,27 @@ __global__ __launch_bounds__(256) void k_lsh_lev(CorpusDev c, LshDev L, GramInde
   __shared__ uint32_t s_w32[4];
   __shared__ uint32_t s_pref[257];
   __shared__ uint32_t s_lev[kLevWin * kLevMaxN];
+  __shared__ uint8_t s_first[kLevWin * kLevMaxN], s_dr[kLevWin * kLevMaxN];
   const uint32_t n_pend = min(st->lsh_pending, cap);
   const uint32_t nn = (uint32_t)L.nn;
   for (uint32_t j0 = blockIdx.x * kLevWin; j0 < n_pend; j0 += gridDim.x * kLevWin) {
     const uint32_t j = j0 + threadIdx.x;
     const uint32_t cnt = (threadIdx.x < kLevWin && j < n_pend) ? mcnt[j] : 0u;
+    // Without the UniqueFilter a script window is kept once per table that found it, and the
+    // copies' Levenshtein distance is the one number: a pair per DISTINCT script window of
+    // the list (first[r]: the first rank with rank r's window; dr[k]: rank of the k-th distinct
+    // one), up to ten times fewer pairs
+    uint32_t dcnt = 0;
+    for (uint32_t r = 0; r < cnt; ++r) {
+      const uint32_t sr = mtop_s[(size_t)j * nn + r];
+      uint32_t fr = r;
+      for (uint32_t x = 0; x < r; ++x)
+        if (mtop_s[(size_t)j * nn + x] == sr) { fr = x; break; }
+      s_first[threadIdx.x * kLevMaxN + r] = (uint8_t)fr;
+      if (fr == r) s_dr[threadIdx.x * kLevMaxN + dcnt++] = (uint8_t)r;
+    }
     uint32_t total;
-    const uint32_t base = block_excl_scan(cnt, s_w32, &total);
+    const uint32_t base = block_excl_scan(dcnt, s_w32, &total);
     s_pref[threadIdx.x] = base;
     if (threadIdx.x == 255) s_pref[256] = total;
     __syncthreads();
@@ -1813,7 +2105,7 @@ __global__ __launch_bounds__(256) void k_lsh_lev(CorpusDev c, LshDev L, GramInde
           const uint32_t mid = (lo + hi) >> 1;
           if (s_pref[mid] <= q) lo = mid; else hi = mid;
         }
-        const uint32_t r = q - s_pref[lo], jj = j0 + lo;
+        const uint32_t r = s_dr[lo * kLevMaxN + (q - s_pref[lo])], jj = j0 + lo;
         const uint32_t s = mtop_s[(size_t)jj * nn + r];
         const uint64_t p = cpos[pend[jj]];
         uint32_t lv = FS_NONE;
@@ -1848,7 +2140,7 @@ __global__ __launch_bounds__(256) void k_lsh_lev(CorpusDev c, LshDev L, GramInde
       b.pad = 0.0;
       for (uint32_t r = 0; r < cnt; ++r) {          // first minimum of dist * lev in rank order
         const double d = mtop_d[(size_t)j * nn + r];
-        const uint32_t lv = s_lev[threadIdx.x * nn + r];
+        const uint32_t lv = s_lev[threadIdx.x * nn + s_first[threadIdx.x * kLevMaxN + r]];
         const double comb = __dmul_rn(d, (double)lv);
         if (r == 0 || comb < b.comb) {
           b.s = mtop_s[(size_t)j * nn + r]; b.lev = lv; b.dist = d; b.comb = comb;
@@ -1871,6 +2163,8 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.atab = ix->d_atab.p; L.nt = ix->d_nt.p; L.boff = ix->d_boff.p; L.bids = ix->d_bids.p;
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
+  L.spos = ix->d_spos.n > 1 ? ix->d_spos.p : nullptr;
+  L.emap = nullptr; L.log2_emap = 0; L.emap_comp = 0; L.skeys = ix->d_skeys.n > 1 ? ix->d_skeys.p : nullptr;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
   L.wild = nullptr; L.log2_wild = 0; L.wild_tok = nullptr; L.selflev = nullptr; L.wmap = nullptr; L.log2_wmap = 0;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
@@ -1944,6 +2238,47 @@ static int build_wild_filter(const std::vector<uint32_t>& st, uint64_t W, int n,
 // ids are a script n-gram's).  Sound: a filter only removes windows that cannot have a
 // neighbour.  Not used when the components are too coarse to filter (one of them holding an
 // eighth of the table or more: zero rows, hubs of tiny norm) or a side holds OOV vectors.
+// The one-slot-wildcard keys of every distinct script n-gram (by vector ids: gram g's first
+// window is gpos[g][0]) as an exact map key -> g, the keys made of `ids` (the script's vector
+// ids, or their component ids): buckets of four {key, g + 1}, a full bucket spills into the next
+// (k_lsh_batch gives a window up to the bucket walk when it meets a full one).
+static int build_emap(fs_index* ix, const std::vector<uint32_t>& ids, DBuf<uint32_t>* out, int* log2_out) {
+  const int n = (int)ix->cfg.window_size;
+  const uint32_t nn = ix->cfg.nearest_n;
+  const uint32_t G = ix->n_grams;
+  *log2_out = 0;
+  if (!G || !ix->d_gpos.p) return FS_OK;
+  std::vector<uint32_t> gpos((size_t)G * nn);
+  FS_HIP(hipMemcpy(gpos.data(), ix->d_gpos.p, gpos.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  int lm = 8;
+  while (lm < 26 && ((uint64_t)1 << lm) < (uint64_t)G * n) ++lm;
+  std::vector<uint32_t> emap((size_t)8 << lm, 0u);
+  const uint32_t mask = (1u << lm) - 1;
+  for (uint32_t g = 0; g < G; ++g) {
+    const uint32_t w = gpos[(size_t)g * nn];
+    uint32_t term[FS_MAX_WINDOW], fold = 0;
+    for (int k = 0; k < n; ++k) {
+      term[k] = fs_rotl(fs_premix(ids[w + k]), fs_rot_of(n - 1 - k));
+      fold ^= term[k];
+    }
+    for (int k = 0; k < n; ++k) {
+      const uint32_t h = fs_wild_key(fold, term[k], k);
+      uint32_t bkt = fs_wmap_slot(h, lm);
+      for (;;) {
+        uint32_t* e = emap.data() + 8 * (size_t)bkt;
+        int at = 0;
+        while (at < 4 && e[2 * at + 1]) ++at;
+        if (at < 4) { e[2 * at] = h; e[2 * at + 1] = g + 1; break; }
+        bkt = (bkt + 1) & mask;
+      }
+    }
+  }
+  FS_TRY(out->upload(emap.data(), emap.size(), ix->stream));
+  FS_HIP(hipStreamSynchronize(ix->stream));
+  *log2_out = lm;
+  return FS_OK;
+}
+
 static int fs_build_components(fs_index* ix) {
   ix->syn_ok = false;
   const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
@@ -2018,6 +2353,7 @@ static int fs_build_components(fs_index* ix) {
   const int lwild = build_wild_filter(sc, W, n, &wild);
   FS_TRY(ix->d_wildc.upload(wild.data(), wild.size(), ix->stream));
   ix->log2_wildc = lwild;
+  FS_TRY(build_emap(ix, sc, &ix->d_emapc, &ix->log2_emapc));
   if (n == 6) {
     // the keys of slots 2 and 3 in a filter of their own for k_scan_near (fs_scan.hip)
     std::vector<uint32_t> keys((size_t)1 << FS_NEAR6_LOG2_WORDS, 0u);
@@ -2106,6 +2442,7 @@ int fs_lsh_build(fs_index* ix) {
       FS_TRY(ix->d_wmap.upload(wmap.data(), wmap.size(), ix->stream));
       ix->log2_wmap = lm;
     }
+    FS_TRY(build_emap(ix, st, &ix->d_emap, &ix->log2_emap));
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
   if ((int)ix->cfg.window_size - ix->lsh_m_min > 1) FS_TRY(fs_build_components(ix));
@@ -2166,8 +2503,13 @@ int fs_lsh_build(fs_index* ix) {
     LshDev L = lsh_dev(ix);
     hipLaunchKernelGGL(k_ss, dim3((uint32_t)((W + 255) / 256)), dim3(256), 0, s, ix->d_stok.p,
                        (uint32_t)W, L, ix->d_ss.p, ix->d_sw.p);
+    FS_TRY(ix->d_spos.reserve(ix->n_script + FS_MAX_WINDOW));
+    FS_HIP(hipMemsetAsync(ix->d_spos.p, 0, (ix->n_script + FS_MAX_WINDOW) * sizeof(fs_spos), s));
+    hipLaunchKernelGGL(k_spos, dim3((uint32_t)((ix->n_script + 255) / 256)), dim3(256), 0, s, ix->d_stok.p,
+                       (uint32_t)ix->n_script, L, ix->d_spos.p);
     // script window keys and their CSR buckets, all on the device
-    DBuf<uint32_t> d_keys, d_cursor, d_big, d_tmp;
+    DBuf<uint32_t> d_cursor, d_big, d_tmp;
+    DBuf<uint32_t>& d_keys = ix->d_skeys;          // (kept: k_lsh_batch compares a window's keys with a script window's)
     FS_TRY(d_keys.reserve(W * H));
     FS_TRY(d_cursor.reserve((size_t)H * nb));
     FS_TRY(d_big.reserve((size_t)H * nb / kSmallBucket + (size_t)H * W / kSmallBucket + 2));
@@ -2286,6 +2628,15 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   if (c->selflev_ready && !c->has_str) L.selflev = c->d_selflev.p;
   // the wildcard-key filter of this search, if any (fs_lsh_wild_of)
   fs_lsh_wild_of(ix, c, &L.wild, &L.log2_wild, &L.wild_tok);
+  // every neighbour within the threshold equals the window in all slots but one (by vector
+  // ids, or by component ids): the exact map enumerates them, no bucket is walked (k_lsh_batch)
+  if (ix->sw.lsh_emap && L.wild) {
+    if (L.wild_tok && ix->d_emapc.p && ix->log2_emapc) {
+      L.emap = reinterpret_cast<const uint2*>(ix->d_emapc.p); L.log2_emap = ix->log2_emapc; L.emap_comp = 1;
+    } else if (!L.wild_tok && ix->d_emap.p && ix->log2_emap) {
+      L.emap = reinterpret_cast<const uint2*>(ix->d_emap.p); L.log2_emap = ix->log2_emap; L.emap_comp = 0;
+    }
+  }
   if (L.wild && !L.wild_tok) {
     // A one-slot neighbour has cosine (n - 1 + c) / n with c the cosine of the two differing
     // vectors: within the threshold iff c > 1 - n * thr.  At n = 8 (c > 0.2) nearly every such
@@ -2367,7 +2718,7 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
   // distances are k_lsh_lev's anyway; a wave per window (k_lsh_verify) otherwise
   void (*batch)(CorpusDev, LshDev, GramIndexDev, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*,
                 fs_status*, const uint32_t*, uint32_t*, uint32_t*, double*) = nullptr;
-  if (defer && ix->sw.lsh_batch && L.H <= kBatchH && L.nn <= 48 && !L.serial_neighbours && !L.diag)
+  if (defer && ix->sw.lsh_batch && L.H <= kBatchH && L.nn <= 48 && !L.serial_neighbours && !(L.diag & 0xFFFF))
     switch (L.n) {
       case 6: batch = k_lsh_batch<6>; break;
       case 7: batch = k_lsh_batch<7>; break;

@@ -119,6 +119,11 @@ def test_one_slot_prefilter_of_the_lsh_pipeline(synth_base, monkeypatch, n, uniq
                         # few; a wave each (k_lsh_verify) with the Levenshtein distances deferred; and
                         # inside k_lsh_verify
                         ({"FS_LSH_DEFER_MIN": "0"}, fused), ({"FS_LSH_BATCH": "0", "FS_LSH_DEFER_MIN": "0"}, fused),
+                        # ... k_lsh_batch walking the buckets of every window instead of enumerating the
+                        # script n-grams one slot away
+                        ({"FS_LSH_DEFER_MIN": "0", "FS_LSH_EMAP": "0"}, fused),
+                        ({"FS_LSH_DEFER_MIN": "0", "FS_LSH_GRAMTAB": "0"}, fused),
+                        ({"FS_LSH_DEFER_MIN": "0", "FS_LSH_WMAP": "0"}, fused),
                         ({"FS_LSH_BATCH": "0", "FS_LSH_DEFER_MIN": "1000000000"}, fused)):
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -86,7 +86,8 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     # the pending windows a wave each (k_lsh_verify) instead of eight per wave (k_lsh_batch), and
     # k_lsh_batch on every search of an index (the second search of a small batch would take
     # k_lsh_verify: few windows pending): the same bytes
-    for env in ({"FS_LSH_BATCH": "0"}, {"FS_LSH_DEFER_MIN": "0"}):
+    for env in ({"FS_LSH_BATCH": "0"}, {"FS_LSH_DEFER_MIN": "0"}, {"FS_LSH_DEFER_MIN": "0", "FS_LSH_EMAP": "0"},
+                {"FS_LSH_DEFER_MIN": "0", "FS_LSH_GRAMTAB": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ixb, cb, gotb, stb = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
