@@ -217,6 +217,71 @@ def cpu_reference_shaped(window):
                                              -(-conf["n_works"] // 31))}
 
 
+def search_companion(ix, corpus, n_works, n_tok, n_fl, reps=24, alone_reps=6):
+    """One workload through one index, measured the way the headline is (as many searches in
+    flight as the timed region keeps, records left in HBM) and by itself, with the per-kernel
+    times of one search (fs_search_profile).  `roofline` is the WHOLE search: algorithmic bytes
+    (4 B per fan token, + 32 B per record where one kernel takes tokens in and puts records
+    out) / the device time of one search alone / HBM peak, and `kernel` is the kernel with the
+    largest share of that search -- for a search of several launches no single kernel's own
+    fraction stands for it (the prefilter scan's is kept as `prefilter_frac`)."""
+    import torch
+    rows, st = ix.search(corpus)
+    best = None
+    for _ in range(alone_reps):
+        rows, st = ix.search(corpus, reuse=True)
+        if st.total_ms > 0:           # (0: the search was repeated to grow a workspace)
+            best = st.total_ms if best is None else min(best, st.total_ms)
+    cap = len(rows) + 64
+    bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(n_fl + 1)]
+    for i in range(2 * n_fl):                                    # (every lane's workspaces grown)
+        ix.search_end(ix.search_begin(corpus, bufs[0].data_ptr(), cap, header=True))
+    ix.set_scan_timing(1 << 20)
+    samples = []
+    for _ in range(3):
+        tickets = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            tickets.append(ix.search_begin(corpus, bufs[i % len(bufs)].data_ptr(), cap, header=True))
+            if len(tickets) >= n_fl:
+                ix.search_end(tickets.pop(0))
+        while tickets:
+            ix.search_end(tickets.pop(0))
+        torch.cuda.synchronize()
+        samples.append((time.perf_counter() - t0) / reps)
+    dt = float(np.median(samples))
+    ix.set_scan_timing(1)
+    prof = None
+    for _ in range(3):                                            # (the last of three: warm)
+        prof = ix.profile(corpus, bufs[0].data_ptr() + 32, cap)
+    del bufs
+    kernel = ix.kernel_name(corpus)
+    fused_rows = kernel.startswith("k_scan_rows")
+    algo = 4.0 * n_tok + (32.0 * len(rows) if fused_rows else 0.0)
+    tot = sum(ms for _, ms in prof) or 1e-9
+    dom, dom_ms = max(prof, key=lambda kv: kv[1])
+    first_ms = prof[0][1]
+    out = {"value": n_works / dt, "unit": "fanworks/s", "ms_per_step": dt * 1e3,
+           "ms_per_search_alone": best, "value_alone": n_works / (best * 1e-3) if best else None,
+           "kernel": kernel, "rows_per_step": int(len(rows)), "candidates": int(st.candidates),
+           "lsh_pending": int(st.lsh_pending), "matches": int(st.matches),
+           "kernels_us": [[k, round(ms * 1e3, 1)] for k, ms in prof],
+           "roofline": {"bound": "hbm", "kernel": dom, "kernel_share_of_search": round(dom_ms / tot, 3),
+                        "bytes_model": "4 B per fan token" + (" + 32 B per record" if fused_rows else "") +
+                                       ", over the whole search (all its kernels), one search alone",
+                        "algorithmic_bytes_per_search": algo, "search_ms_alone": best,
+                        "achieved": algo / (best * 1e-3) / 1e9 if best else None, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS if best else None,
+                        "step": algo / dt / 1e9 / HBM_PEAK_GBS,
+                        "prefilter_frac": (4.0 * n_tok / (first_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                           if len(prof) > 1 and first_ms > 0 else None),
+                        "note": "kernels_us: time between HIP events behind consecutive kernels of one search "
+                                "(each includes ~5-10 us of event and launch gap); frac: whole search alone; "
+                                "step: the same bytes / ms_per_step (searches in flight)"}}
+    return out, rows, st
+
+
 def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb, window, n_works):
     """What `value` leaves out, each on a bounded run of the same c2 batches (N = 1)."""
     import torch
@@ -301,64 +366,58 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
                               "Levenshtein distances inside the same kernel (`kernel`), as many searches in flight as the timed region keeps"}
     cs.close()
     # (4) the LSH pipeline on a table with near-synonyms (c_max ~ 1: the exact-n-gram proof
-    # fails, every real embedding table is of this kind)
+    # fails, every real embedding table is of this kind), under both settings of NearPy's
+    # UniqueFilter (default: off, what NearPy 1.0.0 does for the reference's call)
     emb_c, perm = synth.clustered_table()
-    n_l = n_works                     # the whole batch (round 3 timed 500 works of it)
+    n_l = n_works
     tk = synth.synonym_swaps(toks[0][:n_l * (len(toks[0]) // n_works)], perm)
     of = offs[0][:n_l + 1]
-    t0 = time.perf_counter()
-    ixl = ScriptIndex(script, swords, emb_c, synth.lsh_normals(window),
-                      cfg=abi.make_config(window_size=window))
-    t_index = time.perf_counter() - t0
-    cl = ixl.corpus(tk, of, chars, coff)
-    rows, st = ixl.search(cl)
-    best = None
-    for _ in range(6):
-        rows, st = ixl.search(cl)
-        if st.total_ms > 0:           # (0: the search was repeated to grow a workspace)
-            best = st.total_ms if best is None else min(best, st.total_ms)
-    # ... and as the timed region measures the headline: as many searches in flight as it keeps
-    capl = len(rows) + 64
-    bufl = [torch.zeros(32 + capl * 32, dtype=torch.uint8, device="cuda") for _ in range(n_fl + 1)]
-    for i in range(2 * n_fl):                                    # (every lane's workspaces grown)
-        ixl.search_end(ixl.search_begin(cl, bufl[0].data_ptr(), capl, header=True))
-    repl, tickets = 24, []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(repl):
-        tickets.append(ixl.search_begin(cl, bufl[i % len(bufl)].data_ptr(), capl, header=True))
-        if len(tickets) >= n_fl:
-            ixl.search_end(tickets.pop(0))
-    while tickets:
-        ixl.search_end(tickets.pop(0))
-    torch.cuda.synchronize()
-    dt_l = (time.perf_counter() - t0) / repl
-    del bufl
-    cp = (15 * 14 + 3) & ~3
-    lsh_bytes = float(st.windows_processed) * window * cp * 4
-    out["lsh_clustered_table"] = {
-        "value": n_l / dt_l, "unit": "fanworks/s", "ms_per_step": dt_l * 1e3,
-        "ms_per_search_alone": best, "value_alone": n_l / (best * 1e-3),
-        "kernel": ixl.kernel_name(cl),
-        "roofline": None if not ixl.kernel_name(cl).startswith("k_lsh_scan") else
-                    {"bound": "infinity-cache gather", "kernel": ixl.kernel_name(cl),
-                     "bytes_model": "n rows of %d float32 projections (%d B) per window, gathered from "
-                                    "a %d MB table" % (cp, 4 * cp, window * emb_c.shape[0] * cp * 4 // 1000000),
-                     "algorithmic_bytes_per_launch": lsh_bytes, "launch_ms": st.scan_ms,
-                     "achieved": lsh_bytes / (st.scan_ms * 1e-3) / 1e9 if st.scan_ms else None,
-                     "peak": 8600.0, "unit": "GB/s",
-                     "frac": lsh_bytes / (st.scan_ms * 1e-3) / 1e9 / 8600.0 if st.scan_ms else None},
-        "windows_per_s": st.windows_processed / (best * 1e-3), "works": n_l,
-        "rows_per_step": int(len(rows)), "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()),
-        "c_max": ixl.info["c_max"], "path": "lsh", "index_s": round(t_index, 2),
-        "candidates": int(st.candidates), "lsh_pending": int(st.lsh_pending),
-        "note": "synth.clustered_table (1024 groups of 8 near-synonyms), 10 % of the fan tokens swapped "
-                "for a synonym; the LSH pipeline behind the component-id prefilters (`kernel`: the "
-                "first kernel of the search; k_lsh_scan when they do not apply); value: as many searches "
-                "in flight as the timed region keeps, like the headline; *_alone: device time of one search "
-                "by itself (what rounds 2 and 3 reported)"}
-    cl.close()
-    ixl.close()
+    for name, uf in (("lsh_clustered_table", None), ("lsh_clustered_table_unique_filter_on", True)):
+        t0 = time.perf_counter()
+        ixl = ScriptIndex(script, swords, emb_c, synth.lsh_normals(window),
+                          cfg=abi.make_config(window_size=window, unique_filter=uf))
+        t_index = time.perf_counter() - t0
+        cl = ixl.corpus(tk, of, chars, coff)
+        rec, rows, st = search_companion(ixl, cl, n_l, len(tk), n_fl)
+        rec.update({"windows_per_s": st.windows_processed / (rec["ms_per_search_alone"] * 1e-3), "works": n_l,
+                    "inexact_rows": int((np.abs(rows["dist"]) > 1e-9).sum()), "c_max": ixl.info["c_max"],
+                    "path": "lsh", "index_s": round(t_index, 2),
+                    "unique_filter": bool(abi.default_unique_filter() if uf is None else uf),
+                    "note": "synth.clustered_table (1024 groups of 8 near-synonyms), 10 % of the fan tokens "
+                            "swapped for a synonym; the LSH pipeline behind the component-id prefilters (`kernel`: "
+                            "the first kernel of the search; k_lsh_scan when they do not apply); value: as many "
+                            "searches in flight as the timed region keeps, like the headline; *_alone: device "
+                            "time of one search by itself"})
+        out[name] = rec
+        cl.close()
+        ixl.close()
+    # (5) BASELINE.json configs[3]: the n = 4 / 8 / 10 sweep on the 10k-work corpus (n = 4: exact
+    # pipeline; n = 8, 10: the proof fails by one slot, LSH pipeline behind the integer prefilters)
+    if window == 6:
+        for n in (4, 8, 10):
+            t0 = time.perf_counter()
+            ixn = ScriptIndex(script, swords, emb, synth.lsh_normals(n), cfg=abi.make_config(window_size=n))
+            t_index = time.perf_counter() - t0
+            cn = ixn.corpus(toks[0], offs[0], chars, coff)
+            rec, rows, st = search_companion(ixn, cn, n_works, len(toks[0]), n_fl)
+            rec.update({"window": n, "works": n_works, "index_s": round(t_index, 2),
+                        "path": "exact-ngram-scan" if st.path == abi.FS_MODE_EXACT else "lsh",
+                        "note": "configs[3]: the %d-gram search of the same 10k-work batch, four searches in "
+                                "flight (value) and one alone (roofline)" % n})
+            out["c4_n%d" % n] = rec
+            cn.close()
+            ixn.close()
+        # (6) the headline's search with NearPy's UniqueFilter on (the exact pipeline's records do not
+        # depend on it -- tests/test_golden.py -- and neither does its speed)
+        ixu = ScriptIndex(script, swords, emb, synth.lsh_normals(window),
+                          cfg=abi.make_config(window_size=window, unique_filter=True))
+        cu = ixu.corpus(toks[0], offs[0], chars, coff)
+        rec, rows, st = search_companion(ixu, cu, n_works, len(toks[0]), n_fl)
+        rec.update({"unique_filter": True, "note": "the headline's batch with unique_filter = 1 (NearPy 0.2.x); "
+                                                   "the line itself runs the default, 0"})
+        out["headline_unique_filter_on"] = rec
+        cu.close()
+        ixu.close()
     return out
 
 
@@ -777,6 +836,7 @@ def main():
                        "script_tokens": conf["script_tokens"], "window": args.window,
                        "distinct_batches": rotate,
                        "lanes": int(os.environ.get("FS_LANES", "1")),
+                       "unique_filter": bool(cfg.unique_filter),
                        "ids_bytes_rotated": rotate * shard_bytes,
                        "rows_per_gpu_step": int(round(rows_step)),
                        "wire_record_bytes": rec_bytes if world > 1 else None,
@@ -813,6 +873,11 @@ def main():
                                  "share the GPU; step = (4 B x tokens + 32 B x records) / ms_per_step"
                                  % (int(os.environ.get("FS_LANES", "1")), inflight)},
         }
+        if not exact:
+            # a search of several launches: the whole search, and the kernel with the largest share
+            rec, _, _ = search_companion(ix, corpora[0], n_works, n_tok, inflight)
+            out["roofline"] = dict(rec["roofline"], kernels_us=rec["kernels_us"], build=build, traffic=None,
+                                   overlapped_first_kernel_ms=kernel_ms)
         if world == 1 and not args.no_companions:
             out["companions"] = companions(ix, corpora, toks, offs, chars, coff, words, script,
                                            swords, emb, args.window, n_works)

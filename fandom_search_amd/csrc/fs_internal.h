@@ -280,6 +280,7 @@ struct fs_index {
     DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum, w_pend;
     DBuf<uint32_t> w_mcnt, w_mtop_s;   // k_lsh_verify -> k_lsh_lev: kept matches per pending window
+    DBuf<uint32_t> w_pkeys, w_pwork, w_left;   // k_lsh_pkeys -> k_lsh_enum: keys and work per pending window; what is left to k_lsh_batch
     DBuf<double> w_mtop_d;
     DBuf<uint2> w_recs, w_info;    // direct path: candidate records and counts per wave range
     DBuf<uint32_t> w_slist, w_scount;   // k_near_sift: survivors of the wildcard filter per wave range (caps each), their counts

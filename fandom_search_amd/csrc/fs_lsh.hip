@@ -1578,7 +1578,6 @@ __global__ __launch_bounds__(256, 5) void k_lsh_verify(CorpusDev c, LshDev L, Gr
 constexpr int kBatchW = 8;                // windows per wave and step
 constexpr int kBatchCap = 32;             // members within the threshold kept per window
 constexpr int kBatchH = 16;               // tables (number_of_hashes) this form serves
-constexpr int kBatchG = 3;                // script n-grams one slot away from a window that the enumeration takes
 struct alignas(16) BatchLds {             // per wave
   uint64_t bal[kBatchW][6];               // sign bits of the projection columns (C <= 256), + a zero word
   double qf[kBatchW][FS_MAX_WINDOW];      // q of the windows' slots
@@ -1590,12 +1589,7 @@ struct alignas(16) BatchLds {             // per wave
   uint32_t e0[kBatchW][kBatchH];          // first entry of the window's bucket in table h
   uint32_t pre[kBatchW][kBatchH];         // entries of the window in the tables before h
   uint32_t dh[128];                       // C: (window, script window) -> a lane of the round that holds the pair
-  uint32_t fc[kBatchW][FS_MAX_WINDOW];    // E: the ids the wildcard keys are made of (component ids on tables with near-synonyms)
-  uint32_t va[kBatchW][kBatchCap];        // E: arrival order of a list entry (table * W + script window)
-  double gd[kBatchW][kBatchG];            // E: distance of the window to gram gi
-  uint32_t gg[kBatchW][kBatchG];          // E: the script n-grams one slot away (gram ids)
-  uint32_t gh[kBatchW][kBatchG];          // E: bit h: table h holds the window and the gram in one bucket
-  uint32_t gn[kBatchW];                   // E: number of such n-grams (> kBatchG: the window walks the buckets)
+  uint32_t jj[kBatchW];                   // the window's place in the pending list (mcnt / mtop)
   uint32_t wbase[kBatchW + 1];            // entries of the windows before w
   uint32_t vn[kBatchW];                   // members within the threshold so far (may exceed kBatchCap)
   uint32_t ci[kBatchW];                   // candidate number
@@ -1607,14 +1601,16 @@ static_assert(sizeof(double) * kBatchW * kBatchCap + sizeof(uint32_t) * kBatchW 
               "lsh_window's scratch is laid over vd / vs");
 
 template <int N>
-__global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, GramIndexDev g,
+__global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, GramIndexDev g,
                                                    const uint32_t* __restrict__ cpos, uint32_t cap,
                                                    uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
                                                    uint32_t* __restrict__ bmatch, fs_status* st,
                                                    const uint32_t* __restrict__ pend,
                                                    uint32_t* __restrict__ mcnt,
                                                    uint32_t* __restrict__ mtop_s,
-                                                   double* __restrict__ mtop_d) {
+                                                   double* __restrict__ mtop_d,
+                                                   const uint32_t* __restrict__ left,
+                                                   const uint32_t* __restrict__ n_left) {
   __shared__ BatchLds s_b[4];
   __shared__ uint32_t s_w32[4];
   const int lane = threadIdx.x & 63;
@@ -1622,7 +1618,8 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
   BatchLds& S = s_b[wave];
   uint32_t matches = 0;
   const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
-  const uint32_t n_pend = min(st->lsh_pending, cap);
+  // (left: the windows k_lsh_enum could not finish, as places in the pending list)
+  const uint32_t n_pend = left ? min(*n_left, cap) : min(st->lsh_pending, cap);
   const uint32_t nn = (uint32_t)L.nn;
   const uint32_t nb1 = (1u << L.B) + 1;
   auto sync = [] {
@@ -1636,8 +1633,10 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     if (lane < kBatchW) {
       uint32_t ok = 0, w = 0, i = 0;
       uint64_t p = 0;
+      uint32_t jx = 0;
       if ((uint32_t)lane < nw) {
-        i = pend[j0 + lane];
+        jx = left ? left[j0 + lane] : j0 + lane;
+        i = pend[jx];
         p = cpos[i];
         if (p + N <= c.n_tok) {
           uint64_t work_end;
@@ -1645,7 +1644,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
           ok = p + N <= work_end ? 1u : 0u;       // a window never crosses a work boundary
         }
       }
-      S.ci[lane] = i; S.work[lane] = w; S.ok[lane] = ok; S.vn[lane] = 0;
+      S.ci[lane] = i; S.work[lane] = w; S.ok[lane] = ok; S.vn[lane] = 0; S.jj[lane] = jx;
       S.wbase[lane] = (uint32_t)p;                // (the position, until B overwrites it)
       S.bal[lane][(L.C + 63) >> 6] = 0;
     }
@@ -1658,7 +1657,6 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       if (k < N && S.ok[w]) {
         const uint32_t id = c.tok[(uint64_t)S.wbase[w] + k];
         S.f[w][k] = id;
-        S.fc[w][k] = L.emap_comp ? L.wild_tok[(uint64_t)S.wbase[w] + k] : id;
         S.qf[w][k] = q_of(L, id);
         oov = id & FS_OOV_FLAG;
         if (!oov && L.atab32) am = L.amax[(size_t)k * L.V + id];
@@ -1687,24 +1685,15 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       const int left = L.C - col;
       const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
       const int colc = left > 0 ? col : 0;
-      for (uint32_t w = 0; w < nw; ++w) {
-        if (S.ok[w] != 1u) continue;              // (wave-uniform)
-        float4 r[N];
-#pragma unroll
-        for (int k = 0; k < N; ++k)
-          r[k] = *reinterpret_cast<const float4*>(L.atab32 + ((size_t)k * L.V + S.f[w][k]) * L.Cp + colc);
-        float4 acc = r[0];
-#pragma unroll
-        for (int k = 1; k < N; ++k) {
-          acc.x = __fadd_rn(acc.x, r[k].x); acc.y = __fadd_rn(acc.y, r[k].y);
-          acc.z = __fadd_rn(acc.z, r[k].z); acc.w = __fadd_rn(acc.w, r[k].w);
-        }
+      // (the rows of two windows in flight together where the registers allow: n <= 8)
+      constexpr int PAIR = N <= 8 ? 2 : 1;
+      auto finish = [&](uint32_t w, float4 acc) {
         const float bnd = S.bnd[w];
         const uint32_t sure = (fabsf(acc.x) > bnd ? 1u : 0u) | (fabsf(acc.y) > bnd ? 2u : 0u) |
                               (fabsf(acc.z) > bnd ? 4u : 0u) | (fabsf(acc.w) > bnd ? 8u : 0u);
         if (__any((~sure & cmask) != 0u)) {
           if (lane == 0) S.ok[w] = 2u;            // a sign is not certain: float64 below
-          continue;
+          return;
         }
         uint32_t x = ((acc.x > 0.0f ? 1u : 0u) | (acc.y > 0.0f ? 2u : 0u) |
                       (acc.z > 0.0f ? 4u : 0u) | (acc.w > 0.0f ? 8u : 0u)) & cmask;
@@ -1714,6 +1703,30 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
         x |= (uint32_t)__shfl_down((int)x, 4) << 16;
         uint32_t* pieces = reinterpret_cast<uint32_t*>(S.bal[w]);
         if ((lane & 7) == 0) pieces[lane >> 3] = x;
+      };
+      for (uint32_t w0 = 0; w0 < nw; w0 += PAIR) {
+        float4 r[PAIR][N];
+        bool go[PAIR];
+#pragma unroll
+        for (int u = 0; u < PAIR; ++u) {
+          go[u] = w0 + u < nw && S.ok[w0 + u] == 1u;             // (wave-uniform)
+          if (go[u]) {
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+              r[u][k] = *reinterpret_cast<const float4*>(L.atab32 + ((size_t)k * L.V + S.f[w0 + u][k]) * L.Cp + colc);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < PAIR; ++u)
+          if (go[u]) {
+            float4 acc = r[u][0];
+#pragma unroll
+            for (int k = 1; k < N; ++k) {
+              acc.x = __fadd_rn(acc.x, r[u][k].x); acc.y = __fadd_rn(acc.y, r[u][k].y);
+              acc.z = __fadd_rn(acc.z, r[u][k].z); acc.w = __fadd_rn(acc.w, r[u][k].w);
+            }
+            finish(w0 + u, acc);
+          }
       }
     }
     sync();
@@ -1733,7 +1746,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     }
     sync();
     if (L.diag & 0x10000) {                       // diagnostics: the keys only
-      if (lane < kBatchW && (uint32_t)lane < nw) { mcnt[j0 + lane] = 0; cg[S.ci[lane]] = FS_NONE; }
+      if (lane < kBatchW && (uint32_t)lane < nw) { mcnt[S.jj[lane]] = 0; cg[S.ci[lane]] = FS_NONE; }
       continue;
     }
     // the keys
@@ -1742,149 +1755,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       const int w = (t * 64 + lane) / kBatchH, h = (t * 64 + lane) % kBatchH;
       if (h < L.H && S.ok[w]) S.key[w][h] = assemble_key(S.bal[w], h, L.B);
     }
-    if (lane < kBatchW) S.gn[lane] = 0xFFFFu;     // (not enumerated)
     sync();
-    // ---- E: the script n-grams one slot away, enumerated --------------------------------------
-    // Every script window within the threshold equals the fan window in all slots but one (by
-    // vector ids where the table's c_max proves it, by component ids on tables with near-
-    // synonyms), so its n-gram is found under one of the window's n one-slot-wildcard keys in
-    // the exact map.  What LSH finds of it: the tables in which its key is the window's
-    // (the script windows' keys are kept); all its occurrences share those buckets, in
-    // ascending order.  So the window's list is made without walking a bucket: per n-gram its
-    // first nn entries in arrival order (table, script window), then the stable order by
-    // distance as in D.  (Windows beyond the threshold never reach the list: NearestFilter
-    // sorts by distance and everything within the threshold is in front of them.)
-    if (L.emap && L.skeys && nn * kBatchG <= (uint32_t)kBatchCap) {
-      if (lane < kBatchW) S.gn[lane] = 0;
-      sync();
-      uint32_t hit[kBatchW * FS_MAX_WINDOW / 64][4];
-#pragma unroll
-      for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t) {
-        const int w = (t * 64 + lane) / FS_MAX_WINDOW, k = (t * 64 + lane) % FS_MAX_WINDOW;
-        const bool live = k < N && S.ok[w];
-        const uint32_t term = live ? fs_rotl(fs_premix(S.fc[w][k]), fs_rot_of(N - 1 - k)) : 0u;
-        uint32_t fold = term;
-#pragma unroll
-        for (int d = 8; d > 0; d >>= 1) fold ^= (uint32_t)__shfl_xor((int)fold, d);
-        hit[t][0] = hit[t][1] = hit[t][2] = hit[t][3] = 0;
-        if (live) {
-          const uint32_t h = fs_wild_key(fold, term, k);
-          const uint4* bp = reinterpret_cast<const uint4*>(L.emap + 4 * (size_t)fs_wmap_slot(h, L.log2_emap));
-          const uint4 a = bp[0], b = bp[1];
-          hit[t][0] = a.y && a.x == h ? a.y : 0u; hit[t][1] = a.w && a.z == h ? a.w : 0u;
-          hit[t][2] = b.y && b.x == h ? b.y : 0u; hit[t][3] = b.w && b.z == h ? b.w : 0u;
-          if (b.w) S.gn[w] = 0xFFFFu;             // a full bucket: entries may have spilt -- the bucket walk
-        }
-      }
-      sync();
-      // the distinct n-grams of a window, slot after slot (eight windows side by side)
-#pragma unroll
-      for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t)
-        for (int k = 0; k < N; ++k) {
-          const int w = (t * 64 + lane) / FS_MAX_WINDOW;
-          if ((t * 64 + lane) % FS_MAX_WINDOW == k) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (hit[t][e]) {
-                const uint32_t gid = hit[t][e] - 1;
-                if (gid >= g.n_grams) { atomicMax(&st->max_rows, 0x70000001u); continue; }   // (cannot happen: the map holds gram ids)
-                uint32_t cn = S.gn[w];
-                bool seen = false;
-                for (uint32_t x = 0; x < cn && x < (uint32_t)kBatchG; ++x) seen = seen || S.gg[w][x] == gid;
-                if (!seen && cn != 0xFFFFu) {
-                  if (cn < (uint32_t)kBatchG) { S.gg[w][cn] = gid; S.gn[w] = cn + 1; }
-                  else S.gn[w] = 0xFFFFu;         // more n-grams than the lists hold: the bucket walk
-                }
-              }
-          }
-          sync();
-        }
-      // distance to each n-gram (its first window), lane per (window, n-gram)
-      {
-        const int w = lane / 4, gi = lane % 4;
-        if (lane < kBatchW * 4 && gi < kBatchG && S.ok[w] && S.gn[w] != 0xFFFFu && (uint32_t)gi < S.gn[w]) {
-          const uint32_t s0 = g.gpos[(size_t)S.gg[w][gi] * nn];
-          if (s0 >= L.W) atomicMax(&st->max_rows, 0x70000002u);               // (cannot happen)
-          double d = 0.0;
-          const bool v = s0 < L.W && window_distance_flat<N>(L, s0, S.f[w], S.qf[w], S.ff[w], S.rff[w], &d) && d < L.thr;
-          S.gd[w][gi] = v ? d : __longlong_as_double(0x7FF8000000000000ll);   // (NaN: beyond the threshold; a distance may be -2e-16)
-          S.gh[w][gi] = 0;
-        }
-      }
-      sync();
-      // the tables that hold window and n-gram in one bucket, lane per (window, n-gram, table)
-      for (int t0 = 0; t0 < kBatchW * kBatchG * kBatchH; t0 += 64) {
-        const int x = t0 + lane;
-        const int w = x / (kBatchG * kBatchH), gi = (x / kBatchH) % kBatchG, h = x % kBatchH;
-        if (w < kBatchW && h < L.H && S.ok[w] && S.gn[w] != 0xFFFFu && (uint32_t)gi < S.gn[w] && S.gd[w][gi] == S.gd[w][gi]) {
-          const uint32_t s0 = g.gpos[(size_t)S.gg[w][gi] * nn];
-          if (L.skeys[(size_t)s0 * L.H + h] == S.key[w][h]) atomicOr(&S.gh[w][gi], 1u << h);
-        }
-      }
-      sync();
-      // the lists: per n-gram its first nn entries in arrival order
-      {
-        const int w = lane / 4, gi = lane % 4;
-        if (lane < kBatchW * 4 && gi < kBatchG && S.gn[w] != 0xFFFFu) {
-          uint32_t made = 0;               // (a window that is none -- across a work boundary -- gets empty lists)
-          if (S.ok[w] && (uint32_t)gi < S.gn[w] && S.gd[w][gi] == S.gd[w][gi]) {
-            const uint32_t gid = S.gg[w][gi], occ = g.gcnt[gid];
-            uint32_t tables = S.gh[w][gi];
-            if (L.unique && tables) tables &= 0u - tables;         // a script window counts where it arrives first
-            const double d = S.gd[w][gi];
-            while (tables && made < nn) {
-              const uint32_t h = (uint32_t)__ffs((int)tables) - 1;
-              tables &= tables - 1;
-              for (uint32_t r = 0; r < occ && made < nn; ++r) {
-                const uint32_t sr = g.gpos[(size_t)gid * nn + r];
-                S.vs[w][gi * nn + made] = sr; S.vd[w][gi * nn + made] = d;
-                S.va[w][gi * nn + made] = h * L.W + sr;
-                ++made;
-              }
-            }
-          }
-          for (uint32_t e = made; e < nn; ++e) S.vs[w][gi * nn + e] = FS_NONE;
-        }
-      }
-      sync();
-      // NearestFilter: rank in (distance, arrival) order, eight lanes a window
-      {
-        const int w = lane >> 3, t = lane & 7;
-        const bool mine = (uint32_t)w < nw && S.gn[w] != 0xFFFFu;
-        const uint32_t V = mine ? (uint32_t)kBatchG * nn : 0u;
-        uint32_t kept = 0;
-        for (uint32_t e = t; e < V; e += 8) {
-          const uint32_t se = S.vs[w][e];
-          if (se == FS_NONE) continue;
-          ++kept;
-          const double de = S.vd[w][e];
-          const uint32_t ae = S.va[w][e];
-          uint32_t rank = 0;
-          for (uint32_t x = 0; x < V; ++x) {
-            const double dx = S.vd[w][x];
-            rank += (S.vs[w][x] != FS_NONE && (dx < de || (dx == de && S.va[w][x] < ae))) ? 1u : 0u;
-          }
-          if (rank < nn) { mtop_s[(size_t)(j0 + w) * nn + rank] = se; mtop_d[(size_t)(j0 + w) * nn + rank] = de; }
-        }
-        kept += (uint32_t)__shfl_xor((int)kept, 1);
-        kept += (uint32_t)__shfl_xor((int)kept, 2);
-        kept += (uint32_t)__shfl_xor((int)kept, 4);
-        kept = min(kept, nn);
-        if (t == 0 && mine) {
-          const uint32_t i = S.ci[w];
-          mcnt[j0 + w] = kept;
-          cg[i] = kept ? FS_PENDING : FS_NONE;
-          cw[i] = S.work[w];
-          matches += kept;
-        }
-      }
-      sync();
-      // (what is left for the bucket walk below: the windows whose map buckets were full or held
-      // more n-grams than the lists take)
-      if (lane < kBatchW && S.gn[lane] != 0xFFFFu) S.ok[lane] = 0;
-      sync();
-      if (!__any(lane < kBatchW && (uint32_t)lane < nw && S.ok[lane] != 0)) continue;
-    }
     // ---- B: bucket ranges, lane per (window, table) ----------------------------------------
 #pragma unroll
     for (int t = 0; t < kBatchW * kBatchH / 64; ++t) {
@@ -1971,7 +1842,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     {
       const int w = lane >> 3, t = lane & 7;
       const uint32_t V = min(S.vn[w], (uint32_t)kBatchCap);
-      const bool over = S.vn[w] > (uint32_t)kBatchCap || S.gn[w] != 0xFFFFu;    // (or enumerated above: done)
+      const bool over = S.vn[w] > (uint32_t)kBatchCap;
       if (L.unique && !over) {
         for (uint32_t e = t; e < V; e += 8) {
           const uint32_t se = S.vs[w][e] & 0x7FFFFFFFu;
@@ -1983,7 +1854,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       sync();
       uint32_t kept = 0;
       if (!over && (uint32_t)w < nw) {
-        const uint32_t jj = j0 + w;
+        const uint32_t jj = S.jj[w];
         for (uint32_t e = t; e < V; e += 8) {
           const uint32_t se = S.vs[w][e];
           if (se & 0x80000000u) continue;
@@ -2003,7 +1874,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       kept = min(kept, nn);
       if (t == 0 && (uint32_t)w < nw && !over) {
         const uint32_t i = S.ci[w];
-        mcnt[j0 + w] = kept;
+        mcnt[S.jj[w]] = kept;
         cg[i] = kept ? FS_PENDING : FS_NONE;
         cw[i] = S.work[w];
         matches += kept;
@@ -2031,7 +1902,7 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
       sync();
       fs_best b;
       const int cnt = lsh_window(c, L, g, X, st, &b, true);
-      const uint32_t jj = j0 + w;
+      const uint32_t jj = S.jj[w];
       if (lane < cnt) {
         mtop_s[(size_t)jj * nn + lane] = X.top_s[lane];
         mtop_d[(size_t)jj * nn + lane] = X.top_d[lane];
@@ -2043,6 +1914,310 @@ __global__ __launch_bounds__(256, 4) void k_lsh_batch(CorpusDev c, LshDev L, Gra
         matches += (uint32_t)cnt;
       }
       sync();
+    }
+  }
+  uint32_t tot;
+  block_excl_scan(matches, s_w32, &tot);
+  if (threadIdx.x == 0) bmatch[blockIdx.x] += tot;       // (on top of k_lsh_sift's)
+}
+
+// ---- the pending windows without a bucket walk (round 5) --------------------------------------
+// Every script window within the threshold of a pending window equals it in all slots but one --
+// by vector ids where the table's c_max proves it (m_min = n - 1), by component ids on tables
+// with near-synonyms -- so its n-gram sits in an exact map under one of the window's n one-slot-
+// wildcard keys (build_emap).  What LSH finds of such an n-gram is decided by the keys alone:
+// the tables in which its key is the window's (the script windows' keys are kept, d_skeys); all
+// its occurrences share those buckets in ascending order; and everything beyond the threshold
+// comes behind everything within it in NearestFilter's stable order, so it never changes the
+// list.  A C2 batch on the clustered table walks 67 bucket members per pending window -- 18.9 M
+// distances, nearly all of unrelated windows -- for lists that hold one script n-gram.
+//   k_lsh_pkeys   the windows' 15 keys, eight windows per wave (k_lsh_batch's first stage)
+//   k_lsh_enum    a LANE per window: the n map lookups, the n-gram's occurrences, keys and
+//                 canonical distance, the list written in arrival order (table, occurrence)
+// Windows with more than one such n-gram, a long chain in the map, or nn > 10 go to k_lsh_batch's
+// bucket walk through a list of their own (a percent or two).
+constexpr int kEnumNN = 10;               // NearestFilter sizes k_lsh_enum serves
+struct alignas(16) PkeysLds {             // per wave
+  uint64_t bal[kBatchW][6];
+  uint32_t f[kBatchW][FS_MAX_WINDOW];
+  uint32_t pos[kBatchW], ok[kBatchW], work[kBatchW];
+  float bnd[kBatchW];
+};
+
+template <int N>
+__global__ __launch_bounds__(256) void k_lsh_pkeys(CorpusDev c, LshDev L, const uint32_t* __restrict__ cpos,
+                                                   uint32_t cap, const uint32_t* __restrict__ pend,
+                                                   const fs_status* st, uint32_t* __restrict__ pkeys,
+                                                   uint32_t* __restrict__ pwork) {
+  __shared__ PkeysLds s_b[4];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  PkeysLds& S = s_b[wave];
+  const uint32_t gw = blockIdx.x * 4 + wave, NWAVES = gridDim.x * 4;
+  const uint32_t n_pend = min(st->lsh_pending, cap);
+  auto sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  for (uint32_t j0 = gw * kBatchW; j0 < n_pend; j0 += NWAVES * kBatchW) {
+    const uint32_t nw = min((uint32_t)kBatchW, n_pend - j0);
+    if (lane < kBatchW) {
+      uint32_t ok = 0, w = FS_NONE;
+      uint64_t p = 0;
+      if ((uint32_t)lane < nw) {
+        p = cpos[pend[j0 + lane]];
+        if (p + N <= c.n_tok) {
+          uint64_t work_end;
+          const uint32_t wk = work_of_token(c, p, &work_end);
+          if (p + N <= work_end) { ok = 1u; w = wk; }           // a window never crosses a work boundary
+        }
+      }
+      S.pos[lane] = (uint32_t)p; S.ok[lane] = ok; S.work[lane] = w;
+      S.bal[lane][(L.C + 63) >> 6] = 0;
+    }
+    sync();
+#pragma unroll
+    for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t) {      // lane per (window, slot)
+      const int w = (t * 64 + lane) / FS_MAX_WINDOW, k = (t * 64 + lane) % FS_MAX_WINDOW;
+      float am = 0.0f;
+      uint32_t oov = 0;
+      if (k < N && S.ok[w]) {
+        const uint32_t id = c.tok[(uint64_t)S.pos[w] + k];
+        S.f[w][k] = id;
+        oov = id & FS_OOV_FLAG;
+        if (!oov && L.atab32) am = L.amax[(size_t)k * L.V + id];
+      }
+#pragma unroll
+      for (int d = 8; d > 0; d >>= 1) { am += __shfl_xor(am, d); oov |= (uint32_t)__shfl_xor((int)oov, d); }
+      if (k == 0 && S.ok[w]) {
+        S.bnd[w] = L.bound_scale * am;
+        if (oov || !L.atab32 || L.C > 256) S.ok[w] = 2u;
+      }
+    }
+    sync();
+    {
+      const int col = 4 * lane;
+      const int left = L.C - col;
+      const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
+      const int colc = left > 0 ? col : 0;
+      for (uint32_t w = 0; w < nw; ++w) {
+        if (S.ok[w] != 1u) continue;              // (wave-uniform)
+        float4 r[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          r[k] = *reinterpret_cast<const float4*>(L.atab32 + ((size_t)k * L.V + S.f[w][k]) * L.Cp + colc);
+        float4 acc = r[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) {
+          acc.x = __fadd_rn(acc.x, r[k].x); acc.y = __fadd_rn(acc.y, r[k].y);
+          acc.z = __fadd_rn(acc.z, r[k].z); acc.w = __fadd_rn(acc.w, r[k].w);
+        }
+        const float bnd = S.bnd[w];
+        const uint32_t sure = (fabsf(acc.x) > bnd ? 1u : 0u) | (fabsf(acc.y) > bnd ? 2u : 0u) |
+                              (fabsf(acc.z) > bnd ? 4u : 0u) | (fabsf(acc.w) > bnd ? 8u : 0u);
+        if (__any((~sure & cmask) != 0u)) {
+          if (lane == 0) S.ok[w] = 2u;            // a sign is not certain: float64 below
+          continue;
+        }
+        uint32_t x = ((acc.x > 0.0f ? 1u : 0u) | (acc.y > 0.0f ? 2u : 0u) |
+                      (acc.z > 0.0f ? 4u : 0u) | (acc.w > 0.0f ? 8u : 0u)) & cmask;
+        x |= (uint32_t)__shfl_down((int)x, 1) << 4;
+        x |= (uint32_t)__shfl_down((int)x, 2) << 8;
+        x |= (uint32_t)__shfl_down((int)x, 4) << 16;
+        uint32_t* pieces = reinterpret_cast<uint32_t*>(S.bal[w]);
+        if ((lane & 7) == 0) pieces[lane >> 3] = x;
+      }
+    }
+    sync();
+    for (uint32_t w = 0; w < nw; ++w) {           // float64 keys where needed (rare)
+      if (S.ok[w] != 2u) continue;
+      for (int ch = 0; ch < (L.C + 63) >> 6; ++ch) {
+        const int col = ch * 64 + lane;
+        bool bit = false;
+        if (col < L.C) {
+          double acc = a_value(L, 0, S.f[w][0], col);
+          for (int k = 1; k < N; ++k) acc = __dadd_rn(acc, a_value(L, k, S.f[w][k], col));
+          bit = acc > 0.0;
+        }
+        const uint64_t b = __ballot(bit);
+        if (lane == 0) S.bal[w][ch] = b;
+      }
+    }
+    sync();
+#pragma unroll
+    for (int t = 0; t < kBatchW * kBatchH / 64; ++t) {
+      const int w = (t * 64 + lane) / kBatchH, h = (t * 64 + lane) % kBatchH;
+      if ((uint32_t)w < nw) pkeys[(size_t)(j0 + w) * kBatchH + h] = (h < L.H && S.ok[w]) ? assemble_key(S.bal[w], h, L.B) : 0u;
+    }
+    if (lane < kBatchW && (uint32_t)lane < nw) pwork[j0 + lane] = S.work[lane];
+    sync();
+  }
+}
+
+template <int N>
+__global__ __launch_bounds__(256, 4) void k_lsh_enum(CorpusDev c, LshDev L, GramIndexDev g,
+                                                  const uint32_t* __restrict__ cpos, uint32_t cap,
+                                                  uint32_t* __restrict__ cg, uint32_t* __restrict__ cw,
+                                                  uint32_t* __restrict__ bmatch, fs_status* st,
+                                                  const uint32_t* __restrict__ pend,
+                                                  const uint32_t* __restrict__ pkeys,
+                                                  const uint32_t* __restrict__ pwork,
+                                                  uint32_t* __restrict__ mcnt, uint32_t* __restrict__ mtop_s,
+                                                  double* __restrict__ mtop_d,
+                                                  uint32_t* __restrict__ left, uint32_t* __restrict__ n_left) {
+  __shared__ uint32_t s_w32[4];
+  const int lane = threadIdx.x & 63;
+  const uint32_t n_pend = min(st->lsh_pending, cap);
+  const uint32_t nn = (uint32_t)L.nn;
+  uint32_t matches = 0;
+  for (uint32_t j0 = blockIdx.x * 256; j0 < n_pend; j0 += gridDim.x * 256) {
+    const uint32_t j = j0 + threadIdx.x;
+    const bool live = j < n_pend;
+    bool give_up = false;
+    uint32_t work = FS_NONE, i = 0;
+    uint64_t p = 0;
+    if (live) { i = pend[j]; work = pwork[j]; p = cpos[i]; }
+    const bool ok = live && work != FS_NONE;
+    // ids (the buffers are padded: reading up to 12 is in bounds), the keys' ids, q
+    uint32_t f[N], fc[N];
+    double qf[N];
+    {
+      const uint4* a = reinterpret_cast<const uint4*>(c.tok + (ok ? p : 0));
+      const uint4* b = reinterpret_cast<const uint4*>((L.emap_comp ? L.wild_tok : c.tok) + (ok ? p : 0));
+#pragma unroll
+      for (int q4 = 0; q4 < (N + 3) / 4; ++q4) {
+        const uint4 x = a[q4], y = b[q4];
+        const uint32_t xv[4] = {x.x, x.y, x.z, x.w}, yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (4 * q4 + e < N) { f[4 * q4 + e] = xv[e]; fc[4 * q4 + e] = yv[e]; }
+      }
+    }
+    uint32_t term[N], fold = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      term[k] = fs_rotl(fs_premix(fc[k]), fs_rot_of(N - 1 - k));
+      fold ^= term[k];
+      qf[k] = ok ? L.q[f[k]] : 0.0;             // (no OOV id on this path: the prefilters exclude them)
+    }
+    // the n map lookups, four requested together; the (one) n-gram they name
+    uint32_t gid = FS_NONE;
+#pragma unroll
+    for (int k0 = 0; k0 < N; k0 += 4) {
+      uint4 ba[4], bb[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u < N) {
+          const uint32_t h = fs_wild_key(fold, term[k0 + u], k0 + u);
+          const uint4* bp = reinterpret_cast<const uint4*>(L.emap + 4 * (size_t)fs_wmap_slot(h, L.log2_emap));
+          ba[u] = bp[0]; bb[u] = bp[1];
+        }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (k0 + u < N) {
+          const uint32_t h = fs_wild_key(fold, term[k0 + u], k0 + u);
+          const uint32_t key[4] = {ba[u].x, ba[u].z, bb[u].x, bb[u].z}, val[4] = {ba[u].y, ba[u].w, bb[u].y, bb[u].w};
+          if (val[3]) give_up = true;             // a full bucket: entries may have spilt
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (val[e] && key[e] == h) {
+              if (gid == FS_NONE) gid = val[e] - 1;
+              else if (gid != val[e] - 1) give_up = true;    // a second n-gram: the bucket walk ranks them
+            }
+        }
+    }
+    if (!ok) give_up = false;
+    uint32_t made = 0;
+    if (ok && !give_up && gid != FS_NONE && gid < g.n_grams) {
+      const uint32_t occ = g.gcnt[gid];
+      uint32_t o[kEnumNN];
+#pragma unroll
+      for (int r = 0; r < kEnumNN; ++r) o[r] = (uint32_t)r < nn ? g.gpos[(size_t)gid * nn + r] : 0u;
+      const uint32_t s0 = o[0];
+      uint32_t tables = 0;
+      {
+        uint32_t kk[kBatchH], mine[kBatchH];
+#pragma unroll
+        for (int q4 = 0; q4 < kBatchH / 4; ++q4) {
+          const uint4 m = reinterpret_cast<const uint4*>(pkeys + (size_t)j * kBatchH)[q4];
+          mine[4 * q4] = m.x; mine[4 * q4 + 1] = m.y; mine[4 * q4 + 2] = m.z; mine[4 * q4 + 3] = m.w;
+        }
+#pragma unroll
+        for (int h = 0; h < kBatchH; ++h) kk[h] = h < L.H ? L.skeys[(size_t)s0 * L.H + h] : 0u;
+#pragma unroll
+        for (int h = 0; h < kBatchH; ++h) tables |= (h < L.H && kk[h] == mine[h]) ? 1u << h : 0u;
+      }
+      // canonical distance to the n-gram's first window (window_distance_flat's arithmetic, the
+      // fan side in registers)
+      double ff = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, qf[k]);
+      const double rff = __dsqrt_rn(ff);
+      const fs_swin sw = L.sw[s0];
+      uint4 rec[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k) rec[k] = *reinterpret_cast<const uint4*>(L.spos + s0 + k);
+      int same = 0;
+      uint32_t diff = 0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) {
+        const bool eq = rec[k].w == f[k];
+        same += eq;
+        diff |= eq ? 0u : 1u << k;
+      }
+      double d = 0.0;
+      bool v = !(L.m_min > 0 && same < L.m_min);
+      if (v) {
+        const double norm = __dmul_rn(sw.rss, rff);
+        double sf;
+        if (same == N) {
+          sf = sw.ss;
+        } else {
+          double gk[N];
+#pragma unroll
+          for (int k = 0; k < N; ++k) {
+            gk[k] = qf[k];
+            if (diff >> k & 1u) gk[k] = L.gtab[(size_t)(int32_t)rec[k].z * L.V + f[k]];
+          }
+          sf = 0.0;
+#pragma unroll
+          for (int k = 0; k < N; ++k) sf = __dadd_rn(sf, gk[k]);
+        }
+        d = __dsub_rn(1.0, __ddiv_rn(sf, norm));
+        v = d == d && d < L.thr;
+      }
+      if (!v) tables = 0;
+      if (L.unique && tables) tables &= 0u - tables;             // a script window counts where it arrives first
+      // the list: the n-gram's entries in arrival order (table, then occurrence), nn at most
+      uint32_t tb = tables, r = 0;
+      const size_t jj = (size_t)j * nn;
+#pragma unroll
+      for (int e = 0; e < kEnumNN; ++e)
+        if ((uint32_t)e < nn && tb) {
+          uint32_t sel = o[0];
+#pragma unroll
+          for (int x = 1; x < kEnumNN; ++x) sel = r == (uint32_t)x ? o[x] : sel;
+          mtop_s[jj + e] = sel;
+          mtop_d[jj + e] = d;
+          ++made;
+          if (++r == occ) { r = 0; tb &= tb - 1; }
+        }
+    }
+    if (live && !give_up) {
+      mcnt[j] = made;
+      cg[i] = made ? FS_PENDING : FS_NONE;
+      if (ok) cw[i] = work;
+      matches += made;
+    }
+    // the windows left to the bucket walk, one addition per wave
+    const uint64_t gm = __ballot(live && give_up);
+    if (gm) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(n_left, (uint32_t)__popcll(gm));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, 0);
+      if (live && give_up)
+        left[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u))] = j;
     }
   }
   uint32_t tot;
@@ -2250,8 +2425,8 @@ static int build_emap(fs_index* ix, const std::vector<uint32_t>& ids, DBuf<uint3
   if (!G || !ix->d_gpos.p) return FS_OK;
   std::vector<uint32_t> gpos((size_t)G * nn);
   FS_HIP(hipMemcpy(gpos.data(), ix->d_gpos.p, gpos.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  int lm = 8;
-  while (lm < 26 && ((uint64_t)1 << lm) < (uint64_t)G * n) ++lm;
+  int lm = 8;                                    // two buckets per entry: a full one (four entries) is rare
+  while (lm < 26 && ((uint64_t)1 << lm) < 2 * (uint64_t)G * n) ++lm;
   std::vector<uint32_t> emap((size_t)8 << lm, 0u);
   const uint32_t mask = (1u << lm) - 1;
   for (uint32_t g = 0; g < G; ++g) {
@@ -2715,24 +2890,50 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
     FS_TRY(ix->cur->w_mtop_d.reserve((size_t)ccap * L.nn));
   }
   // the pending windows eight at a time per wave (k_lsh_batch) where the kept matches' Levenshtein
-  // distances are k_lsh_lev's anyway; a wave per window (k_lsh_verify) otherwise
-  void (*batch)(CorpusDev, LshDev, GramIndexDev, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*,
-                fs_status*, const uint32_t*, uint32_t*, uint32_t*, double*) = nullptr;
+  // distances are k_lsh_lev's anyway; a wave per window (k_lsh_verify) otherwise.  Where the script
+  // n-grams one slot away can be enumerated (L.emap), k_lsh_pkeys + k_lsh_enum take the windows
+  // first and k_lsh_batch only what they leave.
+  typedef void (*BatchFn)(CorpusDev, LshDev, GramIndexDev, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*,
+                          fs_status*, const uint32_t*, uint32_t*, uint32_t*, double*, const uint32_t*, const uint32_t*);
+  typedef void (*PkeysFn)(CorpusDev, LshDev, const uint32_t*, uint32_t, const uint32_t*, const fs_status*, uint32_t*, uint32_t*);
+  typedef void (*EnumFn)(CorpusDev, LshDev, GramIndexDev, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*,
+                         fs_status*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, double*,
+                         uint32_t*, uint32_t*);
+  BatchFn batch = nullptr;
+  PkeysFn pkeys = nullptr;
+  EnumFn enumk = nullptr;
   if (defer && ix->sw.lsh_batch && L.H <= kBatchH && L.nn <= 48 && !L.serial_neighbours && !(L.diag & 0xFFFF))
     switch (L.n) {
-      case 6: batch = k_lsh_batch<6>; break;
-      case 7: batch = k_lsh_batch<7>; break;
-      case 8: batch = k_lsh_batch<8>; break;
-      case 9: batch = k_lsh_batch<9>; break;
-      case 10: batch = k_lsh_batch<10>; break;
-      case 12: batch = k_lsh_batch<12>; break;
+#define FS_B(N) case N: batch = k_lsh_batch<N>; pkeys = k_lsh_pkeys<N>; enumk = k_lsh_enum<N>; break
+      FS_B(6); FS_B(7); FS_B(8); FS_B(9); FS_B(10); FS_B(12);
+#undef FS_B
       default: break;
     }
   if (batch) {
+    const bool enumerate = L.emap && L.skeys && L.spos && L.gtab && L.nn <= kEnumNN;
+    const uint32_t* left = nullptr;
+    const uint32_t* n_left = nullptr;
+    if (enumerate) {
+      FS_TRY(ix->cur->w_pkeys.reserve((size_t)ccap * kBatchH));
+      FS_TRY(ix->cur->w_pwork.reserve(ccap));
+      FS_TRY(ix->cur->w_left.reserve(ccap));
+      const uint32_t kb = full_grid ? kNB : resident(reinterpret_cast<const void*>(pkeys));
+      hipLaunchKernelGGL(pkeys, dim3(kb), dim3(256), 0, s, c->dev(), L, ix->cur->w_cpos.p, ccap, ix->cur->w_pend.p,
+                         st, ix->cur->w_pkeys.p, ix->cur->w_pwork.p);
+      if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_pkeys");
+      const uint32_t eb = full_grid ? kNB : resident(reinterpret_cast<const void*>(enumk));
+      hipLaunchKernelGGL(enumk, dim3(eb), dim3(256), 0, s, c->dev(), L, ix->gram_dev(), ix->cur->w_cpos.p, ccap,
+                         ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_bsum.p + kNB, st, ix->cur->w_pend.p,
+                         ix->cur->w_pkeys.p, ix->cur->w_pwork.p, ix->cur->w_mcnt.p, ix->cur->w_mtop_s.p,
+                         ix->cur->w_mtop_d.p, ix->cur->w_left.p, &st->n_hits);
+      if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_enum");
+      left = ix->cur->w_left.p;
+      n_left = &st->n_hits;
+    }
     const uint32_t blocks = full_grid ? kNB : resident(reinterpret_cast<const void*>(batch));
     hipLaunchKernelGGL(batch, dim3(blocks), dim3(256), 0, s, c->dev(), L, ix->gram_dev(),
                        ix->cur->w_cpos.p, ccap, ix->cur->w_cg.p, ix->cur->w_cw.p, ix->cur->w_bsum.p + kNB, st,
-                       ix->cur->w_pend.p, ix->cur->w_mcnt.p, ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p);
+                       ix->cur->w_pend.p, ix->cur->w_mcnt.p, ix->cur->w_mtop_s.p, ix->cur->w_mtop_d.p, left, n_left);
     if (ix->prof.on) fs_prof_mark(ix, s, "k_lsh_batch");
   } else {
   auto verify = defer ? k_lsh_verify<true> : k_lsh_verify<false>;
