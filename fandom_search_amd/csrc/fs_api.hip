@@ -1230,7 +1230,7 @@ extern "C" int fs_search_corpus_end(fs_index* ix, uint32_t ticket, uint64_t* n_r
     total_ms = 0;
     if (sl.whole_timed) FS_HIP(hipEventElapsedTime(&total_ms, sl.ev_begin, sl.ev_end));
     const fs_status& hs = *sl.h_status;
-    if (!sl.exact && ((ix->sw.lsh_diag & 0x180000) || hs.max_rows >= 0x70000000u)) fprintf(stderr, "lsh diag: %u (0x%x) bucket members / code for %u pending windows\n", hs.max_rows, hs.max_rows, hs.lsh_pending);
+    if (!sl.exact && ((ix->sw.lsh_diag & 0x780000) || hs.max_rows >= 0x70000000u)) fprintf(stderr, "lsh diag: %u (0x%x) bucket members / code for %u pending windows\n", hs.max_rows, hs.max_rows, hs.lsh_pending);
     if (hs.bad_string) { fs_set_error("fan string id outside the string table"); return FS_E_INVALID; }
     if (hs.lev_overflow) {
       fs_set_error("an n-gram text exceeds %d code points", FS_LEV_MAX);

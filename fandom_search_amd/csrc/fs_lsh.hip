@@ -1627,8 +1627,12 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  for (uint32_t j0 = gw * kBatchW; j0 < n_pend; j0 += NWAVES * kBatchW) {
-    const uint32_t nw = min((uint32_t)kBatchW, n_pend - j0);
+  // (few windows: fewer per wave, so that every wave has some -- a wave's eight windows take
+  // a hundred microseconds when each walks sixty bucket members)
+  const uint32_t per = max(1u, min((uint32_t)kBatchW, (n_pend + NWAVES - 1) / NWAVES));
+  if ((L.diag & 0x100000) && left && blockIdx.x == 0 && threadIdx.x == 0) atomicMax(&st->max_rows, n_pend);   // diagnostics: windows left to the walk
+  for (uint32_t j0 = gw * per; j0 < n_pend; j0 += NWAVES * per) {
+    const uint32_t nw = min(per, n_pend - j0);
     // ---- A: the windows ------------------------------------------------------------------
     if (lane < kBatchW) {
       uint32_t ok = 0, w = 0, i = 0;
@@ -1937,6 +1941,7 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
 // Windows with more than one such n-gram, a long chain in the map, or nn > 10 go to k_lsh_batch's
 // bucket walk through a list of their own (a percent or two).
 constexpr int kEnumNN = 10;               // NearestFilter sizes k_lsh_enum serves
+constexpr int kEnumG = 4;                 // script n-grams one slot away from a window that it takes
 struct alignas(16) PkeysLds {             // per wave
   uint64_t bal[kBatchW][6];
   uint32_t f[kBatchW][FS_MAX_WINDOW];
@@ -1960,8 +1965,9 @@ __global__ __launch_bounds__(256) void k_lsh_pkeys(CorpusDev c, LshDev L, const 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-  for (uint32_t j0 = gw * kBatchW; j0 < n_pend; j0 += NWAVES * kBatchW) {
-    const uint32_t nw = min((uint32_t)kBatchW, n_pend - j0);
+  const uint32_t per = max(1u, min((uint32_t)kBatchW, (n_pend + NWAVES - 1) / NWAVES));
+  for (uint32_t j0 = gw * per; j0 < n_pend; j0 += NWAVES * per) {
+    const uint32_t nw = min(per, n_pend - j0);
     if (lane < kBatchW) {
       uint32_t ok = 0, w = FS_NONE;
       uint64_t p = 0;
@@ -2101,8 +2107,22 @@ __global__ __launch_bounds__(256, 4) void k_lsh_enum(CorpusDev c, LshDev L, Gram
       fold ^= term[k];
       qf[k] = ok ? L.q[f[k]] : 0.0;             // (no OOV id on this path: the prefilters exclude them)
     }
-    // the n map lookups, four requested together; the (one) n-gram they name
-    uint32_t gid = FS_NONE;
+    // the n map lookups, four requested together; the n-grams they name (kEnumG at most; a full
+    // bucket's chain is followed twice)
+    uint32_t gl[kEnumG];
+    uint32_t gn = 0;
+#pragma unroll
+    for (int x = 0; x < kEnumG; ++x) gl[x] = FS_NONE;
+    auto add_gram = [&](uint32_t gid) {
+      bool seen = false;
+#pragma unroll
+      for (int x = 0; x < kEnumG; ++x) seen = seen || gl[x] == gid;
+      if (seen) return;
+      if (gn >= (uint32_t)kEnumG) { give_up = true; return; }
+#pragma unroll
+      for (int x = 0; x < kEnumG; ++x) gl[x] = gn == (uint32_t)x ? gid : gl[x];
+      ++gn;
+    };
 #pragma unroll
     for (int k0 = 0; k0 < N; k0 += 4) {
       uint4 ba[4], bb[4];
@@ -2117,92 +2137,128 @@ __global__ __launch_bounds__(256, 4) void k_lsh_enum(CorpusDev c, LshDev L, Gram
       for (int u = 0; u < 4; ++u)
         if (k0 + u < N) {
           const uint32_t h = fs_wild_key(fold, term[k0 + u], k0 + u);
-          const uint32_t key[4] = {ba[u].x, ba[u].z, bb[u].x, bb[u].z}, val[4] = {ba[u].y, ba[u].w, bb[u].y, bb[u].w};
-          if (val[3]) give_up = true;             // a full bucket: entries may have spilt
+          uint4 a = ba[u], b = bb[u];
+          uint32_t bkt = fs_wmap_slot(h, L.log2_emap);
+          for (int probe = 0;; ++probe) {
+            const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (val[e] && key[e] == h) {
-              if (gid == FS_NONE) gid = val[e] - 1;
-              else if (gid != val[e] - 1) give_up = true;    // a second n-gram: the bucket walk ranks them
-            }
+            for (int e = 0; e < 4; ++e)
+              if (val[e] && key[e] == h && ok) add_gram(val[e] - 1);
+            if (!val[3] || !ok) break;            // (not full: nothing has spilt past it)
+            if (probe == 2) { give_up = true; break; }
+            bkt = (bkt + 1) & ((1u << L.log2_emap) - 1u);
+            const uint4* bp = reinterpret_cast<const uint4*>(L.emap + 4 * (size_t)bkt);
+            a = bp[0]; b = bp[1];
+          }
         }
     }
     if (!ok) give_up = false;
-    uint32_t made = 0;
-    if (ok && !give_up && gid != FS_NONE && gid < g.n_grams) {
-      const uint32_t occ = g.gcnt[gid];
-      uint32_t o[kEnumNN];
+    // per n-gram: the canonical distance to its first window (window_distance_flat's arithmetic,
+    // the fan side in registers) and the tables that hold both in one bucket
+    double gd[kEnumG];
+    uint32_t gt[kEnumG];
 #pragma unroll
-      for (int r = 0; r < kEnumNN; ++r) o[r] = (uint32_t)r < nn ? g.gpos[(size_t)gid * nn + r] : 0u;
-      const uint32_t s0 = o[0];
-      uint32_t tables = 0;
-      {
-        uint32_t kk[kBatchH], mine[kBatchH];
-#pragma unroll
-        for (int q4 = 0; q4 < kBatchH / 4; ++q4) {
-          const uint4 m = reinterpret_cast<const uint4*>(pkeys + (size_t)j * kBatchH)[q4];
-          mine[4 * q4] = m.x; mine[4 * q4 + 1] = m.y; mine[4 * q4 + 2] = m.z; mine[4 * q4 + 3] = m.w;
-        }
-#pragma unroll
-        for (int h = 0; h < kBatchH; ++h) kk[h] = h < L.H ? L.skeys[(size_t)s0 * L.H + h] : 0u;
-#pragma unroll
-        for (int h = 0; h < kBatchH; ++h) tables |= (h < L.H && kk[h] == mine[h]) ? 1u << h : 0u;
-      }
-      // canonical distance to the n-gram's first window (window_distance_flat's arithmetic, the
-      // fan side in registers)
+    for (int x = 0; x < kEnumG; ++x) { gd[x] = 0.0; gt[x] = 0; }
+    if (ok && !give_up && gn) {
       double ff = 0.0;
 #pragma unroll
       for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, qf[k]);
       const double rff = __dsqrt_rn(ff);
-      const fs_swin sw = L.sw[s0];
-      uint4 rec[N];
+      uint32_t mine[kBatchH];
 #pragma unroll
-      for (int k = 0; k < N; ++k) rec[k] = *reinterpret_cast<const uint4*>(L.spos + s0 + k);
-      int same = 0;
-      uint32_t diff = 0;
-#pragma unroll
-      for (int k = 0; k < N; ++k) {
-        const bool eq = rec[k].w == f[k];
-        same += eq;
-        diff |= eq ? 0u : 1u << k;
+      for (int q4 = 0; q4 < kBatchH / 4; ++q4) {
+        const uint4 m = reinterpret_cast<const uint4*>(pkeys + (size_t)j * kBatchH)[q4];
+        mine[4 * q4] = m.x; mine[4 * q4 + 1] = m.y; mine[4 * q4 + 2] = m.z; mine[4 * q4 + 3] = m.w;
       }
-      double d = 0.0;
-      bool v = !(L.m_min > 0 && same < L.m_min);
-      if (v) {
-        const double norm = __dmul_rn(sw.rss, rff);
-        double sf;
-        if (same == N) {
-          sf = sw.ss;
-        } else {
-          double gk[N];
+      for (uint32_t gi = 0; gi < gn; ++gi) {
+        uint32_t gid = gl[0];
 #pragma unroll
-          for (int k = 0; k < N; ++k) {
-            gk[k] = qf[k];
-            if (diff >> k & 1u) gk[k] = L.gtab[(size_t)(int32_t)rec[k].z * L.V + f[k]];
-          }
-          sf = 0.0;
+        for (int x = 1; x < kEnumG; ++x) gid = gi == (uint32_t)x ? gl[x] : gid;
+        if (gid >= g.n_grams) continue;           // (cannot happen: the map holds gram ids)
+        const uint32_t s0 = g.gpos[(size_t)gid * nn];
+        uint32_t tables = 0;
 #pragma unroll
-          for (int k = 0; k < N; ++k) sf = __dadd_rn(sf, gk[k]);
+        for (int h = 0; h < kBatchH; ++h)
+          tables |= (h < L.H && L.skeys[(size_t)s0 * L.H + h] == mine[h]) ? 1u << h : 0u;
+        const fs_swin sw = L.sw[s0];
+        uint4 rec[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) rec[k] = *reinterpret_cast<const uint4*>(L.spos + s0 + k);
+        int same = 0;
+        uint32_t diff = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const bool eq = rec[k].w == f[k];
+          same += eq;
+          diff |= eq ? 0u : 1u << k;
         }
-        d = __dsub_rn(1.0, __ddiv_rn(sf, norm));
-        v = d == d && d < L.thr;
+        double d = 0.0;
+        bool v = !(L.m_min > 0 && same < L.m_min);
+        if (v) {
+          const double norm = __dmul_rn(sw.rss, rff);
+          double sf;
+          if (same == N) {
+            sf = sw.ss;
+          } else {
+            double gk[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+              gk[k] = qf[k];
+              if (diff >> k & 1u) gk[k] = L.gtab[(size_t)(int32_t)rec[k].z * L.V + f[k]];
+            }
+            sf = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) sf = __dadd_rn(sf, gk[k]);
+          }
+          d = __dsub_rn(1.0, __ddiv_rn(sf, norm));
+          v = d == d && d < L.thr;
+        }
+        if (!v) tables = 0;
+        if (L.unique && tables) tables &= 0u - tables;           // a script window counts where it arrives first
+#pragma unroll
+        for (int x = 0; x < kEnumG; ++x)
+          if (gi == (uint32_t)x) { gd[x] = d; gt[x] = tables; }
       }
-      if (!v) tables = 0;
-      if (L.unique && tables) tables &= 0u - tables;             // a script window counts where it arrives first
-      // the list: the n-gram's entries in arrival order (table, then occurrence), nn at most
-      uint32_t tb = tables, r = 0;
+    }
+    // NearestFilter's order: by distance, the n-grams one after the other (entries of one n-gram
+    // share its distance and are in arrival order).  Two n-grams at exactly the same distance
+    // would interleave by arrival: left to the bucket walk.
+    auto cswap = [&](int a, int b) {
+      const bool sw2 = (gt[b] != 0 && (gt[a] == 0 || gd[b] < gd[a]));
+      const double da = gd[a], db = gd[b];
+      const uint32_t ta = gt[a], tb2 = gt[b], ga = gl[a], gb = gl[b];
+      gd[a] = sw2 ? db : da; gd[b] = sw2 ? da : db;
+      gt[a] = sw2 ? tb2 : ta; gt[b] = sw2 ? ta : tb2;
+      gl[a] = sw2 ? gb : ga; gl[b] = sw2 ? ga : gb;
+    };
+    static_assert(kEnumG == 4, "a sorting network of four");
+    cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+#pragma unroll
+    for (int x = 0; x + 1 < kEnumG; ++x)
+      if (gt[x] && gt[x + 1] && gd[x] == gd[x + 1]) give_up = true;
+    uint32_t made = 0;
+    if (ok && !give_up) {
       const size_t jj = (size_t)j * nn;
 #pragma unroll
-      for (int e = 0; e < kEnumNN; ++e)
-        if ((uint32_t)e < nn && tb) {
-          uint32_t sel = o[0];
+      for (int x = 0; x < kEnumG; ++x) {
+        if (!gt[x] || made >= nn) continue;
+        const uint32_t gid = gl[x], occ = g.gcnt[gid];
+        uint32_t o[kEnumNN];
 #pragma unroll
-          for (int x = 1; x < kEnumNN; ++x) sel = r == (uint32_t)x ? o[x] : sel;
-          mtop_s[jj + e] = sel;
-          mtop_d[jj + e] = d;
-          ++made;
-          if (++r == occ) { r = 0; tb &= tb - 1; }
-        }
+        for (int r = 0; r < kEnumNN; ++r) o[r] = (uint32_t)r < nn ? g.gpos[(size_t)gid * nn + r] : 0u;
+        uint32_t tb = gt[x], r = 0;
+#pragma unroll
+        for (int e = 0; e < kEnumNN; ++e)
+          if (tb && made < nn) {
+            uint32_t sel = o[0];
+#pragma unroll
+            for (int y = 1; y < kEnumNN; ++y) sel = r == (uint32_t)y ? o[y] : sel;
+            mtop_s[jj + made] = sel;
+            mtop_d[jj + made] = gd[x];
+            ++made;
+            if (++r == occ) { r = 0; tb &= tb - 1; }
+          }
+      }
     }
     if (live && !give_up) {
       mcnt[j] = made;

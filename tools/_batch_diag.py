@@ -9,7 +9,7 @@ tok, off = synth.corpus_tokens_parallel(10000, 2000, script)
 emb, perm = synth.clustered_table(); tok = synth.synonym_swaps(tok, perm)
 chars, coff = vocab.pack_strings(words); swords = [words[int(t)] for t in script]
 cfg = abi.make_config(window_size=6); normals = synth.lsh_normals(6)
-for diag in (0x10000, 0x200000, 0):
+for diag in (0x200000, 0x400000):
     os.environ["FS_LSH_DIAG"] = str(diag)
     ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
     c = ix.corpus(tok, off, chars, coff)
