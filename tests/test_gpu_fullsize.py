@@ -127,6 +127,63 @@ def test_c2_full_properties_and_pipeline_equality(c2, synth_base, monkeypatch):
     util.assert_rows_equal(rows[rows["work"] < 300], want)
 
 
+@pytest.mark.parametrize("n", [4, 8, 10])
+def test_c4_full_size(c2, synth_base, monkeypatch, n):
+    """BASELINE.json configs[3]: the n = 4 / 8 / 10 sweep on the whole 10k-work corpus (VERDICT r4:
+    only 16-30 works were ever held against the oracle at those window sizes).  n = 4 takes the
+    exact pipeline; at n = 8 and 10 the table's proof fails by one slot: the LSH pipeline behind
+    the integer prefilters (k_near_sift, k_lsh_sift2, k_lsh_pkeys / k_lsh_enum / k_lsh_batch).
+    The first 300 works against the C oracle (embedded in the full run), the whole batch against
+    the unfiltered LSH pipeline (keys and buckets for every one of the 20 M windows), the
+    properties of the exact records, a second search."""
+    from fandom_search_amd.engine import ScriptIndex
+    script, tok, off = c2
+    words, emb = synth_base["words"], synth_base["emb"]
+    normals = synth.lsh_normals(n)
+    swords = [words[int(t)] for t in script]
+    cfg = abi.make_config(window_size=n)
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
+    rows, st = ix.search(corpus)
+    assert st.windows_processed == 10000 * (2000 - n + 1)
+    assert ix.kernel_name(corpus) == ("k_scan_rows<4,3>" if n == 4 else "k_near_sift<%d>" % n)
+    assert st.path == (abi.FS_MODE_EXACT if n == 4 else abi.FS_MODE_GENERAL)
+    rows2, st2 = ix.search(corpus)
+    assert rows.tobytes() == rows2.tobytes() and st.matches == st2.matches
+    # the records of exact matches (all of them at n = 4; at n = 8, 10 those with distance ~ 0)
+    exact = np.abs(rows["dist"]) < 1e-12
+    if n == 4:
+        assert exact.all()
+        pos = _check_rows(rows, tok, off, script, n)
+        want_pos, _ = _covered_words(tok, off, script, n)
+        assert np.array_equal(pos, want_pos)
+    else:
+        assert 0 < int((~exact).sum()) < len(rows) // 10          # genuine one-slot neighbours are records too
+        pos = off[rows["work"]].astype(np.int64) + rows["fan_ix"].astype(np.int64)
+        assert np.all(np.diff(pos) > 0)
+        want_pos, _ = _covered_words(tok, off, script, n)
+        assert np.isin(want_pos, pos).all()                       # every word of a verbatim n-gram has its record
+        ex = rows[exact]
+        assert np.array_equal(tok[pos[exact]], script[ex["orig_ix"]])
+        assert np.all(ex["lev"] == n + 1) and np.array_equal(rows["comb"], rows["dist"] * rows["lev"])
+        # the unfiltered LSH pipeline over all 20 M windows: the same bytes
+        monkeypatch.setenv("FS_LSH_PREFILTER", "0")
+        full = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+        cf = full.corpus(tok, off, synth_base["chars"], synth_base["off"])
+        assert full.kernel_name(cf) == "k_lsh_scan"
+        frows, fst = full.search(cf)
+        monkeypatch.delenv("FS_LSH_PREFILTER")
+        assert frows.tobytes() == rows.tobytes() and fst.matches == st.matches
+        full.close()
+    # a 300-work slice against the oracle, embedded in the full run
+    cut = int(off[300])
+    oi = util.oracle_index(cfg, script, words, emb, normals)
+    want, _ = oi.search(tok[:cut], off[:301], synth_base["chars"], synth_base["off"])
+    util.assert_rows_equal(rows[rows["work"] < 300], want)
+    oi.close()
+    ix.close()
+
+
 def test_c3_shard_properties(synth_base):
     """One GPU's share of BASELINE.json configs[2]: 12.5k works x 5k tokens."""
     from fandom_search_amd.engine import ScriptIndex
