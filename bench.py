@@ -418,6 +418,21 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
         out["headline_unique_filter_on"] = rec
         cu.close()
         ixu.close()
+        # (7) a table shaped like a real one (synth.realistic_table: 20k unnormalised rows, similarity at
+        # three scales, duplicate and zero rows), fan text with near-synonyms, capitalised words and --
+        # first entry -- 8 % out-of-vocabulary names.  What every user's own table looks like: here the
+        # near-pair components merge (norms spread over a factor of ten) and a batch with OOV ids is
+        # outside every integer prefilter, so both take the plain LSH pipeline (keys for every window)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("realistic_bench", os.path.join(ROOT, "tools", "realistic_bench.py"))
+        rb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(rb)
+        for name, oov in (("lsh_realistic_table", 0.08), ("lsh_realistic_table_no_oov", 0.0)):
+            rec = rb.run(works=1000, oov=oov)
+            rec["value"] = rec["value_alone"]
+            rec["note"] = ("1000 works x 2000 tokens on synth.realistic_table, one search alone (device time); "
+                           "kernel: the search's first kernel -- k_lsh_scan = no integer prefilter applies")
+            out[name] = rec
     return out
 
 

@@ -156,6 +156,9 @@ def load():
     if hasattr(L, "fs_debug_stamps"):      # (absent from older builds loaded through FS_LIB_FILE)
         L.fs_debug_stamps.restype = C.c_int
         L.fs_debug_stamps.argtypes = [C.c_void_p, C.c_uint32, u64p, C.c_uint64, u64p]
+    if hasattr(L, "fs_index_component_sizes"):
+        L.fs_index_component_sizes.restype = C.c_int
+        L.fs_index_component_sizes.argtypes = [C.c_void_p, u32p, C.c_uint64, u64p, u32p]
     if hasattr(L, "fs_search_profile"):    # (absent from older builds loaded through FS_LIB_FILE)
         L.fs_search_profile.restype = C.c_int
         L.fs_search_profile.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int,

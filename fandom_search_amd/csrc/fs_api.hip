@@ -534,6 +534,16 @@ extern "C" int fs_index_info_get(const fs_index* ix, fs_index_info* info) {
   return FS_OK;
 }
 
+extern "C" int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uint64_t cap, uint64_t* n,
+                                        uint32_t* in_use) {
+  if (!ix || !n) return FS_E_INVALID;
+  *n = ix->comp_sizes.size();
+  if (in_use) *in_use = ix->syn_ok ? 1u : 0u;
+  if (sizes)
+    for (uint64_t i = 0; i < cap && i < ix->comp_sizes.size(); ++i) sizes[i] = ix->comp_sizes[i];
+  return FS_OK;
+}
+
 extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   static thread_local char name[64];
   if (!ix || !c || c->ix != ix) return "";

@@ -268,6 +268,7 @@ struct fs_index {
   int log2_wildc = 0;
   bool syn_ok = false;
   uint32_t n_comp = 0, comp_largest = 0;
+  std::vector<uint32_t> comp_sizes;   // members per component of the near-pair graph (fs_index_component_sizes)
 
   // Lanes: a stream with its own workspaces (grown on demand) and status block.
   // Searches are spread over n_lanes of them (FS_LANES in the environment, default

@@ -2566,6 +2566,7 @@ static int fs_build_components(fs_index* ix) {
     }
   }
   ix->n_comp = (uint32_t)size.size();
+  ix->comp_sizes = size;
   ix->comp_largest = *std::max_element(size.begin(), size.end());
   if ((uint64_t)ix->comp_largest * 8 > V && ix->comp_largest > 64) return FS_OK;
   FS_TRY(ix->d_comp.upload(comp.data(), comp.size(), ix->stream));

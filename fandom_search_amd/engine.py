@@ -243,6 +243,18 @@ class ScriptIndex(object):
         """Diagnostics: the kernel that dominates a search of `corpus` (profile name)."""
         return _lib.load().fs_search_kernel_name(self._h, corpus._h).decode()
 
+    def component_sizes(self):
+        """Diagnostics: (sizes of the components of near vectors, whether the prefilters use
+        them) -- fs_index_component_sizes."""
+        n, used = C.c_uint64(), C.c_uint32()
+        L = _lib.load()
+        _lib.check(L.fs_index_component_sizes(self._h, None, 0, C.byref(n), C.byref(used)), "fs_index_component_sizes")
+        sizes = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _lib.check(L.fs_index_component_sizes(self._h, abi.ptr(sizes, C.c_uint32), n.value, C.byref(n),
+                                                  C.byref(used)), "fs_index_component_sizes")
+        return sizes, bool(used.value)
+
     def profile(self, corpus, rows_ptr, cap):
         """Diagnostics: one search of `corpus` (records to the device buffer at `rows_ptr`)
         with a HIP event behind each of its kernels; returns [(kernel name, ms), ...] in

@@ -92,6 +92,118 @@ def synonym_swaps(tok, perm, per=8, rate=0.1, seed=9):
     return tok
 
 
+def realistic_words(size):
+    """`size` distinct lower-case pseudo-words, one token each: vocab_words() and, beyond its
+    reach, three-syllable ones."""
+    syl = [c + v for c in _CONS for v in _VOWS]
+    words = vocab_words(min(size, len(syl) ** 2 - 64))
+    seen = set(words)
+    i = 0
+    while len(words) < size:
+        w = syl[i % 100] + syl[(i // 100) % 100] + syl[(i // 10000) % 100]
+        i += 1
+        if w not in seen:
+            seen.add(w)
+            words.append(w)
+    return words
+
+
+def realistic_table(rows=20000, dim=EMB_DIM, seed=11, sigma=0.3, dup_share=0.05, zero_rows=16):
+    """A table with the features of a real word-embedding table (en_core_web_md keeps 20k
+    unique rows) that the benchmark tables lack, as far as they matter to this search:
+      * vectors are NOT unit length: norms lognormal(log 6, sigma) -- a factor of ~3 between
+        the short and the long ones at sigma = 0.3;
+      * similarity at several scales: a three-level hierarchy, cosine ~0.95 inside the
+        innermost groups (5 words), ~0.8 inside the middle ones (20), ~0.6 inside the outer
+        ones (80), ~0 across;
+      * `dup_share` of the rows are exact copies of other rows (spaCy prunes vectors: many
+        keys share a row's content), and `zero_rows` rows are zero.
+    Returns (emb float32 [rows][dim], group): group[r] = (outer, middle, inner) of row r."""
+    rng = np.random.default_rng(seed)
+    inner, mid, outer = 5, 4, 4                     # words per inner group, inner per middle, middle per outer
+    n_inner = -(-rows // inner)
+    n_mid = -(-n_inner // mid)
+    n_out = -(-n_mid // outer)
+    unit = lambda m: (lambda a: a / np.linalg.norm(a, axis=1, keepdims=True))(rng.standard_normal((m, dim)))
+    u1, u2, u3 = unit(n_out), unit(n_mid), unit(n_inner)
+    r = np.arange(rows)
+    gi, gm, go = r // inner, r // (inner * mid), r // (inner * mid * outer)
+    a, b, c, d = np.sqrt(0.6), np.sqrt(0.2), np.sqrt(0.15), np.sqrt(0.05)
+    emb = a * u1[go] + b * u2[gm] + c * u3[gi] + d * unit(rows)
+    emb /= np.linalg.norm(emb, axis=1, keepdims=True)
+    emb *= rng.lognormal(np.log(6.0), sigma, size=(rows, 1))
+    n_dup = int(rows * dup_share)
+    dst = rng.choice(rows, size=n_dup, replace=False)
+    src = rng.integers(0, rows, size=n_dup)
+    emb[dst] = emb[src]
+    emb[rng.choice(rows, size=zero_rows, replace=False)] = 0.0
+    perm = rng.permutation(rows)                    # related words are not neighbours in id space
+    out = np.empty_like(emb)
+    out[perm] = emb
+    group = np.empty((rows, 3), dtype=np.int32)
+    group[perm] = np.stack([go, gm, gi], axis=1)
+    return np.ascontiguousarray(out, dtype=np.float32), group
+
+
+def realistic_corpus(n_works, tokens_per_work, script, group, n_table, oov_rate=0.08, cap_rate=0.06,
+                     swap_rate=0.12, n_oov_words=400, seed=5, first_work=0):
+    """Fan works over a `realistic_table`: Zipf text with planted script spans (fanwork_tokens),
+    `swap_rate` of the tokens replaced by a word of the same inner group (near-synonym,
+    cosine ~0.95) or, one time in four, of the same middle group (~0.8); `oov_rate` of the
+    tokens out-of-vocabulary words (names: `n_oov_words` distinct strings without a row -- the
+    reference gives them 3-hot vectors, search.py:79-83); `cap_rate` of the in-vocabulary
+    tokens capitalised (the fan side is case-sensitive, search.py:166: same row, other
+    string).  Returns (tok_str, work_off, strings): string ids into `strings` =
+    realistic_words(n_table) + capitalised forms + the OOV words; the caller maps strings to
+    vector ids (vocab.Vocab.encode, or vector_ids_of below)."""
+    rng = np.random.default_rng(seed + 7919 * first_work)
+    tok = np.empty(n_works * tokens_per_work, dtype=np.uint32)
+    for i in range(n_works):
+        tok[i * tokens_per_work:(i + 1) * tokens_per_work] = fanwork_tokens(
+            first_work + i, tokens_per_work, script, n_table)
+    # members of every inner / middle group
+    order_i = np.argsort(group[:, 2], kind="stable")
+    start_i = np.searchsorted(group[order_i, 2], np.arange(group[:, 2].max() + 2))
+    order_m = np.argsort(group[:, 1], kind="stable")
+    start_m = np.searchsorted(group[order_m, 1], np.arange(group[:, 1].max() + 2))
+    sel = np.nonzero(rng.random(len(tok)) < swap_rate)[0]
+    wide = rng.random(len(sel)) < 0.25
+    for idxs, order, start, col in ((sel[~wide], order_i, start_i, 2), (sel[wide], order_m, start_m, 1)):
+        gsel = group[tok[idxs], col]
+        lo, hi = start[gsel], start[gsel + 1]
+        tok[idxs] = order[lo + (rng.random(len(idxs)) * (hi - lo)).astype(np.int64)].astype(np.uint32)
+    tok_str = tok.copy()
+    cap = rng.random(len(tok)) < cap_rate
+    tok_str[cap] += np.uint32(n_table)                         # capitalised form of the same row
+    oov = rng.random(len(tok)) < oov_rate
+    tok_str[oov] = (2 * n_table + rng.integers(0, n_oov_words, size=int(oov.sum()))).astype(np.uint32)
+    off = np.arange(n_works + 1, dtype=np.uint64) * np.uint64(tokens_per_work)
+    return tok_str, off
+
+
+def realistic_strings(n_table, n_oov_words=400):
+    """String table of realistic_corpus: the table's words, their capitalised forms, OOV names."""
+    words = realistic_words(n_table)
+    syl = [c + v for c in _CONS for v in _VOWS]
+    names = ["Q" + syl[i % 100] + "x" + syl[(i // 100) % 100] + "q" for i in range(n_oov_words)]
+    return words + [w.capitalize() for w in words] + names
+
+
+def realistic_vector_ids(n_table, n_oov_words=400, dim=EMB_DIM):
+    """Vector id per string of realistic_strings: the row for a table word and its capitalised
+    form, the out-of-vocabulary code (3-hot positions by the seeded hash, vocab.Vocab) for a name."""
+    from . import vocab as vocab_mod
+    strings = realistic_strings(n_table, n_oov_words)
+    vid = np.empty(len(strings), dtype=np.uint32)
+    vid[:n_table] = np.arange(n_table, dtype=np.uint32)
+    vid[n_table:2 * n_table] = np.arange(n_table, dtype=np.uint32)
+    h = vocab_mod.default_oov_hash
+    for i, w in enumerate(strings[2 * n_table:]):
+        hot = sorted((h(w) % dim, h(w * 2) % dim, h(w * 3) % dim))
+        vid[2 * n_table + i] = vocab_mod.OOV_FLAG | ((hot[0] * dim + hot[1]) * dim + hot[2])
+    return strings, vid
+
+
 def lsh_normals(window_size=6, number_of_hashes=15, hash_dimensions=14,
                 dim=EMB_DIM, seed=NORMALS_SEED):
     rng = np.random.default_rng(seed)

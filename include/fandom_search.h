@@ -262,6 +262,14 @@ int fs_index_set_scan_timing(fs_index* ix, uint32_t period);
  * of the search lists first.  Static storage, valid until the next call on this thread. */
 const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c);
 
+/* Diagnostics: tables with near-synonyms -- the sizes of the connected components of the graph
+ * of "near" vector pairs that the integer prefilters of the LSH pipeline work over (0 entries:
+ * the graph was not built: the exact pipeline, or a proof that fails by one slot only).
+ * *in_use = 1 when the prefilters run over component ids, 0 when the components were judged
+ * too coarse (one holds an eighth of the table) and searches take the plain LSH pipeline. */
+int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uint64_t cap, uint64_t* n,
+                             uint32_t* in_use);
+
 /* Diagnostics: one synchronous search of `c` (arguments as fs_search_corpus) with a HIP event
  * behind every kernel of it.  names: the kernels' names in launch order, '\n'-separated;
  * ms[i]: time from the previous mark to the one behind kernel i (its duration when nothing else

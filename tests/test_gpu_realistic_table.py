@@ -1,0 +1,65 @@
+"""A table with the features of a real embedding table (synth.realistic_table: unnormalised
+vectors, similarity at three scales, duplicate and zero rows) under fan text with
+out-of-vocabulary names and capitalised words: records as the C oracle's, byte for byte, on
+more than fifty works, with and without the out-of-vocabulary tokens (which decide the
+pipeline: a batch that holds any takes the plain LSH pipeline)."""
+
+import numpy as np
+import pytest
+
+from fandom_search_amd import abi, synth
+from fandom_search_amd.vocab import pack_strings
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+ROWS = 6000
+
+
+@pytest.fixture(scope="module")
+def real():
+    emb, group = synth.realistic_table(rows=ROWS)
+    strings, vid = synth.realistic_vector_ids(ROWS)
+    script = synth._draw(np.random.default_rng(77), 3000, ROWS)
+    return emb, group, strings, vid, script
+
+
+@pytest.mark.parametrize("oov", [True, False])
+@pytest.mark.parametrize("unique", [0, 1])
+def test_realistic_table_equals_oracle(real, oov, unique):
+    from oracle import c_oracle
+    from fandom_search_amd.engine import ScriptIndex
+    emb, group, strings, vid, script = real
+    tok_str, off = synth.realistic_corpus(60, 700, script, group, ROWS, oov_rate=0.08 if oov else 0.0)
+    # planted quotes that are sure to be there: verbatim, with near-synonyms, with a name inside
+    rng = np.random.default_rng(3)
+    for j in range(12):
+        at = int(off[j]) + 50 + 7 * j
+        span = script[200 + 40 * j:200 + 40 * j + 14].astype(np.uint32)
+        tok_str[at:at + len(span)] = span
+        if j % 3 == 1:
+            k = at + 3 + j % 5
+            mates = np.nonzero(group[:, 2] == group[int(tok_str[k]), 2])[0]
+            tok_str[k] = mates[int(rng.integers(0, len(mates)))]
+        if j % 3 == 2 and oov:
+            tok_str[at + 6] = 2 * ROWS + j
+    tok_vec = vid[tok_str]
+    swords = [strings[int(t)].upper() if i % 9 == 0 else strings[int(t)] for i, t in enumerate(script)]
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config(unique_filter=unique)
+    normals = synth.lsh_normals(6)
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    c = ix.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+    got, st = ix.search(c)
+    again, _ = ix.search(c)
+    assert st.path == abi.FS_MODE_GENERAL and got.tobytes() == again.tobytes()
+    if oov:
+        assert ix.kernel_name(c) == "k_lsh_scan"          # out-of-vocabulary ids: no integer prefilter
+    sch, so = pack_strings(swords)
+    oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
+    want, ost = oi.search(tok_vec, off, chars, coff, tok_str=tok_str)
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and len(got) > 100
+    assert int((got["dist"] > 1e-3).sum()) > 0            # near-synonym matches are records
+    oi.close()
+    ix.close()

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""The search on synth.realistic_table (unnormalised vectors, three scales of similarity,
+duplicate and zero rows) under fan text with and without out-of-vocabulary names: which
+pipeline runs, the component statistics of the near-synonym prefilter, fanworks/s.
+
+  python tools/realistic_bench.py [--works 2000] [--rows 20000] [--oov 0.08]
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, window=6, reps=3):
+    from fandom_search_amd import abi, synth
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+    emb, group = synth.realistic_table(rows=rows)
+    strings, vid = synth.realistic_vector_ids(rows)
+    script = synth._draw(np.random.default_rng(77), script_tokens, rows)
+    tok_str, off = synth.realistic_corpus(works, tokens, script, group, rows, oov_rate=oov)
+    tok_vec = vid[tok_str]
+    chars, coff = pack_strings(strings)
+    swords = [strings[int(t)] for t in script]
+    t0 = time.perf_counter()
+    ix = ScriptIndex(script, swords, emb, synth.lsh_normals(window), cfg=abi.make_config(window_size=window))
+    t_index = time.perf_counter() - t0
+    c = ix.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+    rows_out, st = ix.search(c)
+    best = None
+    for _ in range(reps):
+        rows_out, st = ix.search(c, reuse=True)
+        if st.total_ms > 0:
+            best = st.total_ms if best is None else min(best, st.total_ms)
+    out = {"rows": rows, "works": works, "tokens_per_work": tokens, "oov_rate": oov, "window": window,
+           "kernel": ix.kernel_name(c), "path": "lsh" if st.path == abi.FS_MODE_GENERAL else "exact",
+           "c_max": ix.info["c_max"], "norm_min": ix.info["norm_min"], "norm_max": ix.info["norm_max"],
+           "index_s": round(t_index, 2), "ms_per_search_alone": best,
+           "value_alone": works / (best * 1e-3) if best else None, "unit": "fanworks/s",
+           "windows_per_s": st.windows_processed / (best * 1e-3) if best else None,
+           "candidates": int(st.candidates), "lsh_pending": int(st.lsh_pending),
+           "records": int(len(rows_out)), "inexact_records": int((np.abs(rows_out["dist"]) > 1e-9).sum()),
+           "oov_share_of_tokens": float((tok_vec & abi.FS_OOV_FLAG != 0).mean())}
+    sizes, used = ix.component_sizes()
+    if len(sizes):
+        edges = [1, 2, 3, 5, 9, 17, 65, 257, 1025, 1 << 30]
+        out["components"] = {"count": int(len(sizes)), "largest": int(sizes.max()), "in_use": used,
+                             "histogram": {"%d-%d" % (lo, hi - 1) if hi < (1 << 30) else "%d+" % lo:
+                                           int(((sizes >= lo) & (sizes < hi)).sum())
+                                           for lo, hi in zip(edges[:-1], edges[1:])},
+                             "share_of_table_in_largest": float(sizes.max()) / rows}
+    c.close()
+    ix.close()
+    return out
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--works", type=int, default=2000)
+    ap.add_argument("--rows", type=int, default=20000)
+    ap.add_argument("--oov", type=float, default=0.08)
+    a = ap.parse_args()
+    for oov in (a.oov, 0.0):
+        print(json.dumps(run(a.works, a.rows, oov)), flush=True)
