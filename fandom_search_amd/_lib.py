@@ -22,7 +22,9 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_host_alloc", "fs_host_free", "fs_rows_unpack", "fs_rows_unpack8",
            "fs_reuse_histogram", "fs_reuse_histogram_rows",
            "fs_search_corpus_begin", "fs_search_corpus_end", "fs_index_set_scan_timing",
-           "fs_index_reload_switches", "fs_search_kernel_name", "fs_debug_stamps")
+           "fs_index_reload_switches", "fs_search_kernel_name", "fs_debug_stamps",
+           "fs_search_profile", "fs_index_component_sizes",
+           "fs_textenc_create", "fs_textenc_destroy", "fs_textenc_add", "fs_textenc_encode_files")
 
 
 class FsError(RuntimeError):

@@ -275,17 +275,24 @@ class TokenPool(object):
         self.processes = int(processes)
         self.pool = multiprocessing.get_context("fork").Pool(self.processes) if self.processes > 1 else None
         self.pending = {}
+        self.native = None                     # textenc.TextEncoder: reading and tokenising on native threads
         self.writes = []                       # [job or None, function, arguments] of queued writes
         self._pids = sorted(p.pid for p in self.pool._pool) if self.pool is not None else None
 
     def start(self, filenames):
         key = tuple(filenames)
+        if self.native is not None:
+            self.native.start(key)
+            return
         if self.pool is None or not key or key in self.pending:
             return
         chunks = [list(key[i:i + self.CHUNK]) for i in range(0, len(key), self.CHUNK)]
         self.pending[key] = self.pool.map_async(tokenize_files, chunks, chunksize=1)
 
     def get(self, filenames):
+        if self.native is not None:
+            lens, sids = self.native.encode_files(list(filenames))
+            return [(lens, sids, [])]
         job = self.pending.pop(tuple(filenames), None)
         # (jobs queued for a list that was never asked for -- share() and the split of a batch
         # disagreeing -- are dropped, not kept for the life of the pool: only the next cluster's
@@ -435,8 +442,17 @@ class AnnIndexSearch(object):
         v = self.vocab
         # (the workers hold the process-wide vocabulary; an index built on another one
         # tokenises here)
-        parts = self.token_pool.get(filenames) if self.token_pool is not None and v is _VOCAB \
-            else [tokenize_files(list(filenames), v)]
+        if self.token_pool is not None and v is _VOCAB:
+            parts = self.token_pool.get(filenames)
+        else:
+            from . import textenc
+            if textenc.enabled():
+                if getattr(self, "_text", None) is None:
+                    self._text = textenc.TextEncoder(v)
+                lens, sids = self._text.encode_files(list(filenames))
+                parts = [(lens, sids, [])]
+            else:
+                parts = [tokenize_files(list(filenames), v)]
         lens = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
         off = np.zeros(len(lens) + 1, dtype=np.uint64)
         off[1:] = np.cumsum(lens, dtype=np.uint64)
@@ -668,6 +684,12 @@ def analyze(args,
         _startup_lap("vector table")
         pool = TokenPool(default_workers(dist.env_world()[2]))
         _startup_lap("fork the token pool")
+        from . import textenc
+        if textenc.enabled():
+            # reading and tokenising on native threads of this process (fs_textenc_*); the
+            # forked workers then only write the batch files
+            pool.native = textenc.TextEncoder(get_vocab(), default_workers(dist.env_world()[2]))
+            _startup_lap("native text encoder")
     try:
         return _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_threshold,
                         chunk_size, searcher, pool)

@@ -262,6 +262,28 @@ int fs_index_set_scan_timing(fs_index* ix, uint32_t period);
  * of the search lists first.  Static storage, valid until the next call on this thread. */
 const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c);
 
+/* ---- host text front end (search.py:164-166: read a fan work, tokenise, drop whitespace) ----
+ * spaCy's tokenizer splits a text on whitespace and treats every chunk by itself, with a cache
+ * chunk -> tokens; fs_textenc is that cache and the splitting, natively and on `threads` host
+ * threads: files in, string ids out.  The host teaches it what a chunk's tokens are
+ * (fs_textenc_add: the vocabulary's plain words to start with, then every chunk its rule
+ * tokenizer has been run on); a chunk it has not been taught comes back as a placeholder
+ * 0x80000000 | k with its text (unk_bytes[unk_off[k] .. unk_off[k+1])), never as a guess.
+ * status[i]: 0 encoded; 1 left to the host (a text of 100000 bytes or more -- the reference
+ * cuts such texts into pieces first, search.py:47-63 -- or malformed UTF-8); < 0: -errno of
+ * the read.  The result pointers are the encoder's own buffers, valid until the next call on
+ * it.  No GPU is involved. */
+typedef struct fs_textenc fs_textenc;
+int fs_textenc_create(fs_textenc** out);
+void fs_textenc_destroy(fs_textenc* enc);
+int fs_textenc_add(fs_textenc* enc, const uint8_t* chunk_bytes, const uint64_t* chunk_off, uint64_t n_chunks,
+                   const uint64_t* piece_off, const uint32_t* piece_ids);
+int fs_textenc_encode_files(fs_textenc* enc, const char* paths /* n_files strings, each 0-terminated */,
+                            uint64_t n_files, uint32_t threads,
+                            const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off /* n_files + 1 */,
+                            const int32_t** status, const uint8_t** unk_bytes, const uint64_t** unk_off,
+                            uint64_t* n_unk);
+
 /* Diagnostics: tables with near-synonyms -- the sizes of the connected components of the graph
  * of "near" vector pairs that the integer prefilters of the LSH pipeline work over (0 entries:
  * the graph was not built: the exact pipeline, or a proof that fails by one slot only).
