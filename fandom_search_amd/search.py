@@ -491,7 +491,15 @@ class AnnIndexSearch(object):
     def search_rows(self, filenames):
         """(fs_row array with work indices into `filenames`, fan word text per
         row) -- the form that travels between ranks (fandom_search_amd.dist)."""
-        return self._search_encoded(*self._encode_files(filenames))
+        import time
+        t0 = time.perf_counter()
+        enc = self._encode_files(filenames)
+        t1 = time.perf_counter()
+        out = self._search_encoded(*enc)
+        t = self.__dict__.setdefault("host_times", {"encode": 0.0, "search": 0.0})
+        t["encode"] += t1 - t0
+        t["search"] += time.perf_counter() - t1
+        return out
 
     def _corpus_of_ids(self, tok_str, tok_vec, off):
         """(string ids, vector ids, work offsets, device corpus) of encoded works."""
@@ -500,8 +508,20 @@ class AnnIndexSearch(object):
         self.last_oov_rate = float((tok_vec & np.uint32(abi.FS_OOV_FLAG)).astype(bool).mean()) \
             if len(tok_vec) else 0.0
         same = bool(np.array_equal(tok_str, tok_vec))
-        corpus = self.engine.corpus(tok_vec, off, chars, coff,
-                                    tok_str=None if same else tok_str)
+        # one device corpus serves batch after batch while the string table stays as it is
+        # (fs_corpus_update_begin/_end: the ids are replaced, the tables built once per string
+        # table -- Levenshtein per n-gram, the batch table of k_scan_rows -- are kept)
+        kept = getattr(self, "_corpus", None)
+        if kept is not None and kept[0] == len(v.strings) and kept[1]._h:
+            corpus = kept[1]
+            corpus.update_begin(tok_vec, off, tok_str=None if same else tok_str)
+            corpus.update_end()
+        else:
+            if kept is not None:
+                kept[1].close()
+            corpus = self.engine.corpus(tok_vec, off, chars, coff,
+                                        tok_str=None if same else tok_str)
+            self._corpus = (len(v.strings), corpus)
         return tok_str, tok_vec, off, corpus
 
     def search_tokens(self, texts):
@@ -515,17 +535,22 @@ class AnnIndexSearch(object):
         return self._search_encoded(tok_str, tok_vec, off)
 
     def _search_encoded(self, tok_str, tok_vec, off):
+        import time
         v = self.vocab
+        ht = self.__dict__.setdefault("host_times", {"encode": 0.0, "search": 0.0})
+        t0 = time.perf_counter()
         tok_str, tok_vec, off, corpus = self._corpus_of_ids(tok_str, tok_vec, off)
-        try:
-            rows, st = self.engine.search(corpus, reuse=True)
-            rows = rows.copy()                    # (the engine's buffer is written by the next batch)
-        finally:
-            corpus.close()
+        t1 = time.perf_counter()
+        rows, st = self.engine.search(corpus, reuse=True)
+        rows = rows.copy()                        # (the engine's buffer is written by the next batch)
+        t2 = time.perf_counter()
         self.last_stats = st
         self._windows_processed += int(st.windows_processed)
         pos = off[rows['work']].astype(np.int64) + rows['fan_ix'].astype(np.int64)
         words = [v.strings[s] for s in tok_str[pos].tolist()]
+        t3 = time.perf_counter()
+        for k, dt in (("corpus to the GPU", t1 - t0), ("fs_search_corpus", t2 - t1), ("fan words of the records", t3 - t2)):
+            ht[k] = ht.get(k, 0.0) + dt
         return rows, words
 
     def search_shard(self, filenames):
@@ -545,19 +570,16 @@ class AnnIndexSearch(object):
             packed = 8 if len(self.word_lowercase) < abi.PACKED8_MAX_SCRIPT else 16
         rec = packed if packed else 32
         cap = max(1024, len(tok_vec) // 16)
-        try:
-            while True:
-                buf = torch.zeros(HDR + cap * rec, dtype=torch.uint8, device="cuda")
-                try:
-                    n, st = self.engine.search_end(self.engine.search_begin(
-                        corpus, buf.data_ptr(), cap, packed=packed, header=True))
-                    break
-                except _lib.FsError as e:
-                    if e.code != abi.FS_E_CAPACITY:
-                        raise
-                    cap = int(e.required) + 16
-        finally:
-            corpus.close()
+        while True:
+            buf = torch.zeros(HDR + cap * rec, dtype=torch.uint8, device="cuda")
+            try:
+                n, st = self.engine.search_end(self.engine.search_begin(
+                    corpus, buf.data_ptr(), cap, packed=packed, header=True))
+                break
+            except _lib.FsError as e:
+                if e.code != abi.FS_E_CAPACITY:
+                    raise
+                cap = int(e.required) + 16
         self.last_stats = st
         self._windows_processed += int(st.windows_processed)
         host = buf[HDR:HDR + n * rec].cpu().numpy()
@@ -832,6 +854,9 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
         if _startup:
             print("since process start: " + ", ".join("%s %.3f s" % kv for kv in _startup), file=sys.stderr)
         print("analyze: " + ", ".join("%s %.3f s" % kv for kv in timing.items()), file=sys.stderr)
+        ht = getattr(ann_index, "host_times", None)
+        if ht:
+            print("tokens + search = " + ", ".join("%s %.3f s" % kv for kv in ht.items()), file=sys.stderr)
     if world > 1:
         dist.finalize()
     return name

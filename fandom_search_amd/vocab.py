@@ -225,8 +225,13 @@ class Vocab(object):
         return usid[codes], uvid[codes]
 
     def string_table(self):
-        """UTF-32 code points of all strings + offsets (n_strings + 1)."""
-        return pack_strings(self.strings)
+        """UTF-32 code points of all strings + offsets (n_strings + 1); remembered until the
+        table grows (a batch of 500 works asks once, and most batches add no string)."""
+        cached = getattr(self, "_string_table", None)
+        if cached is None or cached[0] != len(self.strings):
+            chars, off = pack_strings(self.strings)
+            self._string_table = cached = (len(self.strings), chars, off)
+        return cached[1], cached[2]
 
 
 def oov_vector(vid, dim):
