@@ -782,6 +782,9 @@ def main():
             search_alone_ms = float(np.mean(one))
             kernel1 = ix1.kernel_name(c1s[0])
             ix1.close()
+        # what the launch shape costs for this many bytes with no work at all: a kernel that only
+        # reads the ids the way k_scan_rows does (rotating over the distinct batches: from HBM)
+        floor_ms = float(np.mean([ix.stream_floor(corpora[i % rotate], reps=4) for i in range(2 * rotate)]))
         rows_step = float(np.mean(rows_per_corpus))
         exact = st.path == abi.FS_MODE_EXACT
         fused = kernel.startswith("k_scan_rows")
@@ -872,6 +875,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": algo_bytes, "build": build,
                          "search_ms_alone": search_alone_ms, "kernel_alone": kernel1,
+                         "stream_floor_ms": floor_ms,
+                         "stream_floor_frac": 4.0 * n_tok / (floor_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "stream_floor_note": "k_stream_floor: the ids of a batch read in k_scan_rows' launch shape "
+                                              "and nothing else (fs_stream_floor), one launch at a time: the part of "
+                                              "search_ms_alone that is the launch and the HBM stream",
                          "launch_ms_alone": alone_ms,
                          "frac_alone": algo_bytes / (alone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "overlapped_launch_ms": kernel_ms, "timed_launches": len(scan_ms),

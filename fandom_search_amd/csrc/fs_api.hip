@@ -1398,6 +1398,12 @@ extern "C" int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, doub
   return FS_OK;
 }
 
+extern "C" int fs_stream_floor(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms) {
+  if (!ix || !c || c->ix != ix || !avg_ms || reps == 0) return FS_E_INVALID;
+  FS_ENTER(ix->device);
+  return fs_launch_stream_floor(ix, c, reps, avg_ms);
+}
+
 extern "C" int fs_rows_unpack8(fs_index* ix, const void* packed, uint64_t n,
                                const uint64_t* work_off, uint64_t n_works, fs_row* rows) {
   if (!ix || (n && (!packed || !rows || !work_off || !n_works))) { fs_set_error("null argument"); return FS_E_INVALID; }

@@ -436,6 +436,7 @@ int fs_launch_lsh_verify(fs_index* ix, fs_corpus* c, uint32_t ccap, hipStream_t 
 int fs_prof_mark(fs_index* ix, hipStream_t s, const char* name);      // fs_api.hip
 void fs_lsh_wild_of(const fs_index* ix, const fs_corpus* c, const uint32_t** wild, int* log2_wild,
                     const uint32_t** wild_tok);                        // fs_lsh.hip
+int fs_launch_stream_floor(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms);   // fs_scan.hip
 bool fs_near_fused(const fs_index* ix, const fs_corpus* c);            // fs_scan.hip: k_near_sift takes this search's prefilter
 uint32_t fs_near_ranges();                                              // wave ranges of k_near_sift
 int fs_launch_near_sift(const fs_index* ix, const fs_corpus* c, uint32_t* slist, uint32_t caps, uint32_t* scount,

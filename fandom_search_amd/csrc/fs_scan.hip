@@ -1473,6 +1473,60 @@ int fs_launch_scan_rows(fs_index* ix, fs_corpus* c, uint32_t waves, uint32_t blo
   return FS_OK;
 }
 
+// ---- the floor under k_scan_rows (diagnostics) -----------------------------------------------
+// k_stream_floor reads a corpus' ids the way k_scan_rows does -- one workgroup of sixteen waves
+// per CU, a contiguous run of 512-token sub-tiles per wave, two 16-byte loads per lane and
+// sub-tile, a pair of sub-tiles requested ahead -- and does nothing with them (an XOR, one word
+// written per wave).  Its duration is what the launch shape itself costs for this many bytes:
+// dispatch, ramp-up of 4096 waves, the HBM stream, completion.  fs_stream_floor times it the way
+// bench.py times a search alone (events on each dispatch).
+__global__ __launch_bounds__(1024) void k_stream_floor(const uint32_t* __restrict__ tok, uint32_t n_sub,
+                                                       uint32_t* __restrict__ sink) {
+  const uint32_t n_ranges = gridDim.x * 16, r = blockIdx.x * 16 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const uint32_t s0 = (uint32_t)((uint64_t)n_sub * r / n_ranges), s1 = (uint32_t)((uint64_t)n_sub * (r + 1) / n_ranges);
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  uint32_t s = s0;
+  for (; s + 2 <= s1; s += 2) {
+    const uint4* p = reinterpret_cast<const uint4*>(tok + (size_t)s * 512 + 8 * lane);
+    const uint4 a0 = p[0], a1 = p[1], b0 = p[128], b1 = p[129];
+    acc.x ^= a0.x ^ a1.x ^ b0.x ^ b1.x; acc.y ^= a0.y ^ a1.y ^ b0.y ^ b1.y;
+    acc.z ^= a0.z ^ a1.z ^ b0.z ^ b1.z; acc.w ^= a0.w ^ a1.w ^ b0.w ^ b1.w;
+  }
+  for (; s < s1; ++s) {
+    const uint4* p = reinterpret_cast<const uint4*>(tok + (size_t)s * 512 + 8 * lane);
+    const uint4 a0 = p[0], a1 = p[1];
+    acc.x ^= a0.x ^ a1.x; acc.y ^= a0.y ^ a1.y; acc.z ^= a0.z ^ a1.z; acc.w ^= a0.w ^ a1.w;
+  }
+  uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d);
+  if (lane == 0) sink[r] = x;
+}
+
+int fs_launch_stream_floor(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms) {
+  const uint32_t n_sub = (uint32_t)(c->n_tok / 512);             // whole sub-tiles (the rest is noise)
+  const uint32_t blocks = (uint32_t)ix->num_cu;
+  FS_TRY(ix->cur->w_bsum.reserve(blocks * 16));
+  hipStream_t s = ix->stream;
+  hipEvent_t e0, e1;
+  FS_HIP(hipEventCreate(&e0));
+  FS_HIP(hipEventCreate(&e1));
+  double sum = 0;
+  for (uint32_t r = 0; r < reps + 2; ++r) {
+    hipExtLaunchKernelGGL(k_stream_floor, dim3(blocks), dim3(1024), 0, s, e0, e1, 0u, c->dev().tok, n_sub, ix->cur->w_bsum.p);
+    FS_HIP(hipGetLastError());
+    FS_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    FS_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) sum += ms;                                        // (two launches to warm up)
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *avg_ms = sum / reps;
+  return FS_OK;
+}
+
 // ---- k_scan_near (integer prefilter of the LSH pipeline) --------------------------------
 // 0: none; 1: at most one slot of a neighbour may differ in its vector id (k_scan_near over
 // the vector ids); 2: tables with near-synonyms, the same over component ids (fs_lsh.hip)

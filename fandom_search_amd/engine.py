@@ -243,6 +243,13 @@ class ScriptIndex(object):
         """Diagnostics: the kernel that dominates a search of `corpus` (profile name)."""
         return _lib.load().fs_search_kernel_name(self._h, corpus._h).decode()
 
+    def stream_floor(self, corpus, reps=20):
+        """Diagnostics: ms of a kernel that only reads `corpus`' ids in k_scan_rows' launch
+        shape (fs_stream_floor)."""
+        ms = C.c_double()
+        _lib.check(_lib.load().fs_stream_floor(self._h, corpus._h, reps, C.byref(ms)), "fs_stream_floor")
+        return ms.value
+
     def component_sizes(self):
         """Diagnostics: (sizes of the components of near vectors, whether the prefilters use
         them) -- fs_index_component_sizes."""

@@ -312,6 +312,13 @@ int fs_index_reload_switches(fs_index* ix);
  * overhead.  Not part of the search path. */
 int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms);
 
+/* Diagnostics: the floor under k_scan_rows.  `reps` launches of a kernel that only READS the ids
+ * of `c` in k_scan_rows' launch shape (a workgroup of sixteen waves per CU, contiguous runs of
+ * 512-token sub-tiles, 16-byte loads, pairs requested ahead) and keeps nothing; *avg_ms = its
+ * dispatch-to-completion time, HIP events on every dispatch, one launch at a time.  What a
+ * search's own kernel takes above this is its own work. */
+int fs_stream_floor(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms);
+
 /* Diagnostics (FS_DIAG=2 in the environment at fs_index_create): per wave range of the
  * last k_scan_rows launch on stream `lane`, eight uint64 {entry, filter staged, scan done,
  * rounds done, finished (ticks of the 100 MHz constant clock), rounds, flushes, records}.
