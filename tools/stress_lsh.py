@@ -17,7 +17,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SWITCHES = ("FS_LSH_PREFILTER", "FS_LSH_WILD", "FS_LSH_SELFLEV", "FS_LSH_GRAMTAB", "FS_LSH_WMAP")
+SWITCHES = ("FS_LSH_PREFILTER", "FS_LSH_WILD", "FS_LSH_SELFLEV", "FS_LSH_GRAMTAB", "FS_LSH_WMAP", "FS_LSH_SYN",
+            "FS_NEAR_FUSED", "FS_LSH_BATCH", "FS_LSH_EMAP")
 
 
 def main():
@@ -30,11 +31,20 @@ def main():
     from fandom_search_amd.vocab import pack_strings
 
     rng = np.random.default_rng(a.seed)
-    words, emb = synth.vocab_words(), synth.embedding()
+    words, emb_u = synth.vocab_words(), synth.embedding()
+    emb_c, perm = synth.clustered_table()
     chars, coff = pack_strings(words)
     bad = 0
     for case in range(a.cases):
-        n = int(rng.choice([8, 9, 10, 12]))
+        # round 5: every other case on the table with near-synonyms (component-id prefilters,
+        # n = 6 .. 10 there), 10 % of the fan tokens swapped for a synonym; both settings of the
+        # UniqueFilter; and the pending windows through k_lsh_pkeys / k_lsh_enum / k_lsh_batch
+        # however few they are (FS_LSH_DEFER_MIN=0) on every third case
+        clustered = case % 2 == 1
+        emb = emb_c if clustered else emb_u
+        n = int(rng.choice([6, 7, 8, 10])) if clustered else int(rng.choice([8, 9, 10, 12]))
+        unique = bool(case % 4 >= 2)
+        os.environ["FS_LSH_DEFER_MIN"] = "0" if case % 3 == 0 else "8192"
         n_script = int(rng.choice([300, 2000, 8000]))
         script = synth.script_tokens(n_script)
         swords = [words[int(t)].upper() if rng.random() < 0.1 else words[int(t)] for t in script]
@@ -53,7 +63,9 @@ def main():
         off = np.zeros(n_works + 1, dtype=np.uint64)
         off[1:] = np.cumsum([len(p) for p in parts])
         tok = np.concatenate(parts).astype(np.uint32) if n_works else np.zeros(0, np.uint32)
-        cfg = abi.make_config(window_size=n)
+        if clustered and len(tok):
+            tok = synth.synonym_swaps(tok, perm, seed=case)
+        cfg = abi.make_config(window_size=n, unique_filter=unique)
         normals = synth.lsh_normals(n)
         results = []
         for on in ("1", "0"):
@@ -66,8 +78,8 @@ def main():
                             int(ix.info["path"])))
             ix.close()
         ok = results[0][:3] == results[1][:3]
-        print("case %3d n=%2d script=%5d works=%3d tokens=%7d rows=%6d inexact=%4d %s/%s %s"
-              % (case, n, n_script, n_works, len(tok), len(results[0][0]) // 32,
+        print("case %3d %s u%d n=%2d script=%5d works=%3d tokens=%7d rows=%6d inexact=%4d %s/%s %s"
+              % (case, "clustered" if clustered else "synthetic", unique, n, n_script, n_works, len(tok), len(results[0][0]) // 32,
                  int((np.frombuffer(results[0][0], dtype=abi.ROW_DTYPE)["dist"] > 1e-9).sum()),
                  results[0][3], results[1][3], "ok" if ok else "MISMATCH"), flush=True)
         bad += not ok
