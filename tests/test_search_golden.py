@@ -187,3 +187,77 @@ def test_hip_search_is_the_references_on_the_mixed_case(tmp_path, monkeypatch):
     search.write_records(recs, "got.csv")
     assert (tmp_path / "got.csv").read_bytes() == g["csv"].encode("utf-8")
     assert ann.windows_processed == g["windows_processed"]
+
+
+# ---- the driver: analyze (search.py:336-399) ------------------------------------------------
+
+class _CannedSearcher(object):
+    """Stands where AnnIndexSearch stands in search.analyze: the records the fixture's stand-in
+    returned per file name, as the numeric rows + fan words the product's searcher hands over."""
+
+    def __init__(self, script_words):
+        from fandom_search_amd import abi
+        from tests.golden.make_search_golden import canned_records
+        self._canned, self._abi, self._words = canned_records, abi, script_words
+        self.word_lowercase = tuple(script_words)
+        self.orth_id = tuple(vocab.hash_string(w) for w in script_words)
+        self.character = tuple("CHAR%d" % (o % 3) for o in range(len(script_words)))
+        self.scene = tuple(o // 4 for o in range(len(script_words)))
+
+    def search_rows(self, filenames):
+        rows, words = [], []
+        for w, f in enumerate(filenames):
+            for r in self._canned(f, self._words):
+                rows.append((w, r[1], r[4], r[10], r[9], r[11]))
+                words.append(r[2])
+        return np.array(rows, dtype=self._abi.ROW_DTYPE), words
+
+
+@pytest.mark.parametrize("label", [c["label"] for c in G["analyze"]["cases"]])
+def test_analyze_writes_what_the_references_driver_writes(tmp_path, monkeypatch, capsys, label):
+    """Listing, seeded shuffle, -s / -n window, clusters, batch files, the dated file and its
+    -k suffix, the printed lines: search.analyze against the reference's own analyze, which
+    make_search_golden.py ran around a stand-in index and pool (the listing order -- sorted --
+    and today's date are inputs there and here)."""
+    import base64 as b64
+    import datetime as real_datetime
+    import types
+    g = G["analyze"]
+    case = next(c for c in g["cases"] if c["label"] == label)
+    monkeypatch.chdir(tmp_path)
+    (tmp_path / "fan").mkdir()
+    for name in g["names"]:
+        (tmp_path / "fan" / name).write_text("x")
+    for name in case["pre_existing"]:
+        (tmp_path / name).write_text("old\n")
+    fixed = types.SimpleNamespace(date=types.SimpleNamespace(today=lambda: real_datetime.date(2020, 2, 29)))
+    monkeypatch.setattr(search, "datetime", fixed)
+    args = types.SimpleNamespace(fan_works="fan", script="script.txt", skip_works=case["skip_works"],
+                                 num_works=case["num_works"])
+    search.analyze(args, chunk_size=case["chunk_size"], searcher=_CannedSearcher(g["script_words"]))
+    assert capsys.readouterr().out == case["stdout"]
+    got = {f: (tmp_path / f).read_bytes() for f in sorted(os.listdir(tmp_path)) if (tmp_path / f).is_file()}
+    want = {f: b64.b64decode(v) for f, v in case["files"].items()}
+    assert sorted(got) == sorted(want)
+    for f in want:
+        assert got[f] == want[f], f
+    # (the reference's pool call, for the record: Pool(4, maxtasksperchild=10).map(..., chunksize = chunk_size // 16))
+    pools = [c for c in case["calls"] if "processes" in c]
+    assert all(c["processes"] == 4 and c["maxtasksperchild"] == 10 and c["chunksize"] == case["chunk_size"] // 16
+               for c in pools)
+
+
+# ---- the script parser: load_markup_script (search.py:290-329) ------------------------------
+
+@pytest.mark.parametrize("name", sorted(G["load_markup_script"]))
+def test_load_markup_script_rows_are_the_references(tmp_path, capsys, name):
+    """Regex precedence per text line, scene numbers (digits only), the permanent fall-back to
+    the running count after the first label without digits, the lines it prints: the rows the
+    reference's own parser made (around a whitespace splitter; the words of these scripts are
+    plain, so the rule tokenizer splits them the same way)."""
+    case = G["load_markup_script"][name]
+    p = tmp_path / "script.txt"
+    p.write_bytes(case["markup"].encode("utf-8"))
+    rows = search.load_markup_script(str(p))
+    assert capsys.readouterr().out == case["stdout"]
+    assert rows == case["rows"]
