@@ -49,6 +49,11 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
            "records": int(len(rows_out)), "inexact_records": int((np.abs(rows_out["dist"]) > 1e-9).sum()),
            "oov_share_of_tokens": float((tok_vec & abi.FS_OOV_FLAG != 0).mean())}
     sizes, used = ix.component_sizes()
+    if not len(sizes):
+        out["components"] = {"count": 0, "in_use": False,
+                             "note": "the graph of near pairs was not kept: more than 2^23 pairs of (script vector, "
+                                     "table vector) lie above the line a pair must be above to be near -- with norms "
+                                     "spread over a factor of ten the line is below cosine -1 for typical pairs"}
     if len(sizes):
         edges = [1, 2, 3, 5, 9, 17, 65, 257, 1025, 1 << 30]
         out["components"] = {"count": int(len(sizes)), "largest": int(sizes.max()), "in_use": used,
