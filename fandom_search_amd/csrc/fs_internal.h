@@ -248,7 +248,7 @@ struct fs_index {
   DBuf<uint32_t> d_skeys;    // [W][H] LSH keys of the script windows
   DBuf<uint32_t> d_emap, d_emapc;   // wildcard keys -> distinct script n-gram, over vector ids / component ids (build_emap)
   int log2_emap = 0, log2_emapc = 0;
-  DBuf<float> d_atab32, d_amax;
+  DBuf<float> d_atab32, d_amax, d_nt32, d_ntmax;
   DBuf<uint32_t> d_boff, d_bids;
   bool lsh_ready = false;
   double lsh_cmax = 1.0;     // sound bound on the cosine of two distinct table vectors

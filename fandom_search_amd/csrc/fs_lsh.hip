@@ -67,6 +67,9 @@ struct LshDev {
   const float* atab32;     // [n][V][Cp] float32 copy of atab (rows padded to Cp = 4*ceil(C/4)
                            // floats with zeros, 16-byte aligned), or nullptr
   const float* amax;       // [n][V] >= max_c |atab[k][v][c]|
+  const float* nt32;       // [n][D][Cp] float32 copy of nt (rows padded like atab32): the projection row of an
+                           // out-of-vocabulary vector is the sum of the rows of its (up to three) hot positions
+  const float* ntmax;      // [n][D] >= max_c |nt[k][d][c]|
   float bound_scale;       // n * 2^-22 (times a test factor)
   int m_min;               // fewer id-identical slots than this cannot reach the threshold
   int diag;                // diagnostics: 1 = skip candidate walk, 2 = skip key computation,
@@ -109,6 +112,36 @@ __device__ __forceinline__ double a_value(const LshDev& L, int k, uint32_t id, i
   if (b != a) acc = __dadd_rn(acc, nt[(size_t)b * L.C]);
   if (cc != b) acc = __dadd_rn(acc, nt[(size_t)cc * L.C]);
   return acc;
+}
+
+// Float32 projection row (four columns from `colc`) of slot k's vector: the table row, or for
+// an out-of-vocabulary id the sum of the rows of its distinct hot positions, in a_value's
+// order.  *m gets >= max_c |row| added, *terms the number of float32 addends behind the row
+// (1, or up to 3): what the decision bound of the float32 keys is made of.
+__device__ __forceinline__ float4 row32(const LshDev& L, int k, uint32_t id, int colc) {
+  if (!(id & FS_OOV_FLAG)) return *reinterpret_cast<const float4*>(L.atab32 + ((size_t)k * L.V + id) * L.Cp + colc);
+  uint32_t a, b, c;
+  oov_hot(id, L.D, &a, &b, &c);
+  const float* base = L.nt32 + (size_t)k * L.D * L.Cp + colc;
+  float4 r = *reinterpret_cast<const float4*>(base + (size_t)a * L.Cp);
+  if (b != a) {
+    const float4 t = *reinterpret_cast<const float4*>(base + (size_t)b * L.Cp);
+    r.x = __fadd_rn(r.x, t.x); r.y = __fadd_rn(r.y, t.y); r.z = __fadd_rn(r.z, t.z); r.w = __fadd_rn(r.w, t.w);
+  }
+  if (c != b) {
+    const float4 t = *reinterpret_cast<const float4*>(base + (size_t)c * L.Cp);
+    r.x = __fadd_rn(r.x, t.x); r.y = __fadd_rn(r.y, t.y); r.z = __fadd_rn(r.z, t.z); r.w = __fadd_rn(r.w, t.w);
+  }
+  return r;
+}
+__device__ __forceinline__ void row32_bound(const LshDev& L, int k, uint32_t id, float* m, int* terms) {
+  if (!(id & FS_OOV_FLAG)) { *m += L.amax[(size_t)k * L.V + id]; *terms += 1; return; }
+  uint32_t a, b, c;
+  oov_hot(id, L.D, &a, &b, &c);
+  const float* mx = L.ntmax + (size_t)k * L.D;
+  *m += mx[a]; *terms += 1;
+  if (b != a) { *m += mx[b]; *terms += 1; }
+  if (c != b) { *m += mx[c]; *terms += 1; }
 }
 
 __device__ __forceinline__ double q_of(const LshDev& L, uint32_t id) {
@@ -482,6 +515,24 @@ __global__ void k_nt(const double* __restrict__ normals, int n, int D, int C,
   }
 }
 
+// float32 copy of nt, rows padded to Cp, and the rows' largest magnitudes (rounded up)
+__global__ __launch_bounds__(256) void k_nt32(const double* __restrict__ nt, int rows, int C, int Cp,
+                                              float* __restrict__ nt32, float* __restrict__ ntmax) {
+  __shared__ float s_m[4];
+  const int r = blockIdx.x;
+  if (r >= rows) return;
+  float mx = 0.0f;
+  for (int c = threadIdx.x; c < Cp; c += blockDim.x) {
+    const double v = c < C ? nt[(size_t)r * C + c] : 0.0;
+    nt32[(size_t)r * Cp + c] = (float)v;
+    mx = fmaxf(mx, __double2float_ru(fabs(v)));
+  }
+  for (int d = 32; d > 0; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) ntmax[r] = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+}
+
 // A[k][v][c] = seqsum_d nt[k][d][c] * (double)E[v][d]; block = one (k, v)
 __global__ __launch_bounds__(256) void k_atab(const double* __restrict__ nt,
                                               const float* __restrict__ emb, uint32_t V, int D,
@@ -740,12 +791,18 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
       // per window: the float32 decision bound, or -1 when the window needs float64
       const int w = threadIdx.x;
       float m = 0.0f;
-      bool f64 = L.atab32 == nullptr;
+      int terms = 0;
+      const bool f64 = L.atab32 == nullptr || (L.diag & 64);       // (diag 64: float64 for OOV windows as before round 5)
+      bool oov = false;
       for (int k = 0; k < n; ++k) {
         const uint32_t id = s_tok[w + k];
-        if (id & FS_OOV_FLAG) f64 = true; else m += L.amax[(size_t)k * L.V + id];
+        oov = oov || (id & FS_OOV_FLAG);
+        if (!f64 || !(id & FS_OOV_FLAG)) row32_bound(L, k, id, &m, &terms);
       }
-      s_bound[w] = f64 ? -1.0f : L.bound_scale * m;
+      // (an out-of-vocabulary slot is up to three float32 addends instead of one: the bound's
+      // n becomes the number of addends)
+      s_bound[w] = (L.atab32 == nullptr || (f64 && oov)) ? -1.0f : L.bound_scale * m * ((float)terms / (float)n);
+      s_key[w] = oov ? 1u : 0u;                    // (phase 1 only: s_key is written behind it)
     }
     __syncthreads();
     // phase 1: a wave takes four windows at a time; lane l holds projection columns
@@ -774,19 +831,39 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
         bool redo[4] = {true, true, true, true};
         if (fast) {                                                  // wave-uniform
           float4 acc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            acc[u] = *reinterpret_cast<const float4*>(L.atab32 + (size_t)s_tok[w0 + u] * L.Cp + colc);
-          for (int k = 1; k < n; ++k) {
-            float4 r[4];
+          // (table rows only -- the common case -- with no branch between the loads; a group
+          // of four windows that holds an out-of-vocabulary token takes the rows through row32)
+          const bool plain = !(s_key[w0] | s_key[w0 + 1] | s_key[w0 + 2] | s_key[w0 + 3]);
+          if (plain) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              r[u] = *reinterpret_cast<const float4*>(
-                  L.atab32 + ((size_t)k * L.V + s_tok[w0 + u + k]) * L.Cp + colc);
+              acc[u] = *reinterpret_cast<const float4*>(L.atab32 + (size_t)s_tok[w0 + u] * L.Cp + colc);
+            for (int k = 1; k < n; ++k) {
+              float4 r[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              acc[u].x = __fadd_rn(acc[u].x, r[u].x); acc[u].y = __fadd_rn(acc[u].y, r[u].y);
-              acc[u].z = __fadd_rn(acc[u].z, r[u].z); acc[u].w = __fadd_rn(acc[u].w, r[u].w);
+              for (int u = 0; u < 4; ++u)
+                r[u] = *reinterpret_cast<const float4*>(
+                    L.atab32 + ((size_t)k * L.V + s_tok[w0 + u + k]) * L.Cp + colc);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                acc[u].x = __fadd_rn(acc[u].x, r[u].x); acc[u].y = __fadd_rn(acc[u].y, r[u].y);
+                acc[u].z = __fadd_rn(acc[u].z, r[u].z); acc[u].w = __fadd_rn(acc[u].w, r[u].w);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+              acc[u] = row32(L, 0, s_tok[w0 + u], colc);
+            for (int k = 1; k < n; ++k) {
+              float4 r[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                r[u] = row32(L, k, s_tok[w0 + u + k], colc);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                acc[u].x = __fadd_rn(acc[u].x, r[u].x); acc[u].y = __fadd_rn(acc[u].y, r[u].y);
+                acc[u].z = __fadd_rn(acc[u].z, r[u].z); acc[u].w = __fadd_rn(acc[u].w, r[u].w);
+              }
             }
           }
 #pragma unroll
@@ -1327,17 +1404,19 @@ __device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, c
   bool keys_done = false;
   if (L.atab32 && L.C <= 256 && !(L.diag & 8)) {
     float am = 0.0f;
+    int terms = 0;
     bool oov = false;
     if (lane < L.n) {
       const uint32_t id = S.f[lane];
-      oov = (id & FS_OOV_FLAG) != 0;
-      if (!oov) am = L.amax[(size_t)lane * L.V + id];
+      oov = (id & FS_OOV_FLAG) != 0 && (L.diag & 64);              // (diag 64: float64 for OOV windows as before round 5)
+      if (!oov) row32_bound(L, lane, id, &am, &terms);
     }
 #pragma unroll
-    for (int d = 8; d > 0; d >>= 1) am += __shfl_xor(am, d);      // n <= 16 lanes hold a value
+    for (int d = 8; d > 0; d >>= 1) { am += __shfl_xor(am, d); terms += __shfl_xor(terms, d); }   // n <= 16 lanes hold a value
     am = __shfl(am, 0);
+    terms = __shfl(terms, 0);
     if (!__any(oov)) {
-      const float bnd = L.bound_scale * am;
+      const float bnd = L.bound_scale * am * ((float)terms / (float)L.n);
       const int col = 4 * lane;
       const int left = L.C - col;
       const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
@@ -1349,8 +1428,7 @@ __device__ __forceinline__ int lsh_window(const CorpusDev& c, const LshDev& L, c
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k0 + k < L.n)
-            r[k] = *reinterpret_cast<const float4*>(
-                L.atab32 + ((size_t)(k0 + k) * L.V + S.f[k0 + k]) * L.Cp + colc);
+            r[k] = row32(L, k0 + k, S.f[k0 + k], colc);
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (k0 + k < L.n) {
@@ -1657,20 +1735,21 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
     for (int t = 0; t < kBatchW * FS_MAX_WINDOW / 64; ++t) {      // lane per (window, slot)
       const int w = (t * 64 + lane) / FS_MAX_WINDOW, k = (t * 64 + lane) % FS_MAX_WINDOW;
       float am = 0.0f;
+      int terms = 0;
       uint32_t oov = 0;
       if (k < N && S.ok[w]) {
         const uint32_t id = c.tok[(uint64_t)S.wbase[w] + k];
         S.f[w][k] = id;
         S.qf[w][k] = q_of(L, id);
-        oov = id & FS_OOV_FLAG;
-        if (!oov && L.atab32) am = L.amax[(size_t)k * L.V + id];
+        oov = (L.diag & 64) ? id & FS_OOV_FLAG : 0u;                // (diag 64: float64 for OOV windows as before round 5)
+        if (!oov && L.atab32) row32_bound(L, k, id, &am, &terms);
       }
       // sum / or over the window's FS_MAX_WINDOW lanes
       static_assert(FS_MAX_WINDOW == 16, "a window's slots are one row of sixteen lanes");
 #pragma unroll
-      for (int d = 8; d > 0; d >>= 1) { am += __shfl_xor(am, d); oov |= (uint32_t)__shfl_xor((int)oov, d); }
+      for (int d = 8; d > 0; d >>= 1) { am += __shfl_xor(am, d); terms += __shfl_xor(terms, d); oov |= (uint32_t)__shfl_xor((int)oov, d); }
       if (k == 0 && S.ok[w]) {
-        S.bnd[w] = L.bound_scale * am;
+        S.bnd[w] = L.bound_scale * am * ((float)terms / (float)N);
         if (oov || !L.atab32 || L.C > 256) S.ok[w] = 2u;
       }
     }
@@ -1717,7 +1796,7 @@ __global__ __launch_bounds__(256, 5) void k_lsh_batch(CorpusDev c, LshDev L, Gra
           if (go[u]) {
 #pragma unroll
             for (int k = 0; k < N; ++k)
-              r[u][k] = *reinterpret_cast<const float4*>(L.atab32 + ((size_t)k * L.V + S.f[w0 + u][k]) * L.Cp + colc);
+              r[u][k] = row32(L, k, S.f[w0 + u][k], colc);
           }
         }
 #pragma unroll
@@ -2397,6 +2476,7 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.spos = ix->d_spos.n > 1 ? ix->d_spos.p : nullptr;
   L.emap = nullptr; L.log2_emap = 0; L.emap_comp = 0; L.skeys = ix->d_skeys.n > 1 ? ix->d_skeys.p : nullptr;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
+  L.nt32 = ix->d_nt32.p; L.ntmax = ix->d_ntmax.p;
   L.wild = nullptr; L.log2_wild = 0; L.wild_tok = nullptr; L.selflev = nullptr; L.wmap = nullptr; L.log2_wmap = 0;
   L.V = (uint32_t)ix->n_vec; L.W = (uint32_t)ix->n_windows;
   L.n = (int)ix->cfg.window_size; L.H = (int)ix->cfg.number_of_hashes;
@@ -2691,6 +2771,9 @@ int fs_lsh_build(fs_index* ix) {
   FS_TRY(ix->d_ss.reserve(W));
   FS_TRY(ix->d_sw.reserve(W));
   hipLaunchKernelGGL(k_nt, dim3(1024), dim3(256), 0, s, ix->d_normals.p, n, D, C, ix->d_nt.p);
+  FS_TRY(ix->d_nt32.reserve((size_t)n * D * Cp + 4));
+  FS_TRY(ix->d_ntmax.reserve((size_t)n * D + 1));
+  hipLaunchKernelGGL(k_nt32, dim3((uint32_t)(n * D)), dim3(256), 0, s, ix->d_nt.p, n * D, C, Cp, ix->d_nt32.p, ix->d_ntmax.p);
   if (V)
     hipLaunchKernelGGL(k_atab, dim3((uint32_t)V, n), dim3(256), 0, s, ix->d_nt.p, ix->d_emb.p,
                        (uint32_t)V, D, C, Cp, ix->d_atab.p, ix->d_atab32.p, ix->d_amax.p);

@@ -323,8 +323,8 @@ def test_oov_corpus_on_an_exact_index(synth_base):
     assert st2.path == abi.FS_MODE_EXACT and len(got2) >= len(got)
 
 
-@pytest.mark.parametrize("env", [{}, {"FS_LSH_F32_SLACK": "2e5"}, {"FS_LSH_F32": "0"}],
-                         ids=["f32-sign-path", "forced-f64-fallbacks", "f64-only"])
+@pytest.mark.parametrize("env", [{}, {"FS_LSH_F32_SLACK": "2e5"}, {"FS_LSH_F32": "0"}, {"FS_LSH_DIAG": "64"}],
+                         ids=["f32-sign-path", "forced-f64-fallbacks", "f64-only", "f64-for-oov-windows"])
 def test_lsh_key_paths_agree(synth_base, env, monkeypatch):
     """The float32 sign fast path of the LSH keys (with its float64 fallback for
     windows inside the error bound) must give the canonical float64 keys: same rows
@@ -337,9 +337,16 @@ def test_lsh_key_paths_agree(synth_base, env, monkeypatch):
     tok, off = util.ragged_corpus([900] * 10 + [0, 7, 2000], script)
     tok = tok.copy()
     tok[11::131] = abi.FS_OOV_FLAG | ((3 * 300 + 4) * 300 + 250)      # windows with an OOV token
+    # (round 5: an OOV slot's float32 projection row is the sum of its hot positions' rows --
+    # also with two or three of them coinciding, and with two OOV tokens in one window)
+    tok[40::173] = abi.FS_OOV_FLAG | ((5 * 300 + 5) * 300 + 9)
+    tok[41::173] = abi.FS_OOV_FLAG | ((7 * 300 + 7) * 300 + 7)
     strings = list(words) + ["Oov"]
     tok_str = np.where(tok & abi.FS_OOV_FLAG, len(words), tok).astype(np.uint32)
     chars, coff = pack_strings(strings)
+    tok[int(off[3]) + 100:int(off[3]) + 120] = script[500:520]       # a quote with an OOV token inside: records across it
+    tok[int(off[3]) + 107] = abi.FS_OOV_FLAG | ((1 * 300 + 2) * 300 + 3)
+    tok_str = np.where(tok & abi.FS_OOV_FLAG, len(words), tok).astype(np.uint32)
     cfg = abi.make_config(window_size=8)
     _run(cfg, script, [words[int(t)] for t in script], emb, synth.lsh_normals(8), tok, off,
          chars, coff, tok_str=tok_str)
