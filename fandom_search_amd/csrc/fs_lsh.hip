@@ -936,6 +936,11 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
       if (w == 255) s_pref[256 * L.H] = total;
       __syncthreads();
       const uint32_t n_b = 256u * (uint32_t)L.H;
+      // (round 5 measured this loop two and four pairs at a time, level by level -- bucket entry,
+      // the window's record, the first slot's pair-table entry, window_distance's first early exit
+      // on those: 2.58 and 3.96 ms per search against 2.41 on the realistic table, where the loop
+      // is 58 % of the search.  It is not the latency of one thread's chain that bounds it but
+      // the number of 64-byte sectors: three random ones per pair, 134 M pairs per 2 M windows)
       for (uint32_t j = threadIdx.x; j < total; j += 256) {
         uint32_t lo = 0, hi = n_b;               // s_pref[lo] <= j < s_pref[hi]
         while (hi - lo > 1) {
