@@ -940,7 +940,11 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
       // the window's record, the first slot's pair-table entry, window_distance's first early exit
       // on those: 2.58 and 3.96 ms per search against 2.41 on the realistic table, where the loop
       // is 58 % of the search.  It is not the latency of one thread's chain that bounds it but
-      // the number of 64-byte sectors: three random ones per pair, 134 M pairs per 2 M windows)
+      // the number of random sectors: 134 M pairs per 2 M windows, each with a pair-table entry
+      // out of a table far larger than the caches.  The window's record is not one of them: with
+      // the records carried in the bucket entries (32 B, in bucket order) the kernel took 5.87 ms
+      // against 5.86 ms on 4 M windows.  By switches (FS_LSH_DIAG 1, 3) on those 4 M windows:
+      // keys 1.4 ms, the walk without distances 0.7 ms, the distances 2.5 ms)
       for (uint32_t j = threadIdx.x; j < total; j += 256) {
         uint32_t lo = 0, hi = n_b;               // s_pref[lo] <= j < s_pref[hi]
         while (hi - lo > 1) {

@@ -48,6 +48,13 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
            "candidates": int(st.candidates), "lsh_pending": int(st.lsh_pending),
            "records": int(len(rows_out)), "inexact_records": int((np.abs(rows_out["dist"]) > 1e-9).sum()),
            "oov_share_of_tokens": float((tok_vec & abi.FS_OOV_FLAG != 0).mean())}
+    import torch
+    cap = len(rows_out) + 64
+    buf = torch.zeros(cap * 32, dtype=torch.uint8, device="cuda")
+    prof = None
+    for _ in range(3):
+        prof = ix.profile(c, buf.data_ptr(), cap)
+    out["kernels_us"] = [[k, round(ms * 1e3, 1)] for k, ms in prof]
     sizes, used = ix.component_sizes()
     if not len(sizes):
         out["components"] = {"count": 0, "in_use": False,
