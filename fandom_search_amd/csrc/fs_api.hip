@@ -104,6 +104,8 @@ void fs_read_switches(fs_switches* sw) {
   sw->diag = num("FS_DIAG");
   if (const char* e = getenv("FS_LSH_GRAMTAB")) sw->lsh_gramtab = atoi(e) != 0;
   if (const char* e = getenv("FS_LSH_SYN")) sw->lsh_syn = atoi(e) != 0;
+  if (getenv("FS_LSH_SHARE")) sw->lsh_share = num("FS_LSH_SHARE");
+  if (const char* e = getenv("FS_SHARE_GAMMA")) sw->share_gamma = atof(e);
   if (const char* e = getenv("FS_LSH_KEYS6")) sw->lsh_keys6 = atoi(e) != 0;
   if (const char* e = getenv("FS_LSH_WMAP")) sw->lsh_wmap = atoi(e) != 0;
   if (const char* e = getenv("FS_WAIT_SPINS")) sw->wait_spins = atoi(e);
@@ -544,13 +546,24 @@ extern "C" int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uin
   return FS_OK;
 }
 
+extern "C" int fs_index_share_info(const fs_index* ix, uint32_t* flags, uint32_t* components, uint32_t* largest,
+                                   double* gamma) {
+  if (!ix) return FS_E_INVALID;
+  if (flags) *flags = (uint32_t)ix->share_flags;
+  if (components) *components = ix->share_comps;
+  if (largest) *largest = ix->share_largest;
+  if (gamma) *gamma = ix->share_gamma;
+  return FS_OK;
+}
+
 extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   static thread_local char name[64];
   if (!ix || !c || c->ix != ix) return "";
   const int n = (int)ix->cfg.window_size;
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   if (!exact) {
-    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? "k_lsh_scan" : fs_near_fused(ix, c) ? "k_near_sift<%d>" :
+    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? ((ix->share_flags & 32) ? "k_share_enum<%d>" : "k_lsh_scan") :
+                                fs_near_fused(ix, c) ? "k_near_sift<%d>" :
                                 fs_scan_near8(ix) ? "k_scan_near8<%d>" : "k_scan_near<%d>", n);
   } else if (uint32_t blocks = 0; fs_scan_rows_shape(ix, c, &blocks)) {
     const int k = ix->sw.scan_sub && ix->d_sfilter.p ? fs_sub_k(n) : 0;

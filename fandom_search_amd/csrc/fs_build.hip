@@ -102,12 +102,14 @@ __global__ __launch_bounds__(256) void k_cmax(const float* __restrict__ emb,
 
 // Pairs (script vector u, table vector v) that are *near*: cos(u, v) > 1 - coef / (|u| |v|), with
 // coef = n * thr * a_max^2 / 2 (fs_lsh.hip, component ids): same tiling as k_cmax, the pairs
-// appended to a list (float32 cosines, 1e-4 of slack towards more pairs).
+// appended to a list (float32 cosines, 1e-4 of slack towards more pairs).  With gamma > -1.5 the
+// relation is angular instead: cos(u, v) > gamma, and a vector of norm 0 is near nothing (the
+// share rule of fs_lsh.hip, where a far slot's dot product is bounded by gamma |u| |v|: 0 for it).
 __global__ __launch_bounds__(256) void k_near_pairs(const float* __restrict__ emb,
                                                     const float* __restrict__ embT, uint32_t n_vec,
                                                     int D, const double* __restrict__ q,
                                                     const uint32_t* __restrict__ rows_u, uint32_t n_u,
-                                                    float coef, uint2* __restrict__ pairs, uint32_t cap,
+                                                    float coef, float gamma, uint2* __restrict__ pairs, uint32_t cap,
                                                     uint32_t* __restrict__ count) {
   extern __shared__ float s_u[];   // [kCmaxU][D], unit-normalised
   __shared__ float s_nu[kCmaxU];
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(256) void k_near_pairs(const float* __restrict__ em
     if (ui >= n_u || rows_u[ui] == v) continue;
     const float nn = s_nu[i] * nv;
     // (a vector of norm 0 is near everything: its slot adds nothing to a window's cosine)
-    const bool near = !(nn > 0.0f) || acc[i] > 1.0f - coef / nn - 1e-4f;
+    const bool near = gamma > -1.5f ? (nn > 0.0f && acc[i] > gamma - 1e-4f)
+                                    : (!(nn > 0.0f) || acc[i] > 1.0f - coef / nn - 1e-4f);
     if (near) {
       const uint32_t at = atomicAdd(count, 1u);
       if (at < cap) pairs[at] = make_uint2(rows_u[ui], v);
@@ -150,10 +153,33 @@ __global__ __launch_bounds__(256) void k_near_pairs(const float* __restrict__ em
   }
 }
 
+// max over the script's vectors u of max_d |u[d]| / |u| (the share rule of fs_lsh.hip: the cosine of a
+// vector with at most three non-zero coordinates, all 1, to u is at most sqrt(3) times that)
+__global__ void k_coordmax(const float* __restrict__ emb, int D, const double* __restrict__ q,
+                           const uint32_t* __restrict__ rows_u, uint32_t n_u, int* __restrict__ out_bits) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_u) return;
+  const uint32_t row = rows_u[i];
+  const double qq = q[row];
+  if (!(qq > 0.0)) return;
+  float m = 0.0f;
+  for (int d = 0; d < D; ++d) m = fmaxf(m, fabsf(emb[(size_t)row * D + d]));
+  const float r = (float)((double)m / sqrt(qq)) * (1.0f + 1e-6f);
+  atomicMax(out_bits, __float_as_int(r));
+}
+
 }  // namespace
 
+int fs_launch_coordmax(const float* emb, int D, const uint32_t* rows_u, uint32_t n_u, const double* q,
+                       int* d_out_bits, hipStream_t s) {
+  if (!n_u) return FS_OK;
+  hipLaunchKernelGGL(k_coordmax, dim3((n_u + 255) / 256), dim3(256), 0, s, emb, D, q, rows_u, n_u, d_out_bits);
+  FS_HIP(hipGetLastError());
+  return FS_OK;
+}
+
 int fs_launch_near_pairs(const float* emb, uint64_t n_vec, int D, const uint32_t* rows_u, uint32_t n_u,
-                         const double* q, float* embT_scratch, float coef, uint2* pairs, uint32_t cap,
+                         const double* q, float* embT_scratch, float coef, float gamma, uint2* pairs, uint32_t cap,
                          uint32_t* count, hipStream_t s) {
   if (!n_vec || !n_u) return FS_OK;
   hipLaunchKernelGGL(k_transpose, dim3((uint32_t)((n_vec + 255) / 256)), dim3(256), 0, s, emb,
@@ -163,7 +189,7 @@ int fs_launch_near_pairs(const float* emb, uint64_t n_vec, int D, const uint32_t
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   dim3 grid((uint32_t)((n_vec + 255) / 256), (n_u + kCmaxU - 1) / kCmaxU);
   hipLaunchKernelGGL(k_near_pairs, grid, dim3(256), lds, s, emb, embT_scratch, (uint32_t)n_vec, D, q,
-                     rows_u, n_u, coef, pairs, cap, count);
+                     rows_u, n_u, coef, gamma, pairs, cap, count);
   FS_HIP(hipGetLastError());
   return FS_OK;
 }

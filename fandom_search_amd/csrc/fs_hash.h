@@ -168,3 +168,17 @@ FS_HD uint32_t fs_wild_fbit(uint32_t h, int i) { return (h >> (8 * i)) & 31u; } 
 // script n-gram and slot, a full bucket spills into the next): the script windows that equal a
 // fan window in all slots but one can be enumerated, not just shown to be possible.
 FS_HD uint32_t fs_wmap_slot(uint32_t h, int log2_slots) { return (h * 0x9E3779B1u) >> (32 - log2_slots); }
+
+// Subset keys of the share rule (fs_lsh.hip, "windows on tables that are not unit length"): a key
+// names the slots of a subset (`mask`) and the component ids the window holds there -- the fold of
+// the subset's terms, mixed with the mask.  A blocked Bloom filter (one 32-bit word, three bits:
+// fs_bloom_word / fs_bloom_test) holds the keys of every script window.
+FS_HD uint32_t fs_share_term(uint32_t comp, int k) { return fs_rotl(fs_premix(comp), fs_rot_of(k)); }
+FS_HD uint32_t fs_share_key(uint32_t fold, uint32_t mask) {
+  uint32_t h = fold + 0x9E3779B9u * mask;
+  h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+  return h;
+}
+// ... and the few bits of a component id the pairs' test compares: n of them in a 64-bit word
+FS_HD int fs_share_sig_bits(int n) { return 64 / n > 10 ? 10 : 64 / n; }
+FS_HD uint32_t fs_share_sig(uint32_t comp, int n) { return (fs_mix24(comp) >> 7) & ((1u << fs_share_sig_bits(n)) - 1u); }

@@ -196,6 +196,8 @@ struct fs_switches {
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
   bool lsh_keys6 = true;          // FS_LSH_KEYS6=0: n = 6 over component ids without the middle-slot key filter in k_scan_near
   bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
+  int lsh_share = 35;             // FS_LSH_SHARE: the share rule in k_lsh_scan on tables no integer prefilter applies to; bit 0 the windows' gate, bit 1 the pairs' test, bit 2 the gate asks for every heavy subset (the script's filter holds its heavy subsets only), bit 3 out-of-vocabulary fan tokens count as possibly near, bit 5 the script windows behind the gate's keys are enumerated (k_share_enum) instead of the key scan behind the gate; 0: off.  Read when the index is built
+  double share_gamma = 0.7;       // FS_SHARE_GAMMA: cosine above which two vectors are near in the share rule
   bool lsh_emap = true;           // FS_LSH_EMAP=0: k_lsh_batch walks the buckets of every pending window instead of enumerating the script n-grams one slot away
   bool lsh_batch = true;          // FS_LSH_BATCH=0: the pending windows a wave each (k_lsh_verify) instead of eight per wave level by level (k_lsh_batch)
   int lsh_defer_min = 8192;       // FS_LSH_DEFER_MIN: pending windows of the lane's last search from which on the kept matches' Levenshtein distances go to k_lsh_lev (and the windows to k_lsh_batch)
@@ -264,6 +266,16 @@ struct fs_index {
   // over *component ids* -- connected components of "near" pairs of table vectors, at most one
   // slot of a neighbour within the threshold joins two components (fs_lsh.hip)
   DBuf<uint32_t> d_comp;     // [V] component id of a table vector
+  DBuf<uint32_t> d_compa;    // [V] component id of a table vector under the angular relation of the share rule
+  DBuf<uint64_t> d_ssig;     // [W] the script windows' component signatures (fs_share_sig)
+  DBuf<uint32_t> d_sharef;   // the script windows' subset keys (fs_hash.h), a blocked Bloom filter
+  int log2_sharef = 0;
+  DBuf<uint32_t> d_smap;     // ... as an exact map (k_share_enum): 2^log2_smap buckets of four {key, list + 1}
+  DBuf<uint32_t> d_slists;   // a key's script windows behind their number (the map names the first of them)
+  int log2_smap = 0;
+  int share_flags = 0;       // 0: the share rule is not in use; else sw.lsh_share's bits (bit 3 also set when the table does not prove out-of-vocabulary tokens far)
+  double share_gamma = 0.0;
+  uint32_t share_comps = 0, share_largest = 0;
   DBuf<uint32_t> d_sfilter3c, d_wildc, d_keys6c;   // (d_keys6c: n = 6, the wildcard keys of slots 2 and 3)
   int log2_wildc = 0;
   bool syn_ok = false;
@@ -278,7 +290,7 @@ struct fs_index {
   // everything that is not a search.
   struct Lane {
     hipStream_t stream = nullptr;
-    DBuf<uint64_t> w_qbm, w_bsum64, w_hv;
+    DBuf<uint64_t> w_qbm, w_bsum64, w_hv, w_gate;   // (w_gate: the share rule's gate bits, k_share_gate)
     DBuf<uint32_t> w_qcnt, w_cpos, w_cg, w_cw, w_mlev, w_bsum, w_pend;
     DBuf<uint32_t> w_mcnt, w_mtop_s;   // k_lsh_verify -> k_lsh_lev: kept matches per pending window
     DBuf<uint32_t> w_pkeys, w_pwork, w_left;   // k_lsh_pkeys -> k_lsh_enum: keys and work per pending window; what is left to k_lsh_batch
@@ -426,8 +438,10 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
 int fs_launch_selflev(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_lsh_gramtab(fs_index* ix, fs_corpus* c, hipStream_t s);
 int fs_launch_near_pairs(const float* emb, uint64_t n_vec, int D, const uint32_t* rows_u, uint32_t n_u,
-                         const double* q, float* embT_scratch, float coef, uint2* pairs, uint32_t cap,
-                         uint32_t* count, hipStream_t s);
+                         const double* q, float* embT_scratch, float coef, float gamma, uint2* pairs, uint32_t cap,
+                         uint32_t* count, hipStream_t s);      // gamma > -1.5: the angular relation cos > gamma
+int fs_launch_coordmax(const float* emb, int D, const uint32_t* rows_u, uint32_t n_u, const double* q,
+                       int* d_out_bits, hipStream_t s);
 int fs_launch_comp_map(fs_index* ix, fs_corpus* c, hipStream_t s);      // component ids of a batch's tokens
 int fs_lsh_prefilter_mode(const fs_index* ix, const fs_corpus* c);
 int fs_scan_near_k(int n);                                               // K of k_scan_near's K-gram tests      // 0 none, 1 vector ids, 2 component ids

@@ -45,6 +45,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <mutex>
@@ -90,6 +91,18 @@ struct LshDev {
                            // component ids of the batch's tokens (tables with near-synonyms)
   const uint2* wmap;       // the same keys as an exact map: 2^log2_wmap buckets of four {key, script window + 1}, or nullptr
   int log2_wmap;
+  // the share rule (fs_build_share): component ids under the angular relation of the table's vectors and
+  // of the script's tokens, the script windows' subset keys, and its constants
+  const uint32_t* compa;   // [V], or nullptr: the rule is not in use
+  const uint64_t* ssig;    // [W] the script windows' component signatures (share_pair_possible)
+  const uint32_t* sharef;  // 2^log2_sharef filter words
+  const uint2* smap;       // the same keys as an exact map: 2^log2_smap buckets of four {key, list + 1} (k_share_enum)
+  const uint32_t* slists;  // the lists of the map: a list's length, then its script windows (the map names the first of those)
+  int log2_smap;
+  int log2_sharef, share_flags;
+  float share_lim;         // <= 1 - phi: the share of a window's squared norm its near slots must hold
+  double share_scale;      // squared norms as integers: floor(q * share_scale) <= 2^20
+  double share_phi, share_tau, share_gamma;
   uint32_t V, W;
   int n, H, B, D, C, Cp, nn, unique;
   double thr, cmax;
@@ -762,9 +775,307 @@ __global__ __launch_bounds__(256) void k_bucket_sort_big(uint32_t W, uint32_t nb
   }
 }
 
+// ---- the share rule ----------------------------------------------------------------
+//
+// For tables whose vectors are not unit length none of the integer prefilters applies ("at most
+// one slot may differ" is false there: a window's squared norm may sit in a few slots, and the
+// others may then hold anything).  What holds for any norms: call two vectors *near* when their
+// cosine exceeds gamma (components of that relation over the table: compa; a vector of norm 0 is
+// near nothing), let D be the slots of a window pair (F, S) whose vectors lie in different
+// components, and A, B the shares of |F|^2 and |S|^2 those slots hold.  Then, slot by slot
+// dot(f_k, s_k) <= |f_k||s_k| and <= gamma |f_k||s_k| on D, and by Cauchy-Schwarz on either group
+//   cos(F, S) <= sqrt((1 - A)(1 - B)) + gamma sqrt(A B)  <=  sqrt(1 - A (1 - gamma^2)),
+// so a pair within the threshold (cos > tau = 1 - thr - 1e-6) has A < phi and B < phi,
+// phi = (1 - tau^2) / (1 - gamma^2): the slots that agree in their components hold more than
+// 1 - phi of either window's squared norm.  Two sound skips come of it, both in k_lsh_scan:
+//   * the gate, per fan window: the subsets M of slots that are *heavy* (hold that share of the
+//     fan window) and minimal (no slot can go) are asked for in a filter that holds, for every
+//     script window, the key (slots, component ids there) of every subset of its slots.  The set
+//     of agreeing slots of a pair within the threshold is heavy, so it contains a minimal heavy
+//     subset, and that one's key is in the filter: a window none of whose keys is there has no
+//     script window within the threshold, needs no LSH keys and walks no bucket.  (FS_LSH_SHARE
+//     bit 2: the filter holds the script windows' own heavy subsets only and every heavy subset
+//     of the fan window is asked for -- the agreeing set is heavy on both sides.)  Squared norms
+//     are integers here (floor(q * share_scale)), so "heavy" is one exact comparison however the
+//     subset is summed, with the slack of the rounding on the permissive side.
+//   * the test, per (fan window, bucket member): A from the fan side alone (LDS), then B and the
+//     two-sided bound, in front of window_distance and its pair-table entries.
+// An out-of-vocabulary fan token (at most three coordinates, all 1) is far from every script
+// vector when sqrt(3) max_d |u_d| / |u| <= gamma for all of them (checked at index build);
+// otherwise (share_flags bit 3) its slot counts as agreeing with anything.  Scripts with
+// out-of-vocabulary tokens do not use the rule.
+// The keys a fan window asks for (its minimal heavy subsets; all heavy ones under share_flags bit 2),
+// into list[j * 256]: their number, or -1 when the window is not constrained (the rule says nothing
+// about it, or the list is too short for its keys).
+template <int N>
+__device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, const double* qd,
+                                          uint32_t* list, int cap) {
+  uint32_t qi[N], t[N];
+  uint32_t all = 0, base = 0, usable = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    qi[k] = (uint32_t)(qd[k] * L.share_scale);
+    all += qi[k];
+    const uint32_t c = cmp[k];
+    t[k] = 0;
+    if (c == FS_NONE) base += (L.share_flags & 8) ? qi[k] + 1 : 0u;
+    else { usable |= 1u << k; t[k] = fs_share_term(c, k); }
+  }
+  // heavy(M): sum_M qi >= thr.  (With x = q * scale real and qi = floor(x): a truly heavy M has
+  // sum_M x >= lim sum x - sum_O x, so sum_M qi > lim * all - base - N.)
+  const int thr = (int)floorf(L.share_lim * (float)all) - (int)base - N - 2;
+  if (thr <= 0) return -1;
+  const bool every = (L.share_flags & 4) != 0;
+  int cnt = 0;
+#pragma unroll
+  for (uint32_t m = 1; m < (1u << N); ++m) {
+    uint32_t sum = 0, mn = 0xFFFFFFFFu, fold = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      if ((m >> k) & 1u) { sum += qi[k]; mn = qi[k] < mn ? qi[k] : mn; fold ^= t[k]; }
+    const bool ask = (m & ~usable) == 0u && (int)sum >= thr && (every || (int)(sum - mn) < thr);
+    if (ask) {
+      if (cnt < cap) list[cnt * 256] = fs_share_key(fold, m);
+      ++cnt;
+    }
+  }
+  return cnt > cap ? -1 : cnt;
+}
+
+template <int N>
+__device__ __forceinline__ bool share_gate(const LshDev& L, const uint32_t* cmp, const double* qd,
+                                           uint32_t* list, int cap) {
+  const int cnt = share_asks<N>(L, cmp, qd, list, cap);
+  if (cnt < 0) return true;
+  bool hit = false;
+  for (int j = 0; j < cnt && !hit; j += 4) {
+    uint32_t h[4], wd[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? list[(j + u) * 256] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) hit = hit || (j + u < cnt && fs_bloom_test(wd[u], h[u]));
+  }
+  return hit;
+}
+
+// The pairs' test: false when script window s cannot be within the threshold of the fan window whose
+// slots' component signatures and squared norms are sg[] / qd[] (sum ff).  A signature is a few bits
+// of a hash of the component id (fs_share_sig; FS_NONE: an out-of-vocabulary token), the script
+// window's n of them are one 64-bit word: slots whose signatures differ lie in different components,
+// slots whose signatures agree count as agreeing.
+__device__ __forceinline__ bool share_pair_possible(const LshDev& L, uint32_t s, const uint32_t* sg,
+                                                    const double* qd, double ff) {
+  const uint64_t ssig = L.ssig[s];
+  const int b = fs_share_sig_bits(L.n);
+  double af = 0.0;
+  uint32_t dm = 0;
+  for (int k = 0; k < L.n; ++k) {
+    const uint32_t c = sg[k];
+    const bool far = c == FS_NONE ? !(L.share_flags & 8) : c != (uint32_t)((ssig >> (k * b)) & ((1u << b) - 1u));
+    if (far) { af = af + qd[k]; dm |= 1u << k; }
+  }
+  if (!(ff > 0.0) || dm == 0u) return true;
+  const double A = fmin(af / ff, 1.0);
+  if (A >= L.share_phi * (1.0 + 1e-9)) return false;
+  double bs = 0.0;
+  for (int k = 0; k < L.n; ++k)
+    if ((dm >> k) & 1u) bs = bs + L.spos[s + k].q;
+  const double ss = L.ss[s];
+  if (!(ss > 0.0)) return true;
+  const double B = fmin(bs / ss, 1.0);
+  return sqrt((1.0 - A) * (1.0 - B)) + L.share_gamma * sqrt(A * B) > L.share_tau;
+}
+
 // ---- search kernels ------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
+// The share rule's gate for every window of a token stream: bit w of gbm = window w may have a
+// script window within the threshold.  A thread per window, 256 to a workgroup as k_lsh_scan's
+// sub-tiles (which read the bits).  A kernel of its own: inside k_lsh_scan its 63 subsets cost a
+// wave slot per SIMD (154 registers against 103).
+constexpr int kGateCap = 32;
+template <int N>
+__global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint64_t* __restrict__ gbm, uint32_t n_sub) {
+  __shared__ uint32_t s_tok[256 + 16], s_cmp[256 + 16];
+  __shared__ double s_qd[256 + 16];
+  __shared__ uint32_t s_keys[kGateCap * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
+    const uint64_t p0 = (uint64_t)sub * 256;
+    for (int i = threadIdx.x; i < 256 + N - 1; i += 256) {
+      const uint32_t id = c.tok[p0 + i];
+      s_tok[i] = id;
+      s_cmp[i] = (id & FS_OOV_FLAG) ? FS_NONE : L.compa[id];
+      s_qd[i] = q_of(L, id);
+    }
+    __syncthreads();
+    bool pass = p0 + threadIdx.x + N <= c.n_tok;
+    if (pass) pass = share_gate<N>(L, s_cmp + threadIdx.x, s_qd + threadIdx.x, s_keys + threadIdx.x, kGateCap);
+    if (L.diag == 4) pass = false;                 // diagnostics: k_lsh_scan's cost with no window to work on
+    const uint64_t b = __ballot(pass);
+    if (lane == 0) gbm[(size_t)sub * 4 + wave] = b;
+    __syncthreads();
+  }
+}
+
+// The share rule instead of the key scan: for the windows through the gate, the script windows that
+// hold one of the window's keys, one by one -- the subset keys as an exact map (smap: buckets of four
+// {key, list}, a full bucket spills into the next; slists: a key's script windows behind their
+// number) -- through the pairs' test and, what is left, the canonical distance.  A pair within
+// the threshold agrees on a heavy set of slots, that set contains one of the fan window's minimal
+// heavy subsets, and the script window is in that key's list: every script window within the
+// threshold is met, whatever buckets it shares with the fan window.  The windows flagged here are
+// therefore a superset of k_lsh_scan's (it flags those with a script window within the threshold
+// in a shared bucket); the kernels behind it make a window's neighbour list from its buckets and
+// drop a window whose list is empty, as behind the other prefilters.  A window the rule does not
+// constrain is flagged as it is.
+constexpr int kShareChunk = 1024;    // windows per workgroup pass: four of the gate's sub-tiles
+constexpr int kEnumCap = 20;         // keys per window (six slots have at most 20 minimal heavy subsets)
+constexpr int kEnumWork = 512;       // (window, key with script windows) entries per round of 256 windows
+template <int N>
+__global__ __launch_bounds__(256) void k_share_enum(CorpusDev c, LshDev L, const uint64_t* __restrict__ gbm,
+                                                    uint64_t* __restrict__ qbm, uint32_t* __restrict__ qcnt,
+                                                    uint32_t n_sub) {
+  __shared__ uint16_t s_pos[kShareChunk];
+  __shared__ uint32_t s_f[256 * N], s_cm[256 * N];
+  __shared__ double s_q[256 * N], s_ff[256];
+  __shared__ uint32_t s_keys[kEnumCap * 256];      // phase A; phase B/C: the entries' offsets (s_wpref)
+  __shared__ uint32_t s_wstart[kEnumWork], s_wmeta[kEnumWork];
+  __shared__ uint8_t s_found[256];
+  __shared__ uint32_t s_w[4], s_nwork;
+  uint32_t* s_wpref = s_keys;                      // [kEnumWork + 1]
+  static_assert(kEnumWork + 1 <= kEnumCap * 256 && kEnumWork == 2 * 256, "the offsets take the keys' place; two entries per thread in phase B");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t n_chunks = (n_sub + 3) / 4;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    uint32_t total = 0;
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t sub = chunk * 4 + j;
+      const bool pass = sub < n_sub && ((gbm[(size_t)sub * 4 + wave] >> lane) & 1ull);
+      const uint64_t b = __ballot(pass);
+      if (lane == 0) s_w[wave] = __popcll(b);
+      __syncthreads();
+      uint32_t before = total;
+      for (int i = 0; i < wave; ++i) before += s_w[i];
+      if (pass) s_pos[before + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)(j * 256 + threadIdx.x);
+      total += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+      __syncthreads();
+    }
+    uint32_t* f = s_f + threadIdx.x * N;
+    uint32_t* cm = s_cm + threadIdx.x * N;
+    double* qd = s_q + threadIdx.x * N;
+    for (uint32_t r0 = 0; r0 < total; r0 += 256) {
+      // phase A, a thread per window: its keys, the filter, the map -- the lists to walk as entries
+      const uint32_t i = r0 + threadIdx.x;
+      const bool active = i < total;
+      const uint64_t p = (uint64_t)chunk * kShareChunk + (active ? s_pos[i] : 0);
+      if (threadIdx.x == 0) s_nwork = 0;
+      s_found[threadIdx.x] = 0;
+      __syncthreads();
+      if (active) {
+        double ff = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+          const uint32_t id = c.tok[p + k];
+          f[k] = id;
+          cm[k] = (id & FS_OOV_FLAG) ? FS_NONE : L.compa[id];
+          qd[k] = q_of(L, id);
+          ff = __dadd_rn(ff, qd[k]);
+        }
+        s_ff[threadIdx.x] = ff;
+        uint32_t* list = s_keys + threadIdx.x;
+        const int cnt = share_asks<N>(L, cm, qd, list, kEnumCap);
+        bool found = cnt < 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) cm[k] = cm[k] == FS_NONE ? FS_NONE : fs_share_sig(cm[k], N);
+        const uint32_t bmask = (1u << L.log2_smap) - 1u;
+        for (int j = 0; j < cnt && !found; j += 4) {
+          uint32_t h[4], wd[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? list[(j + u) * 256] : 0u;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
+          for (int u = 0; u < 4 && !found; ++u) {
+            if (!(j + u < cnt && fs_bloom_test(wd[u], h[u])) || L.diag == 6) continue;                  // (diagnostics 6: no lists)
+            uint32_t bkt = fs_wmap_slot(h[u], L.log2_smap);
+            for (int probe = 0;; ++probe) {
+              if (probe == 64) { found = true; break; }          // (never seen: the window goes on as it is)
+              const uint4* bp = reinterpret_cast<const uint4*>(L.smap + 4 * (size_t)bkt);
+              const uint4 a = bp[0], b = bp[1];
+              const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
+              for (int e = 0; e < 4; ++e) {
+                if (!val[e] || key[e] != h[u]) continue;
+                const uint32_t len = L.slists[val[e] - 1];       // a list: its length, then its script windows
+                const uint32_t at = atomicAdd(&s_nwork, 1u);
+                if (at < (uint32_t)kEnumWork && len < (1u << 24)) {
+                  s_wstart[at] = val[e];
+                  s_wmeta[at] = (uint32_t)threadIdx.x << 24 | len;
+                } else {
+                  found = true;                                   // (no room: the window goes on as it is)
+                }
+              }
+              if (!val[3]) break;                                 // (not full: nothing has spilt past it)
+              bkt = (bkt + 1) & bmask;
+            }
+          }
+        }
+        if (found) s_found[threadIdx.x] = 1;
+      }
+      __syncthreads();
+      // phase B: the entries' offsets among the round's (window, script window) pairs
+      const uint32_t n_work = s_nwork < (uint32_t)kEnumWork ? s_nwork : (uint32_t)kEnumWork;
+      uint32_t mine[2], sum = 0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t e = threadIdx.x * 2 + u;
+        mine[u] = e < n_work ? s_wmeta[e] & 0xFFFFFFu : 0u;
+        sum += mine[u];
+      }
+      uint32_t pairs;
+      uint32_t base = block_excl_scan(sum, s_w, &pairs);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t e = threadIdx.x * 2 + u;
+        if (e < n_work) s_wpref[e] = base;
+        base += mine[u];
+      }
+      if (threadIdx.x == 0) s_wpref[n_work] = pairs;
+      __syncthreads();
+      // phase C: the pairs dealt out evenly, pair j to thread j mod 256
+      for (uint32_t j = threadIdx.x; j < pairs && L.diag != 5; j += 256) {                       // (diagnostics 5: no pairs)
+        uint32_t lo = 0, hi = n_work;                             // s_wpref[lo] <= j < s_wpref[hi]
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (s_wpref[mid] <= j) lo = mid; else hi = mid;
+        }
+        const uint32_t t = s_wmeta[lo] >> 24;
+        if (s_found[t]) continue;                                 // the window has its answer already
+        const uint32_t sw = L.slists[s_wstart[lo] + (j - s_wpref[lo])];
+        const double pff = s_ff[t];
+        double d;
+        if (share_pair_possible(L, sw, s_cm + t * N, s_q + t * N, pff) && L.diag != 7 &&                // (diagnostics 7: no distances)
+            window_distance(L, sw, s_f + t * N, nullptr, pff, __dsqrt_rn(pff), &d) && d < L.thr)
+          s_found[t] = 1;
+      }
+      __syncthreads();
+      if (active && s_found[threadIdx.x]) {
+        // (k_lsh_scan's bitmap: window w of a sub-tile is bit w / 4 of the sub-tile's word w mod 4)
+        const uint32_t w = (uint32_t)(p & 255);
+        atomicOr(reinterpret_cast<unsigned long long*>(qbm) + (p >> 8) * 4 + (w & 3), 1ull << (w >> 2));
+        atomicAdd(qcnt + (p >> 8), 1u);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// 64-bit words of k_lsh_scan's first LDS array: the ballot words of 256 windows in phase 1; in phase 2
+// s_ff, s_flag and behind them (384 words in) the share rule's per-token arrays
+__host__ __device__ inline int lsh_scan_bal_words(int NW) { return 256 * NW > 800 ? 256 * NW : 800; }
+__host__ __device__ inline int lsh_scan_pref_words(int H) { return 256 * H + 1 > 512 ? 256 * H + 1 : 512; }
+
+__global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L, const uint64_t* __restrict__ gbm,
                                                   uint64_t* __restrict__ qbm,
                                                   uint32_t* __restrict__ qcnt, uint32_t n_sub) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
@@ -773,14 +1084,21 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
   // ballot words are dead once the keys are assembled and then hold the phase-2 arrays
   // s_ff and s_flag; s_bound, phase 1 only, lies where phase 2 keeps its pair offsets.)
   uint64_t* s_bal = reinterpret_cast<uint64_t*>(s_raw);                 // [256][NW]
-  const int bal_words = 256 * NW > 384 ? 256 * NW : 384;                // (room for s_ff + s_flag)
+  const int bal_words = lsh_scan_bal_words(NW);                         // (room for s_ff + s_flag + the share rule's arrays)
   uint32_t* s_key = reinterpret_cast<uint32_t*>(s_bal + bal_words);     // [256][H]
   uint32_t* s_tok = s_key + 256 * L.H;                                  // [256 + 16]
   uint32_t* s_pref = s_tok + 256 + 16;                                  // [256 * H + 1] pair offsets
   double* s_ff = reinterpret_cast<double*>(s_bal);                      // [256]  (phase 2)
   uint32_t* s_flag = reinterpret_cast<uint32_t*>(s_bal + 256);          // [256]  (phase 2)
   float* s_bound = reinterpret_cast<float*>(s_pref);                    // [256]  (phase 1)
+  uint32_t* s_list = s_pref + 256;                                      // [256]  the windows phase 1 makes keys for
+  // the share rule's test of the pairs: component id and squared norm per token of the sub-tile
+  uint32_t* s_cmp2 = reinterpret_cast<uint32_t*>(s_bal + 384);          // [256 + 16]  (phase 2)
+  double* s_qd2 = reinterpret_cast<double*>(s_cmp2 + 272);              // [256 + 16]  (phase 2)
+  const bool pair_test = (L.share_flags & 2) != 0;
   __shared__ uint32_t s_cnt[4];
+  __shared__ uint64_t s_gate[4];
+  __shared__ uint32_t s_nlist;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int n = L.n;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
@@ -788,8 +1106,23 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
     for (int i = threadIdx.x; i < 256 + n - 1; i += 256) s_tok[i] = c.tok[p0 + i];
     __syncthreads();
     {
+      // the windows that need keys at all: those inside the token stream -- and, under the share
+      // rule, through its gate
+      bool pass = p0 + threadIdx.x + n <= c.n_tok;
+      if (gbm) pass = pass && ((gbm[(size_t)sub * 4 + wave] >> lane) & 1ull);
+      const uint64_t b = __ballot(pass);
+      if (lane == 0) s_gate[wave] = b;
+      __syncthreads();
+      uint32_t before = 0;
+      for (int j = 0; j < wave; ++j) before += __popcll(s_gate[j]);
+      if (pass) s_list[before + __popcll(b & ((1ull << lane) - 1ull))] = threadIdx.x;
+      if (threadIdx.x == 255) s_nlist = before + __popcll(b);
+    }
+    __syncthreads();
+    const int n_list = __builtin_amdgcn_readfirstlane((int)s_nlist);
+    if ((int)threadIdx.x < n_list) {
       // per window: the float32 decision bound, or -1 when the window needs float64
-      const int w = threadIdx.x;
+      const int w = (int)s_list[threadIdx.x];
       float m = 0.0f;
       int terms = 0;
       const bool f64 = L.atab32 == nullptr || (L.diag & 64);       // (diag 64: float64 for OOV windows as before round 5)
@@ -821,29 +1154,33 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
       const uint32_t cmask = left >= 4 ? 0xFu : left > 0 ? (1u << left) - 1 : 0u;
       const int colc = left > 0 ? col : 0;
       const bool store = (lane & 7) == 0 && (c0 >> 5) + (lane >> 3) < 2 * NW;
-      for (int i = 0; i < 64; i += 4) {
-        const int w0 = wave * 64 + i;
+      for (int g = wave; 4 * g < n_list; g += 4) {
+        // (four windows of the list at a time; the last group repeats the list's last window)
+        int wl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          wl[u] = __builtin_amdgcn_readfirstlane((int)s_list[4 * g + u < n_list ? 4 * g + u : n_list - 1]);
         float bnd[4];
         bool fast = true;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { bnd[u] = s_bound[w0 + u]; fast = fast && bnd[u] >= 0.0f; }
+        for (int u = 0; u < 4; ++u) { bnd[u] = s_bound[wl[u]]; fast = fast && bnd[u] >= 0.0f; }
         uint32_t nib[4];
         bool redo[4] = {true, true, true, true};
         if (fast) {                                                  // wave-uniform
           float4 acc[4];
           // (table rows only -- the common case -- with no branch between the loads; a group
           // of four windows that holds an out-of-vocabulary token takes the rows through row32)
-          const bool plain = !(s_key[w0] | s_key[w0 + 1] | s_key[w0 + 2] | s_key[w0 + 3]);
+          const bool plain = !(s_key[wl[0]] | s_key[wl[1]] | s_key[wl[2]] | s_key[wl[3]]);
           if (plain) {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              acc[u] = *reinterpret_cast<const float4*>(L.atab32 + (size_t)s_tok[w0 + u] * L.Cp + colc);
+              acc[u] = *reinterpret_cast<const float4*>(L.atab32 + (size_t)s_tok[wl[u]] * L.Cp + colc);
             for (int k = 1; k < n; ++k) {
               float4 r[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u)
                 r[u] = *reinterpret_cast<const float4*>(
-                    L.atab32 + ((size_t)k * L.V + s_tok[w0 + u + k]) * L.Cp + colc);
+                    L.atab32 + ((size_t)k * L.V + s_tok[wl[u] + k]) * L.Cp + colc);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 acc[u].x = __fadd_rn(acc[u].x, r[u].x); acc[u].y = __fadd_rn(acc[u].y, r[u].y);
@@ -853,12 +1190,12 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
           } else {
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              acc[u] = row32(L, 0, s_tok[w0 + u], colc);
+              acc[u] = row32(L, 0, s_tok[wl[u]], colc);
             for (int k = 1; k < n; ++k) {
               float4 r[4];
 #pragma unroll
               for (int u = 0; u < 4; ++u)
-                r[u] = row32(L, k, s_tok[w0 + u + k], colc);
+                r[u] = row32(L, k, s_tok[wl[u] + k], colc);
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 acc[u].x = __fadd_rn(acc[u].x, r[u].x); acc[u].y = __fadd_rn(acc[u].y, r[u].y);
@@ -881,9 +1218,9 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
             uint32_t bits = 0;
             for (int j = 0; j < 4; ++j) {
               if (!((cmask >> j) & 1u)) continue;
-              double acc = a_value(L, 0, s_tok[w0 + u], col + j);
+              double acc = a_value(L, 0, s_tok[wl[u]], col + j);
               for (int k = 1; k < n; ++k)
-                acc = __dadd_rn(acc, a_value(L, k, s_tok[w0 + u + k], col + j));
+                acc = __dadd_rn(acc, a_value(L, k, s_tok[wl[u] + k], col + j));
               bits |= acc > 0.0 ? 1u << j : 0u;
             }
             nib[u] = bits;
@@ -893,14 +1230,14 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
           x |= (uint32_t)__shfl_down((int)x, 1) << 4;
           x |= (uint32_t)__shfl_down((int)x, 2) << 8;
           x |= (uint32_t)__shfl_down((int)x, 4) << 16;
-          if (store) s_bits[(size_t)(w0 + u) * 2 * NW + (c0 >> 5) + (lane >> 3)] = x;
+          if (store) s_bits[(size_t)wl[u] * 2 * NW + (c0 >> 5) + (lane >> 3)] = x;
         }
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 256 * L.H; i += 256) {
-      const int w = i / L.H, h = i - w * L.H;
-      s_key[i] = assemble_key(s_bal + w * NW, h, L.B);
+    for (int i = threadIdx.x; i < n_list * L.H; i += 256) {
+      const int li = i / L.H, h = i - li * L.H, w = (int)s_list[li];
+      s_key[w * L.H + h] = assemble_key(s_bal + w * NW, h, L.B);
     }
     __syncthreads();
     // phase 2: "is any bucket candidate of the window within the threshold?"  The 256 x H
@@ -912,7 +1249,13 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
     // the threshold sets its window's flag.
     {
       const int w = threadIdx.x;
-      const bool valid = p0 + w + n <= c.n_tok && L.diag != 1;
+      const bool valid = ((s_gate[w >> 6] >> (w & 63)) & 1ull) && L.diag != 1;
+      if (pair_test)
+        for (int i = threadIdx.x; i < 256 + n - 1; i += 256) {
+          const uint32_t id = s_tok[i];
+          s_cmp2[i] = (id & FS_OOV_FLAG) ? FS_NONE : fs_share_sig(L.compa[id], n);
+          s_qd2[i] = q_of(L, id);
+        }
       const uint32_t nb1 = (1u << L.B) + 1;
       uint32_t sum = 0;
       for (int h = 0; h < L.H; ++h) {
@@ -956,6 +1299,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L,
         const uint32_t sidx = L.bids[(size_t)ph * L.W + s_key[lo] + (j - s_pref[lo])];
         if (L.diag == 3) continue;               // diagnostics: bucket walk only
         const double pff = s_ff[pw];
+        if (pair_test && !share_pair_possible(L, sidx, s_cmp2 + pw, s_qd2 + pw, pff)) continue;
         double d;
         if (window_distance(L, sidx, s_tok + pw, nullptr, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_flag[pw] = 1;
       }
@@ -2483,6 +2827,18 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.spos = ix->d_spos.n > 1 ? ix->d_spos.p : nullptr;
+  L.compa = nullptr; L.ssig = nullptr; L.sharef = nullptr; L.smap = nullptr; L.slists = nullptr; L.log2_smap = 0; L.log2_sharef = 0; L.share_flags = 0;
+  L.share_lim = 0.0f; L.share_scale = 0.0; L.share_phi = 1.0; L.share_tau = 0.0; L.share_gamma = 1.0;
+  if (ix->share_flags) {
+    L.compa = ix->d_compa.p; L.ssig = ix->d_ssig.p; L.sharef = ix->d_sharef.p;
+    L.log2_sharef = ix->log2_sharef; L.share_flags = ix->share_flags;
+    L.smap = reinterpret_cast<const uint2*>(ix->d_smap.p); L.slists = ix->d_slists.p; L.log2_smap = ix->log2_smap;
+    L.share_gamma = ix->share_gamma;
+    L.share_tau = 1.0 - ix->cfg.distance_threshold - 1e-6;
+    L.share_phi = (1.0 - L.share_tau * L.share_tau) / (1.0 - L.share_gamma * L.share_gamma);
+    L.share_lim = (float)((1.0 - L.share_phi) * (1.0 - 1e-6));
+    L.share_scale = ldexp(1.0, 20) / std::max(ix->info.norm_max * ix->info.norm_max * (1.0 + 1e-9), 3.0);
+  }
   L.emap = nullptr; L.log2_emap = 0; L.emap_comp = 0; L.skeys = ix->d_skeys.n > 1 ? ix->d_skeys.p : nullptr;
   L.atab32 = ix->d_atab32.n > 1 ? ix->d_atab32.p : nullptr; L.amax = ix->d_amax.p;
   L.nt32 = ix->d_nt32.p; L.ntmax = ix->d_ntmax.p;
@@ -2626,7 +2982,7 @@ static int fs_build_components(fs_index* ix) {
   FS_HIP(hipMemsetAsync(d_cnt.p, 0, sizeof(uint32_t), ix->stream));
   const double T = ix->cfg.distance_threshold * n * ix->info.norm_max * ix->info.norm_max * (1.0 + 1e-6);
   FS_TRY(fs_launch_near_pairs(ix->d_emb.p, V, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p, embT.p,
-                              (float)(T / 2.0), d_pairs.p, cap, d_cnt.p, ix->stream));
+                              (float)(T / 2.0), -2.0f, d_pairs.p, cap, d_cnt.p, ix->stream));
   uint32_t n_pairs = 0;
   FS_HIP(hipMemcpyAsync(&n_pairs, d_cnt.p, sizeof n_pairs, hipMemcpyDeviceToHost, ix->stream));
   FS_HIP(hipStreamSynchronize(ix->stream));
@@ -2693,6 +3049,172 @@ static int fs_build_components(fs_index* ix) {
   }
   FS_HIP(hipStreamSynchronize(ix->stream));
   ix->syn_ok = true;
+  return FS_OK;
+}
+
+// The share rule's index side (k_lsh_scan, "the share rule" above): the components of the angular
+// relation cos > gamma over (script vector, table vector) pairs, the proof that out-of-vocabulary
+// fan tokens are far from every script vector, and the filter of the script windows' subset keys.
+static int fs_build_share(fs_index* ix) {
+  ix->share_flags = 0;
+  const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
+  const uint64_t V = ix->n_vec, W = ix->n_windows;
+  const double gamma = ix->sw.share_gamma;
+  const double tau = 1.0 - ix->cfg.distance_threshold - 1e-6;
+  if (!(ix->sw.lsh_share & 3) || ix->script_oov || !W || !V || V > FS_MAX_EXACT_ID || n < 2 ||
+      !(ix->info.norm_max > 0.0) || !(gamma >= 0.05 && gamma <= 0.995) || !(tau > gamma + 1e-3))
+    return FS_OK;
+  hipStream_t s = ix->stream;
+  std::vector<uint32_t> st(ix->n_script);
+  FS_HIP(hipMemcpyAsync(st.data(), ix->d_stok.p, ix->n_script * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  std::vector<uint32_t> rows_u;
+  {
+    std::vector<uint8_t> seen(V, 0);
+    for (uint32_t id : st)
+      if (!seen[id]) { seen[id] = 1; rows_u.push_back(id); }
+  }
+  const uint32_t cap = 1u << 23;
+  DBuf<float> embT;
+  DBuf<uint32_t> d_rows_u, d_cnt;
+  DBuf<uint2> d_pairs;
+  FS_TRY(embT.reserve((size_t)V * D));
+  FS_TRY(d_rows_u.upload(rows_u.data(), rows_u.size(), s));
+  FS_TRY(d_cnt.reserve(2));
+  FS_TRY(d_pairs.reserve(cap));
+  FS_HIP(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(uint32_t), s));
+  FS_TRY(fs_launch_near_pairs(ix->d_emb.p, V, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p, embT.p, 0.0f,
+                              (float)gamma, d_pairs.p, cap, d_cnt.p, s));
+  FS_TRY(fs_launch_coordmax(ix->d_emb.p, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p,
+                            reinterpret_cast<int*>(d_cnt.p + 1), s));
+  uint32_t res[2] = {0, 0};
+  FS_HIP(hipMemcpyAsync(res, d_cnt.p, sizeof res, hipMemcpyDeviceToHost, s));
+  FS_HIP(hipStreamSynchronize(s));
+  const uint32_t n_pairs = res[0];
+  if (n_pairs > cap) return FS_OK;                 // (far too many near pairs: nothing to filter with)
+  float kappa;
+  memcpy(&kappa, &res[1], sizeof kappa);
+  const bool oov_far = sqrt(3.0) * (double)kappa * (1.0 + 1e-6) <= gamma - 1e-4;
+  std::vector<uint2> pairs(n_pairs);
+  if (n_pairs) FS_HIP(hipMemcpy(pairs.data(), d_pairs.p, (size_t)n_pairs * sizeof(uint2), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> parent(V);
+  for (uint64_t v = 0; v < V; ++v) parent[v] = (uint32_t)v;
+  auto find = [&](uint32_t v) {
+    while (parent[v] != v) { parent[v] = parent[parent[v]]; v = parent[v]; }
+    return v;
+  };
+  for (const uint2& e : pairs) {
+    const uint32_t a = find(e.x), b = find(e.y);
+    if (a != b) parent[a > b ? a : b] = a > b ? b : a;
+  }
+  std::vector<uint32_t> comp(V), size;
+  {
+    std::vector<uint32_t> id_of(V, FS_NONE);
+    for (uint64_t v = 0; v < V; ++v) {
+      const uint32_t r = find((uint32_t)v);
+      if (id_of[r] == FS_NONE) { id_of[r] = (uint32_t)size.size(); size.push_back(0); }
+      comp[v] = id_of[r];
+      ++size[comp[v]];
+    }
+  }
+  ix->share_comps = (uint32_t)size.size();
+  ix->share_largest = *std::max_element(size.begin(), size.end());
+  int flags = ix->sw.lsh_share & 47;
+  if (!oov_far) flags |= 8;
+  if (flags & 8) flags &= ~4;                      // (a slot that agrees with anything has no share on the script's side)
+  if (n > 6) flags &= ~1;
+  if ((flags & 35) != 35 || W * (((uint64_t)1 << n) - 1) > ((uint64_t)1 << 25)) flags &= ~32;   // (the enumeration needs the gate and the pairs' test)
+  if (flags & 32) flags &= ~4;                     // (... and every subset of every script window in the filter)
+  if (!(flags & 3)) return FS_OK;
+  FS_TRY(ix->d_compa.upload(comp.data(), comp.size(), s));
+  std::vector<uint32_t> sc(st.size() + FS_MAX_WINDOW, FS_NONE);
+  for (size_t i = 0; i < st.size(); ++i) sc[i] = comp[st[i]];
+  {
+    std::vector<uint64_t> sig(W, 0);
+    const int b = fs_share_sig_bits(n);
+    for (uint64_t w = 0; w < W; ++w)
+      for (int k = 0; k < n; ++k) sig[w] |= (uint64_t)fs_share_sig(sc[w + k], n) << (k * b);
+    FS_TRY(ix->d_ssig.upload(sig.data(), sig.size(), s));
+  }
+  if (flags & 1) {
+    std::vector<double> q(V);
+    FS_HIP(hipMemcpyAsync(q.data(), ix->d_q.p, V * sizeof(double), hipMemcpyDeviceToHost, s));
+    FS_HIP(hipStreamSynchronize(s));
+    const uint32_t n_masks = (1u << n) - 1;
+    const uint64_t keys = W * (uint64_t)n_masks / ((flags & 4) ? 3 : 1);
+    int lw = 10;
+    while (lw < 26 && ((uint64_t)1 << lw) * 4 < keys * 3) ++lw;    // about 24 filter bits per key and more
+    std::vector<uint32_t> f((size_t)1 << lw, 0u);
+    const double phi = (1.0 - tau * tau) / (1.0 - gamma * gamma);
+    for (uint64_t w = 0; w < W; ++w) {
+      uint32_t t[6];
+      double qs[6], all = 0.0;
+      for (int k = 0; k < n; ++k) {
+        t[k] = fs_share_term(sc[w + k], k);
+        qs[k] = q[st[w + k]];
+        all += qs[k];
+      }
+      const double need = (1.0 - phi) * all * (1.0 - 1e-6);
+      for (uint32_t m = 1; m <= n_masks; ++m) {
+        uint32_t fold = 0;
+        double sum = 0.0;
+        for (int k = 0; k < n; ++k)
+          if ((m >> k) & 1u) { fold ^= t[k]; sum += qs[k]; }
+        if ((flags & 4) && sum < need) continue;     // (only the subsets that hold the share on this side too)
+        const uint32_t h = fs_share_key(fold, m);
+        f[fs_bloom_word(h, lw)] |= fs_bloom_mask(h);
+      }
+    }
+    FS_TRY(ix->d_sharef.upload(f.data(), f.size(), s));
+    ix->log2_sharef = lw;
+    if (flags & 32) {
+      // the same keys as an exact map: key -> its script windows
+      std::vector<uint64_t> ent;
+      ent.reserve(W * n_masks);
+      for (uint64_t w = 0; w < W; ++w) {
+        uint32_t t[6];
+        for (int k = 0; k < n; ++k) t[k] = fs_share_term(sc[w + k], k);
+        for (uint32_t m = 1; m <= n_masks; ++m) {
+          uint32_t fold = 0;
+          for (int k = 0; k < n; ++k)
+            if ((m >> k) & 1u) fold ^= t[k];
+          ent.push_back((uint64_t)fs_share_key(fold, m) << 32 | w);
+        }
+      }
+      std::sort(ent.begin(), ent.end());
+      uint64_t distinct = 0;
+      for (size_t i = 0; i < ent.size(); ++i) distinct += i == 0 || (ent[i] >> 32) != (ent[i - 1] >> 32);
+      int lm = 8;                                  // two buckets per key: a full one (four entries) is rare
+      while (lm < 26 && ((uint64_t)1 << lm) < 2 * distinct) ++lm;
+      std::vector<uint32_t> smap((size_t)8 << lm, 0u), lists;
+      lists.reserve(ent.size() + distinct + 1);
+      lists.push_back(0);                          // (a list is named by the index of its first script window: never 0)
+      const uint32_t bmask = (1u << lm) - 1;
+      for (size_t i = 0; i < ent.size();) {
+        const uint32_t h = (uint32_t)(ent[i] >> 32);
+        size_t e1 = i;
+        while (e1 < ent.size() && (uint32_t)(ent[e1] >> 32) == h) ++e1;
+        lists.push_back((uint32_t)(e1 - i));       // its length, then its script windows
+        const uint32_t first = (uint32_t)lists.size();
+        for (size_t x = i; x < e1; ++x) lists.push_back((uint32_t)ent[x]);
+        uint32_t bkt = fs_wmap_slot(h, lm);
+        for (;;) {
+          uint32_t* e = smap.data() + 8 * (size_t)bkt;
+          int at = 0;
+          while (at < 4 && e[2 * at + 1]) ++at;
+          if (at < 4) { e[2 * at] = h; e[2 * at + 1] = first; break; }
+          bkt = (bkt + 1) & bmask;
+        }
+        i = e1;
+      }
+      FS_TRY(ix->d_smap.upload(smap.data(), smap.size(), s));
+      FS_TRY(ix->d_slists.upload(lists.data(), lists.size(), s));
+      ix->log2_smap = lm;
+    }
+  }
+  FS_HIP(hipStreamSynchronize(s));
+  ix->share_gamma = gamma;
+  ix->share_flags = flags | 16;                    // (bit 4: in use, whatever else is set)
   return FS_OK;
 }
 
@@ -2767,6 +3289,10 @@ int fs_lsh_build(fs_index* ix) {
     FS_HIP(hipStreamSynchronize(ix->stream));
   }
   if ((int)ix->cfg.window_size - ix->lsh_m_min > 1) FS_TRY(fs_build_components(ix));
+  // (where neither integer prefilter applies the search is k_lsh_scan: the share rule is for it)
+  if (((int)ix->cfg.window_size - ix->lsh_m_min > 1 || ix->script_oov || ix->cfg.window_size < 4 ||
+       ix->n_vec > FS_MAX_EXACT_ID) && !ix->syn_ok)
+    FS_TRY(fs_build_share(ix));
   if (!ix->d_normals.p) { fs_set_error("normals are required for the LSH pipeline"); return FS_E_INVALID; }
   hipStream_t s = ix->stream;
   const int n = (int)ix->cfg.window_size, D = (int)ix->cfg.emb_dim;
@@ -2866,13 +3392,46 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   if (!n_sub) return FS_OK;
   const LshDev L = lsh_dev(ix);
   const int NW = (L.C + 63) >> 6;
-  const size_t lds = std::max<size_t>((size_t)256 * NW, 384) * 8 + (size_t)256 * L.H * 4 +
-                     (256 + 16) * 4 + ((size_t)256 * L.H + 2) * 4;
+  const size_t lds = (size_t)lsh_scan_bal_words(NW) * 8 + (size_t)256 * L.H * 4 + (256 + 16) * 4 +
+                     ((size_t)lsh_scan_pref_words(L.H) + 1) * 4;
   FS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lsh_scan),
                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 64)));
   const uint32_t blocks = std::min<uint32_t>(n_sub, ix->num_cu * per_cu);
-  hipExtLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), (uint32_t)lds, s, e0, e1, 0u, c, L, qbm,
+  const uint64_t* gbm = nullptr;
+  if ((L.share_flags & 1) && L.n >= 2 && L.n <= 6) {
+    // the share rule's gate first: the windows that need keys at all
+    FS_TRY(ix->cur->w_gate.reserve((size_t)n_sub * 4));
+    const uint32_t gblocks = std::min<uint32_t>(n_sub, ix->num_cu * 4);
+    uint64_t* g = ix->cur->w_gate.p;
+    switch (L.n) {
+      case 2: hipExtLaunchKernelGGL(k_share_gate<2>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+      case 3: hipExtLaunchKernelGGL(k_share_gate<3>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+      case 4: hipExtLaunchKernelGGL(k_share_gate<4>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+      case 5: hipExtLaunchKernelGGL(k_share_gate<5>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+      default: hipExtLaunchKernelGGL(k_share_gate<6>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+    }
+    FS_HIP(hipGetLastError());
+    if (ix->prof.on) fs_prof_mark(ix, s, "k_share_gate");
+    e0 = nullptr;
+    gbm = g;
+    if (L.share_flags & 32) {
+      // ... and the script windows behind the gate's keys instead of the key scan
+      FS_HIP(hipMemsetAsync(qbm, 0, (size_t)n_sub * 4 * sizeof(uint64_t), s));
+      FS_HIP(hipMemsetAsync(qcnt, 0, (size_t)n_sub * sizeof(uint32_t), s));
+      const uint32_t eblocks = std::min<uint32_t>((n_sub + 3) / 4, ix->num_cu * 8);
+      switch (L.n) {
+        case 2: hipExtLaunchKernelGGL(k_share_enum<2>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
+        case 3: hipExtLaunchKernelGGL(k_share_enum<3>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
+        case 4: hipExtLaunchKernelGGL(k_share_enum<4>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
+        case 5: hipExtLaunchKernelGGL(k_share_enum<5>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
+        default: hipExtLaunchKernelGGL(k_share_enum<6>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
+      }
+      FS_HIP(hipGetLastError());
+      return FS_OK;
+    }
+  }
+  hipExtLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), (uint32_t)lds, s, e0, e1, 0u, c, L, gbm, qbm,
                         qcnt, n_sub);
   FS_HIP(hipGetLastError());
   return FS_OK;

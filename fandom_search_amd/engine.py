@@ -262,6 +262,14 @@ class ScriptIndex(object):
                                                   C.byref(used)), "fs_index_component_sizes")
         return sizes, bool(used.value)
 
+    def share_info(self):
+        """Diagnostics: the share rule of the LSH pipeline on this index (fs_index_share_info):
+        {"flags", "components", "largest", "gamma"}; flags 0 = not in use."""
+        f, n, m, g = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_double()
+        _lib.check(_lib.load().fs_index_share_info(self._h, C.byref(f), C.byref(n), C.byref(m), C.byref(g)),
+                   "fs_index_share_info")
+        return {"flags": f.value, "components": n.value, "largest": m.value, "gamma": g.value}
+
     def profile(self, corpus, rows_ptr, cap):
         """Diagnostics: one search of `corpus` (records to the device buffer at `rows_ptr`)
         with a HIP event behind each of its kernels; returns [(kernel name, ms), ...] in

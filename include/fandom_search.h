@@ -292,6 +292,14 @@ int fs_textenc_encode_files(fs_textenc* enc, const char* paths /* n_files string
 int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uint64_t cap, uint64_t* n,
                              uint32_t* in_use);
 
+/* Diagnostics: the share rule of the LSH pipeline (tables whose vectors are not unit length, where
+ * neither integer prefilter applies).  *flags = 0: not in use; else bit 0 the
+ * windows' gate, bit 1 the pairs' test, bit 2 the gate over heavy subsets of both sides, bit 3
+ * out-of-vocabulary fan tokens count as possibly near, bit 4 set.  *components / *largest: the
+ * components of the relation "cosine > *gamma" over the table. */
+int fs_index_share_info(const fs_index* ix, uint32_t* flags, uint32_t* components, uint32_t* largest,
+                        double* gamma);
+
 /* Diagnostics: one synchronous search of `c` (arguments as fs_search_corpus) with a HIP event
  * behind every kernel of it.  names: the kernels' names in launch order, '\n'-separated;
  * ms[i]: time from the previous mark to the one behind kernel i (its duration when nothing else

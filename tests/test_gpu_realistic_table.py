@@ -26,7 +26,7 @@ def real():
 
 @pytest.mark.parametrize("oov", [True, False])
 @pytest.mark.parametrize("unique", [0, 1])
-def test_realistic_table_equals_oracle(real, oov, unique):
+def test_realistic_table_equals_oracle(real, oov, unique, monkeypatch):
     from oracle import c_oracle
     from fandom_search_amd.engine import ScriptIndex
     emb, group, strings, vid, script = real
@@ -53,8 +53,8 @@ def test_realistic_table_equals_oracle(real, oov, unique):
     got, st = ix.search(c)
     again, _ = ix.search(c)
     assert st.path == abi.FS_MODE_GENERAL and got.tobytes() == again.tobytes()
-    if oov:
-        assert ix.kernel_name(c) == "k_lsh_scan"          # out-of-vocabulary ids: no integer prefilter
+    # neither integer prefilter applies (norms from 1.8 to 18): the share rule in front of the LSH work
+    assert ix.kernel_name(c) == "k_share_enum<6>" and ix.share_info()["flags"] & 32
     sch, so = pack_strings(swords)
     oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
     want, ost = oi.search(tok_vec, off, chars, coff, tok_str=tok_str)
@@ -63,3 +63,16 @@ def test_realistic_table_equals_oracle(real, oov, unique):
     assert int((got["dist"] > 1e-3).sum()) > 0            # near-synonym matches are records
     oi.close()
     ix.close()
+    # the share rule's other forms, and none: the same bytes.  0: the key scan over every window;
+    # 3: the gate and the pairs' test inside the key scan; 1, 2: either by itself; 7: the gate over
+    # the subsets that are heavy on both sides; 43, 11: out-of-vocabulary fan tokens as possibly
+    # near anything (what an index does whose table does not prove them far)
+    for share, kernel in (("0", "k_lsh_scan"), ("3", "k_lsh_scan"), ("1", "k_lsh_scan"), ("2", "k_lsh_scan"),
+                          ("7", "k_lsh_scan"), ("43", "k_share_enum<6>"), ("11", "k_lsh_scan")):
+        monkeypatch.setenv("FS_LSH_SHARE", share)
+        ix2 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+        c2 = ix2.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+        got2, st2 = ix2.search(c2)
+        assert ix2.kernel_name(c2) == kernel
+        assert got2.tobytes() == got.tobytes() and st2.matches == st.matches, share
+        ix2.close()

@@ -77,11 +77,21 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     util.assert_rows_equal(got, want)
     assert st.matches == ost.matches
     assert int((got["dist"] > 0.001).sum()) > 0                        # approximate matches are records
-    # the unfiltered LSH pipeline (keys and buckets for every window): the same bytes
+    # the unfiltered LSH pipeline (keys and buckets for every window): the same bytes; and with the
+    # share rule in front of it, which the index takes where the component prefilter is not there
+    # (window sizes up to six: the windows' gate and the script windows behind its keys; above,
+    # the test of the pairs inside the key scan)
     monkeypatch.setenv("FS_LSH_SYN", "0")
-    ix2, c2, got2, st2 = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
-    assert ix2.kernel_name(c2) == "k_lsh_scan"
-    assert got.tobytes() == got2.tobytes() and st.matches == st2.matches
+    for share, kernel in (("0", "k_lsh_scan"), (None, "k_share_enum<6>" if n <= 6 else "k_lsh_scan"),
+                          ("3", "k_lsh_scan")):
+        if share is not None:
+            monkeypatch.setenv("FS_LSH_SHARE", share)
+        ix2, c2, got2, st2 = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
+        assert ix2.kernel_name(c2) == kernel
+        assert (ix2.share_info()["flags"] != 0) == (share != "0")
+        assert got.tobytes() == got2.tobytes() and st.matches == st2.matches, share
+        ix2.close()
+        monkeypatch.delenv("FS_LSH_SHARE", raising=False)
     monkeypatch.delenv("FS_LSH_SYN")
     # the pending windows a wave each (k_lsh_verify) instead of eight per wave (k_lsh_batch), and
     # k_lsh_batch on every search of an index (the second search of a small batch would take
@@ -123,7 +133,7 @@ def test_vectors_of_different_length(synth_base, monkeypatch):
     assert st.matches == ost.matches and len(got) > 0
 
 
-def test_coarse_components_fall_back(synth_base):
+def test_coarse_components_fall_back(synth_base, monkeypatch):
     """Sixteen clusters of 512 near-synonyms: a component holds a sixteenth... of the table
     each, and a zero row joins every component it touches -- more than an eighth of the table
     in one component: no prefilter, the plain LSH pipeline, the oracle's records."""
@@ -139,12 +149,15 @@ def test_coarse_components_fall_back(synth_base):
     normals = synth.lsh_normals(6)
     ix, c, got, st = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL
-    assert ix.kernel_name(c) == "k_lsh_scan"          # fell back
+    assert ix.kernel_name(c) == "k_share_enum<6>"     # fell back: no component prefilter -- the share rule then
     sch, so = pack_strings(swords)
     want, ost = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8).search(
         tok, off, synth_base["chars"], synth_base["off"])
     util.assert_rows_equal(got, want)
     assert st.matches == ost.matches
+    monkeypatch.setenv("FS_LSH_SHARE", "0")           # ... and the key scan by itself
+    ix2, c2, got2, st2 = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
+    assert ix2.kernel_name(c2) == "k_lsh_scan" and got2.tobytes() == got.tobytes()
 
 
 def test_largest_filter_at_n6_leaves_the_second_filter_out(synth_base, monkeypatch):

@@ -55,6 +55,7 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
     for _ in range(3):
         prof = ix.profile(c, buf.data_ptr(), cap)
     out["kernels_us"] = [[k, round(ms * 1e3, 1)] for k, ms in prof]
+    out["share_rule"] = ix.share_info()
     sizes, used = ix.component_sizes()
     if not len(sizes):
         out["components"] = {"count": 0, "in_use": False,
