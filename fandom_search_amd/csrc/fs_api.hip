@@ -562,7 +562,7 @@ extern "C" const char* fs_search_kernel_name(fs_index* ix, fs_corpus* c) {
   const int n = (int)ix->cfg.window_size;
   const bool exact = ix->info.path == FS_MODE_EXACT && !c->has_oov;
   if (!exact) {
-    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? ((ix->share_flags & 32) ? "k_share_enum<%d>" : "k_lsh_scan") :
+    snprintf(name, sizeof name, !fs_lsh_prefilter_ok(ix, c) ? ((ix->share_flags & 32) ? "k_share_scan<%d>" : "k_lsh_scan") :
                                 fs_near_fused(ix, c) ? "k_near_sift<%d>" :
                                 fs_scan_near8(ix) ? "k_scan_near8<%d>" : "k_scan_near<%d>", n);
   } else if (uint32_t blocks = 0; fs_scan_rows_shape(ix, c, &blocks)) {

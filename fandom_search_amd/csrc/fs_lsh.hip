@@ -865,22 +865,28 @@ __device__ __forceinline__ bool share_gate(const LshDev& L, const uint32_t* cmp,
 // of a hash of the component id (fs_share_sig; FS_NONE: an out-of-vocabulary token), the script
 // window's n of them are one 64-bit word: slots whose signatures differ lie in different components,
 // slots whose signatures agree count as agreeing.
+template <int N>                  // (N = 0: the window size at run time)
 __device__ __forceinline__ bool share_pair_possible(const LshDev& L, uint32_t s, const uint32_t* sg,
                                                     const double* qd, double ff) {
+  const int n = N ? N : L.n;
   const uint64_t ssig = L.ssig[s];
-  const int b = fs_share_sig_bits(L.n);
+  const int b = fs_share_sig_bits(n);
   double af = 0.0;
   uint32_t dm = 0;
-  for (int k = 0; k < L.n; ++k) {
+#pragma unroll
+  for (int k = 0; k < n; ++k) {
     const uint32_t c = sg[k];
     const bool far = c == FS_NONE ? !(L.share_flags & 8) : c != (uint32_t)((ssig >> (k * b)) & ((1u << b) - 1u));
-    if (far) { af = af + qd[k]; dm |= 1u << k; }
+    af = far ? af + qd[k] : af;
+    dm |= far ? 1u << k : 0u;
   }
   if (!(ff > 0.0) || dm == 0u) return true;
+  // (A >= phi: the bound is at most tau whatever B is)
+  if (af >= L.share_phi * (1.0 + 1e-9) * ff) return false;
   const double A = fmin(af / ff, 1.0);
-  if (A >= L.share_phi * (1.0 + 1e-9)) return false;
   double bs = 0.0;
-  for (int k = 0; k < L.n; ++k)
+#pragma unroll
+  for (int k = 0; k < n; ++k)
     if ((dm >> k) & 1u) bs = bs + L.spos[s + k].q;
   const double ss = L.ss[s];
   if (!(ss > 0.0)) return true;
@@ -919,154 +925,155 @@ __global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint6
   }
 }
 
-// The share rule instead of the key scan: for the windows through the gate, the script windows that
-// hold one of the window's keys, one by one -- the subset keys as an exact map (smap: buckets of four
-// {key, list}, a full bucket spills into the next; slists: a key's script windows behind their
-// number) -- through the pairs' test and, what is left, the canonical distance.  A pair within
-// the threshold agrees on a heavy set of slots, that set contains one of the fan window's minimal
-// heavy subsets, and the script window is in that key's list: every script window within the
-// threshold is met, whatever buckets it shares with the fan window.  The windows flagged here are
-// therefore a superset of k_lsh_scan's (it flags those with a script window within the threshold
-// in a shared bucket); the kernels behind it make a window's neighbour list from its buckets and
-// drop a window whose list is empty, as behind the other prefilters.  A window the rule does not
-// constrain is flagged as it is.
-constexpr int kShareChunk = 1024;    // windows per workgroup pass: four of the gate's sub-tiles
+// The share rule instead of the key scan: the script windows that hold one of a fan window's keys,
+// one by one -- the subset keys as an exact map (smap: buckets of four {key, list}, a full bucket
+// spills into the next; slists: a key's script windows behind their number) -- through the pairs'
+// test and, what is left, the canonical distance.  A pair within the threshold agrees on a heavy
+// set of slots, that set contains one of the fan window's minimal heavy subsets, and the script
+// window is in that key's list: every script window within the threshold is met, whatever buckets
+// it shares with the fan window.  The windows flagged here are therefore a superset of
+// k_lsh_scan's (it flags those with a script window within the threshold in a shared bucket); the
+// kernels behind it make a window's neighbour list from its buckets and drop a window whose list
+// is empty, as behind the other prefilters.  A window the rule does not constrain, or whose work
+// finds no room in the workgroup's lists, is flagged as it is.
+// One kernel, a workgroup per sub-tile of 256 windows (k_lsh_scan's, and its bitmap), every stage
+// dealt out evenly over the 256 threads -- the work per window is very uneven (most windows end
+// at the filter, a few have lists of hundreds of script windows):
+//   1  a thread per window: its keys (share_asks), the filter; the keys that are there stay;
+//   2  a thread per such key: the map -- (window, list) entries;
+//   3  a thread per (window, script window) pair of the entries: the pairs' test, the distance.
 constexpr int kEnumCap = 20;         // keys per window (six slots have at most 20 minimal heavy subsets)
-constexpr int kEnumWork = 512;       // (window, key with script windows) entries per round of 256 windows
+constexpr int kEnumWork = 512;       // keys that are in the filter, and (window, list) entries, per sub-tile
 template <int N>
-__global__ __launch_bounds__(256) void k_share_enum(CorpusDev c, LshDev L, const uint64_t* __restrict__ gbm,
-                                                    uint64_t* __restrict__ qbm, uint32_t* __restrict__ qcnt,
-                                                    uint32_t n_sub) {
-  __shared__ uint16_t s_pos[kShareChunk];
-  __shared__ uint32_t s_f[256 * N], s_cm[256 * N];
-  __shared__ double s_q[256 * N], s_ff[256];
-  __shared__ uint32_t s_keys[kEnumCap * 256];      // phase A; phase B/C: the entries' offsets (s_wpref)
-  __shared__ uint32_t s_wstart[kEnumWork], s_wmeta[kEnumWork];
+__global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, uint64_t* __restrict__ qbm,
+                                                    uint32_t* __restrict__ qcnt, uint32_t n_sub) {
+  __shared__ uint32_t s_tok[256 + 16], s_cmp[256 + 16], s_sg[256 + 16];
+  __shared__ double s_qd[256 + 16], s_ff[256];
+  __shared__ uint32_t s_keys[kEnumCap * 256];      // stage 1; stage 3: the entries' offsets (s_wpref)
+  __shared__ uint32_t s_hit[kEnumWork], s_wstart[kEnumWork], s_wmeta[kEnumWork];
   __shared__ uint8_t s_found[256];
   __shared__ uint32_t s_w[4], s_nwork;
   uint32_t* s_wpref = s_keys;                      // [kEnumWork + 1]
-  static_assert(kEnumWork + 1 <= kEnumCap * 256 && kEnumWork == 2 * 256, "the offsets take the keys' place; two entries per thread in phase B");
+  static_assert(kEnumWork + 1 <= kEnumCap * 256 && kEnumWork == 2 * 256, "the offsets take the keys' place; two entries per thread");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint32_t n_chunks = (n_sub + 3) / 4;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    uint32_t total = 0;
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t sub = chunk * 4 + j;
-      const bool pass = sub < n_sub && ((gbm[(size_t)sub * 4 + wave] >> lane) & 1ull);
-      const uint64_t b = __ballot(pass);
-      if (lane == 0) s_w[wave] = __popcll(b);
-      __syncthreads();
-      uint32_t before = total;
-      for (int i = 0; i < wave; ++i) before += s_w[i];
-      if (pass) s_pos[before + __popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)(j * 256 + threadIdx.x);
-      total += s_w[0] + s_w[1] + s_w[2] + s_w[3];
-      __syncthreads();
+  for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
+    const uint64_t p0 = (uint64_t)sub * 256;
+    for (int i = threadIdx.x; i < 256 + N - 1; i += 256) {
+      const uint32_t id = c.tok[p0 + i];
+      const uint32_t cm = (id & FS_OOV_FLAG) ? FS_NONE : L.compa[id];
+      s_tok[i] = id;
+      s_cmp[i] = cm;
+      s_sg[i] = cm == FS_NONE ? FS_NONE : fs_share_sig(cm, N);
+      s_qd[i] = q_of(L, id);
     }
-    uint32_t* f = s_f + threadIdx.x * N;
-    uint32_t* cm = s_cm + threadIdx.x * N;
-    double* qd = s_q + threadIdx.x * N;
-    for (uint32_t r0 = 0; r0 < total; r0 += 256) {
-      // phase A, a thread per window: its keys, the filter, the map -- the lists to walk as entries
-      const uint32_t i = r0 + threadIdx.x;
-      const bool active = i < total;
-      const uint64_t p = (uint64_t)chunk * kShareChunk + (active ? s_pos[i] : 0);
-      if (threadIdx.x == 0) s_nwork = 0;
-      s_found[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nwork = 0;
+    s_found[threadIdx.x] = 0;
+    __syncthreads();
+    // stage 1
+    uint32_t hc = 0;
+    bool flag = false;
+    if (p0 + threadIdx.x + N <= c.n_tok && L.diag != 4) {
+      double ff = 0.0;
+#pragma unroll
+      for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, s_qd[threadIdx.x + k]);
+      s_ff[threadIdx.x] = ff;
+      uint32_t* list = s_keys + threadIdx.x;
+      const int cnt = share_asks<N>(L, s_cmp + threadIdx.x, s_qd + threadIdx.x, list, kEnumCap);
+      flag = cnt < 0;
+      for (int j = 0; j < cnt; j += 8) {
+        uint32_t h[8], wd[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) h[u] = j + u < cnt ? list[(j + u) * 256] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (j + u < cnt && fs_bloom_test(wd[u], h[u])) list[hc++ * 256] = h[u];      // (hc <= j + u: behind what is read)
+      }
+      if (L.diag == 6) hc = 0;                                    // diagnostics: no lists
+    }
+    {
+      uint32_t n_hit;
+      const uint32_t base = block_excl_scan(hc, s_w, &n_hit);
+      for (uint32_t i = 0; i < hc; ++i) {
+        if (base + i < (uint32_t)kEnumWork) s_hit[base + i] = threadIdx.x | i << 8;
+        else flag = true;                                         // (no room: the window goes on as it is)
+      }
+      if (flag) s_found[threadIdx.x] = 1;
       __syncthreads();
-      if (active) {
-        double ff = 0.0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) {
-          const uint32_t id = c.tok[p + k];
-          f[k] = id;
-          cm[k] = (id & FS_OOV_FLAG) ? FS_NONE : L.compa[id];
-          qd[k] = q_of(L, id);
-          ff = __dadd_rn(ff, qd[k]);
-        }
-        s_ff[threadIdx.x] = ff;
-        uint32_t* list = s_keys + threadIdx.x;
-        const int cnt = share_asks<N>(L, cm, qd, list, kEnumCap);
-        bool found = cnt < 0;
-#pragma unroll
-        for (int k = 0; k < N; ++k) cm[k] = cm[k] == FS_NONE ? FS_NONE : fs_share_sig(cm[k], N);
-        const uint32_t bmask = (1u << L.log2_smap) - 1u;
-        for (int j = 0; j < cnt && !found; j += 4) {
-          uint32_t h[4], wd[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? list[(j + u) * 256] : 0u;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
-          for (int u = 0; u < 4 && !found; ++u) {
-            if (!(j + u < cnt && fs_bloom_test(wd[u], h[u])) || L.diag == 6) continue;                  // (diagnostics 6: no lists)
-            uint32_t bkt = fs_wmap_slot(h[u], L.log2_smap);
-            for (int probe = 0;; ++probe) {
-              if (probe == 64) { found = true; break; }          // (never seen: the window goes on as it is)
-              const uint4* bp = reinterpret_cast<const uint4*>(L.smap + 4 * (size_t)bkt);
-              const uint4 a = bp[0], b = bp[1];
-              const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
-              for (int e = 0; e < 4; ++e) {
-                if (!val[e] || key[e] != h[u]) continue;
-                const uint32_t len = L.slists[val[e] - 1];       // a list: its length, then its script windows
-                const uint32_t at = atomicAdd(&s_nwork, 1u);
-                if (at < (uint32_t)kEnumWork && len < (1u << 24)) {
-                  s_wstart[at] = val[e];
-                  s_wmeta[at] = (uint32_t)threadIdx.x << 24 | len;
-                } else {
-                  found = true;                                   // (no room: the window goes on as it is)
-                }
-              }
-              if (!val[3]) break;                                 // (not full: nothing has spilt past it)
-              bkt = (bkt + 1) & bmask;
+      // stage 2
+      const uint32_t bmask = (1u << L.log2_smap) - 1u;
+      n_hit = n_hit < (uint32_t)kEnumWork ? n_hit : (uint32_t)kEnumWork;
+      for (uint32_t x = threadIdx.x; x < n_hit; x += 256) {
+        const uint32_t t = s_hit[x] & 255u, h = s_keys[(s_hit[x] >> 8) * 256 + t];
+        uint32_t bkt = fs_wmap_slot(h, L.log2_smap);
+        for (int probe = 0;; ++probe) {
+          if (probe == 64) { s_found[t] = 1; break; }             // (never seen: the window goes on as it is)
+          const uint4* bp = reinterpret_cast<const uint4*>(L.smap + 4 * (size_t)bkt);
+          const uint4 a = bp[0], b = bp[1];
+          const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
+          for (int e = 0; e < 4; ++e) {
+            if (!val[e] || key[e] != h) continue;
+            const uint32_t len = L.slists[val[e] - 1];             // a list: its length, then its script windows
+            const uint32_t at = atomicAdd(&s_nwork, 1u);
+            if (at < (uint32_t)kEnumWork && len < (1u << 24)) {
+              s_wstart[at] = val[e];
+              s_wmeta[at] = t << 24 | len;
+            } else {
+              s_found[t] = 1;                                      // (no room: the window goes on as it is)
             }
           }
+          if (!val[3]) break;                                      // (not full: nothing has spilt past it)
+          bkt = (bkt + 1) & bmask;
         }
-        if (found) s_found[threadIdx.x] = 1;
       }
-      __syncthreads();
-      // phase B: the entries' offsets among the round's (window, script window) pairs
-      const uint32_t n_work = s_nwork < (uint32_t)kEnumWork ? s_nwork : (uint32_t)kEnumWork;
-      uint32_t mine[2], sum = 0;
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const uint32_t e = threadIdx.x * 2 + u;
-        mine[u] = e < n_work ? s_wmeta[e] & 0xFFFFFFu : 0u;
-        sum += mine[u];
-      }
-      uint32_t pairs;
-      uint32_t base = block_excl_scan(sum, s_w, &pairs);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const uint32_t e = threadIdx.x * 2 + u;
-        if (e < n_work) s_wpref[e] = base;
-        base += mine[u];
-      }
-      if (threadIdx.x == 0) s_wpref[n_work] = pairs;
-      __syncthreads();
-      // phase C: the pairs dealt out evenly, pair j to thread j mod 256
-      for (uint32_t j = threadIdx.x; j < pairs && L.diag != 5; j += 256) {                       // (diagnostics 5: no pairs)
-        uint32_t lo = 0, hi = n_work;                             // s_wpref[lo] <= j < s_wpref[hi]
-        while (hi - lo > 1) {
-          const uint32_t mid = (lo + hi) >> 1;
-          if (s_wpref[mid] <= j) lo = mid; else hi = mid;
-        }
-        const uint32_t t = s_wmeta[lo] >> 24;
-        if (s_found[t]) continue;                                 // the window has its answer already
-        const uint32_t sw = L.slists[s_wstart[lo] + (j - s_wpref[lo])];
-        const double pff = s_ff[t];
-        double d;
-        if (share_pair_possible(L, sw, s_cm + t * N, s_q + t * N, pff) && L.diag != 7 &&                // (diagnostics 7: no distances)
-            window_distance(L, sw, s_f + t * N, nullptr, pff, __dsqrt_rn(pff), &d) && d < L.thr)
-          s_found[t] = 1;
-      }
-      __syncthreads();
-      if (active && s_found[threadIdx.x]) {
-        // (k_lsh_scan's bitmap: window w of a sub-tile is bit w / 4 of the sub-tile's word w mod 4)
-        const uint32_t w = (uint32_t)(p & 255);
-        atomicOr(reinterpret_cast<unsigned long long*>(qbm) + (p >> 8) * 4 + (w & 3), 1ull << (w >> 2));
-        atomicAdd(qcnt + (p >> 8), 1u);
-      }
-      __syncthreads();
     }
+    __syncthreads();
+    // stage 3: the entries' offsets among the sub-tile's pairs, then the pairs, pair j to thread j mod 256
+    const uint32_t n_work = s_nwork < (uint32_t)kEnumWork ? s_nwork : (uint32_t)kEnumWork;
+    uint32_t mine[2], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t e = threadIdx.x * 2 + u;
+      mine[u] = e < n_work ? s_wmeta[e] & 0xFFFFFFu : 0u;
+      sum += mine[u];
+    }
+    uint32_t pairs;
+    uint32_t at = block_excl_scan(sum, s_w, &pairs);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t e = threadIdx.x * 2 + u;
+      if (e < n_work) s_wpref[e] = at;
+      at += mine[u];
+    }
+    if (threadIdx.x == 0) s_wpref[n_work] = pairs;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < pairs && L.diag != 5; j += 256) {                            // (diagnostics 5: no pairs)
+      uint32_t lo = 0, hi = n_work;                               // s_wpref[lo] <= j < s_wpref[hi]
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_wpref[mid] <= j) lo = mid; else hi = mid;
+      }
+      const uint32_t t = s_wmeta[lo] >> 24;
+      if (s_found[t]) continue;                                   // the window has its answer already
+      const uint32_t sw = L.slists[s_wstart[lo] + (j - s_wpref[lo])];
+      const double pff = s_ff[t];
+      double d;
+      if (share_pair_possible<N>(L, sw, s_sg + t, s_qd + t, pff) && L.diag != 7 &&                     // (diagnostics 7: no distances)
+          window_distance_flat<N>(L, sw, s_tok + t, s_qd + t, pff, __dsqrt_rn(pff), &d) && d < L.thr)
+        s_found[t] = 1;
+    }
+    __syncthreads();
+    // thread (wave j, lane l) reports window 4 l + j, as k_lsh_scan does: wave j's ballot is bitmap
+    // word j of the sub-tile
+    const uint64_t b = __ballot(s_found[4 * lane + wave] != 0);
+    if (lane == 0) {
+      qbm[(size_t)sub * 4 + wave] = b;
+      s_w[wave] = __popcll(b);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) qcnt[sub] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    __syncthreads();
   }
 }
 
@@ -1299,7 +1306,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L, const u
         const uint32_t sidx = L.bids[(size_t)ph * L.W + s_key[lo] + (j - s_pref[lo])];
         if (L.diag == 3) continue;               // diagnostics: bucket walk only
         const double pff = s_ff[pw];
-        if (pair_test && !share_pair_possible(L, sidx, s_cmp2 + pw, s_qd2 + pw, pff)) continue;
+        if (pair_test && !share_pair_possible<0>(L, sidx, s_cmp2 + pw, s_qd2 + pw, pff)) continue;
         double d;
         if (window_distance(L, sidx, s_tok + pw, nullptr, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_flag[pw] = 1;
       }
@@ -3399,6 +3406,19 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 64)));
   const uint32_t blocks = std::min<uint32_t>(n_sub, ix->num_cu * per_cu);
   const uint64_t* gbm = nullptr;
+  if ((L.share_flags & 32) && L.n >= 2 && L.n <= 6) {
+    // the share rule by itself: the script windows behind every window's keys
+    const uint32_t sblocks = std::min<uint32_t>(n_sub, ix->num_cu * 4);
+    switch (L.n) {
+      case 2: hipExtLaunchKernelGGL(k_share_scan<2>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+      case 3: hipExtLaunchKernelGGL(k_share_scan<3>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+      case 4: hipExtLaunchKernelGGL(k_share_scan<4>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+      case 5: hipExtLaunchKernelGGL(k_share_scan<5>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+      default: hipExtLaunchKernelGGL(k_share_scan<6>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+    }
+    FS_HIP(hipGetLastError());
+    return FS_OK;
+  }
   if ((L.share_flags & 1) && L.n >= 2 && L.n <= 6) {
     // the share rule's gate first: the windows that need keys at all
     FS_TRY(ix->cur->w_gate.reserve((size_t)n_sub * 4));
@@ -3415,21 +3435,6 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
     if (ix->prof.on) fs_prof_mark(ix, s, "k_share_gate");
     e0 = nullptr;
     gbm = g;
-    if (L.share_flags & 32) {
-      // ... and the script windows behind the gate's keys instead of the key scan
-      FS_HIP(hipMemsetAsync(qbm, 0, (size_t)n_sub * 4 * sizeof(uint64_t), s));
-      FS_HIP(hipMemsetAsync(qcnt, 0, (size_t)n_sub * sizeof(uint32_t), s));
-      const uint32_t eblocks = std::min<uint32_t>((n_sub + 3) / 4, ix->num_cu * 8);
-      switch (L.n) {
-        case 2: hipExtLaunchKernelGGL(k_share_enum<2>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
-        case 3: hipExtLaunchKernelGGL(k_share_enum<3>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
-        case 4: hipExtLaunchKernelGGL(k_share_enum<4>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
-        case 5: hipExtLaunchKernelGGL(k_share_enum<5>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
-        default: hipExtLaunchKernelGGL(k_share_enum<6>, dim3(eblocks), dim3(256), 0, s, nullptr, e1, 0u, c, L, gbm, qbm, qcnt, n_sub); break;
-      }
-      FS_HIP(hipGetLastError());
-      return FS_OK;
-    }
   }
   hipExtLaunchKernelGGL(k_lsh_scan, dim3(blocks), dim3(256), (uint32_t)lds, s, e0, e1, 0u, c, L, gbm, qbm,
                         qcnt, n_sub);

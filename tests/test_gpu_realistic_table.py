@@ -54,7 +54,7 @@ def test_realistic_table_equals_oracle(real, oov, unique, monkeypatch):
     again, _ = ix.search(c)
     assert st.path == abi.FS_MODE_GENERAL and got.tobytes() == again.tobytes()
     # neither integer prefilter applies (norms from 1.8 to 18): the share rule in front of the LSH work
-    assert ix.kernel_name(c) == "k_share_enum<6>" and ix.share_info()["flags"] & 32
+    assert ix.kernel_name(c) == "k_share_scan<6>" and ix.share_info()["flags"] & 32
     sch, so = pack_strings(swords)
     oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
     want, ost = oi.search(tok_vec, off, chars, coff, tok_str=tok_str)
@@ -68,7 +68,7 @@ def test_realistic_table_equals_oracle(real, oov, unique, monkeypatch):
     # the subsets that are heavy on both sides; 43, 11: out-of-vocabulary fan tokens as possibly
     # near anything (what an index does whose table does not prove them far)
     for share, kernel in (("0", "k_lsh_scan"), ("3", "k_lsh_scan"), ("1", "k_lsh_scan"), ("2", "k_lsh_scan"),
-                          ("7", "k_lsh_scan"), ("43", "k_share_enum<6>"), ("11", "k_lsh_scan")):
+                          ("7", "k_lsh_scan"), ("43", "k_share_scan<6>"), ("11", "k_lsh_scan")):
         monkeypatch.setenv("FS_LSH_SHARE", share)
         ix2 = ScriptIndex(script, swords, emb, normals, cfg=cfg)
         c2 = ix2.corpus(tok_vec, off, chars, coff, tok_str=tok_str)

@@ -82,7 +82,7 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     # (window sizes up to six: the windows' gate and the script windows behind its keys; above,
     # the test of the pairs inside the key scan)
     monkeypatch.setenv("FS_LSH_SYN", "0")
-    for share, kernel in (("0", "k_lsh_scan"), (None, "k_share_enum<6>" if n <= 6 else "k_lsh_scan"),
+    for share, kernel in (("0", "k_lsh_scan"), (None, "k_share_scan<6>" if n <= 6 else "k_lsh_scan"),
                           ("3", "k_lsh_scan")):
         if share is not None:
             monkeypatch.setenv("FS_LSH_SHARE", share)
@@ -149,7 +149,7 @@ def test_coarse_components_fall_back(synth_base, monkeypatch):
     normals = synth.lsh_normals(6)
     ix, c, got, st = _search(cfg, script, swords, emb, normals, tok, off, synth_base["chars"], synth_base["off"])
     assert st.path == abi.FS_MODE_GENERAL
-    assert ix.kernel_name(c) == "k_share_enum<6>"     # fell back: no component prefilter -- the share rule then
+    assert ix.kernel_name(c) == "k_share_scan<6>"     # fell back: no component prefilter -- the share rule then
     sch, so = pack_strings(swords)
     want, ost = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8).search(
         tok, off, synth_base["chars"], synth_base["off"])

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised cross-check of the share rule (the LSH pipeline's prefilter on tables whose vectors
+are not unit length: k_share_gate, k_share_enum, the pairs' test in k_lsh_scan) against the key
+scan over every window (FS_LSH_SHARE=0; both on the GPU -- the key scan is held against the oracle
+by tests/): tables with norms spread by a factor of 1.2 to 50, similarity at three scales,
+duplicate and zero rows; window sizes 3..8, thresholds 0.05..0.25, gamma 0.5..0.85; fan text with
+near-synonyms, out-of-vocabulary names, and planted script spans whose *lightest* slots hold
+unrelated words (the pairs "at most one slot may differ" misses).
+
+  python tools/stress_share.py [--cases 36] [--seed 1]
+"""
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=36)
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    from fandom_search_amd import abi, synth
+    from fandom_search_amd.engine import ScriptIndex
+    from fandom_search_amd.vocab import pack_strings
+
+    rng = np.random.default_rng(a.seed)
+    bad = 0
+    for case in range(a.cases):
+        rows = int(rng.choice([1500, 4000]))
+        sigma = float(rng.choice([0.05, 0.3, 0.6, 1.0]))
+        n = int(rng.choice([3, 4, 5, 6, 6, 6, 7, 8]))
+        thr = float(rng.choice([0.05, 0.1, 0.1, 0.25]))
+        gamma = float(rng.choice([0.5, 0.7, 0.7, 0.85]))
+        oov = float(rng.choice([0.0, 0.08, 0.3]))
+        unique = bool(case % 2)
+        emb, group = synth.realistic_table(rows=rows, sigma=sigma, seed=11 + case)
+        strings, vid = synth.realistic_vector_ids(rows)
+        n_script = int(rng.choice([400, 3000]))
+        script = synth._draw(np.random.default_rng(77 + case), n_script, rows)
+        n_works, per = int(rng.choice([3, 40])), int(rng.choice([200, 900]))
+        tok_str, off = synth.realistic_corpus(n_works, per, script, group, rows, oov_rate=oov, seed=5 + case)
+        # planted spans: the script's words with the lightest slots of every window-sized piece
+        # replaced by unrelated words (and now and then a heavy one)
+        norm = np.linalg.norm(emb.astype(np.float64), axis=1)
+        for j in range(4 * n_works):
+            w = int(rng.integers(0, n_works))
+            if per < 3 * n or n_script < 3 * n:
+                break
+            at = int(off[w]) + int(rng.integers(0, per - 2 * n))
+            src = int(rng.integers(0, n_script - 2 * n))
+            span = script[src:src + 2 * n].astype(np.uint32).copy()
+            order = np.argsort(norm[span])
+            for k in order[:int(rng.integers(0, n))]:
+                span[k] = int(rng.integers(0, rows))
+            if rng.random() < 0.2:
+                span[order[-1]] = int(rng.integers(0, rows))
+            tok_str[at:at + len(span)] = span
+        tok_vec = vid[tok_str]
+        swords = [strings[int(t)] for t in script]
+        chars, coff = pack_strings(strings)
+        cfg = abi.make_config(window_size=n, unique_filter=unique, distance_threshold=thr)
+        normals = synth.lsh_normals(n)
+        os.environ["FS_SHARE_GAMMA"] = str(gamma)
+        results = []
+        for share in ("0", "35", "3", "43"):
+            os.environ["FS_LSH_SHARE"] = share
+            ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+            c = ix.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+            r, st = ix.search(c)
+            results.append((r.tobytes(), int(st.matches), ix.kernel_name(c), ix.share_info()["flags"], int(st.candidates)))
+            ix.close()
+        ok = all(x[:2] == results[0][:2] for x in results)
+        r0 = np.frombuffer(results[0][0], dtype=abi.ROW_DTYPE)
+        print("case %3d rows=%4d sigma=%.2f n=%d thr=%.2f gamma=%.2f oov=%.2f u%d script=%4d tokens=%6d records=%5d inexact=%5d "
+              "kernels=%s flags=%s candidates=%s %s"
+              % (case, rows, sigma, n, thr, gamma, oov, unique, n_script, len(tok_vec), len(r0),
+                 int((np.abs(r0["dist"]) > 1e-9).sum()), [x[2] for x in results], [x[3] for x in results],
+                 [x[4] for x in results], "ok" if ok else "MISMATCH"), flush=True)
+        bad += not ok
+    print("mismatches: %d" % bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
