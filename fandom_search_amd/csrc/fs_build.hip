@@ -153,13 +153,13 @@ __global__ __launch_bounds__(256) void k_near_pairs(const float* __restrict__ em
   }
 }
 
-// max over the script's vectors u of max_d |u[d]| / |u| (the share rule of fs_lsh.hip: the cosine of a
+// max over the script's vectors u (rows_u; nullptr: the n_u rows of the table) of max_d |u[d]| / |u| (the share rule of fs_lsh.hip: the cosine of a
 // vector with at most three non-zero coordinates, all 1, to u is at most sqrt(3) times that)
 __global__ void k_coordmax(const float* __restrict__ emb, int D, const double* __restrict__ q,
                            const uint32_t* __restrict__ rows_u, uint32_t n_u, int* __restrict__ out_bits) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_u) return;
-  const uint32_t row = rows_u[i];
+  const uint32_t row = rows_u ? rows_u[i] : i;     // (no list: every row of the table)
   const double qq = q[row];
   if (!(qq > 0.0)) return;
   float m = 0.0f;

@@ -273,6 +273,8 @@ struct fs_index {
   DBuf<uint32_t> d_smap;     // ... as an exact map (k_share_enum): 2^log2_smap buckets of four {key, list + 1}
   DBuf<uint32_t> d_slists;   // a key's script windows behind their number (the map names the first of them)
   int log2_smap = 0;
+  DBuf<uint32_t> d_oovmap;   // the script's out-of-vocabulary vectors for share_comp: 2^log2_oovmap {key, component + 1}
+  int log2_oovmap = 0;
   int share_flags = 0;       // 0: the share rule is not in use; else sw.lsh_share's bits (bit 3 also set when the table does not prove out-of-vocabulary tokens far)
   double share_gamma = 0.0;
   uint32_t share_comps = 0, share_largest = 0;

@@ -100,6 +100,8 @@ struct LshDev {
   const uint32_t* slists;  // the lists of the map: a list's length, then its script windows (the map names the first of those)
   int log2_smap;
   int log2_sharef, share_flags;
+  const uint2* oovmap;     // the script's out-of-vocabulary vectors (share_comp): 2^log2_oovmap {key, component}, or nullptr
+  int log2_oovmap;
   float share_lim;         // <= 1 - phi: the share of a window's squared norm its near slots must hold
   double share_scale;      // squared norms as integers: floor(q * share_scale) <= 2^20
   double share_phi, share_tau, share_gamma;
@@ -804,6 +806,44 @@ __global__ __launch_bounds__(256) void k_bucket_sort_big(uint32_t W, uint32_t nb
 // vector when sqrt(3) max_d |u_d| / |u| <= gamma for all of them (checked at index build);
 // otherwise (share_flags bit 3) its slot counts as agreeing with anything.  Scripts with
 // out-of-vocabulary tokens do not use the rule.
+// Component id of a fan token under the share rule.  A table row: compa.  An out-of-vocabulary
+// token is a vector of at most three ones: far from every table row of the script (checked at
+// index build), and against the script's own out-of-vocabulary vectors, by the sets of hot
+// positions -- equal sets are the same vector (cosine 1: that script vector's component), three
+// distinct positions against another three share at most two (2/3: far, gamma >= 0.668 is
+// required of such an index), and every other case involves a set of fewer than three (a hash
+// that met itself): cosines 0.71 and 0.82 occur there, so a fan token with fewer than three
+// distinct positions, or one that contains a two-position vector of the script, is FS_WILD: it
+// counts as agreeing with anything.  (A script token with fewer than three positions has a
+// component of its own that no fan token carries: fan tokens near it are all FS_WILD.)
+#define FS_WILD 0xFFFFFFFEu
+__device__ __forceinline__ uint32_t share_oov_lookup(const LshDev& L, uint32_t key) {
+  const uint32_t mask = (1u << L.log2_oovmap) - 1u;
+  for (uint32_t at = fs_mix24(key) & mask;; at = (at + 1) & mask) {
+    const uint2 e = L.oovmap[at];
+    if (e.y == 0u) return 0u;                      // (values are stored + 1)
+    if (e.x == key) return e.y;
+  }
+}
+__device__ __forceinline__ uint32_t share_comp(const LshDev& L, uint32_t id) {
+  if (!(id & FS_OOV_FLAG)) return L.compa[id];
+  if (L.share_flags & 8) return FS_WILD;
+  if (!L.oovmap || L.diag == 0x1000000) return FS_NONE;   // (diagnostics 0x1000000, a wrong rule on purpose: what tools/stress_share.py must catch)
+  uint32_t x, y, z;
+  oov_hot(id, L.D, &x, &y, &z);
+  uint32_t t;
+  if (x > y) { t = x; x = y; y = t; }
+  if (y > z) { t = y; y = z; z = t; }
+  if (x > y) { t = x; x = y; y = t; }
+  if (x == y || y == z) return FS_WILD;
+  const uint32_t D = (uint32_t)L.D;
+  if (share_oov_lookup(L, 0x80000000u | (x * D + y)) || share_oov_lookup(L, 0x80000000u | (x * D + z)) ||
+      share_oov_lookup(L, 0x80000000u | (y * D + z)))
+    return FS_WILD;
+  const uint32_t c = share_oov_lookup(L, (x * D + y) * D + z);
+  return c ? c - 1u : FS_NONE;
+}
+
 // The keys a fan window asks for (its minimal heavy subsets; all heavy ones under share_flags bit 2),
 // into list[j * 256]: their number, or -1 when the window is not constrained (the rule says nothing
 // about it, or the list is too short for its keys).
@@ -818,8 +858,8 @@ __device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, 
     all += qi[k];
     const uint32_t c = cmp[k];
     t[k] = 0;
-    if (c == FS_NONE) base += (L.share_flags & 8) ? qi[k] + 1 : 0u;
-    else { usable |= 1u << k; t[k] = fs_share_term(c, k); }
+    if (c == FS_WILD) base += qi[k] + 1;
+    else if (c != FS_NONE) { usable |= 1u << k; t[k] = fs_share_term(c, k); }
   }
   // heavy(M): sum_M qi >= thr.  (With x = q * scale real and qi = floor(x): a truly heavy M has
   // sum_M x >= lim sum x - sum_O x, so sum_M qi > lim * all - base - N.)
@@ -876,7 +916,7 @@ __device__ __forceinline__ bool share_pair_possible(const LshDev& L, uint32_t s,
 #pragma unroll
   for (int k = 0; k < n; ++k) {
     const uint32_t c = sg[k];
-    const bool far = c == FS_NONE ? !(L.share_flags & 8) : c != (uint32_t)((ssig >> (k * b)) & ((1u << b) - 1u));
+    const bool far = c == FS_WILD ? false : c == FS_NONE ? true : c != (uint32_t)((ssig >> (k * b)) & ((1u << b) - 1u));
     af = far ? af + qd[k] : af;
     dm |= far ? 1u << k : 0u;
   }
@@ -912,7 +952,7 @@ __global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint6
     for (int i = threadIdx.x; i < 256 + N - 1; i += 256) {
       const uint32_t id = c.tok[p0 + i];
       s_tok[i] = id;
-      s_cmp[i] = (id & FS_OOV_FLAG) ? FS_NONE : L.compa[id];
+      s_cmp[i] = share_comp(L, id);
       s_qd[i] = q_of(L, id);
     }
     __syncthreads();
@@ -960,10 +1000,10 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
     const uint64_t p0 = (uint64_t)sub * 256;
     for (int i = threadIdx.x; i < 256 + N - 1; i += 256) {
       const uint32_t id = c.tok[p0 + i];
-      const uint32_t cm = (id & FS_OOV_FLAG) ? FS_NONE : L.compa[id];
+      const uint32_t cm = share_comp(L, id);
       s_tok[i] = id;
       s_cmp[i] = cm;
-      s_sg[i] = cm == FS_NONE ? FS_NONE : fs_share_sig(cm, N);
+      s_sg[i] = cm >= FS_WILD ? cm : fs_share_sig(cm, N);
       s_qd[i] = q_of(L, id);
     }
     if (threadIdx.x == 0) s_nwork = 0;
@@ -1260,7 +1300,8 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L, const u
       if (pair_test)
         for (int i = threadIdx.x; i < 256 + n - 1; i += 256) {
           const uint32_t id = s_tok[i];
-          s_cmp2[i] = (id & FS_OOV_FLAG) ? FS_NONE : fs_share_sig(L.compa[id], n);
+          const uint32_t cm = share_comp(L, id);
+          s_cmp2[i] = cm >= FS_WILD ? cm : fs_share_sig(cm, n);
           s_qd2[i] = q_of(L, id);
         }
       const uint32_t nb1 = (1u << L.B) + 1;
@@ -2834,11 +2875,12 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.spos = ix->d_spos.n > 1 ? ix->d_spos.p : nullptr;
-  L.compa = nullptr; L.ssig = nullptr; L.sharef = nullptr; L.smap = nullptr; L.slists = nullptr; L.log2_smap = 0; L.log2_sharef = 0; L.share_flags = 0;
+  L.oovmap = nullptr; L.log2_oovmap = 0; L.compa = nullptr; L.ssig = nullptr; L.sharef = nullptr; L.smap = nullptr; L.slists = nullptr; L.log2_smap = 0; L.log2_sharef = 0; L.share_flags = 0;
   L.share_lim = 0.0f; L.share_scale = 0.0; L.share_phi = 1.0; L.share_tau = 0.0; L.share_gamma = 1.0;
   if (ix->share_flags) {
     L.compa = ix->d_compa.p; L.ssig = ix->d_ssig.p; L.sharef = ix->d_sharef.p;
     L.log2_sharef = ix->log2_sharef; L.share_flags = ix->share_flags;
+    if (ix->log2_oovmap) { L.oovmap = reinterpret_cast<const uint2*>(ix->d_oovmap.p); L.log2_oovmap = ix->log2_oovmap; }
     L.smap = reinterpret_cast<const uint2*>(ix->d_smap.p); L.slists = ix->d_slists.p; L.log2_smap = ix->log2_smap;
     L.share_gamma = ix->share_gamma;
     L.share_tau = 1.0 - ix->cfg.distance_threshold - 1e-6;
@@ -3068,9 +3110,11 @@ static int fs_build_share(fs_index* ix) {
   const uint64_t V = ix->n_vec, W = ix->n_windows;
   const double gamma = ix->sw.share_gamma;
   const double tau = 1.0 - ix->cfg.distance_threshold - 1e-6;
-  if (!(ix->sw.lsh_share & 3) || ix->script_oov || !W || !V || V > FS_MAX_EXACT_ID || n < 2 ||
+  if (!(ix->sw.lsh_share & 3) || !W || !V || V > FS_MAX_EXACT_ID || n < 2 ||
       !(ix->info.norm_max > 0.0) || !(gamma >= 0.05 && gamma <= 0.995) || !(tau > gamma + 1e-3))
     return FS_OK;
+  // (a script with out-of-vocabulary tokens: share_comp's case analysis needs 2/3 to be far)
+  if (ix->script_oov && !(gamma >= 0.668)) return FS_OK;
   hipStream_t s = ix->stream;
   std::vector<uint32_t> st(ix->n_script);
   FS_HIP(hipMemcpyAsync(st.data(), ix->d_stok.p, ix->n_script * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -3079,7 +3123,7 @@ static int fs_build_share(fs_index* ix) {
   {
     std::vector<uint8_t> seen(V, 0);
     for (uint32_t id : st)
-      if (!seen[id]) { seen[id] = 1; rows_u.push_back(id); }
+      if (!(id & FS_OOV_FLAG) && !seen[id]) { seen[id] = 1; rows_u.push_back(id); }
   }
   const uint32_t cap = 1u << 23;
   DBuf<float> embT;
@@ -3092,8 +3136,13 @@ static int fs_build_share(fs_index* ix) {
   FS_HIP(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(uint32_t), s));
   FS_TRY(fs_launch_near_pairs(ix->d_emb.p, V, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p, embT.p, 0.0f,
                               (float)gamma, d_pairs.p, cap, d_cnt.p, s));
-  FS_TRY(fs_launch_coordmax(ix->d_emb.p, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p,
-                            reinterpret_cast<int*>(d_cnt.p + 1), s));
+  // (out-of-vocabulary fan tokens against the script's rows; with out-of-vocabulary tokens in the
+  // script also those against every row a fan token may be)
+  if (ix->script_oov)
+    FS_TRY(fs_launch_coordmax(ix->d_emb.p, D, nullptr, (uint32_t)V, ix->d_q.p, reinterpret_cast<int*>(d_cnt.p + 1), s));
+  else
+    FS_TRY(fs_launch_coordmax(ix->d_emb.p, D, d_rows_u.p, (uint32_t)rows_u.size(), ix->d_q.p,
+                              reinterpret_cast<int*>(d_cnt.p + 1), s));
   uint32_t res[2] = {0, 0};
   FS_HIP(hipMemcpyAsync(res, d_cnt.p, sizeof res, hipMemcpyDeviceToHost, s));
   FS_HIP(hipStreamSynchronize(s));
@@ -3127,15 +3176,71 @@ static int fs_build_share(fs_index* ix) {
   ix->share_comps = (uint32_t)size.size();
   ix->share_largest = *std::max_element(size.begin(), size.end());
   int flags = ix->sw.lsh_share & 47;
-  if (!oov_far) flags |= 8;
-  if (flags & 8) flags &= ~4;                      // (a slot that agrees with anything has no share on the script's side)
+  if (!oov_far) {
+    if (ix->script_oov) return FS_OK;               // (the script's 3-hot vectors may be near table rows: no rule)
+    flags |= 8;
+  }
+  if ((flags & 8) || ix->script_oov) flags &= ~4;  // (a slot that agrees with anything has no share on the script's side)
   if (n > 6) flags &= ~1;
   if ((flags & 35) != 35 || W * (((uint64_t)1 << n) - 1) > ((uint64_t)1 << 25)) flags &= ~32;   // (the enumeration needs the gate and the pairs' test)
   if (flags & 32) flags &= ~4;                     // (... and every subset of every script window in the filter)
   if (!(flags & 3)) return FS_OK;
   FS_TRY(ix->d_compa.upload(comp.data(), comp.size(), s));
+  // the script's out-of-vocabulary vectors (share_comp): a component per distinct set of three
+  // positions, in a map for the fan tokens; a component of its own per vector of fewer positions,
+  // its pair of positions in the map so that a fan token that contains it counts as agreeing with
+  // anything
+  ix->log2_oovmap = 0;
+  std::vector<uint32_t> oov_comp_of;               // per script token (OOV ones), by index into st
+  std::vector<std::pair<uint32_t, uint32_t>> oov_entries;   // {key, component}
+  auto hot_of = [&](uint32_t id, uint32_t h[3]) {
+    const uint32_t code = id & ~FS_OOV_FLAG, Du = (uint32_t)D;
+    h[2] = code % Du; h[1] = (code / Du) % Du; h[0] = code / (Du * Du);
+    std::sort(h, h + 3);
+  };
+  auto q_host = [&](uint32_t id, const std::vector<double>& qv) {
+    if (!(id & FS_OOV_FLAG)) return qv[id];
+    uint32_t h[3];
+    hot_of(id, h);
+    return 1.0 + (h[1] != h[0] ? 1.0 : 0.0) + (h[2] != h[1] ? 1.0 : 0.0);
+  };
   std::vector<uint32_t> sc(st.size() + FS_MAX_WINDOW, FS_NONE);
-  for (size_t i = 0; i < st.size(); ++i) sc[i] = comp[st[i]];
+  {
+    uint32_t next = (uint32_t)V;
+    std::vector<std::pair<uint64_t, uint32_t>> sets;         // distinct position sets -> component
+    for (size_t i = 0; i < st.size(); ++i) {
+      if (!(st[i] & FS_OOV_FLAG)) { sc[i] = comp[st[i]]; continue; }
+      uint32_t h[3];
+      hot_of(st[i], h);
+      const uint64_t set = ((uint64_t)h[0] << 40) | ((uint64_t)h[1] << 20) | h[2];
+      uint32_t c = FS_NONE;
+      for (const auto& e : sets)
+        if (e.first == set) { c = e.second; break; }
+      if (c == FS_NONE) {
+        c = next++;
+        sets.push_back({set, c});
+        const uint32_t Du = (uint32_t)D;
+        if (h[0] != h[1] && h[1] != h[2]) oov_entries.push_back({(h[0] * Du + h[1]) * Du + h[2], c});
+        else if (h[0] != h[2]) oov_entries.push_back({0x80000000u | (h[0] * Du + h[2]), FS_WILD});   // two positions
+      }
+      sc[i] = c;
+    }
+    if ((uint64_t)D * D * D >= (1ull << 31)) { if (!oov_entries.empty()) return FS_OK; }
+    if (!oov_entries.empty()) {
+      int lo = 4;
+      while (((size_t)1 << lo) < 2 * oov_entries.size()) ++lo;
+      std::vector<uint32_t> m((size_t)2 << lo, 0u);
+      const uint32_t mask = (1u << lo) - 1;
+      for (const auto& e : oov_entries) {
+        uint32_t at = fs_mix24(e.first) & mask;
+        while (m[2 * at + 1]) at = (at + 1) & mask;
+        m[2 * at] = e.first;
+        m[2 * at + 1] = e.second + 1;                // (0: empty; FS_WILD + 1 = FS_NONE: share_comp reads it as "there")
+      }
+      FS_TRY(ix->d_oovmap.upload(m.data(), m.size(), s));
+      ix->log2_oovmap = lo;
+    }
+  }
   {
     std::vector<uint64_t> sig(W, 0);
     const int b = fs_share_sig_bits(n);
@@ -3158,7 +3263,7 @@ static int fs_build_share(fs_index* ix) {
       double qs[6], all = 0.0;
       for (int k = 0; k < n; ++k) {
         t[k] = fs_share_term(sc[w + k], k);
-        qs[k] = q[st[w + k]];
+        qs[k] = q_host(st[w + k], q);
         all += qs[k];
       }
       const double need = (1.0 - phi) * all * (1.0 - 1e-6);

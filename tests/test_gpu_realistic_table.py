@@ -76,3 +76,65 @@ def test_realistic_table_equals_oracle(real, oov, unique, monkeypatch):
         assert ix2.kernel_name(c2) == kernel
         assert got2.tobytes() == got.tobytes() and st2.matches == st.matches, share
         ix2.close()
+
+
+def test_script_with_names_of_its_own(real, monkeypatch):
+    """A script whose tokens include out-of-vocabulary names (what every real script does): the
+    share rule still applies -- the names' 3-hot vectors get components of their own, by their
+    sets of hot positions -- and the cases its analysis singles out are all in the text: a name
+    whose three hashes fell on two positions, the same set under another id, a name that contains
+    it, a one-position name and a two-position name over it, a two-position subset of a
+    three-position name of the script.  Records as the C oracle's and as the key scan's."""
+    from oracle import c_oracle
+    from fandom_search_amd.engine import ScriptIndex
+    emb, group, strings, vid, script = real
+    D, F = 300, abi.FS_OOV_FLAG
+    code = lambda a, b, c: np.uint32(F | ((a * D + b) * D + c))
+    h = lambda i: [int(x) for x in ((int(vid[2 * ROWS + i]) & ~F) // (D * D), ((int(vid[2 * ROWS + i]) & ~F) // D) % D, (int(vid[2 * ROWS + i]) & ~F) % D)]
+    x, y, z = h(0)                                    # a regular name of the script: three positions
+    assert x < y < z
+    extra = [("Deg0", code(7, 7, 19)), ("Deg1", code(7, 19, 19)), ("Deg2", code(7, 19, 123)), ("One0", code(55, 55, 55)),
+             ("Two0", code(55, 55, 201)), ("Sub0", code(x, y, y)), ("Sub1", code(x, x, z))]
+    strings = list(strings) + [w for w, _ in extra]
+    vid = np.concatenate([vid, np.array([v for _, v in extra], dtype=np.uint32)])
+    sid = {w: len(strings) - len(extra) + i for i, (w, _) in enumerate(extra)}
+    name = lambda i: 2 * ROWS + i
+    rng = np.random.default_rng(21)
+    script_str = script.astype(np.uint32).copy()
+    for i in range(0, len(script_str), 9):            # a name every ninth token, thirty of them in turn
+        script_str[i] = name((i // 9) % 30)
+    script_str[100], script_str[103] = sid["Deg0"], sid["One0"]
+    script_str[1000], script_str[1002] = sid["Deg0"], name(0)
+    script_vec = vid[script_str]
+    tok_str, off = synth.realistic_corpus(50, 600, script, group, ROWS, oov_rate=0.08)
+    for j in range(20):                               # quotes, names and all; the singled-out ones varied
+        at = int(off[j]) + 40 + 11 * j
+        src = 94 if j % 2 else 994
+        span = script_str[src:src + 14].copy()
+        swap = {sid["Deg0"]: [sid["Deg0"], sid["Deg1"], sid["Deg2"], name(44)][j % 4],
+                sid["One0"]: [sid["One0"], sid["Two0"]][(j // 2) % 2],
+                name(0): [name(0), sid["Sub0"], sid["Sub1"], name(45)][(j // 2) % 4]}
+        tok_str[at:at + 14] = [swap.get(int(t), int(t)) for t in span]
+    tok_vec = vid[tok_str]
+    swords = [strings[int(t)] for t in script_str]
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config()
+    normals = synth.lsh_normals(6)
+    ix = ScriptIndex(script_vec, swords, emb, normals, cfg=cfg)
+    c = ix.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+    got, st = ix.search(c)
+    assert ix.kernel_name(c) == "k_share_scan<6>" and ix.share_info()["flags"] & 32
+    sch, so = pack_strings(swords)
+    oi = c_oracle.OracleIndex(cfg, script_vec, sch, so, emb, normals, threads=8)
+    want, ost = oi.search(tok_vec, off, chars, coff, tok_str=tok_str)
+    util.assert_rows_equal(got, want)
+    assert st.matches == ost.matches and len(got) > 200
+    oi.close()
+    ix.close()
+    for share in ("0", "3"):
+        monkeypatch.setenv("FS_LSH_SHARE", share)
+        ix2 = ScriptIndex(script_vec, swords, emb, normals, cfg=cfg)
+        c2 = ix2.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+        got2, st2 = ix2.search(c2)
+        assert ix2.kernel_name(c2) == "k_lsh_scan" and got2.tobytes() == got.tobytes(), share
+        ix2.close()

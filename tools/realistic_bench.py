@@ -18,7 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, window=6, reps=3):
+def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, window=6, reps=3, companion=None):
+    """companion: called with (index, corpus, works, tokens in the corpus) before they are closed; the dict it
+    returns is merged into the result (bench.py measures the search with others in flight through it)."""
     from fandom_search_amd import abi, synth
     from fandom_search_amd.engine import ScriptIndex
     from fandom_search_amd.vocab import pack_strings
@@ -69,6 +71,8 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
                                            int(((sizes >= lo) & (sizes < hi)).sum())
                                            for lo, hi in zip(edges[:-1], edges[1:])},
                              "share_of_table_in_largest": float(sizes.max()) / rows}
+    if companion is not None:
+        out.update(companion(ix, c, works, len(tok_vec)))
     c.close()
     ix.close()
     return out

@@ -3,7 +3,9 @@
 are not unit length: k_share_gate, k_share_enum, the pairs' test in k_lsh_scan) against the key
 scan over every window (FS_LSH_SHARE=0; both on the GPU -- the key scan is held against the oracle
 by tests/): tables with norms spread by a factor of 1.2 to 50, similarity at three scales,
-duplicate and zero rows; window sizes 3..8, thresholds 0.05..0.25, gamma 0.5..0.85; fan text with
+duplicate and zero rows, long and short vectors (next to the short ones an out-of-vocabulary
+name is the heavy slot); scripts with names of their own, the odd ones among them (fewer than
+three hot positions); window sizes 3..8, thresholds 0.05..0.25, gamma 0.5..0.85; fan text with
 near-synonyms, out-of-vocabulary names, and planted script spans whose *lightest* slots hold
 unrelated words (the pairs "at most one slot may differ" misses).
 
@@ -40,11 +42,32 @@ def main():
         oov = float(rng.choice([0.0, 0.08, 0.3]))
         unique = bool(case % 2)
         emb, group = synth.realistic_table(rows=rows, sigma=sigma, seed=11 + case)
+        # (norms around 6, 1 or 0.3: next to short table vectors an out-of-vocabulary name -- norm up to
+        # sqrt(3) -- is the heavy slot of its window)
+        scale = float(rng.choice([1.0, 0.15, 0.05]))
+        emb = (emb * np.float32(scale)).astype(np.float32)
         strings, vid = synth.realistic_vector_ids(rows)
+        # names whose three hashes fell on fewer than three positions, the same sets under other ids,
+        # names that contain them (share_comp's case analysis), as strings of their own
+        D, F = 300, abi.FS_OOV_FLAG
+        code = lambda a, b, c: np.uint32(F | ((a * D + b) * D + c))
+        x, y, z = sorted(((int(vid[2 * rows]) & ~F) // (D * D), ((int(vid[2 * rows]) & ~F) // D) % D, (int(vid[2 * rows]) & ~F) % D))
+        family = [code(7, 7, 19), code(7, 19, 19), code(7, 19, 123), code(7, 19, 250), code(55, 55, 55), code(55, 55, 201),
+                  code(x, y, y), code(x, x, z), code(x, y, z)]
+        strings = list(strings) + ["Odd%d" % i for i in range(len(family))]
+        vid = np.concatenate([vid, np.array(family, dtype=np.uint32)])
+        odd0 = len(strings) - len(family)
         n_script = int(rng.choice([400, 3000]))
         script = synth._draw(np.random.default_rng(77 + case), n_script, rows)
         n_works, per = int(rng.choice([3, 40])), int(rng.choice([200, 900]))
         tok_str, off = synth.realistic_corpus(n_works, per, script, group, rows, oov_rate=oov, seed=5 + case)
+        names = case % 3 != 0                          # two cases in three: a script with names of its own
+        script_str = script.astype(np.uint32).copy()
+        if names:
+            for i in range(0, n_script, int(rng.choice([4, 9]))):
+                script_str[i] = (2 * rows + int(rng.integers(0, 25))) if rng.random() < 0.7 else odd0 + int(rng.choice([0, 4, 8]))
+            sel = np.nonzero(rng.random(len(tok_str)) < 0.03)[0]      # the odd names in the fan text too
+            tok_str[sel] = odd0 + rng.integers(0, len(family), size=len(sel))
         # planted spans: the script's words with the lightest slots of every window-sized piece
         # replaced by unrelated words (and now and then a heavy one)
         norm = np.linalg.norm(emb.astype(np.float64), axis=1)
@@ -56,13 +79,19 @@ def main():
             src = int(rng.integers(0, n_script - 2 * n))
             span = script[src:src + 2 * n].astype(np.uint32).copy()
             order = np.argsort(norm[span])
+            keep = script_str[src:src + 2 * n].copy()
             for k in order[:int(rng.integers(0, n))]:
                 span[k] = int(rng.integers(0, rows))
             if rng.random() < 0.2:
                 span[order[-1]] = int(rng.integers(0, rows))
+            if names:                                  # the script's names stay, or become a relative
+                for k in range(len(span)):
+                    if keep[k] >= 2 * rows and span[k] == script[src + k]:
+                        span[k] = keep[k] if keep[k] < odd0 or rng.random() < 0.4 else odd0 + int(rng.integers(0, len(family)))
             tok_str[at:at + len(span)] = span
         tok_vec = vid[tok_str]
-        swords = [strings[int(t)] for t in script]
+        script = vid[script_str]
+        swords = [strings[int(t)] for t in script_str]
         chars, coff = pack_strings(strings)
         cfg = abi.make_config(window_size=n, unique_filter=unique, distance_threshold=thr)
         normals = synth.lsh_normals(n)
@@ -77,9 +106,9 @@ def main():
             ix.close()
         ok = all(x[:2] == results[0][:2] for x in results)
         r0 = np.frombuffer(results[0][0], dtype=abi.ROW_DTYPE)
-        print("case %3d rows=%4d sigma=%.2f n=%d thr=%.2f gamma=%.2f oov=%.2f u%d script=%4d tokens=%6d records=%5d inexact=%5d "
+        print("case %3d rows=%4d sigma=%.2f scale=%.2f names=%d n=%d thr=%.2f gamma=%.2f oov=%.2f u%d script=%4d tokens=%6d records=%5d inexact=%5d "
               "kernels=%s flags=%s candidates=%s %s"
-              % (case, rows, sigma, n, thr, gamma, oov, unique, n_script, len(tok_vec), len(r0),
+              % (case, rows, sigma, scale, names, n, thr, gamma, oov, unique, n_script, len(tok_vec), len(r0),
                  int((np.abs(r0["dist"]) > 1e-9).sum()), [x[2] for x in results], [x[3] for x in results],
                  [x[4] for x in results], "ok" if ok else "MISMATCH"), flush=True)
         bad += not ok
