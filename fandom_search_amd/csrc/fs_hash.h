@@ -174,11 +174,12 @@ FS_HD uint32_t fs_wmap_slot(uint32_t h, int log2_slots) { return (h * 0x9E3779B1
 // the subset's terms, mixed with the mask.  A blocked Bloom filter (one 32-bit word, three bits:
 // fs_bloom_word / fs_bloom_test) holds the keys of every script window.
 FS_HD uint32_t fs_share_term(uint32_t comp, int k) { return fs_rotl(fs_premix(comp), fs_rot_of(k)); }
-FS_HD uint32_t fs_share_key(uint32_t fold, uint32_t mask) {
-  uint32_t h = fold + 0x9E3779B9u * mask;
+FS_HD uint32_t fs_share_raw(uint32_t fold, uint32_t mask) { return fold + 0x9E3779B9u * mask; }
+FS_HD uint32_t fs_share_finish(uint32_t h) {
   h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
   return h;
 }
+FS_HD uint32_t fs_share_key(uint32_t fold, uint32_t mask) { return fs_share_finish(fs_share_raw(fold, mask)); }
 // ... and the few bits of a component id the pairs' test compares: n of them in a 64-bit word
 FS_HD int fs_share_sig_bits(int n) { return 64 / n > 10 ? 10 : 64 / n; }
 FS_HD uint32_t fs_share_sig(uint32_t comp, int n) { return (fs_mix24(comp) >> 7) & ((1u << fs_share_sig_bits(n)) - 1u); }

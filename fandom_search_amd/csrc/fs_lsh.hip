@@ -847,6 +847,30 @@ __device__ __forceinline__ uint32_t share_comp(const LshDev& L, uint32_t id) {
 // The keys a fan window asks for (its minimal heavy subsets; all heavy ones under share_flags bit 2),
 // into list[j * 256]: their number, or -1 when the window is not constrained (the rule says nothing
 // about it, or the list is too short for its keys).
+// (the subsets of the slots depth first: a subset's sum, minimum and fold are its parent's and one
+// operation each; the keys leave as fs_share_raw -- whoever reads the list finishes them, once
+// per key asked for instead of once per subset)
+template <int N, int K, uint32_t M>
+struct ShareSubsets {
+  static __device__ __forceinline__ void go(const uint32_t (&qi)[N], const uint32_t (&t)[N], uint32_t usable, int thr,
+                                            bool every, uint32_t sum, uint32_t mn, uint32_t fold, uint32_t* list,
+                                            int cap, int& cnt) {
+    if constexpr (K == N) {
+      if constexpr (M != 0u) {
+        const bool ask = (M & ~usable) == 0u && (int)sum >= thr && (every || (int)(sum - mn) < thr);
+        if (ask) {
+          if (cnt < cap) list[cnt * 256] = fs_share_raw(fold, M);
+          ++cnt;
+        }
+      }
+    } else {
+      ShareSubsets<N, K + 1, M>::go(qi, t, usable, thr, every, sum, mn, fold, list, cap, cnt);
+      ShareSubsets<N, K + 1, (M | (1u << K))>::go(qi, t, usable, thr, every, sum + qi[K], qi[K] < mn ? qi[K] : mn,
+                                                  fold ^ t[K], list, cap, cnt);
+    }
+  }
+};
+
 template <int N>
 __device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, const double* qd,
                                           uint32_t* list, int cap) {
@@ -867,18 +891,7 @@ __device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, 
   if (thr <= 0) return -1;
   const bool every = (L.share_flags & 4) != 0;
   int cnt = 0;
-#pragma unroll
-  for (uint32_t m = 1; m < (1u << N); ++m) {
-    uint32_t sum = 0, mn = 0xFFFFFFFFu, fold = 0;
-#pragma unroll
-    for (int k = 0; k < N; ++k)
-      if ((m >> k) & 1u) { sum += qi[k]; mn = qi[k] < mn ? qi[k] : mn; fold ^= t[k]; }
-    const bool ask = (m & ~usable) == 0u && (int)sum >= thr && (every || (int)(sum - mn) < thr);
-    if (ask) {
-      if (cnt < cap) list[cnt * 256] = fs_share_key(fold, m);
-      ++cnt;
-    }
-  }
+  ShareSubsets<N, 0, 0u>::go(qi, t, usable, thr, every, 0u, 0xFFFFFFFFu, 0u, list, cap, cnt);
   return cnt > cap ? -1 : cnt;
 }
 
@@ -891,7 +904,7 @@ __device__ __forceinline__ bool share_gate(const LshDev& L, const uint32_t* cmp,
   for (int j = 0; j < cnt && !hit; j += 4) {
     uint32_t h[4], wd[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? list[(j + u) * 256] : 0u;
+    for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? fs_share_finish(list[(j + u) * 256]) : 0u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
 #pragma unroll
@@ -1018,12 +1031,13 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, s_qd[threadIdx.x + k]);
       s_ff[threadIdx.x] = ff;
       uint32_t* list = s_keys + threadIdx.x;
-      const int cnt = share_asks<N>(L, s_cmp + threadIdx.x, s_qd + threadIdx.x, list, kEnumCap);
+      int cnt = share_asks<N>(L, s_cmp + threadIdx.x, s_qd + threadIdx.x, list, kEnumCap);
       flag = cnt < 0;
+      if (L.diag == 10) cnt = 0;                                  // diagnostics: the keys only
       for (int j = 0; j < cnt; j += 8) {
         uint32_t h[8], wd[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) h[u] = j + u < cnt ? list[(j + u) * 256] : 0u;
+        for (int u = 0; u < 8; ++u) h[u] = j + u < cnt ? fs_share_finish(list[(j + u) * 256]) : 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
 #pragma unroll

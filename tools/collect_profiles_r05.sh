@@ -87,6 +87,11 @@ if [ "$part" = part2 ]; then
   prof_stats ${R}_clustered $ROOTDIR/tools/near_bench.py --window 6 --table clustered --rounds 2 "FS_NEAR_FUSED=1"
   echo "== a table shaped like a real one (unnormalised, three scales, OOV names)"
   run ${R}_realistic.log tools/realistic_bench.py --works 2000
+  FS_LSH_SHARE=3 run ${R}_realistic_gate_in_front_of_the_key_scan.log tools/realistic_bench.py --works 2000
+  FS_LSH_SHARE=0 run ${R}_realistic_key_scan_only.log tools/realistic_bench.py --works 2000
+  for d in 4 10 6 5 7; do FS_LSH_DIAG=$d run ${R}_realistic_share_scan_diag$d.log tools/realistic_bench.py --works 2000 --oov 0.0; done
+  prof_stats ${R}_realistic $ROOTDIR/tools/realistic_bench.py --works 2000
+  run ${R}_stress_share.log tools/stress_share.py --cases 60
   echo "== stress cross-checks"
   run ${R}_stress_lsh.log tools/stress_lsh.py --cases 48
   run ${R}_stress_rows.log tools/stress_rows.py
