@@ -271,7 +271,7 @@ struct fs_index {
   DBuf<uint32_t> d_sharef;   // the script windows' subset keys (fs_hash.h), a blocked Bloom filter
   int log2_sharef = 0;
   DBuf<uint32_t> d_smap;     // ... as an exact map (k_share_enum): 2^log2_smap buckets of four {key, list + 1}
-  DBuf<uint32_t> d_slists;   // a key's script windows behind their number (the map names the first of them)
+  DBuf<uint32_t> d_slists;   // a key's script windows behind their number, four words each: {window, signature word, 0} (the map names the first of them)
   int log2_smap = 0;
   DBuf<uint32_t> d_oovmap;   // the script's out-of-vocabulary vectors for share_comp: 2^log2_oovmap {key, component + 1}
   int log2_oovmap = 0;

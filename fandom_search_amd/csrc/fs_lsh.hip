@@ -97,7 +97,8 @@ struct LshDev {
   const uint64_t* ssig;    // [W] the script windows' component signatures (share_pair_possible)
   const uint32_t* sharef;  // 2^log2_sharef filter words
   const uint2* smap;       // the same keys as an exact map: 2^log2_smap buckets of four {key, list + 1} (k_share_enum)
-  const uint32_t* slists;  // the lists of the map: a list's length, then its script windows (the map names the first of those)
+  const uint4* slists;     // the lists of the map: a list's length (.x), then its script windows with their signature words
+                           // {window, word's low half, high half, 0} (the map names the first of those)
   int log2_smap;
   int log2_sharef, share_flags;
   const uint2* oovmap;     // the script's out-of-vocabulary vectors (share_comp): 2^log2_oovmap {key, component}, or nullptr
@@ -919,10 +920,9 @@ __device__ __forceinline__ bool share_gate(const LshDev& L, const uint32_t* cmp,
 // window's n of them are one 64-bit word: slots whose signatures differ lie in different components,
 // slots whose signatures agree count as agreeing.
 template <int N>                  // (N = 0: the window size at run time)
-__device__ __forceinline__ bool share_pair_possible(const LshDev& L, uint32_t s, const uint32_t* sg,
+__device__ __forceinline__ bool share_pair_possible(const LshDev& L, uint32_t s, uint64_t ssig, const uint32_t* sg,
                                                     const double* qd, double ff) {
   const int n = N ? N : L.n;
-  const uint64_t ssig = L.ssig[s];
   const int b = fs_share_sig_bits(n);
   double af = 0.0;
   uint32_t dm = 0;
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
   __shared__ uint32_t s_keys[kEnumCap * 256];      // stage 1; stage 3: the entries' offsets (s_wpref)
   __shared__ uint32_t s_hit[kEnumWork], s_wstart[kEnumWork], s_wmeta[kEnumWork];
   __shared__ uint8_t s_found[256];
-  __shared__ uint32_t s_w[4], s_nwork;
+  __shared__ uint32_t s_w[4], s_nwork, s_ndist;
   uint32_t* s_wpref = s_keys;                      // [kEnumWork + 1]
   static_assert(kEnumWork + 1 <= kEnumCap * 256 && kEnumWork == 2 * 256, "the offsets take the keys' place; two entries per thread");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       s_sg[i] = cm >= FS_WILD ? cm : fs_share_sig(cm, N);
       s_qd[i] = q_of(L, id);
     }
-    if (threadIdx.x == 0) s_nwork = 0;
+    if (threadIdx.x == 0) { s_nwork = 0; s_ndist = 0; }
     s_found[threadIdx.x] = 0;
     __syncthreads();
     // stage 1
@@ -1068,7 +1068,7 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
           const uint32_t key[4] = {a.x, a.z, b.x, b.z}, val[4] = {a.y, a.w, b.y, b.w};
           for (int e = 0; e < 4; ++e) {
             if (!val[e] || key[e] != h) continue;
-            const uint32_t len = L.slists[val[e] - 1];             // a list: its length, then its script windows
+            const uint32_t len = L.slists[val[e] - 1].x;           // a list: its length, then its script windows
             const uint32_t at = atomicAdd(&s_nwork, 1u);
             if (at < (uint32_t)kEnumWork && len < (1u << 24)) {
               s_wstart[at] = val[e];
@@ -1110,12 +1110,30 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       }
       const uint32_t t = s_wmeta[lo] >> 24;
       if (s_found[t]) continue;                                   // the window has its answer already
-      const uint32_t sw = L.slists[s_wstart[lo] + (j - s_wpref[lo])];
+      // (a list's entry: the script window and its signature word, one 16-byte load)
+      const uint4 it = L.slists[s_wstart[lo] + (j - s_wpref[lo])];
       const double pff = s_ff[t];
-      double d;
-      if (share_pair_possible<N>(L, sw, s_sg + t, s_qd + t, pff) && L.diag != 7 &&                     // (diagnostics 7: no distances)
-          window_distance_flat<N>(L, sw, s_tok + t, s_qd + t, pff, __dsqrt_rn(pff), &d) && d < L.thr)
-        s_found[t] = 1;
+      if (!share_pair_possible<N>(L, it.x, (uint64_t)it.z << 32 | it.y, s_sg + t, s_qd + t, pff) || L.diag == 7) continue;   // (diagnostics 7: no distances)
+      // what is left needs the distance: all of the sub-tile's at once behind the loop (a distance
+      // inside it holds the thread's wave for four more levels of loads in every pass)
+      const uint32_t at = atomicAdd(&s_ndist, 1u);
+      if (at < (uint32_t)kEnumWork) {
+        s_hit[at] = t << 24 | it.x;                               // (s_hit is free since stage 2; script windows < 2^24: 2^18 at most)
+      } else {
+        double d;
+        if (window_distance_flat<N>(L, it.x, s_tok + t, s_qd + t, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_found[t] = 1;
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t nd = s_ndist < (uint32_t)kEnumWork ? s_ndist : (uint32_t)kEnumWork;
+      for (uint32_t x = threadIdx.x; x < nd; x += 256) {
+        const uint32_t t = s_hit[x] >> 24, sw = s_hit[x] & 0xFFFFFFu;
+        if (s_found[t]) continue;
+        const double pff = s_ff[t];
+        double d;
+        if (window_distance_flat<N>(L, sw, s_tok + t, s_qd + t, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_found[t] = 1;
+      }
     }
     __syncthreads();
     // thread (wave j, lane l) reports window 4 l + j, as k_lsh_scan does: wave j's ballot is bitmap
@@ -1361,7 +1379,7 @@ __global__ __launch_bounds__(256) void k_lsh_scan(CorpusDev c, LshDev L, const u
         const uint32_t sidx = L.bids[(size_t)ph * L.W + s_key[lo] + (j - s_pref[lo])];
         if (L.diag == 3) continue;               // diagnostics: bucket walk only
         const double pff = s_ff[pw];
-        if (pair_test && !share_pair_possible<0>(L, sidx, s_cmp2 + pw, s_qd2 + pw, pff)) continue;
+        if (pair_test && !share_pair_possible<0>(L, sidx, L.ssig[sidx], s_cmp2 + pw, s_qd2 + pw, pff)) continue;
         double d;
         if (window_distance(L, sidx, s_tok + pw, nullptr, pff, __dsqrt_rn(pff), &d) && d < L.thr) s_flag[pw] = 1;
       }
@@ -2895,7 +2913,7 @@ static LshDev lsh_dev(const fs_index* ix) {
     L.compa = ix->d_compa.p; L.ssig = ix->d_ssig.p; L.sharef = ix->d_sharef.p;
     L.log2_sharef = ix->log2_sharef; L.share_flags = ix->share_flags;
     if (ix->log2_oovmap) { L.oovmap = reinterpret_cast<const uint2*>(ix->d_oovmap.p); L.log2_oovmap = ix->log2_oovmap; }
-    L.smap = reinterpret_cast<const uint2*>(ix->d_smap.p); L.slists = ix->d_slists.p; L.log2_smap = ix->log2_smap;
+    L.smap = reinterpret_cast<const uint2*>(ix->d_smap.p); L.slists = reinterpret_cast<const uint4*>(ix->d_slists.p); L.log2_smap = ix->log2_smap;
     L.share_gamma = ix->share_gamma;
     L.share_tau = 1.0 - ix->cfg.distance_threshold - 1e-6;
     L.share_phi = (1.0 - L.share_tau * L.share_tau) / (1.0 - L.share_gamma * L.share_gamma);
@@ -3255,8 +3273,8 @@ static int fs_build_share(fs_index* ix) {
       ix->log2_oovmap = lo;
     }
   }
+  std::vector<uint64_t> sig(W, 0);
   {
-    std::vector<uint64_t> sig(W, 0);
     const int b = fs_share_sig_bits(n);
     for (uint64_t w = 0; w < W; ++w)
       for (int k = 0; k < n; ++k) sig[w] |= (uint64_t)fs_share_sig(sc[w + k], n) << (k * b);
@@ -3312,17 +3330,21 @@ static int fs_build_share(fs_index* ix) {
       for (size_t i = 0; i < ent.size(); ++i) distinct += i == 0 || (ent[i] >> 32) != (ent[i - 1] >> 32);
       int lm = 8;                                  // two buckets per key: a full one (four entries) is rare
       while (lm < 26 && ((uint64_t)1 << lm) < 2 * distinct) ++lm;
-      std::vector<uint32_t> smap((size_t)8 << lm, 0u), lists;
+      std::vector<uint32_t> smap((size_t)8 << lm, 0u);
+      std::vector<uint4> lists;
       lists.reserve(ent.size() + distinct + 1);
-      lists.push_back(0);                          // (a list is named by the index of its first script window: never 0)
+      lists.push_back(make_uint4(0, 0, 0, 0));      // (a list is named by the index of its first script window: never 0)
       const uint32_t bmask = (1u << lm) - 1;
       for (size_t i = 0; i < ent.size();) {
         const uint32_t h = (uint32_t)(ent[i] >> 32);
         size_t e1 = i;
         while (e1 < ent.size() && (uint32_t)(ent[e1] >> 32) == h) ++e1;
-        lists.push_back((uint32_t)(e1 - i));       // its length, then its script windows
+        lists.push_back(make_uint4((uint32_t)(e1 - i), 0, 0, 0));       // its length, then its script windows
         const uint32_t first = (uint32_t)lists.size();
-        for (size_t x = i; x < e1; ++x) lists.push_back((uint32_t)ent[x]);
+        for (size_t x = i; x < e1; ++x) {
+          const uint32_t w = (uint32_t)ent[x];
+          lists.push_back(make_uint4(w, (uint32_t)sig[w], (uint32_t)(sig[w] >> 32), 0));
+        }
         uint32_t bkt = fs_wmap_slot(h, lm);
         for (;;) {
           uint32_t* e = smap.data() + 8 * (size_t)bkt;
@@ -3334,7 +3356,7 @@ static int fs_build_share(fs_index* ix) {
         i = e1;
       }
       FS_TRY(ix->d_smap.upload(smap.data(), smap.size(), s));
-      FS_TRY(ix->d_slists.upload(lists.data(), lists.size(), s));
+      FS_TRY(ix->d_slists.upload(reinterpret_cast<const uint32_t*>(lists.data()), lists.size() * 4, s));
       ix->log2_smap = lm;
     }
   }
