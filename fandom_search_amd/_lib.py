@@ -23,7 +23,7 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_reuse_histogram", "fs_reuse_histogram_rows",
            "fs_search_corpus_begin", "fs_search_corpus_end", "fs_index_set_scan_timing",
            "fs_index_reload_switches", "fs_search_kernel_name", "fs_debug_stamps",
-           "fs_search_profile", "fs_index_component_sizes", "fs_index_share_info", "fs_stream_floor",
+           "fs_search_profile", "fs_index_component_sizes", "fs_index_share_info", "fs_index_share_counts", "fs_stream_floor",
            "fs_textenc_create", "fs_textenc_destroy", "fs_textenc_add", "fs_textenc_encode_files")
 
 
@@ -161,6 +161,9 @@ def load():
     if hasattr(L, "fs_stream_floor"):
         L.fs_stream_floor.restype = C.c_int
         L.fs_stream_floor.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
+    if hasattr(L, "fs_index_share_counts"):
+        L.fs_index_share_counts.restype = C.c_int
+        L.fs_index_share_counts.argtypes = [C.c_void_p, u64p]
     if hasattr(L, "fs_index_share_info"):
         L.fs_index_share_info.restype = C.c_int
         L.fs_index_share_info.argtypes = [C.c_void_p, u32p, u32p, u32p, C.POINTER(C.c_double)]

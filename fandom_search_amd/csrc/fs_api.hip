@@ -540,7 +540,7 @@ extern "C" int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uin
                                         uint32_t* in_use) {
   if (!ix || !n) return FS_E_INVALID;
   *n = ix->comp_sizes.size();
-  if (in_use) *in_use = ix->syn_ok ? 1u : 0u;
+  if (in_use) *in_use = (ix->syn_ok || ix->share_flags) ? 1u : 0u;
   if (sizes)
     for (uint64_t i = 0; i < cap && i < ix->comp_sizes.size(); ++i) sizes[i] = ix->comp_sizes[i];
   return FS_OK;
@@ -553,6 +553,17 @@ extern "C" int fs_index_share_info(const fs_index* ix, uint32_t* flags, uint32_t
   if (components) *components = ix->share_comps;
   if (largest) *largest = ix->share_largest;
   if (gamma) *gamma = ix->share_gamma;
+  return FS_OK;
+}
+
+extern "C" int fs_index_share_counts(fs_index* ix, uint64_t* out8) {
+  if (!ix || !out8) return FS_E_INVALID;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  if (ix->d_share_cnt.n < 16) return FS_OK;
+  FS_ENTER(ix->device);
+  FS_HIP(hipDeviceSynchronize());
+  FS_HIP(hipMemcpy(out8, ix->d_share_cnt.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  FS_HIP(hipMemset(ix->d_share_cnt.p, 0, 8 * sizeof(uint64_t)));
   return FS_OK;
 }
 

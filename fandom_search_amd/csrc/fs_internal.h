@@ -275,6 +275,7 @@ struct fs_index {
   int log2_smap = 0;
   DBuf<uint32_t> d_oovmap;   // the script's out-of-vocabulary vectors for share_comp: 2^log2_oovmap {key, component + 1}
   int log2_oovmap = 0;
+  DBuf<uint32_t> d_share_cnt; // diagnostics (FS_SHARE_COUNT=1): eight 64-bit counters of k_share_scan
   int share_flags = 0;       // 0: the share rule is not in use; else sw.lsh_share's bits (bit 3 also set when the table does not prove out-of-vocabulary tokens far)
   double share_gamma = 0.0;
   uint32_t share_comps = 0, share_largest = 0;

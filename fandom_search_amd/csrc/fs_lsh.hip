@@ -101,6 +101,7 @@ struct LshDev {
                            // {window, word's low half, high half, 0} (the map names the first of those)
   int log2_smap;
   int log2_sharef, share_flags;
+  unsigned long long* share_cnt;   // diagnostics (FS_SHARE_COUNT=1): k_share_scan's counters, or nullptr
   const uint2* oovmap;     // the script's out-of-vocabulary vectors (share_comp): 2^log2_oovmap {key, component}, or nullptr
   int log2_oovmap;
   float share_lim;         // <= 1 - phi: the share of a window's squared norm its near slots must hold
@@ -1054,6 +1055,15 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
         else flag = true;                                         // (no room: the window goes on as it is)
       }
       if (flag) s_found[threadIdx.x] = 1;
+      if (L.share_cnt) {                                          // diagnostics: what passes what (fs_index_share_counts)
+        const bool in = p0 + threadIdx.x + N <= c.n_tok;
+        const uint64_t b0 = __ballot(in), b1 = __ballot(hc > 0), b2 = __ballot(flag);
+        if (lane == 0) {
+          atomicAdd(L.share_cnt + 0, (unsigned long long)__popcll(b0));
+          atomicAdd(L.share_cnt + 1, (unsigned long long)__popcll(b1));
+          atomicAdd(L.share_cnt + 6, (unsigned long long)__popcll(b2));
+        }
+      }
       __syncthreads();
       // stage 2
       const uint32_t bmask = (1u << L.log2_smap) - 1u;
@@ -1100,7 +1110,10 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       if (e < n_work) s_wpref[e] = at;
       at += mine[u];
     }
-    if (threadIdx.x == 0) s_wpref[n_work] = pairs;
+    if (threadIdx.x == 0) {
+      s_wpref[n_work] = pairs;
+      if (L.share_cnt) { atomicAdd(L.share_cnt + 2, (unsigned long long)n_work); atomicAdd(L.share_cnt + 3, (unsigned long long)pairs); }
+    }
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < pairs && L.diag != 5; j += 256) {                            // (diagnostics 5: no pairs)
       uint32_t lo = 0, hi = n_work;                               // s_wpref[lo] <= j < s_wpref[hi]
@@ -1144,7 +1157,13 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       s_w[wave] = __popcll(b);
     }
     __syncthreads();
-    if (threadIdx.x == 0) qcnt[sub] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    if (threadIdx.x == 0) {
+      qcnt[sub] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+      if (L.share_cnt) {
+        atomicAdd(L.share_cnt + 4, (unsigned long long)s_ndist);
+        atomicAdd(L.share_cnt + 5, (unsigned long long)(s_w[0] + s_w[1] + s_w[2] + s_w[3]));
+      }
+    }
     __syncthreads();
   }
 }
@@ -2907,11 +2926,12 @@ static LshDev lsh_dev(const fs_index* ix) {
   L.ss = ix->d_ss.p; L.sw = ix->d_sw.p; L.q = ix->d_q.p; L.emb = ix->d_emb.p; L.stok = ix->d_stok.p;
   L.gtab = ix->d_gtab.n > 1 ? ix->d_gtab.p : nullptr; L.sidx = ix->d_sidx.p;
   L.spos = ix->d_spos.n > 1 ? ix->d_spos.p : nullptr;
-  L.oovmap = nullptr; L.log2_oovmap = 0; L.compa = nullptr; L.ssig = nullptr; L.sharef = nullptr; L.smap = nullptr; L.slists = nullptr; L.log2_smap = 0; L.log2_sharef = 0; L.share_flags = 0;
+  L.share_cnt = nullptr; L.oovmap = nullptr; L.log2_oovmap = 0; L.compa = nullptr; L.ssig = nullptr; L.sharef = nullptr; L.smap = nullptr; L.slists = nullptr; L.log2_smap = 0; L.log2_sharef = 0; L.share_flags = 0;
   L.share_lim = 0.0f; L.share_scale = 0.0; L.share_phi = 1.0; L.share_tau = 0.0; L.share_gamma = 1.0;
   if (ix->share_flags) {
     L.compa = ix->d_compa.p; L.ssig = ix->d_ssig.p; L.sharef = ix->d_sharef.p;
     L.log2_sharef = ix->log2_sharef; L.share_flags = ix->share_flags;
+    if (ix->d_share_cnt.n > 1) L.share_cnt = reinterpret_cast<unsigned long long*>(ix->d_share_cnt.p);
     if (ix->log2_oovmap) { L.oovmap = reinterpret_cast<const uint2*>(ix->d_oovmap.p); L.log2_oovmap = ix->log2_oovmap; }
     L.smap = reinterpret_cast<const uint2*>(ix->d_smap.p); L.slists = reinterpret_cast<const uint4*>(ix->d_slists.p); L.log2_smap = ix->log2_smap;
     L.share_gamma = ix->share_gamma;
@@ -3205,6 +3225,7 @@ static int fs_build_share(fs_index* ix) {
       ++size[comp[v]];
     }
   }
+  ix->comp_sizes = size;                            // (fs_index_component_sizes: the angular relation's, where the rule is built)
   ix->share_comps = (uint32_t)size.size();
   ix->share_largest = *std::max_element(size.begin(), size.end());
   int flags = ix->sw.lsh_share & 47;
@@ -3359,6 +3380,10 @@ static int fs_build_share(fs_index* ix) {
       FS_TRY(ix->d_slists.upload(reinterpret_cast<const uint32_t*>(lists.data()), lists.size() * 4, s));
       ix->log2_smap = lm;
     }
+  }
+  if (getenv("FS_SHARE_COUNT")) {
+    FS_TRY(ix->d_share_cnt.reserve(16));
+    FS_HIP(hipMemsetAsync(ix->d_share_cnt.p, 0, 16 * sizeof(uint32_t), s));
   }
   FS_HIP(hipStreamSynchronize(s));
   ix->share_gamma = gamma;

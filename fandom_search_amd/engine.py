@@ -270,6 +270,15 @@ class ScriptIndex(object):
                    "fs_index_share_info")
         return {"flags": f.value, "components": n.value, "largest": m.value, "gamma": g.value}
 
+    def share_counts(self):
+        """Diagnostics (FS_SHARE_COUNT=1 when the index was built): what passed what in k_share_scan
+        since the last call -- fs_index_share_counts."""
+        out = (C.c_uint64 * 8)()
+        _lib.check(_lib.load().fs_index_share_counts(self._h, out), "fs_index_share_counts")
+        names = ("windows", "windows_with_a_key_in_the_filter", "map_entries", "pairs_tested", "distances",
+                 "windows_flagged", "windows_flagged_as_they_are")
+        return {k: int(out[i]) for i, k in enumerate(names)}
+
     def profile(self, corpus, rows_ptr, cap):
         """Diagnostics: one search of `corpus` (records to the device buffer at `rows_ptr`)
         with a HIP event behind each of its kernels; returns [(kernel name, ms), ...] in

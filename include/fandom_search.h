@@ -288,7 +288,9 @@ int fs_textenc_encode_files(fs_textenc* enc, const char* paths /* n_files string
  * of "near" vector pairs that the integer prefilters of the LSH pipeline work over (0 entries:
  * the graph was not built: the exact pipeline, or a proof that fails by one slot only).
  * *in_use = 1 when the prefilters run over component ids, 0 when the components were judged
- * too coarse (one holds an eighth of the table) and searches take the plain LSH pipeline. */
+ * too coarse (one holds an eighth of the table) and searches take the plain LSH pipeline.  On an
+ * index that uses the share rule (fs_index_share_info) the components are those of its angular
+ * relation, and *in_use = 1. */
 int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uint64_t cap, uint64_t* n,
                              uint32_t* in_use);
 
@@ -299,6 +301,13 @@ int fs_index_component_sizes(const fs_index* ix, uint32_t* sizes, uint64_t cap, 
  * components of the relation "cosine > *gamma" over the table. */
 int fs_index_share_info(const fs_index* ix, uint32_t* flags, uint32_t* components, uint32_t* largest,
                         double* gamma);
+
+/* Diagnostics: with FS_SHARE_COUNT=1 in the environment when the index is built, k_share_scan counts
+ * what passes what; this reads the eight counters and sets them to zero: windows, windows with a
+ * key in the filter, (window, key) entries of the map, (window, script window) pairs through the
+ * pairs' test, pairs whose distance was computed, windows flagged, windows flagged as they are (no
+ * constraint, or no room), 0.  All zero when the counters are off or the rule is not in use. */
+int fs_index_share_counts(fs_index* ix, uint64_t* out8);
 
 /* Diagnostics: one synchronous search of `c` (arguments as fs_search_corpus) with a HIP event
  * behind every kernel of it.  names: the kernels' names in launch order, '\n'-separated;

@@ -58,6 +58,26 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
         prof = ix.profile(c, buf.data_ptr(), cap)
     out["kernels_us"] = [[k, round(ms * 1e3, 1)] for k, ms in prof]
     out["share_rule"] = ix.share_info()
+    if out["share_rule"]["flags"] & 32:
+        # what passes what, from an index of its own that counts (the counters cost a few atomic
+        # additions per sub-tile: not on the timed index)
+        os.environ["FS_SHARE_COUNT"] = "1"
+        ixc = ScriptIndex(script, swords, emb, synth.lsh_normals(window), cfg=abi.make_config(window_size=window))
+        del os.environ["FS_SHARE_COUNT"]
+        cc = ixc.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+        ixc.search(cc)
+        ixc.share_counts()
+        ixc.search(cc, reuse=True)
+        n = ixc.share_counts()
+        w = max(n["windows"], 1)
+        out["share_rule"]["one_search"] = n
+        out["share_rule"]["shares"] = {
+            "windows_with_a_key_in_the_filter": n["windows_with_a_key_in_the_filter"] / w,
+            "windows_flagged": n["windows_flagged"] / w,
+            "windows_flagged_as_they_are (fallback)": n["windows_flagged_as_they_are"] / w,
+            "pairs_tested_per_window": n["pairs_tested"] / w, "distances_per_window": n["distances"] / w}
+        cc.close()
+        ixc.close()
     sizes, used = ix.component_sizes()
     if not len(sizes):
         out["components"] = {"count": 0, "in_use": False,
@@ -67,6 +87,8 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
     if len(sizes):
         edges = [1, 2, 3, 5, 9, 17, 65, 257, 1025, 1 << 30]
         out["components"] = {"count": int(len(sizes)), "largest": int(sizes.max()), "in_use": used,
+                             "relation": "cosine > %.2f (the share rule)" % out["share_rule"]["gamma"]
+                                         if out["share_rule"]["flags"] else "near pairs of section 4",
                              "histogram": {"%d-%d" % (lo, hi - 1) if hi < (1 << 30) else "%d+" % lo:
                                            int(((sizes >= lo) & (sizes < hi)).sum())
                                            for lo, hi in zip(edges[:-1], edges[1:])},
