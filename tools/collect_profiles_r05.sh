@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (gpurun): the measurements behind DESIGN.md section 8 for round 5, each into
-# gpurun_out/r05/ under the name it keeps in profiles/.  Usage: tools/collect_profiles_r05.sh part1|part2
+# gpurun_out/r05/ under the name it keeps in profiles/.  Usage: tools/collect_profiles_r05.sh part1|part2|realistic_stats
 # (tools/collect_profiles.sh is round 4's; the helpers are the same).  Every artifact carries the
 # hash of the sources it was measured on (fandom_search_amd._lib.source_hash).
 set -eu -o pipefail
@@ -73,6 +73,10 @@ if [ "$part" = part1 ]; then
   ls -la $OUT
 fi
 
+if [ "$part" = realistic_stats ]; then
+  prof_stats ${R}_realistic $ROOTDIR/tools/realistic_bench.py --works 2000 --no-counts
+fi
+
 if [ "$part" = part2 ]; then
   echo "== configs[3]: n = 4, 8, 10 -- bench line, kernel stats, the chain of round 4 beside the fused front end"
   for n in 4 8 10; do
@@ -90,7 +94,7 @@ if [ "$part" = part2 ]; then
   FS_LSH_SHARE=3 run ${R}_realistic_gate_in_front_of_the_key_scan.log tools/realistic_bench.py --works 2000
   FS_LSH_SHARE=0 run ${R}_realistic_key_scan_only.log tools/realistic_bench.py --works 2000
   for d in 4 10 6 5 7; do FS_LSH_DIAG=$d run ${R}_realistic_share_scan_diag$d.log tools/realistic_bench.py --works 2000 --oov 0.0; done
-  prof_stats ${R}_realistic $ROOTDIR/tools/realistic_bench.py --works 2000
+  prof_stats ${R}_realistic $ROOTDIR/tools/realistic_bench.py --works 2000 --no-counts
   run ${R}_stress_share.log tools/stress_share.py --cases 60
   echo "== stress cross-checks"
   run ${R}_stress_lsh.log tools/stress_lsh.py --cases 48

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, window=6, reps=3, companion=None):
+def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, window=6, reps=3, companion=None, counts=True):
     """companion: called with (index, corpus, works, tokens in the corpus) before they are closed; the dict it
     returns is merged into the result (bench.py measures the search with others in flight through it)."""
     from fandom_search_amd import abi, synth
@@ -58,7 +58,7 @@ def run(works=2000, rows=20000, oov=0.08, tokens=2000, script_tokens=20000, wind
         prof = ix.profile(c, buf.data_ptr(), cap)
     out["kernels_us"] = [[k, round(ms * 1e3, 1)] for k, ms in prof]
     out["share_rule"] = ix.share_info()
-    if out["share_rule"]["flags"] & 32:
+    if out["share_rule"]["flags"] & 32 and counts:
         # what passes what, from an index of its own that counts (the counters cost a few atomic
         # additions per sub-tile: not on the timed index)
         os.environ["FS_SHARE_COUNT"] = "1"
@@ -105,6 +105,7 @@ if __name__ == "__main__":
     ap.add_argument("--works", type=int, default=2000)
     ap.add_argument("--rows", type=int, default=20000)
     ap.add_argument("--oov", type=float, default=0.08)
+    ap.add_argument("--no-counts", action="store_true", help="no second index that counts what passes what (under a profiler)")
     a = ap.parse_args()
     for oov in (a.oov, 0.0):
-        print(json.dumps(run(a.works, a.rows, oov)), flush=True)
+        print(json.dumps(run(a.works, a.rows, oov, counts=not a.no_counts)), flush=True)
