@@ -23,8 +23,10 @@
 
 #if defined(__HIPCC__)
 #define FS_HD __host__ __device__ __forceinline__
+#define FS_HDC __host__ __device__ constexpr
 #else
 #define FS_HD static inline
+#define FS_HDC static constexpr
 #endif
 
 #define FS_TOKEN_MUL24 0x9E3779u
@@ -183,3 +185,14 @@ FS_HD uint32_t fs_share_key(uint32_t fold, uint32_t mask) { return fs_share_fini
 // ... and the few bits of a component id the pairs' test compares: n of them in a 64-bit word
 FS_HD int fs_share_sig_bits(int n) { return 64 / n > 10 ? 10 : 64 / n; }
 FS_HD uint32_t fs_share_sig(uint32_t comp, int n) { return (fs_mix24(comp) >> 7) & ((1u << fs_share_sig_bits(n)) - 1u); }
+// Windows of more than six slots take the share rule block by block (fs_lsh.hip): the slots in two or
+// three runs of at most five, the subsets and their keys inside a run.  Run r of a window of n slots
+// starts at fs_share_block_start(n, r) (r = fs_share_blocks(n): the window's end).
+FS_HDC int fs_share_blocks(int n) { return n <= 6 ? 1 : n <= 10 ? 2 : 3; }
+FS_HDC int fs_share_block_start(int n, int r) {
+  const int b = fs_share_blocks(n);
+  if (r <= 0) return 0;
+  if (r >= b) return n;
+  // the longer runs first: 7 = 4 + 3, 9 = 5 + 4, 11 = 4 + 4 + 3
+  return b == 2 ? (n + 1) / 2 : (r == 1 ? (n + 2) / 3 : (n + 2) / 3 + (n + 1) / 3);
+}

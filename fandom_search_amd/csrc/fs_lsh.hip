@@ -849,15 +849,15 @@ __device__ __forceinline__ uint32_t share_comp(const LshDev& L, uint32_t id) {
 // The keys a fan window asks for (its minimal heavy subsets; all heavy ones under share_flags bit 2),
 // into list[j * 256]: their number, or -1 when the window is not constrained (the rule says nothing
 // about it, or the list is too short for its keys).
-// (the subsets of the slots depth first: a subset's sum, minimum and fold are its parent's and one
+// (the subsets of the slots K .. KEND - 1 depth first: a subset's sum, minimum and fold are its parent's and one
 // operation each; the keys leave as fs_share_raw -- whoever reads the list finishes them, once
 // per key asked for instead of once per subset)
-template <int N, int K, uint32_t M>
+template <int N, int K, int KEND, uint32_t M>
 struct ShareSubsets {
   static __device__ __forceinline__ void go(const uint32_t (&qi)[N], const uint32_t (&t)[N], uint32_t usable, int thr,
                                             bool every, uint32_t sum, uint32_t mn, uint32_t fold, uint32_t* list,
                                             int cap, int& cnt) {
-    if constexpr (K == N) {
+    if constexpr (K == KEND) {
       if constexpr (M != 0u) {
         const bool ask = (M & ~usable) == 0u && (int)sum >= thr && (every || (int)(sum - mn) < thr);
         if (ask) {
@@ -866,35 +866,53 @@ struct ShareSubsets {
         }
       }
     } else {
-      ShareSubsets<N, K + 1, M>::go(qi, t, usable, thr, every, sum, mn, fold, list, cap, cnt);
-      ShareSubsets<N, K + 1, (M | (1u << K))>::go(qi, t, usable, thr, every, sum + qi[K], qi[K] < mn ? qi[K] : mn,
-                                                  fold ^ t[K], list, cap, cnt);
+      ShareSubsets<N, K + 1, KEND, M>::go(qi, t, usable, thr, every, sum, mn, fold, list, cap, cnt);
+      ShareSubsets<N, K + 1, KEND, (M | (1u << K))>::go(qi, t, usable, thr, every, sum + qi[K],
+                                                        qi[K] < mn ? qi[K] : mn, fold ^ t[K], list, cap, cnt);
     }
   }
 };
 
+// Windows of more than six slots, run by run (fs_share_blocks): the agreeing slots of a pair within
+// the threshold hold more than `lim` of the fan window's squared norm, so in at least one run they
+// hold more than `lim` of *that run's* -- the run's minimal subsets that do are asked for, with
+// the slots' own numbers in the key.  (A run the rule says nothing about -- all of it slots that
+// agree with anything -- leaves the window unconstrained.)
+template <int N, int R>
+__device__ __forceinline__ bool share_asks_run(const LshDev& L, const uint32_t (&qi)[N], const uint32_t (&t)[N],
+                                               const uint32_t (&wild)[N], uint32_t usable, bool every, uint32_t* list,
+                                               int cap, int& cnt) {
+  constexpr int K0 = fs_share_block_start(N, R), K1 = fs_share_block_start(N, R + 1);
+  uint32_t all = 0, base = 0;
+#pragma unroll
+  for (int k = K0; k < K1; ++k) { all += qi[k]; base += wild[k]; }
+  // heavy(M): sum_M qi >= thr.  (With x = q * scale real and qi = floor(x): a truly heavy M has
+  // sum_M x >= lim sum x - sum_O x, so sum_M qi > lim * all - base - (K1 - K0).)
+  const int thr = (int)floorf(L.share_lim * (float)all) - (int)base - (K1 - K0) - 2;
+  if (thr <= 0) return false;
+  ShareSubsets<N, K0, K1, 0u>::go(qi, t, usable, thr, every, 0u, 0xFFFFFFFFu, 0u, list, cap, cnt);
+  return true;
+}
+
 template <int N>
 __device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, const double* qd,
                                           uint32_t* list, int cap) {
-  uint32_t qi[N], t[N];
-  uint32_t all = 0, base = 0, usable = 0;
+  uint32_t qi[N], t[N], wild[N];
+  uint32_t usable = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     qi[k] = (uint32_t)(qd[k] * L.share_scale);
-    all += qi[k];
     const uint32_t c = cmp[k];
     t[k] = 0;
-    if (c == FS_WILD) base += qi[k] + 1;
-    else if (c != FS_NONE) { usable |= 1u << k; t[k] = fs_share_term(c, k); }
+    wild[k] = c == FS_WILD ? qi[k] + 1 : 0u;
+    if (c < FS_WILD) { usable |= 1u << k; t[k] = fs_share_term(c, k); }
   }
-  // heavy(M): sum_M qi >= thr.  (With x = q * scale real and qi = floor(x): a truly heavy M has
-  // sum_M x >= lim sum x - sum_O x, so sum_M qi > lim * all - base - N.)
-  const int thr = (int)floorf(L.share_lim * (float)all) - (int)base - N - 2;
-  if (thr <= 0) return -1;
   const bool every = (L.share_flags & 4) != 0;
   int cnt = 0;
-  ShareSubsets<N, 0, 0u>::go(qi, t, usable, thr, every, 0u, 0xFFFFFFFFu, 0u, list, cap, cnt);
-  return cnt > cap ? -1 : cnt;
+  bool ok = share_asks_run<N, 0>(L, qi, t, wild, usable, every, list, cap, cnt);
+  if constexpr (fs_share_blocks(N) > 1) ok = ok && share_asks_run<N, 1>(L, qi, t, wild, usable, every, list, cap, cnt);
+  if constexpr (fs_share_blocks(N) > 2) ok = ok && share_asks_run<N, 2>(L, qi, t, wild, usable, every, list, cap, cnt);
+  return !ok || cnt > cap ? -1 : cnt;
 }
 
 template <int N>
@@ -3234,8 +3252,12 @@ static int fs_build_share(fs_index* ix) {
     flags |= 8;
   }
   if ((flags & 8) || ix->script_oov) flags &= ~4;  // (a slot that agrees with anything has no share on the script's side)
-  if (n > 6) flags &= ~1;
-  if ((flags & 35) != 35 || W * (((uint64_t)1 << n) - 1) > ((uint64_t)1 << 25)) flags &= ~32;   // (the enumeration needs the gate and the pairs' test)
+  if (n > FS_MAX_WINDOW || n > 12) flags &= ~1;
+  if (n > 6) flags &= ~4;                          // (run by run: the fan window's side only)
+  uint64_t n_masks_all = 0;                        // subsets per script window, over its runs (fs_share_blocks)
+  for (int r = 0; r < fs_share_blocks(n); ++r)
+    n_masks_all += ((uint64_t)1 << (fs_share_block_start(n, r + 1) - fs_share_block_start(n, r))) - 1;
+  if ((flags & 35) != 35 || W * n_masks_all > ((uint64_t)1 << 25)) flags &= ~32;   // (the enumeration needs the gate and the pairs' test)
   if (flags & 32) flags &= ~4;                     // (... and every subset of every script window in the filter)
   if (!(flags & 3)) return FS_OK;
   FS_TRY(ix->d_compa.upload(comp.data(), comp.size(), s));
@@ -3305,29 +3327,32 @@ static int fs_build_share(fs_index* ix) {
     std::vector<double> q(V);
     FS_HIP(hipMemcpyAsync(q.data(), ix->d_q.p, V * sizeof(double), hipMemcpyDeviceToHost, s));
     FS_HIP(hipStreamSynchronize(s));
-    const uint32_t n_masks = (1u << n) - 1;
-    const uint64_t keys = W * (uint64_t)n_masks / ((flags & 4) ? 3 : 1);
+    const uint64_t keys = W * n_masks_all / ((flags & 4) ? 3 : 1);
     int lw = 10;
     while (lw < 26 && ((uint64_t)1 << lw) * 4 < keys * 3) ++lw;    // about 24 filter bits per key and more
     std::vector<uint32_t> f((size_t)1 << lw, 0u);
     const double phi = (1.0 - tau * tau) / (1.0 - gamma * gamma);
     for (uint64_t w = 0; w < W; ++w) {
-      uint32_t t[6];
-      double qs[6], all = 0.0;
+      uint32_t t[FS_MAX_WINDOW];
+      double qs[FS_MAX_WINDOW], all = 0.0;
       for (int k = 0; k < n; ++k) {
         t[k] = fs_share_term(sc[w + k], k);
         qs[k] = q_host(st[w + k], q);
         all += qs[k];
       }
       const double need = (1.0 - phi) * all * (1.0 - 1e-6);
-      for (uint32_t m = 1; m <= n_masks; ++m) {
-        uint32_t fold = 0;
-        double sum = 0.0;
-        for (int k = 0; k < n; ++k)
-          if ((m >> k) & 1u) { fold ^= t[k]; sum += qs[k]; }
-        if ((flags & 4) && sum < need) continue;     // (only the subsets that hold the share on this side too)
-        const uint32_t h = fs_share_key(fold, m);
-        f[fs_bloom_word(h, lw)] |= fs_bloom_mask(h);
+      for (int r = 0; r < fs_share_blocks(n); ++r) {
+        const int k0 = fs_share_block_start(n, r), k1 = fs_share_block_start(n, r + 1);
+        for (uint32_t sub = 1; sub < (1u << (k1 - k0)); ++sub) {
+          const uint32_t m = sub << k0;
+          uint32_t fold = 0;
+          double sum = 0.0;
+          for (int k = k0; k < k1; ++k)
+            if ((m >> k) & 1u) { fold ^= t[k]; sum += qs[k]; }
+          if ((flags & 4) && sum < need) continue;   // (only the subsets that hold the share on this side too)
+          const uint32_t h = fs_share_key(fold, m);
+          f[fs_bloom_word(h, lw)] |= fs_bloom_mask(h);
+        }
       }
     }
     FS_TRY(ix->d_sharef.upload(f.data(), f.size(), s));
@@ -3335,15 +3360,19 @@ static int fs_build_share(fs_index* ix) {
     if (flags & 32) {
       // the same keys as an exact map: key -> its script windows
       std::vector<uint64_t> ent;
-      ent.reserve(W * n_masks);
+      ent.reserve(W * n_masks_all);
       for (uint64_t w = 0; w < W; ++w) {
-        uint32_t t[6];
+        uint32_t t[FS_MAX_WINDOW];
         for (int k = 0; k < n; ++k) t[k] = fs_share_term(sc[w + k], k);
-        for (uint32_t m = 1; m <= n_masks; ++m) {
-          uint32_t fold = 0;
-          for (int k = 0; k < n; ++k)
-            if ((m >> k) & 1u) fold ^= t[k];
-          ent.push_back((uint64_t)fs_share_key(fold, m) << 32 | w);
+        for (int r = 0; r < fs_share_blocks(n); ++r) {
+          const int k0 = fs_share_block_start(n, r), k1 = fs_share_block_start(n, r + 1);
+          for (uint32_t sub = 1; sub < (1u << (k1 - k0)); ++sub) {
+            const uint32_t m = sub << k0;
+            uint32_t fold = 0;
+            for (int k = k0; k < k1; ++k)
+              if ((m >> k) & 1u) fold ^= t[k];
+            ent.push_back((uint64_t)fs_share_key(fold, m) << 32 | w);
+          }
         }
       }
       std::sort(ent.begin(), ent.end());
@@ -3572,30 +3601,32 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 64)));
   const uint32_t blocks = std::min<uint32_t>(n_sub, ix->num_cu * per_cu);
   const uint64_t* gbm = nullptr;
-  if ((L.share_flags & 32) && L.n >= 2 && L.n <= 6) {
+  if ((L.share_flags & 32) && L.n >= 2 && L.n <= 12) {
     // the share rule by itself: the script windows behind every window's keys
     const uint32_t sblocks = std::min<uint32_t>(n_sub, ix->num_cu * 4);
     switch (L.n) {
-      case 2: hipExtLaunchKernelGGL(k_share_scan<2>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
-      case 3: hipExtLaunchKernelGGL(k_share_scan<3>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
-      case 4: hipExtLaunchKernelGGL(k_share_scan<4>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
-      case 5: hipExtLaunchKernelGGL(k_share_scan<5>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
-      default: hipExtLaunchKernelGGL(k_share_scan<6>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+#define FS_SHARE_CASE(NN) \
+      case NN: hipExtLaunchKernelGGL(k_share_scan<NN>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
+      FS_SHARE_CASE(2) FS_SHARE_CASE(3) FS_SHARE_CASE(4) FS_SHARE_CASE(5) FS_SHARE_CASE(6) FS_SHARE_CASE(7)
+      FS_SHARE_CASE(8) FS_SHARE_CASE(9) FS_SHARE_CASE(10) FS_SHARE_CASE(11) FS_SHARE_CASE(12)
+#undef FS_SHARE_CASE
+      default: break;
     }
     FS_HIP(hipGetLastError());
     return FS_OK;
   }
-  if ((L.share_flags & 1) && L.n >= 2 && L.n <= 6) {
+  if ((L.share_flags & 1) && L.n >= 2 && L.n <= 12) {
     // the share rule's gate first: the windows that need keys at all
     FS_TRY(ix->cur->w_gate.reserve((size_t)n_sub * 4));
     const uint32_t gblocks = std::min<uint32_t>(n_sub, ix->num_cu * 4);
     uint64_t* g = ix->cur->w_gate.p;
     switch (L.n) {
-      case 2: hipExtLaunchKernelGGL(k_share_gate<2>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
-      case 3: hipExtLaunchKernelGGL(k_share_gate<3>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
-      case 4: hipExtLaunchKernelGGL(k_share_gate<4>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
-      case 5: hipExtLaunchKernelGGL(k_share_gate<5>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
-      default: hipExtLaunchKernelGGL(k_share_gate<6>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+#define FS_SHARE_CASE(NN) \
+      case NN: hipExtLaunchKernelGGL(k_share_gate<NN>, dim3(gblocks), dim3(256), 0, s, e0, nullptr, 0u, c, L, g, n_sub); break;
+      FS_SHARE_CASE(2) FS_SHARE_CASE(3) FS_SHARE_CASE(4) FS_SHARE_CASE(5) FS_SHARE_CASE(6) FS_SHARE_CASE(7)
+      FS_SHARE_CASE(8) FS_SHARE_CASE(9) FS_SHARE_CASE(10) FS_SHARE_CASE(11) FS_SHARE_CASE(12)
+#undef FS_SHARE_CASE
+      default: break;
     }
     FS_HIP(hipGetLastError());
     if (ix->prof.on) fs_prof_mark(ix, s, "k_share_gate");

@@ -79,10 +79,11 @@ def test_component_prefilter_equals_oracle_and_unfiltered_pipeline(synth_base, m
     assert int((got["dist"] > 0.001).sum()) > 0                        # approximate matches are records
     # the unfiltered LSH pipeline (keys and buckets for every window): the same bytes; and with the
     # share rule in front of it, which the index takes where the component prefilter is not there
-    # (window sizes up to six: the windows' gate and the script windows behind its keys; above,
-    # the test of the pairs inside the key scan)
+    # (k_share_scan: the windows' keys -- above six slots run by run --, the script windows behind
+    # them, the pairs' test, the distance; FS_LSH_SHARE=3: a gate and the pairs' test around the
+    # key scan)
     monkeypatch.setenv("FS_LSH_SYN", "0")
-    for share, kernel in (("0", "k_lsh_scan"), (None, "k_share_scan<6>" if n <= 6 else "k_lsh_scan"),
+    for share, kernel in (("0", "k_lsh_scan"), (None, "k_share_scan<%d>" % n),
                           ("3", "k_lsh_scan")):
         if share is not None:
             monkeypatch.setenv("FS_LSH_SHARE", share)

@@ -95,6 +95,10 @@ if [ "$part" = part2 ]; then
   FS_LSH_SHARE=0 run ${R}_realistic_key_scan_only.log tools/realistic_bench.py --works 2000
   for d in 4 10 6 5 7; do FS_LSH_DIAG=$d run ${R}_realistic_share_scan_diag$d.log tools/realistic_bench.py --works 2000 --oov 0.0; done
   prof_stats ${R}_realistic $ROOTDIR/tools/realistic_bench.py --works 2000 --no-counts
+  for n in 8 10; do
+    run ${R}_realistic_n$n.log tools/realistic_bench.py --works 2000 --window $n
+    FS_LSH_SHARE=0 run ${R}_realistic_n${n}_key_scan_only.log tools/realistic_bench.py --works 2000 --window $n
+  done
   run ${R}_stress_share.log tools/stress_share.py --cases 60
   echo "== stress cross-checks"
   run ${R}_stress_lsh.log tools/stress_lsh.py --cases 48

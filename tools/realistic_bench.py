@@ -105,7 +105,8 @@ if __name__ == "__main__":
     ap.add_argument("--works", type=int, default=2000)
     ap.add_argument("--rows", type=int, default=20000)
     ap.add_argument("--oov", type=float, default=0.08)
+    ap.add_argument("--window", type=int, default=6)
     ap.add_argument("--no-counts", action="store_true", help="no second index that counts what passes what (under a profiler)")
     a = ap.parse_args()
     for oov in (a.oov, 0.0):
-        print(json.dumps(run(a.works, a.rows, oov, counts=not a.no_counts)), flush=True)
+        print(json.dumps(run(a.works, a.rows, oov, window=a.window, counts=not a.no_counts)), flush=True)

@@ -5,7 +5,7 @@ scan over every window (FS_LSH_SHARE=0; both on the GPU -- the key scan is held 
 by tests/): tables with norms spread by a factor of 1.2 to 50, similarity at three scales,
 duplicate and zero rows, long and short vectors (next to the short ones an out-of-vocabulary
 name is the heavy slot); scripts with names of their own, the odd ones among them (fewer than
-three hot positions); window sizes 3..8, thresholds 0.05..0.25, gamma 0.5..0.85; fan text with
+three hot positions); window sizes 3..12, thresholds 0.05..0.25, gamma 0.5..0.85; fan text with
 near-synonyms, out-of-vocabulary names, and planted script spans whose *lightest* slots hold
 unrelated words (the pairs "at most one slot may differ" misses).
 
@@ -36,7 +36,7 @@ def main():
     for case in range(a.cases):
         rows = int(rng.choice([1500, 4000]))
         sigma = float(rng.choice([0.05, 0.3, 0.6, 1.0]))
-        n = int(rng.choice([3, 4, 5, 6, 6, 6, 7, 8]))
+        n = int(rng.choice([3, 4, 5, 6, 6, 6, 7, 8, 9, 10, 11, 12]))
         thr = float(rng.choice([0.05, 0.1, 0.1, 0.25]))
         gamma = float(rng.choice([0.5, 0.7, 0.7, 0.85]))
         oov = float(rng.choice([0.0, 0.08, 0.3]))
