@@ -55,6 +55,11 @@ def test_realistic_table_equals_oracle(real, oov, unique, monkeypatch):
     assert st.path == abi.FS_MODE_GENERAL and got.tobytes() == again.tobytes()
     # neither integer prefilter applies (norms from 1.8 to 18): the share rule in front of the LSH work
     assert ix.kernel_name(c) == "k_share_scan<6>" and ix.share_info()["flags"] & 32
+    info = ix.share_info()
+    sizes, used = ix.component_sizes()                 # (the rule's components: the nested groups, not one giant one)
+    assert used and len(sizes) == info["components"] and int(sizes.max()) == info["largest"] < ROWS // 50
+    assert int(sizes.sum()) == ROWS and abs(info["gamma"] - 0.7) < 1e-12
+    assert ix.share_counts()["windows"] == 0           # (counters are off unless FS_SHARE_COUNT is set)
     sch, so = pack_strings(swords)
     oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=8)
     want, ost = oi.search(tok_vec, off, chars, coff, tok_str=tok_str)
@@ -131,6 +136,21 @@ def test_script_with_names_of_its_own(real, monkeypatch):
     assert st.matches == ost.matches and len(got) > 200
     oi.close()
     ix.close()
+    # ... and what passes what, from an index that counts: every window through the filter or not,
+    # the flagged ones a superset of the windows with records
+    monkeypatch.setenv("FS_SHARE_COUNT", "1")
+    ixc = ScriptIndex(script_vec, swords, emb, normals, cfg=cfg)
+    monkeypatch.delenv("FS_SHARE_COUNT")
+    cc = ixc.corpus(tok_vec, off, chars, coff, tok_str=tok_str)
+    gotc, stc = ixc.search(cc)
+    n = ixc.share_counts()
+    assert gotc.tobytes() == got.tobytes()
+    # (the kernel sees the token stream: the windows across two works are dropped behind it)
+    assert n["windows"] == len(tok_vec) - 5 >= stc.windows_processed
+    assert 0 < n["windows_with_a_key_in_the_filter"] < n["windows"]
+    assert n["windows_flagged"] >= stc.candidates > 0 and n["pairs_tested"] >= n["distances"] >= n["windows_flagged"] - n["windows_flagged_as_they_are"]
+    assert len(np.unique(got["work"].astype(np.int64) << 32 | got["fan_ix"])) > 0
+    ixc.close()
     for share in ("0", "3"):
         monkeypatch.setenv("FS_LSH_SHARE", share)
         ix2 = ScriptIndex(script_vec, swords, emb, normals, cfg=cfg)
