@@ -849,26 +849,25 @@ __device__ __forceinline__ uint32_t share_comp(const LshDev& L, uint32_t id) {
 // The keys a fan window asks for (its minimal heavy subsets; all heavy ones under share_flags bit 2),
 // into list[j * 256]: their number, or -1 when the window is not constrained (the rule says nothing
 // about it, or the list is too short for its keys).
-// (the subsets of the slots K .. KEND - 1 depth first: a subset's sum, minimum and fold are its parent's and one
-// operation each; the keys leave as fs_share_raw -- whoever reads the list finishes them, once
-// per key asked for instead of once per subset)
+// (the subsets of the slots K .. KEND - 1 depth first: a subset's sum and minimum are its parent's and
+// one operation each; what leaves is the subset's mask, 16 bits -- its key is made by whoever reads
+// the list, once per subset asked for instead of once per subset)
 template <int N, int K, int KEND, uint32_t M>
 struct ShareSubsets {
-  static __device__ __forceinline__ void go(const uint32_t (&qi)[N], const uint32_t (&t)[N], uint32_t usable, int thr,
-                                            bool every, uint32_t sum, uint32_t mn, uint32_t fold, uint32_t* list,
-                                            int cap, int& cnt) {
+  static __device__ __forceinline__ void go(const uint32_t (&qi)[N], uint32_t usable, int thr, bool every,
+                                            uint32_t sum, uint32_t mn, uint16_t* list, int cap, int& cnt) {
     if constexpr (K == KEND) {
       if constexpr (M != 0u) {
         const bool ask = (M & ~usable) == 0u && (int)sum >= thr && (every || (int)(sum - mn) < thr);
         if (ask) {
-          if (cnt < cap) list[cnt * 256] = fs_share_raw(fold, M);
+          if (cnt < cap) list[cnt * 256] = (uint16_t)M;
           ++cnt;
         }
       }
     } else {
-      ShareSubsets<N, K + 1, KEND, M>::go(qi, t, usable, thr, every, sum, mn, fold, list, cap, cnt);
-      ShareSubsets<N, K + 1, KEND, (M | (1u << K))>::go(qi, t, usable, thr, every, sum + qi[K],
-                                                        qi[K] < mn ? qi[K] : mn, fold ^ t[K], list, cap, cnt);
+      ShareSubsets<N, K + 1, KEND, M>::go(qi, usable, thr, every, sum, mn, list, cap, cnt);
+      ShareSubsets<N, K + 1, KEND, (M | (1u << K))>::go(qi, usable, thr, every, sum + qi[K], qi[K] < mn ? qi[K] : mn,
+                                                        list, cap, cnt);
     }
   }
 };
@@ -879,9 +878,8 @@ struct ShareSubsets {
 // the slots' own numbers in the key.  (A run the rule says nothing about -- all of it slots that
 // agree with anything -- leaves the window unconstrained.)
 template <int N, int R>
-__device__ __forceinline__ bool share_asks_run(const LshDev& L, const uint32_t (&qi)[N], const uint32_t (&t)[N],
-                                               const uint32_t (&wild)[N], uint32_t usable, bool every, uint32_t* list,
-                                               int cap, int& cnt) {
+__device__ __forceinline__ bool share_asks_run(const LshDev& L, const uint32_t (&qi)[N], const uint32_t (&wild)[N],
+                                               uint32_t usable, bool every, uint16_t* list, int cap, int& cnt) {
   constexpr int K0 = fs_share_block_start(N, R), K1 = fs_share_block_start(N, R + 1);
   uint32_t all = 0, base = 0;
 #pragma unroll
@@ -890,41 +888,58 @@ __device__ __forceinline__ bool share_asks_run(const LshDev& L, const uint32_t (
   // sum_M x >= lim sum x - sum_O x, so sum_M qi > lim * all - base - (K1 - K0).)
   const int thr = (int)floorf(L.share_lim * (float)all) - (int)base - (K1 - K0) - 2;
   if (thr <= 0) return false;
-  ShareSubsets<N, K0, K1, 0u>::go(qi, t, usable, thr, every, 0u, 0xFFFFFFFFu, 0u, list, cap, cnt);
+  ShareSubsets<N, K0, K1, 0u>::go(qi, usable, thr, every, 0u, 0xFFFFFFFFu, list, cap, cnt);
   return true;
 }
 
+// The subsets a fan window asks for -- their slots as bit masks, into list[j * 256] --: their number,
+// or -1 when the window is not constrained (the rule says nothing about it, or the list is too
+// short).  The key of a subset is made where it is needed (share_key_of: from the slots' terms).
 template <int N>
 __device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, const double* qd,
-                                          uint32_t* list, int cap) {
-  uint32_t qi[N], t[N], wild[N];
+                                          uint16_t* list, int cap) {
+  uint32_t qi[N], wild[N];
   uint32_t usable = 0;
 #pragma unroll
   for (int k = 0; k < N; ++k) {
     qi[k] = (uint32_t)(qd[k] * L.share_scale);
     const uint32_t c = cmp[k];
-    t[k] = 0;
     wild[k] = c == FS_WILD ? qi[k] + 1 : 0u;
-    if (c < FS_WILD) { usable |= 1u << k; t[k] = fs_share_term(c, k); }
+    usable |= c < FS_WILD ? 1u << k : 0u;
   }
   const bool every = (L.share_flags & 4) != 0;
   int cnt = 0;
-  bool ok = share_asks_run<N, 0>(L, qi, t, wild, usable, every, list, cap, cnt);
-  if constexpr (fs_share_blocks(N) > 1) ok = ok && share_asks_run<N, 1>(L, qi, t, wild, usable, every, list, cap, cnt);
-  if constexpr (fs_share_blocks(N) > 2) ok = ok && share_asks_run<N, 2>(L, qi, t, wild, usable, every, list, cap, cnt);
+  bool ok = share_asks_run<N, 0>(L, qi, wild, usable, every, list, cap, cnt);
+  if constexpr (fs_share_blocks(N) > 1) ok = ok && share_asks_run<N, 1>(L, qi, wild, usable, every, list, cap, cnt);
+  if constexpr (fs_share_blocks(N) > 2) ok = ok && share_asks_run<N, 2>(L, qi, wild, usable, every, list, cap, cnt);
   return !ok || cnt > cap ? -1 : cnt;
 }
 
 template <int N>
+__device__ __forceinline__ void share_terms(const uint32_t* cmp, uint32_t (&t)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) t[k] = fs_share_term(cmp[k], k);   // (a slot without a component is in no subset)
+}
+template <int N>
+__device__ __forceinline__ uint32_t share_key_of(const uint32_t (&t)[N], uint32_t m) {
+  uint32_t fold = 0;
+#pragma unroll
+  for (int k = 0; k < N; ++k) fold ^= ((m >> k) & 1u) ? t[k] : 0u;
+  return fs_share_key(fold, m);
+}
+
+template <int N>
 __device__ __forceinline__ bool share_gate(const LshDev& L, const uint32_t* cmp, const double* qd,
-                                           uint32_t* list, int cap) {
+                                           uint16_t* list, int cap) {
   const int cnt = share_asks<N>(L, cmp, qd, list, cap);
   if (cnt < 0) return true;
+  uint32_t t[N];
+  share_terms<N>(cmp, t);
   bool hit = false;
   for (int j = 0; j < cnt && !hit; j += 4) {
     uint32_t h[4], wd[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? fs_share_finish(list[(j + u) * 256]) : 0u;
+    for (int u = 0; u < 4; ++u) h[u] = j + u < cnt ? share_key_of<N>(t, list[(j + u) * 256]) : 0u;
 #pragma unroll
     for (int u = 0; u < 4; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
 #pragma unroll
@@ -977,7 +992,7 @@ template <int N>
 __global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint64_t* __restrict__ gbm, uint32_t n_sub) {
   __shared__ uint32_t s_tok[256 + 16], s_cmp[256 + 16];
   __shared__ double s_qd[256 + 16];
-  __shared__ uint32_t s_keys[kGateCap * 256];
+  __shared__ uint16_t s_keys[kGateCap * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
     const uint64_t p0 = (uint64_t)sub * 256;
@@ -1017,16 +1032,16 @@ __global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint6
 constexpr int kEnumCap = 20;         // keys per window (six slots have at most 20 minimal heavy subsets)
 constexpr int kEnumWork = 512;       // keys that are in the filter, and (window, list) entries, per sub-tile
 template <int N>
-__global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, uint64_t* __restrict__ qbm,
+__global__ __launch_bounds__(256, 6) void k_share_scan(CorpusDev c, LshDev L, uint64_t* __restrict__ qbm,
                                                     uint32_t* __restrict__ qcnt, uint32_t n_sub) {
   __shared__ uint32_t s_tok[256 + 16], s_cmp[256 + 16], s_sg[256 + 16];
   __shared__ double s_qd[256 + 16], s_ff[256];
-  __shared__ uint32_t s_keys[kEnumCap * 256];      // stage 1; stage 3: the entries' offsets (s_wpref)
+  __shared__ __attribute__((aligned(16))) uint16_t s_keys[kEnumCap * 256];   // stage 1: the subsets asked for; stage 3: the entries' offsets (s_wpref)
   __shared__ uint32_t s_hit[kEnumWork], s_wstart[kEnumWork], s_wmeta[kEnumWork];
   __shared__ uint8_t s_found[256];
   __shared__ uint32_t s_w[4], s_nwork, s_ndist;
-  uint32_t* s_wpref = s_keys;                      // [kEnumWork + 1]
-  static_assert(kEnumWork + 1 <= kEnumCap * 256 && kEnumWork == 2 * 256, "the offsets take the keys' place; two entries per thread");
+  uint32_t* s_wpref = reinterpret_cast<uint32_t*>(s_keys);                   // [kEnumWork + 1]
+  static_assert((kEnumWork + 1) * 4 <= kEnumCap * 256 * 2 && kEnumWork == 2 * 256, "the offsets take the subsets' place; two entries per thread");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
     const uint64_t p0 = (uint64_t)sub * 256;
@@ -1049,19 +1064,21 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
 #pragma unroll
       for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, s_qd[threadIdx.x + k]);
       s_ff[threadIdx.x] = ff;
-      uint32_t* list = s_keys + threadIdx.x;
+      uint16_t* list = s_keys + threadIdx.x;
       int cnt = share_asks<N>(L, s_cmp + threadIdx.x, s_qd + threadIdx.x, list, kEnumCap);
       flag = cnt < 0;
-      if (L.diag == 10) cnt = 0;                                  // diagnostics: the keys only
+      if (L.diag == 10) cnt = 0;                                  // diagnostics: the subsets only
+      uint32_t t[N];
+      share_terms<N>(s_cmp + threadIdx.x, t);
       for (int j = 0; j < cnt; j += 8) {
-        uint32_t h[8], wd[8];
+        uint32_t m[8], h[8], wd[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) h[u] = j + u < cnt ? fs_share_finish(list[(j + u) * 256]) : 0u;
+        for (int u = 0; u < 8; ++u) { m[u] = j + u < cnt ? list[(j + u) * 256] : 0u; h[u] = share_key_of<N>(t, m[u]); }
 #pragma unroll
         for (int u = 0; u < 8; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (j + u < cnt && fs_bloom_test(wd[u], h[u])) list[hc++ * 256] = h[u];      // (hc <= j + u: behind what is read)
+          if (j + u < cnt && fs_bloom_test(wd[u], h[u])) list[hc++ * 256] = (uint16_t)m[u];   // (hc <= j + u: behind what is read)
       }
       if (L.diag == 6) hc = 0;                                    // diagnostics: no lists
     }
@@ -1069,7 +1086,7 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       uint32_t n_hit;
       const uint32_t base = block_excl_scan(hc, s_w, &n_hit);
       for (uint32_t i = 0; i < hc; ++i) {
-        if (base + i < (uint32_t)kEnumWork) s_hit[base + i] = threadIdx.x | i << 8;
+        if (base + i < (uint32_t)kEnumWork) s_hit[base + i] = threadIdx.x | (uint32_t)s_keys[i * 256 + threadIdx.x] << 8;
         else flag = true;                                         // (no room: the window goes on as it is)
       }
       if (flag) s_found[threadIdx.x] = 1;
@@ -1087,7 +1104,10 @@ __global__ __launch_bounds__(256, 4) void k_share_scan(CorpusDev c, LshDev L, ui
       const uint32_t bmask = (1u << L.log2_smap) - 1u;
       n_hit = n_hit < (uint32_t)kEnumWork ? n_hit : (uint32_t)kEnumWork;
       for (uint32_t x = threadIdx.x; x < n_hit; x += 256) {
-        const uint32_t t = s_hit[x] & 255u, h = s_keys[(s_hit[x] >> 8) * 256 + t];
+        const uint32_t t = s_hit[x] & 255u, hm = s_hit[x] >> 8;    // the window and the subset: its key again, from the slots' components
+        uint32_t tt[N];
+        share_terms<N>(s_cmp + t, tt);
+        const uint32_t h = share_key_of<N>(tt, hm);
         uint32_t bkt = fs_wmap_slot(h, L.log2_smap);
         for (int probe = 0;; ++probe) {
           if (probe == 64) { s_found[t] = 1; break; }             // (never seen: the window goes on as it is)
@@ -3603,7 +3623,7 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   const uint64_t* gbm = nullptr;
   if ((L.share_flags & 32) && L.n >= 2 && L.n <= 12) {
     // the share rule by itself: the script windows behind every window's keys
-    const uint32_t sblocks = std::min<uint32_t>(n_sub, ix->num_cu * 4);
+    const uint32_t sblocks = std::min<uint32_t>(n_sub, ix->num_cu * 6);
     switch (L.n) {
 #define FS_SHARE_CASE(NN) \
       case NN: hipExtLaunchKernelGGL(k_share_scan<NN>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
