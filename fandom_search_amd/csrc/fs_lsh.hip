@@ -49,6 +49,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 using namespace fsdev;
@@ -852,15 +853,18 @@ __device__ __forceinline__ uint32_t share_comp(const LshDev& L, uint32_t id) {
 // (the subsets of the slots K .. KEND - 1 depth first: a subset's sum and minimum are its parent's and
 // one operation each; what leaves is the subset's mask, 16 bits -- its key is made by whoever reads
 // the list, once per subset asked for instead of once per subset)
+// (a subset of a window's slots: a byte for windows of up to eight slots)
+template <int N> using share_mask_t = std::conditional_t<(N <= 8), uint8_t, uint16_t>;
+
 template <int N, int K, int KEND, uint32_t M>
 struct ShareSubsets {
   static __device__ __forceinline__ void go(const uint32_t (&qi)[N], uint32_t usable, int thr, bool every,
-                                            uint32_t sum, uint32_t mn, uint16_t* list, int cap, int& cnt) {
+                                            uint32_t sum, uint32_t mn, share_mask_t<N>* list, int cap, int& cnt) {
     if constexpr (K == KEND) {
       if constexpr (M != 0u) {
         const bool ask = (M & ~usable) == 0u && (int)sum >= thr && (every || (int)(sum - mn) < thr);
         if (ask) {
-          if (cnt < cap) list[cnt * 256] = (uint16_t)M;
+          if (cnt < cap) list[cnt * 256] = (share_mask_t<N>)M;
           ++cnt;
         }
       }
@@ -879,7 +883,7 @@ struct ShareSubsets {
 // agree with anything -- leaves the window unconstrained.)
 template <int N, int R>
 __device__ __forceinline__ bool share_asks_run(const LshDev& L, const uint32_t (&qi)[N], const uint32_t (&wild)[N],
-                                               uint32_t usable, bool every, uint16_t* list, int cap, int& cnt) {
+                                               uint32_t usable, bool every, share_mask_t<N>* list, int cap, int& cnt) {
   constexpr int K0 = fs_share_block_start(N, R), K1 = fs_share_block_start(N, R + 1);
   uint32_t all = 0, base = 0;
 #pragma unroll
@@ -897,7 +901,7 @@ __device__ __forceinline__ bool share_asks_run(const LshDev& L, const uint32_t (
 // short).  The key of a subset is made where it is needed (share_key_of: from the slots' terms).
 template <int N>
 __device__ __forceinline__ int share_asks(const LshDev& L, const uint32_t* cmp, const double* qd,
-                                          uint16_t* list, int cap) {
+                                          share_mask_t<N>* list, int cap) {
   uint32_t qi[N], wild[N];
   uint32_t usable = 0;
 #pragma unroll
@@ -930,7 +934,7 @@ __device__ __forceinline__ uint32_t share_key_of(const uint32_t (&t)[N], uint32_
 
 template <int N>
 __device__ __forceinline__ bool share_gate(const LshDev& L, const uint32_t* cmp, const double* qd,
-                                           uint16_t* list, int cap) {
+                                           share_mask_t<N>* list, int cap) {
   const int cnt = share_asks<N>(L, cmp, qd, list, cap);
   if (cnt < 0) return true;
   uint32_t t[N];
@@ -992,7 +996,7 @@ template <int N>
 __global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint64_t* __restrict__ gbm, uint32_t n_sub) {
   __shared__ uint32_t s_tok[256 + 16], s_cmp[256 + 16];
   __shared__ double s_qd[256 + 16];
-  __shared__ uint16_t s_keys[kGateCap * 256];
+  __shared__ share_mask_t<N> s_keys[kGateCap * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
     const uint64_t p0 = (uint64_t)sub * 256;
@@ -1029,19 +1033,22 @@ __global__ __launch_bounds__(256) void k_share_gate(CorpusDev c, LshDev L, uint6
 //   1  a thread per window: its keys (share_asks), the filter; the keys that are there stay;
 //   2  a thread per such key: the map -- (window, list) entries;
 //   3  a thread per (window, script window) pair of the entries: the pairs' test, the distance.
+// workgroups of k_share_scan per CU: the subsets of a window of up to eight slots are bytes (19 KB of
+// LDS: seven, at 72 registers; eight measured slower), above that 16 bits (24 KB: six)
+constexpr int share_scan_occupancy(int n) { return n <= 8 ? 7 : 6; }
 constexpr int kEnumCap = 20;         // keys per window (six slots have at most 20 minimal heavy subsets)
 constexpr int kEnumWork = 512;       // keys that are in the filter, and (window, list) entries, per sub-tile
 template <int N>
-__global__ __launch_bounds__(256, 6) void k_share_scan(CorpusDev c, LshDev L, uint64_t* __restrict__ qbm,
+__global__ __launch_bounds__(256, share_scan_occupancy(N)) void k_share_scan(CorpusDev c, LshDev L, uint64_t* __restrict__ qbm,
                                                     uint32_t* __restrict__ qcnt, uint32_t n_sub) {
   __shared__ uint32_t s_tok[256 + 16], s_cmp[256 + 16], s_sg[256 + 16];
   __shared__ double s_qd[256 + 16], s_ff[256];
-  __shared__ __attribute__((aligned(16))) uint16_t s_keys[kEnumCap * 256];   // stage 1: the subsets asked for; stage 3: the entries' offsets (s_wpref)
+  __shared__ __attribute__((aligned(16))) share_mask_t<N> s_keys[kEnumCap * 256];   // stage 1: the subsets asked for; stage 3: the entries' offsets (s_wpref)
   __shared__ uint32_t s_hit[kEnumWork], s_wstart[kEnumWork], s_wmeta[kEnumWork];
   __shared__ uint8_t s_found[256];
   __shared__ uint32_t s_w[4], s_nwork, s_ndist;
   uint32_t* s_wpref = reinterpret_cast<uint32_t*>(s_keys);                   // [kEnumWork + 1]
-  static_assert((kEnumWork + 1) * 4 <= kEnumCap * 256 * 2 && kEnumWork == 2 * 256, "the offsets take the subsets' place; two entries per thread");
+  static_assert((kEnumWork + 1) * 4 <= kEnumCap * 256 * (int)sizeof(share_mask_t<N>) && kEnumWork == 2 * 256, "the offsets take the subsets' place; two entries per thread");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t sub = blockIdx.x; sub < n_sub; sub += gridDim.x) {
     const uint64_t p0 = (uint64_t)sub * 256;
@@ -1064,7 +1071,7 @@ __global__ __launch_bounds__(256, 6) void k_share_scan(CorpusDev c, LshDev L, ui
 #pragma unroll
       for (int k = 0; k < N; ++k) ff = __dadd_rn(ff, s_qd[threadIdx.x + k]);
       s_ff[threadIdx.x] = ff;
-      uint16_t* list = s_keys + threadIdx.x;
+      share_mask_t<N>* list = s_keys + threadIdx.x;
       int cnt = share_asks<N>(L, s_cmp + threadIdx.x, s_qd + threadIdx.x, list, kEnumCap);
       flag = cnt < 0;
       if (L.diag == 10) cnt = 0;                                  // diagnostics: the subsets only
@@ -1078,7 +1085,7 @@ __global__ __launch_bounds__(256, 6) void k_share_scan(CorpusDev c, LshDev L, ui
         for (int u = 0; u < 8; ++u) wd[u] = j + u < cnt ? L.sharef[fs_bloom_word(h[u], L.log2_sharef)] : 0u;
 #pragma unroll
         for (int u = 0; u < 8; ++u)
-          if (j + u < cnt && fs_bloom_test(wd[u], h[u])) list[hc++ * 256] = (uint16_t)m[u];   // (hc <= j + u: behind what is read)
+          if (j + u < cnt && fs_bloom_test(wd[u], h[u])) list[hc++ * 256] = (share_mask_t<N>)m[u];   // (hc <= j + u: behind what is read)
       }
       if (L.diag == 6) hc = 0;                                    // diagnostics: no lists
     }
@@ -3623,7 +3630,7 @@ int fs_launch_lsh_scan(fs_index* ix, const CorpusDev& c, uint64_t* qbm, uint32_t
   const uint64_t* gbm = nullptr;
   if ((L.share_flags & 32) && L.n >= 2 && L.n <= 12) {
     // the share rule by itself: the script windows behind every window's keys
-    const uint32_t sblocks = std::min<uint32_t>(n_sub, ix->num_cu * 6);
+    const uint32_t sblocks = std::min<uint32_t>(n_sub, ix->num_cu * (uint32_t)share_scan_occupancy(L.n));
     switch (L.n) {
 #define FS_SHARE_CASE(NN) \
       case NN: hipExtLaunchKernelGGL(k_share_scan<NN>, dim3(sblocks), dim3(256), 0, s, e0, e1, 0u, c, L, qbm, qcnt, n_sub); break;
