@@ -158,3 +158,46 @@ def test_script_with_names_of_its_own(real, monkeypatch):
         got2, st2 = ix2.search(c2)
         assert ix2.kernel_name(c2) == "k_lsh_scan" and got2.tobytes() == got.tobytes(), share
         ix2.close()
+
+
+def test_ragged_batches_under_the_share_rule(real):
+    """Empty works, works shorter than a window, a work of exactly one window, a batch of one
+    token and an empty batch through k_share_scan: records as the C oracle's (the kernel sees the
+    token stream -- windows across two works must not become records)."""
+    from oracle import c_oracle
+    from fandom_search_amd.engine import ScriptIndex
+    emb, group, strings, vid, script = real
+    tok_str, off = synth.realistic_corpus(12, 300, script, group, ROWS, oov_rate=0.08)
+    quote = script[500:520].astype(np.uint32)
+    lengths = [0, 3, 6, 300, 0, 0, 5, 7, 250, 1, 6, 20, 0]
+    parts, at = [], 0
+    for i, ln in enumerate(lengths):
+        p = tok_str[at:at + ln].copy()
+        at += 300
+        if ln >= 6:
+            p[:min(ln, 20)] = quote[:min(ln, 20)]       # every work that can hold a window holds a quote
+        parts.append(p)
+    tok_s = np.concatenate(parts).astype(np.uint32)
+    off = np.zeros(len(lengths) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum(lengths)
+    tok_v = vid[tok_s]
+    swords = [strings[int(t)] for t in script]
+    chars, coff = pack_strings(strings)
+    cfg = abi.make_config()
+    normals = synth.lsh_normals(6)
+    ix = ScriptIndex(script, swords, emb, normals, cfg=cfg)
+    sch, so = pack_strings(swords)
+    oi = c_oracle.OracleIndex(cfg, script, sch, so, emb, normals, threads=4)
+    for tv, ts, o in ((tok_v, tok_s, off), (tok_v[:1], tok_s[:1], np.array([0, 1], dtype=np.uint64)),
+                      (tok_v[:0], tok_s[:0], np.array([0], dtype=np.uint64)),
+                      (tok_v[:0], tok_s[:0], np.array([0, 0, 0], dtype=np.uint64))):
+        c = ix.corpus(tv, o, chars, coff, tok_str=ts)
+        got, st = ix.search(c)
+        want, ost = oi.search(tv, o, chars, coff, tok_str=ts)
+        util.assert_rows_equal(got, want)
+        assert st.matches == ost.matches and st.windows_processed == ost.windows_processed
+        if len(tv) > 1:
+            assert ix.kernel_name(c) == "k_share_scan<6>" and len(got) > 50
+        c.close()
+    oi.close()
+    ix.close()
