@@ -196,7 +196,7 @@ struct fs_switches {
   bool lsh_wmap = true;           // FS_LSH_WMAP=0: windows one slot away from a script n-gram always take the full LSH path
   bool lsh_keys6 = true;          // FS_LSH_KEYS6=0: n = 6 over component ids without the middle-slot key filter in k_scan_near
   bool lsh_syn = true;            // FS_LSH_SYN=0: no component-id prefilter for tables with near-synonyms
-  int lsh_share = 35;             // FS_LSH_SHARE: the share rule in k_lsh_scan on tables no integer prefilter applies to; bit 0 the windows' gate, bit 1 the pairs' test, bit 2 the gate asks for every heavy subset (the script's filter holds its heavy subsets only), bit 3 out-of-vocabulary fan tokens count as possibly near, bit 5 the script windows behind the gate's keys are enumerated (k_share_enum) instead of the key scan behind the gate; 0: off.  Read when the index is built
+  int lsh_share = 35;             // FS_LSH_SHARE: the share rule (fs_lsh.hip) on tables no integer prefilter applies to; bit 5 k_share_scan -- the script windows behind a window's keys instead of the key scan --, else bit 0 a gate kernel in front of k_lsh_scan (k_share_gate) and bit 1 the pairs' test inside it; bit 2 the gate asks for every heavy subset (the script's filter holds its heavy subsets only; n <= 6, without bit 5), bit 3 out-of-vocabulary fan tokens count as possibly near; 0: off.  Read when the index is built
   double share_gamma = 0.7;       // FS_SHARE_GAMMA: cosine above which two vectors are near in the share rule
   bool lsh_emap = true;           // FS_LSH_EMAP=0: k_lsh_batch walks the buckets of every pending window instead of enumerating the script n-grams one slot away
   bool lsh_batch = true;          // FS_LSH_BATCH=0: the pending windows a wave each (k_lsh_verify) instead of eight per wave level by level (k_lsh_batch)
@@ -270,7 +270,7 @@ struct fs_index {
   DBuf<uint64_t> d_ssig;     // [W] the script windows' component signatures (fs_share_sig)
   DBuf<uint32_t> d_sharef;   // the script windows' subset keys (fs_hash.h), a blocked Bloom filter
   int log2_sharef = 0;
-  DBuf<uint32_t> d_smap;     // ... as an exact map (k_share_enum): 2^log2_smap buckets of four {key, list + 1}
+  DBuf<uint32_t> d_smap;     // ... as an exact map (k_share_scan): 2^log2_smap buckets of four {key, list}
   DBuf<uint32_t> d_slists;   // a key's script windows behind their number, four words each: {window, signature word, 0} (the map names the first of them)
   int log2_smap = 0;
   DBuf<uint32_t> d_oovmap;   // the script's out-of-vocabulary vectors for share_comp: 2^log2_oovmap {key, component + 1}

@@ -32,6 +32,9 @@
 //                  neighbours list, Levenshtein per kept match, best rank ->
 //                  per-candidate record for k_rows
 //   k_lsh_gramtab  lsh_window once per script n-gram and string table
+//   k_share_scan   (round 5) in k_lsh_scan's place on tables whose vectors are not unit length:
+//                  the windows that can have a script window within the threshold at all, by the
+//                  shares of the squared norms their agreeing slots hold ("the share rule" below)
 //
 // A candidate's exact distance is skipped only when a sound upper bound on its
 // cosine is already below 1 - threshold: too few identical slots for the table's
@@ -97,7 +100,7 @@ struct LshDev {
   const uint32_t* compa;   // [V], or nullptr: the rule is not in use
   const uint64_t* ssig;    // [W] the script windows' component signatures (share_pair_possible)
   const uint32_t* sharef;  // 2^log2_sharef filter words
-  const uint2* smap;       // the same keys as an exact map: 2^log2_smap buckets of four {key, list + 1} (k_share_enum)
+  const uint2* smap;       // the same keys as an exact map: 2^log2_smap buckets of four {key, list} (k_share_scan)
   const uint4* slists;     // the lists of the map: a list's length (.x), then its script windows with their signature words
                            // {window, word's low half, high half, 0} (the map names the first of those)
   int log2_smap;

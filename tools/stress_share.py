@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised cross-check of the share rule (the LSH pipeline's prefilter on tables whose vectors
-are not unit length: k_share_gate, k_share_enum, the pairs' test in k_lsh_scan) against the key
+are not unit length: k_share_scan; k_share_gate and the pairs' test in k_lsh_scan) against the key
 scan over every window (FS_LSH_SHARE=0; both on the GPU -- the key scan is held against the oracle
 by tests/): tables with norms spread by a factor of 1.2 to 50, similarity at three scales,
 duplicate and zero rows, long and short vectors (next to the short ones an out-of-vocabulary
