@@ -45,6 +45,10 @@ def build_parser():
                                help="NearPy's UniqueFilter on a query's bucket contents: 0 = what "
                                     "NearPy 1.0.0 does for the reference's call (default), 1 = "
                                     "NearPy 0.2.x; also FANDOM_SEARCH_UNIQUE_FILTER")
+    search_parser.add_argument('--listing', default=None, choices=('sorted', 'os'),
+                               help="order of the directory listing in front of the seeded shuffle: "
+                                    "'sorted' (default: a run repeats anywhere) or 'os' (os.listdir() as "
+                                    "it comes, what the reference shuffles); also FANDOM_SEARCH_LISTING")
     search_parser.set_defaults(func=_search)
 
     data_parser = subparsers.add_parser(
@@ -86,6 +90,8 @@ def _search(args):
         os.environ['FANDOM_SEARCH_SYNTHETIC_VOCAB'] = '1'
     if getattr(args, 'unique_filter', None) is not None:
         os.environ['FANDOM_SEARCH_UNIQUE_FILTER'] = str(args.unique_filter)
+    if getattr(args, 'listing', None):
+        os.environ['FANDOM_SEARCH_LISTING'] = args.listing
     return search.analyze(args)
 
 

@@ -643,13 +643,27 @@ def _write_batch(script_filename, out_name, filenames, row_bytes, words):
     return len(rows)
 
 
-def list_fan_works(fan_work_directory, skip_works=0, num_works=-1):
-    """Work list of analyze (search.py:345-358): directory listing (sorted
-    here; filesystem order in the reference), the reference's seeded shuffle,
-    then the -s / -n window."""
+def listing_order():
+    """'sorted' (default) or 'os' (FANDOM_SEARCH_LISTING, `ao3.py search --listing`)."""
+    order = os.environ.get("FANDOM_SEARCH_LISTING", "sorted")
+    if order not in ("sorted", "os"):
+        raise ValueError("FANDOM_SEARCH_LISTING must be 'sorted' or 'os', not %r" % (order,))
+    return order
+
+
+def list_fan_works(fan_work_directory, skip_works=0, num_works=-1, order=None):
+    """Work list of analyze (search.py:345-358): directory listing, the reference's
+    seeded shuffle, then the -s / -n window.  The reference shuffles os.listdir()'s list as
+    it comes (search.py:349,354-355) -- an order that belongs to the file system, not to
+    the directory's contents -- so the default here sorts the names first and a run can be
+    repeated anywhere; order='os' (FANDOM_SEARCH_LISTING=os, --listing os) takes the
+    listing as the reference does: on the same directory of the same file system the -s /
+    -n window then selects the very works the reference's run would."""
     subsample_start = 0 if skip_works < 0 else skip_works
     subsample_end = (None if num_works < 0 else num_works + subsample_start)
-    fan_works = sorted(os.listdir(fan_work_directory))
+    fan_works = os.listdir(fan_work_directory)
+    if (order or listing_order()) == "sorted":
+        fan_works = sorted(fan_works)
     fan_works = [os.path.join(fan_work_directory, f) for f in fan_works]
     random.seed(SHUFFLE_SEED)
     random.shuffle(fan_works)
@@ -725,6 +739,12 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
     from . import dist
     rank, local_rank, world = dist.init_from_env()
     fan_works = list_fan_works(args.fan_works, args.skip_works, args.num_works)
+    if world > 1 and listing_order() == "os":
+        # (the file system's order is one process's view: every rank works on rank 0's list)
+        import torch.distributed as tdist
+        box = [fan_works]
+        tdist.broadcast_object_list(box, src=0)
+        fan_works = box[0]
     window_size = getattr(args, 'window_size', None) or window_size
     device = getattr(args, 'device', 0) or 0
     if world > 1:

@@ -24,6 +24,33 @@ def test_list_fan_works_is_sorted_then_seeded_shuffle(tmp_path):
     assert len(search.list_fan_works(str(tmp_path), -5, -1)) == 10
 
 
+def test_listing_order_os_shuffles_the_listing_as_it_comes(tmp_path, monkeypatch):
+    """--listing os / FANDOM_SEARCH_LISTING=os: os.listdir()'s order goes into the seeded
+    shuffle untouched, as in the reference (search.py:349,354-355); the default sorts first."""
+    import random
+    names = ["w%d.txt" % i for i in (7, 2, 9, 0, 4, 1, 8, 3, 6, 5)]
+    for n in names:
+        (tmp_path / n).write_text("x")
+    real = os.listdir
+    monkeypatch.setattr(os, "listdir", lambda d: list(names) if str(d) == str(tmp_path) else real(d))
+    want = list(names)
+    random.seed(search.SHUFFLE_SEED)
+    random.shuffle(want)
+    monkeypatch.setenv("FANDOM_SEARCH_LISTING", "os")
+    got = [os.path.basename(p) for p in search.list_fan_works(str(tmp_path))]
+    assert got == want
+    assert [os.path.basename(p) for p in search.list_fan_works(str(tmp_path), 2, 3)] == want[2:5]
+    monkeypatch.delenv("FANDOM_SEARCH_LISTING")
+    assert [os.path.basename(p) for p in search.list_fan_works(str(tmp_path))] == \
+        ["w%d.txt" % i for i in [5, 4, 2, 3, 1, 8, 7, 0, 6, 9]]
+    assert [os.path.basename(p) for p in search.list_fan_works(str(tmp_path), order="os")] == want
+    monkeypatch.setenv("FANDOM_SEARCH_LISTING", "alphabetical")
+    with pytest.raises(ValueError):
+        search.list_fan_works(str(tmp_path))
+    args = build_parser().parse_args(["search", "fan", "script", "--listing", "os"])
+    assert args.listing == "os"
+
+
 def test_write_records_bytes(tmp_path):
     """csv.writer defaults: \\r\\n terminators, minimal quoting, None -> empty,
     floats by repr (search.py:331-334)."""
