@@ -24,7 +24,10 @@ SYMBOLS = ("fs_version", "fs_strerror", "fs_last_error", "fs_index_create",
            "fs_search_corpus_begin", "fs_search_corpus_end", "fs_index_set_scan_timing",
            "fs_index_reload_switches", "fs_search_kernel_name", "fs_debug_stamps",
            "fs_search_profile", "fs_index_component_sizes", "fs_index_share_info", "fs_index_share_counts", "fs_stream_floor",
-           "fs_textenc_create", "fs_textenc_destroy", "fs_textenc_add", "fs_textenc_encode_files")
+           "fs_textenc_create", "fs_textenc_destroy", "fs_textenc_add", "fs_textenc_encode_files",
+           "fs_textenc_encode_files_vec",
+           "fs_csvw_create", "fs_csvw_destroy", "fs_csvw_set_script", "fs_csvw_add_strings", "fs_csvw_strings",
+           "fs_csvw_format")
 
 
 class FsError(RuntimeError):

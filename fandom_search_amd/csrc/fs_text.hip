@@ -27,6 +27,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -53,13 +54,42 @@ inline uint64_t hash_bytes(const uint8_t* p, size_t n) {
   return h;
 }
 
+// The same value for bytes that have eight readable bytes behind them (a file's buffer is padded):
+// the tail as one masked load instead of a memcpy of variable length.
+inline uint64_t hash_bytes_padded(const uint8_t* p, size_t n) {
+  uint64_t h = 0xcbf29ce484222325ull ^ (n * 0x9E3779B97F4A7C15ull);
+  while (n >= 8) {
+    uint64_t w;
+    memcpy(&w, p, 8);
+    h = (h ^ w) * 0x100000001b3ull;
+    h ^= h >> 29;
+    p += 8; n -= 8;
+  }
+  uint64_t w;
+  memcpy(&w, p, 8);
+  w &= n ? ((1ull << (8 * n)) - 1ull) : 0ull;
+  h = (h ^ w) * 0x100000001b3ull;
+  h ^= h >> 32;
+  h *= 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29;
+  return h;
+}
+
 struct Entry {
   uint64_t hash = 0;
-  uint64_t off = 0;      // the chunk's bytes in `arena`
+  uint64_t off = 0;      // the chunk's bytes in `arena`; a chunk of up to eight bytes: the bytes themselves
   uint32_t len = 0;
   uint32_t n_pieces = 0; // 0: empty slot
-  uint64_t first = 0;    // its string ids in `pieces`
+  uint64_t first = 0;    // its string ids in `pieces`; a chunk of one token: the id itself
 };
+// (a word of up to eight bytes that is one token -- nearly every chunk of a text -- is decided by its
+// 32-byte entry alone: no second and third cache miss for the arena's bytes and the id)
+
+inline uint64_t first_bytes(const uint8_t* p, uint32_t n) {      // n <= 8; p has eight readable bytes
+  uint64_t w;
+  memcpy(&w, p, 8);
+  return n >= 8 ? w : w & ((1ull << (8 * n)) - 1ull);
+}
 
 struct ThreadOut {
   std::vector<uint32_t> tok;
@@ -80,6 +110,7 @@ struct fs_textenc {
   std::vector<uint32_t> pieces;
   // results of the last fs_textenc_encode_files
   std::vector<uint32_t> tok;
+  std::vector<uint32_t> tok_vec;                // (fs_textenc_encode_files_vec)
   std::vector<uint64_t> work_off;
   std::vector<int32_t> status;
   std::vector<uint8_t> unk_bytes;
@@ -96,7 +127,8 @@ const Entry* find(const std::vector<Entry>& table, const std::vector<uint8_t>& a
   for (uint64_t i = h & mask;; i = (i + 1) & mask) {
     const Entry& e = table[i];
     if (!e.n_pieces) return nullptr;
-    if (e.hash == h && e.len == n && memcmp(arena.data() + e.off, p, n) == 0) return &e;
+    if (e.hash == h && e.len == n &&
+        (n <= 8 ? e.off == first_bytes(p, n) : memcmp(arena.data() + e.off, p, n) == 0)) return &e;
   }
 }
 
@@ -222,10 +254,14 @@ int32_t encode_file(const fs_textenc* enc, const char* path, std::vector<uint8_t
     }
     (void)ascii;
     const uint32_t n = (uint32_t)(p - c0);
-    const uint64_t h = hash_bytes(c0, n);
+    const uint64_t h = hash_bytes_padded(c0, n);
     if (const Entry* e = find(enc->table, enc->arena, c0, n, h)) {
-      const uint32_t* ids = enc->pieces.data() + e->first;
-      o.tok.insert(o.tok.end(), ids, ids + e->n_pieces);
+      if (e->n_pieces == 1) {
+        o.tok.push_back((uint32_t)e->first);
+      } else {
+        const uint32_t* ids = enc->pieces.data() + e->first;
+        o.tok.insert(o.tok.end(), ids, ids + e->n_pieces);
+      }
     } else {
       o.tok.push_back(0x80000000u | unknown_index(o, c0, n, h));
     }
@@ -253,13 +289,24 @@ extern "C" int fs_textenc_add(fs_textenc* enc, const uint8_t* chunk_bytes, const
     if (!n || !np || n > 0xFFFFFFFFull || np > 0xFFFFFFFFull) return FS_E_INVALID;
     if ((enc->used + 1) * 2 > enc->table.size()) grow(enc);
     const uint64_t h = hash_bytes(p, n);
-    if (find(enc->table, enc->arena, p, (uint32_t)n, h)) continue;       // known already: kept
+    uint8_t pad[16] = {0};                 // (find reads eight bytes of a short chunk)
+    if (n <= 8) memcpy(pad, p, n);
+    const uint8_t* q = n <= 8 ? pad : p;
+    if (find(enc->table, enc->arena, q, (uint32_t)n, h)) continue;       // known already: kept
     Entry e;
     e.hash = h; e.len = (uint32_t)n; e.n_pieces = (uint32_t)np;
-    e.off = enc->arena.size();
-    enc->arena.insert(enc->arena.end(), p, p + n);
-    e.first = enc->pieces.size();
-    enc->pieces.insert(enc->pieces.end(), piece_ids + piece_off[i], piece_ids + piece_off[i + 1]);
+    if (n <= 8) {
+      e.off = first_bytes(q, (uint32_t)n);
+    } else {
+      e.off = enc->arena.size();
+      enc->arena.insert(enc->arena.end(), p, p + n);
+    }
+    if (np == 1) {
+      e.first = piece_ids[piece_off[i]];
+    } else {
+      e.first = enc->pieces.size();
+      enc->pieces.insert(enc->pieces.end(), piece_ids + piece_off[i], piece_ids + piece_off[i + 1]);
+    }
     const uint64_t mask = enc->table.size() - 1;
     uint64_t s = h & mask;
     while (enc->table[s].n_pieces) s = (s + 1) & mask;
@@ -269,12 +316,20 @@ extern "C" int fs_textenc_add(fs_textenc* enc, const uint8_t* chunk_bytes, const
   return FS_OK;
 }
 
-extern "C" int fs_textenc_encode_files(fs_textenc* enc, const char* paths, uint64_t n_files, uint32_t threads,
-                                       const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off,
-                                       const int32_t** status, const uint8_t** unk_bytes,
-                                       const uint64_t** unk_off, uint64_t* n_unk) {
-  if (!enc || (n_files && !paths) || !tok || !n_tok || !work_off || !status || !unk_bytes || !unk_off || !n_unk)
-    return FS_E_INVALID;
+namespace {
+
+// Reusable two-phase helper: the workers meet the caller once between the phases.
+struct Phase {
+  std::atomic<uint32_t> done{0};
+  std::atomic<uint32_t> go{0};
+};
+
+int encode_files_impl(fs_textenc* enc, const char* paths, uint64_t n_files, uint32_t threads,
+                      const uint32_t* vec_of_sid, uint64_t n_sid,
+                      const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off,
+                      const int32_t** status, const uint8_t** unk_bytes,
+                      const uint64_t** unk_off, uint64_t* n_unk,
+                      const uint32_t** tok_vec, uint64_t* n_oov, int32_t* ids_equal) {
   std::vector<const char*> path(n_files);
   {
     const char* p = paths;
@@ -282,12 +337,18 @@ extern "C" int fs_textenc_encode_files(fs_textenc* enc, const char* paths, uint6
   }
   const uint32_t T = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(threads ? threads : 1, std::max<uint64_t>(1, n_files / 8)));
   std::vector<ThreadOut> outs(T);
-  auto work = [&](uint32_t t) {
+  std::vector<uint64_t> tok_at(T + 1, 0), unk_at(T + 1, 0), oov(T, 0), differ(T, 0), bad_sid(T, 0);
+  Phase ph;
+  // phase 1: a thread's files, tokens into its own vector; phase 2 (once every thread's token
+  // count is known): its tokens into their place of the one output array -- unknown chunks
+  // renumbered into the merged list -- and, with a vector id table, their vector ids beside them
+  auto phase1 = [&](uint32_t t) {
     const uint64_t lo = n_files * t / T, hi = n_files * (t + 1) / T;
     ThreadOut& o = outs[t];
     std::vector<uint8_t> buf;
     o.work_len.reserve(hi - lo);
     o.status.reserve(hi - lo);
+    o.tok.reserve(std::min<uint64_t>((hi - lo) * 2048, 1u << 22));
     for (uint64_t i = lo; i < hi; ++i) {
       const size_t before = o.tok.size();
       const int32_t rc = encode_file(enc, path[i], buf, o);
@@ -296,29 +357,64 @@ extern "C" int fs_textenc_encode_files(fs_textenc* enc, const char* paths, uint6
       o.work_len.push_back(o.tok.size() - before);
     }
   };
+  auto phase2 = [&](uint32_t t) {
+    const ThreadOut& o = outs[t];
+    uint32_t* dst = enc->tok.data() + tok_at[t];
+    uint32_t* vdst = vec_of_sid ? enc->tok_vec.data() + tok_at[t] : nullptr;
+    const uint32_t ub = (uint32_t)unk_at[t];
+    uint64_t n_o = 0, n_d = 0, n_b = 0;
+    const size_t n = o.tok.size();
+    for (size_t i = 0; i < n; ++i) {
+      const uint32_t v = o.tok[i];
+      if (v & 0x80000000u) {
+        dst[i] = 0x80000000u | (ub + (v & 0x7FFFFFFFu));
+        if (vdst) vdst[i] = 0;
+        continue;
+      }
+      dst[i] = v;
+      if (vdst) {
+        uint32_t x = 0;
+        if (v < n_sid) x = vec_of_sid[v]; else ++n_b;
+        vdst[i] = x;
+        n_o += x >> 31;
+        n_d += x != v;
+      }
+    }
+    oov[t] = n_o; differ[t] = n_d; bad_sid[t] = n_b;
+  };
+  auto between = [&]() {
+    for (uint32_t t = 0; t < T; ++t) { tok_at[t + 1] = tok_at[t] + outs[t].tok.size(); unk_at[t + 1] = unk_at[t] + outs[t].unk_count; }
+    enc->tok.resize(tok_at[T]);
+    if (vec_of_sid) enc->tok_vec.resize(tok_at[T]);
+  };
   if (T == 1) {
-    work(0);
+    phase1(0);
+    between();
+    phase2(0);
   } else {
     std::vector<std::thread> th;
-    for (uint32_t t = 0; t < T; ++t) th.emplace_back(work, t);
+    for (uint32_t t = 1; t < T; ++t)
+      th.emplace_back([&, t]() {
+        phase1(t);
+        ph.done.fetch_add(1, std::memory_order_release);
+        while (!ph.go.load(std::memory_order_acquire)) std::this_thread::yield();
+        phase2(t);
+      });
+    phase1(0);
+    while (ph.done.load(std::memory_order_acquire) != T - 1) std::this_thread::yield();
+    between();
+    ph.go.store(1, std::memory_order_release);
+    phase2(0);
     for (auto& x : th) x.join();
   }
-  // merge: tokens in file order, the threads' unknown chunks renumbered into one list (a chunk
-  // two threads met appears twice: the host resolves by text, once each)
-  uint64_t total = 0, unk_total = 0;
-  for (const ThreadOut& o : outs) { total += o.tok.size(); unk_total += o.unk_count; }
-  enc->tok.resize(total);
+  const uint64_t total = tok_at[T], unk_total = unk_at[T];
   enc->work_off.assign(n_files + 1, 0);
   enc->status.resize(n_files);
   enc->unk_bytes.clear();
   enc->unk_off.assign(1, 0);
-  uint64_t at = 0, file = 0, unk_base = 0;
-  for (ThreadOut& o : outs) {
-    for (size_t i = 0; i < o.tok.size(); ++i) {
-      const uint32_t v = o.tok[i];
-      enc->tok[at + i] = (v & 0x80000000u) ? (0x80000000u | (uint32_t)(unk_base + (v & 0x7FFFFFFFu))) : v;
-    }
-    at += o.tok.size();
+  uint64_t file = 0, n_o = 0, n_d = 0, n_b = 0;
+  for (uint32_t t = 0; t < T; ++t) {
+    const ThreadOut& o = outs[t];
     for (size_t i = 0; i < o.work_len.size(); ++i, ++file) {
       enc->work_off[file + 1] = enc->work_off[file] + o.work_len[i];
       enc->status[file] = o.status[i];
@@ -326,10 +422,37 @@ extern "C" int fs_textenc_encode_files(fs_textenc* enc, const char* paths, uint6
     const uint64_t b0 = enc->unk_bytes.size();
     enc->unk_bytes.insert(enc->unk_bytes.end(), o.unk_bytes.begin(), o.unk_bytes.end());
     for (size_t i = 1; i < o.unk_off.size(); ++i) enc->unk_off.push_back(b0 + o.unk_off[i]);
-    unk_base += o.unk_count;
+    n_o += oov[t]; n_d += differ[t]; n_b += bad_sid[t];
   }
   if (unk_total >= 0x7FFFFFFFull) return FS_E_UNSUPPORTED;
+  if (n_b) return FS_E_INVALID;          // a string id the vector id table does not reach
   *tok = enc->tok.data(); *n_tok = total; *work_off = enc->work_off.data(); *status = enc->status.data();
   *unk_bytes = enc->unk_bytes.data(); *unk_off = enc->unk_off.data(); *n_unk = unk_total;
+  if (vec_of_sid) { *tok_vec = enc->tok_vec.data(); *n_oov = n_o; *ids_equal = n_d == 0 && unk_total == 0; }
   return FS_OK;
+}
+
+}  // namespace
+
+extern "C" int fs_textenc_encode_files(fs_textenc* enc, const char* paths, uint64_t n_files, uint32_t threads,
+                                       const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off,
+                                       const int32_t** status, const uint8_t** unk_bytes,
+                                       const uint64_t** unk_off, uint64_t* n_unk) {
+  if (!enc || (n_files && !paths) || !tok || !n_tok || !work_off || !status || !unk_bytes || !unk_off || !n_unk)
+    return FS_E_INVALID;
+  return encode_files_impl(enc, paths, n_files, threads, nullptr, 0, tok, n_tok, work_off, status, unk_bytes, unk_off,
+                           n_unk, nullptr, nullptr, nullptr);
+}
+
+extern "C" int fs_textenc_encode_files_vec(fs_textenc* enc, const char* paths, uint64_t n_files, uint32_t threads,
+                                           const uint32_t* vec_of_sid, uint64_t n_sid,
+                                           const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off,
+                                           const int32_t** status, const uint8_t** unk_bytes,
+                                           const uint64_t** unk_off, uint64_t* n_unk,
+                                           const uint32_t** tok_vec, uint64_t* n_oov, int32_t* ids_equal) {
+  if (!enc || (n_files && !paths) || !tok || !n_tok || !work_off || !status || !unk_bytes || !unk_off || !n_unk ||
+      !vec_of_sid || !tok_vec || !n_oov || !ids_equal)
+    return FS_E_INVALID;
+  return encode_files_impl(enc, paths, n_files, threads, vec_of_sid, n_sid, tok, n_tok, work_off, status, unk_bytes,
+                           unk_off, n_unk, tok_vec, n_oov, ids_equal);
 }

@@ -381,18 +381,65 @@ class TokenPool(object):
             self.pool = None
 
 
-def default_workers(world=1):
-    """Tokeniser (and batch-file writer) processes per rank: FANDOM_SEARCH_WORKERS, else up
-    to 16 of this rank's share of the cores the process may use (0 or 1: tokenise in the
-    parent)."""
-    env = os.environ.get("FANDOM_SEARCH_WORKERS")
-    if env is not None:
-        return max(0, int(env))
+def usable_cpus():
+    """Cores this process may keep busy: its affinity mask, cut down to the CPU quota of its
+    control group (cgroup v2 cpu.max, v1 cpu.cfs_quota_us) -- a container on a 256-core host
+    with a quota of 16 has 16, whatever the mask says; workers beyond it only take turns."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return max(1, min(16, cores // max(1, world)))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:
+            q, period = fh.read().split()[:2]
+            if q != "max" and float(period) > 0:
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, period = float(fq.read()), float(fp.read())
+                if q > 0 and period > 0:
+                    quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        cores = min(cores, max(1, int(quota + 0.999)))
+    return max(1, cores)
+
+
+def default_workers(world=1):
+    """Batch-file writer (and, without the native text front end, tokeniser) processes per
+    rank: FANDOM_SEARCH_WORKERS, else up to 16 of this rank's share of the cores the process
+    may keep busy (0 or 1: in the parent) -- half of that share where the native encoder's
+    threads (default_text_threads) take the other half."""
+    env = os.environ.get("FANDOM_SEARCH_WORKERS")
+    if env is not None:
+        return max(0, int(env))
+    share = usable_cpus() // max(1, world)
+    from . import csvw, textenc
+    if textenc.enabled():
+        if csvw.enabled() and world == 1:
+            return 0                        # text and batch files are both native: nothing left to fork for
+        share = (share + 1) // 2
+    return max(1, min(16, share))
+
+
+def default_text_threads(world=1):
+    """Threads of the native text encoder per rank: FANDOM_SEARCH_TEXT_THREADS, else what
+    FANDOM_SEARCH_WORKERS says, else the half of this rank's share of the cores that
+    default_workers leaves (writers and encoder run at the same time)."""
+    env = os.environ.get("FANDOM_SEARCH_TEXT_THREADS")
+    if env is not None:
+        return max(1, int(env))
+    env = os.environ.get("FANDOM_SEARCH_WORKERS")
+    if env is not None and int(env) > 0:
+        return int(env)
+    from . import csvw
+    share = usable_cpus() // max(1, world)
+    if not (csvw.enabled() and world == 1):
+        share //= 2                         # (the forked writers take the other half)
+    return max(1, min(16, share))
 
 
 class AnnIndexSearch(object):
@@ -442,8 +489,11 @@ class AnnIndexSearch(object):
         v = self.vocab
         # (the workers hold the process-wide vocabulary; an index built on another one
         # tokenises here)
+        made = None          # (tokens, vector ids, OOV tokens, ids equal) where the encoder's thread made them
         if self.token_pool is not None and v is _VOCAB:
             parts = self.token_pool.get(filenames)
+            if self.token_pool.native is not None:
+                made = self.token_pool.native.last_vec
         else:
             from . import textenc
             if textenc.enabled():
@@ -451,8 +501,16 @@ class AnnIndexSearch(object):
                     self._text = textenc.TextEncoder(v)
                 lens, sids = self._text.encode_files(list(filenames))
                 parts = [(lens, sids, [])]
+                made = self._text.last_vec
             else:
                 parts = [tokenize_files(list(filenames), v)]
+        self._made = None
+        if made is not None and len(parts) == 1 and parts[0][1] is made[0] and not parts[0][2]:
+            lens = parts[0][0]
+            off = np.zeros(len(lens) + 1, dtype=np.uint64)
+            off[1:] = np.cumsum(lens, dtype=np.uint64)
+            self._made = made[1:]                # (_corpus_of_ids: for exactly this vector id array)
+            return made[0], made[1], off
         lens = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64)
         off = np.zeros(len(lens) + 1, dtype=np.uint64)
         off[1:] = np.cumsum(lens, dtype=np.uint64)
@@ -505,9 +563,13 @@ class AnnIndexSearch(object):
         """(string ids, vector ids, work offsets, device corpus) of encoded works."""
         v = self.vocab
         chars, coff = v.string_table()
-        self.last_oov_rate = float((tok_vec & np.uint32(abi.FS_OOV_FLAG)).astype(bool).mean()) \
-            if len(tok_vec) else 0.0
-        same = bool(np.array_equal(tok_str, tok_vec))
+        made = getattr(self, "_made", None)
+        if made is not None and made[0] is tok_vec:
+            self.last_oov_rate, same = made[1] / float(len(tok_vec)), made[2]
+        else:
+            self.last_oov_rate = float(np.count_nonzero(tok_vec & np.uint32(abi.FS_OOV_FLAG))) / len(tok_vec) \
+                if len(tok_vec) else 0.0
+            same = bool(np.array_equal(tok_str, tok_vec))
         # one device corpus serves batch after batch while the string table stays as it is
         # (fs_corpus_update_begin/_end: the ids are replaced, the tables built once per string
         # table -- Levenshtein per n-gram, the batch table of k_scan_rows -- are kept)
@@ -547,7 +609,11 @@ class AnnIndexSearch(object):
         self.last_stats = st
         self._windows_processed += int(st.windows_processed)
         pos = off[rows['work']].astype(np.int64) + rows['fan_ix'].astype(np.int64)
-        words = [v.strings[s] for s in tok_str[pos].tolist()]
+        # the fan words of the records: as string ids (what the native batch writer takes, csvw.py)
+        # and, unless the caller has said it does not need them (want_words), as text
+        self.last_word_sids = tok_str[pos]
+        words = list(map(v.strings.__getitem__, self.last_word_sids.tolist())) \
+            if getattr(self, "want_words", True) else None
         t3 = time.perf_counter()
         for k, dt in (("corpus to the GPU", t1 - t0), ("fs_search_corpus", t2 - t1), ("fan words of the records", t3 - t2)):
             ht[k] = ht.get(k, 0.0) + dt
@@ -588,7 +654,7 @@ class AnnIndexSearch(object):
         else:
             r = host.view(np.uint32).reshape(n, rec // 4)
             pos = off[r[:, 0]].astype(np.int64) + r[:, 1].astype(np.int64)
-        words = [self.vocab.strings[s] for s in tok_str[pos].tolist()]
+        words = list(map(self.vocab.strings.__getitem__, tok_str[pos].tolist()))
         return Shard(buf, rec, n, off, words)
 
     def records(self, filenames, rows, words):
@@ -724,7 +790,7 @@ def analyze(args,
         if textenc.enabled():
             # reading and tokenising on native threads of this process (fs_textenc_*); the
             # forked workers then only write the batch files
-            pool.native = textenc.TextEncoder(get_vocab(), default_workers(dist.env_world()[2]))
+            pool.native = textenc.TextEncoder(get_vocab(), default_text_threads(dist.env_world()[2]))
             _startup_lap("native text encoder")
     try:
         return _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_threshold,
@@ -787,6 +853,15 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
             timing[what] = timing.get(what, 0.0) + now - t_last[0]
             t_last[0] = now
 
+    # batch files by the native writer (fs_csvw_*: join and csv bytes in one call per batch, on a
+    # thread of this process) where the records come from this process' own search
+    native_csv = None
+    if searcher is None and world == 1:
+        from . import csvw
+        if csvw.enabled():
+            native_csv = csvw.CsvWriter(ann_index.word_lowercase, ann_index.orth_id, ann_index.character,
+                                        ann_index.scene, ann_index.vocab.strings)
+            ann_index.want_words = False
     lap("index")
     _startup_lap("script index on the GPU (library load, HIP start-up, fs_index_create)")
     failure = None
@@ -818,6 +893,10 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
         if rank != root or failure is not None:
             continue
         try:
+            if native_csv is not None:
+                native_csv.write_async(batch_filename.format(i), fan_cluster, rows, ann_index.last_word_sids)
+                lap("hand batch to a writer")
+                continue
             if pool is not None and pool.pool is not None and searcher is None:
                 # the batch file is written by a worker of the token pool (they are forked, and
                 # parse the script's columns themselves) while this process searches the next
@@ -841,6 +920,10 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
                 raise
             failure = e
     try:
+        if native_csv is not None:
+            ann_index.want_words = True
+            native_csv.finish()                     # (raises what a write raised)
+            native_csv.close()
         if pool is not None:
             pool.finish_writes()                    # (raises what a writer raised)
     except Exception as e:                          # told to the other ranks below, then raised

@@ -45,6 +45,11 @@ def _bind(L):
     L.fs_textenc_encode_files.argtypes = [
         C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, C.POINTER(u32p), u64p, C.POINTER(u64p),
         C.POINTER(C.POINTER(C.c_int32)), C.POINTER(u8p), C.POINTER(u64p), u64p]
+    L.fs_textenc_encode_files_vec.restype = C.c_int
+    L.fs_textenc_encode_files_vec.argtypes = [
+        C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint32, u32p, C.c_uint64, C.POINTER(u32p), u64p, C.POINTER(u64p),
+        C.POINTER(C.POINTER(C.c_int32)), C.POINTER(u8p), C.POINTER(u64p), u64p,
+        C.POINTER(u32p), u64p, C.POINTER(C.c_int32)]
     L._textenc_bound = True
     return L
 
@@ -56,13 +61,17 @@ class TextEncoder(object):
 
     def __init__(self, vocab, threads=0):
         self.vocab = vocab
-        self.threads = int(threads) or min(16, len(os.sched_getaffinity(0)))
+        if not threads:
+            from .search import usable_cpus
+            threads = min(16, usable_cpus())
+        self.threads = int(threads)
         self._L = _bind(_lib.load())
         self._h = C.c_void_p()
         _lib.check(self._L.fs_textenc_create(C.byref(self._h)), "fs_textenc_create")
         self._lock = threading.Lock()
         self._pending = {}
         self._taught = 0
+        self.last_vec = None
         self._teach_plain()
 
     def close(self):
@@ -106,15 +115,27 @@ class TextEncoder(object):
 
     # ---- encoding ---------------------------------------------------------------------------
 
-    def _native(self, filenames):
+    def _native(self, filenames, made=None):
+        """(tokens, work offsets, status per file, unknown chunks' texts).  `made`: a dict that
+        receives "vec" = (vector id per token, OOV tokens, string ids == vector ids) when the
+        batch needs nothing more from the host -- no unknown chunk, no work left to the Python
+        path --, made by the encoding threads themselves (fs_textenc_encode_files_vec)."""
         paths = b"".join(os.fsencode(f) + b"\0" for f in filenames)
         tok, woff = C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint64)()
         status, ub, uo = C.POINTER(C.c_int32)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
         n_tok, n_unk = C.c_uint64(), C.c_uint64()
+        vec, n_oov, same = C.POINTER(C.c_uint32)(), C.c_uint64(), C.c_int32()
         with self._lock:
-            _lib.check(self._L.fs_textenc_encode_files(
-                self._h, paths, len(filenames), self.threads, C.byref(tok), C.byref(n_tok), C.byref(woff),
-                C.byref(status), C.byref(ub), C.byref(uo), C.byref(n_unk)), "fs_textenc_encode_files")
+            if made is not None:
+                vt = self.vocab.vec_ids()          # (covers every string id the encoder has been taught)
+                _lib.check(self._L.fs_textenc_encode_files_vec(
+                    self._h, paths, len(filenames), self.threads, vt.ctypes.data_as(C.POINTER(C.c_uint32)), len(vt),
+                    C.byref(tok), C.byref(n_tok), C.byref(woff), C.byref(status), C.byref(ub), C.byref(uo),
+                    C.byref(n_unk), C.byref(vec), C.byref(n_oov), C.byref(same)), "fs_textenc_encode_files_vec")
+            else:
+                _lib.check(self._L.fs_textenc_encode_files(
+                    self._h, paths, len(filenames), self.threads, C.byref(tok), C.byref(n_tok), C.byref(woff),
+                    C.byref(status), C.byref(ub), C.byref(uo), C.byref(n_unk)), "fs_textenc_encode_files")
             n = len(filenames)
 
             def arr(ptr, count, dtype):          # (an empty vector's data() may be NULL)
@@ -123,6 +144,8 @@ class TextEncoder(object):
             t = arr(tok, n_tok.value, np.uint32)
             w = arr(woff, n + 1, np.uint64)
             st = arr(status, n, np.int32)
+            if made is not None and n_unk.value == 0 and n_tok.value and not st.any():
+                made["vec"] = (arr(vec, n_tok.value, np.uint32), int(n_oov.value), bool(same.value))
             uoff = arr(uo, n_unk.value + 1, np.uint64)
             ubytes = bytes(arr(ub, int(uoff[-1]) if len(uoff) else 0, np.uint8))
         unk = [ubytes[int(uoff[i]):int(uoff[i + 1])].decode("utf-8") for i in range(n_unk.value)]
@@ -136,7 +159,10 @@ class TextEncoder(object):
 
         def run():
             try:
-                box["r"] = self._native(key)
+                # (a batch the encoder knows every chunk of -- any batch, once the first few have
+                # taught it -- comes with its vector ids, made by the encoding threads: the search
+                # then has no pass of its own to make over the batch's tokens)
+                box["r"] = self._native(key, box)
             except BaseException as e:          # (raised again in the caller's thread)
                 box["e"] = e
 
@@ -149,13 +175,21 @@ class TextEncoder(object):
     def encode_files(self, filenames):
         from . import tokenizer
         job = self._pending.pop(tuple(filenames), None)
+        self.last_vec = None                     # (tokens, vector ids, OOV tokens, ids equal) of this call, where the encoder made them
         if job is not None:
             job[0].join()
             if "e" in job[1]:
                 raise job[1]["e"]
             tok, woff, status, unk = job[1]["r"]
+            if "vec" in job[1]:                  # (nothing unknown, nothing left to the Python path: `tok` goes out as it is)
+                self.last_vec = (tok,) + job[1]["vec"]
+                return np.diff(woff).astype(np.int64), tok
         else:
-            tok, woff, status, unk = self._native(filenames)
+            box = {}
+            tok, woff, status, unk = self._native(filenames, box)
+            if "vec" in box:
+                self.last_vec = (tok,) + box["vec"]
+                return np.diff(woff).astype(np.int64), tok
         v = self.vocab
         for i in np.nonzero(status < 0)[0]:
             raise OSError(-int(status[i]), os.strerror(-int(status[i])), filenames[int(i)])

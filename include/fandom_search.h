@@ -283,6 +283,18 @@ int fs_textenc_encode_files(fs_textenc* enc, const char* paths /* n_files string
                             const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off /* n_files + 1 */,
                             const int32_t** status, const uint8_t** unk_bytes, const uint64_t** unk_off,
                             uint64_t* n_unk);
+/* The same with the pass the search makes over a batch's tokens next (search.py:65-84 looks
+ * every token's vector up; here a token's vector id is vec_of_sid[string id], n_sid entries):
+ * tok_vec[i] = vector id of token i (0 for a placeholder), *n_oov = tokens whose vector id has
+ * FS_OOV_FLAG set, *ids_equal = 1 when every token's vector id equals its string id (a batch
+ * without capitalised or out-of-vocabulary words: no string ids need to travel to the GPU).
+ * Made by the threads that encode, each for its own files.  FS_E_INVALID when a string id the
+ * encoder was taught lies beyond n_sid. */
+int fs_textenc_encode_files_vec(fs_textenc* enc, const char* paths, uint64_t n_files, uint32_t threads,
+                                const uint32_t* vec_of_sid, uint64_t n_sid,
+                                const uint32_t** tok, uint64_t* n_tok, const uint64_t** work_off,
+                                const int32_t** status, const uint8_t** unk_bytes, const uint64_t** unk_off,
+                                uint64_t* n_unk, const uint32_t** tok_vec, uint64_t* n_oov, int32_t* ids_equal);
 
 /* Diagnostics: tables with near-synonyms -- the sizes of the connected components of the graph
  * of "near" vector pairs that the integer prefilters of the LSH pipeline work over (0 entries:
@@ -335,6 +347,30 @@ int fs_scan_benchmark(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms)
  * dispatch-to-completion time, HIP events on every dispatch, one launch at a time.  What a
  * search's own kernel takes above this is its own work. */
 int fs_stream_floor(fs_index* ix, fs_corpus* c, uint32_t reps, double* avg_ms);
+
+/* ---- the batch files (search.py:192-218 the twelve fields of a record, :331-334 write_records) ----
+ * fs_row records in, the bytes csv.writer(out).writerows(records) puts into a batch file out:
+ * FAN_WORK_FILENAME = name of rows[i].work, FAN_WORK_WORD / _ORTH_ID = text and spaCy key
+ * (MurmurHash64A of the UTF-8 bytes, seed 1) of string fan_sid[i] of the strings added so far,
+ * the ORIGINAL_SCRIPT_* columns = entry rows[i].orig_ix of the four tables of fs_csvw_set_script
+ * (each the text a record shows: the lower-case word, its key in decimal, the character name,
+ * the scene number; None = the empty string), distances by Python's repr(float).  `excel`
+ * dialect: "\r\n" behind a record, a field quoted -- its quotes doubled -- when it holds ',',
+ * '"', CR or LF.  A string table is {bytes, off[n + 1]}.  *out is the writer's own buffer, valid
+ * until its next call; writing it to a file is the caller's.  No GPU is involved. */
+typedef struct fs_csvw fs_csvw;
+int fs_csvw_create(fs_csvw** out);
+void fs_csvw_destroy(fs_csvw* w);
+int fs_csvw_set_script(fs_csvw* w, uint64_t n_script,
+                       const uint8_t* word_bytes, const uint64_t* word_off,
+                       const uint8_t* orth_bytes, const uint64_t* orth_off,
+                       const uint8_t* char_bytes, const uint64_t* char_off,
+                       const uint8_t* scene_bytes, const uint64_t* scene_off);
+int fs_csvw_add_strings(fs_csvw* w, const uint8_t* bytes, const uint64_t* off, uint64_t n);   /* ids go on counting */
+uint64_t fs_csvw_strings(const fs_csvw* w);                                                  /* strings added so far */
+int fs_csvw_format(fs_csvw* w, const fs_row* rows, uint64_t n_rows,
+                   const uint8_t* name_bytes, const uint64_t* name_off, uint64_t n_works,
+                   const uint32_t* fan_sid, const uint8_t** out, uint64_t* out_len);
 
 /* Diagnostics (FS_DIAG=2 in the environment at fs_index_create): per wave range of the
  * last k_scan_rows launch on stream `lane`, eight uint64 {entry, filter staged, scan done,

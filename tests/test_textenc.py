@@ -110,3 +110,38 @@ def test_switch(monkeypatch):
     monkeypatch.delenv("FANDOM_SEARCH_NATIVE_TEXT")
     monkeypatch.setenv("FANDOM_SEARCH_TOKENIZER", "simple")
     assert not textenc.enabled()
+
+
+def test_a_known_batch_brings_its_vector_ids(corpus):
+    """The encoding threads make what the search asks of a batch's tokens besides the string
+    ids (fs_textenc_encode_files_vec) -- vector id per token, the number of out-of-vocabulary
+    tokens, whether the two id arrays are equal -- when the encoder knows every chunk and no
+    work is left to the Python path; otherwise (first sight of a chunk, a long work) the
+    caller makes them as before."""
+    voc = vocab.Vocab(synth.vocab_words(), synth.embedding())
+    enc = textenc.TextEncoder(voc, threads=4)
+    short = [f for f in corpus if not f.endswith("long.txt")]
+    enc.start(short)
+    lens0, tok0 = enc.encode_files(short)              # chunks it has to be taught: nothing made
+    assert enc.last_vec is None
+    enc.start(short)
+    lens, tok = enc.encode_files(short)                # every chunk known now
+    assert enc.last_vec is not None and enc.last_vec[0] is tok
+    assert np.array_equal(lens, lens0) and np.array_equal(tok, tok0)
+    _, vec, n_oov, same = enc.last_vec
+    want = voc.vec_ids()[tok]
+    assert vec.dtype == np.uint32 and np.array_equal(vec, want)
+    assert n_oov == int(np.count_nonzero(want & np.uint32(vocab.OOV_FLAG))) and n_oov > 0
+    assert same == bool(np.array_equal(tok, want)) and not same
+    lens2, tok2 = enc.encode_files(short)              # not started: the same, on the caller's thread
+    assert enc.last_vec is not None and np.array_equal(tok2, tok) and np.array_equal(enc.last_vec[1], want)
+    enc.start(corpus)                                  # a work of 100000 bytes: the Python path, nothing made
+    enc.encode_files(corpus)
+    assert enc.last_vec is None
+    # a batch whose string ids ARE its vector ids (plain words of the table only)
+    plain = [f for f in short if os.path.basename(f) == "plain.txt"] * 8
+    enc.encode_files(plain)
+    enc.start(plain)
+    _, tokp = enc.encode_files(plain)
+    assert enc.last_vec is not None and enc.last_vec[3] == bool(np.array_equal(tokp, voc.vec_ids()[tokp]))
+    assert enc.last_vec[2] == 0
