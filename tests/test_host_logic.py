@@ -51,6 +51,29 @@ def test_listing_order_os_shuffles_the_listing_as_it_comes(tmp_path, monkeypatch
     assert args.listing == "os"
 
 
+def test_threads_and_workers_follow_the_cpu_share(monkeypatch):
+    """usable_cpus(): the affinity mask cut down to the control group's quota; the encoder's
+    threads and the forked workers share it where both run, and a one-rank run whose text and
+    batch files are both native forks nobody."""
+    for k in ("FANDOM_SEARCH_WORKERS", "FANDOM_SEARCH_TEXT_THREADS", "FANDOM_SEARCH_NATIVE_CSV",
+              "FANDOM_SEARCH_NATIVE_TEXT", "FANDOM_SEARCH_TOKENIZER"):
+        monkeypatch.delenv(k, raising=False)
+    cpus = search.usable_cpus()
+    assert 1 <= cpus <= len(os.sched_getaffinity(0))
+    assert search.default_workers(1) == 0                      # native text + native csv, one rank
+    assert search.default_text_threads(1) == max(1, min(16, cpus))
+    assert search.default_workers(2) == max(1, min(16, (cpus // 2 + 1) // 2))     # ranks write through the pool
+    monkeypatch.setenv("FANDOM_SEARCH_NATIVE_CSV", "0")
+    assert search.default_workers(1) == max(1, min(16, (cpus + 1) // 2))
+    assert search.default_text_threads(1) == max(1, min(16, cpus // 2))
+    monkeypatch.setenv("FANDOM_SEARCH_NATIVE_TEXT", "0")
+    assert search.default_workers(1) == max(1, min(16, cpus))
+    monkeypatch.setenv("FANDOM_SEARCH_WORKERS", "3")
+    assert search.default_workers(1) == 3 and search.default_text_threads(1) == 3
+    monkeypatch.setenv("FANDOM_SEARCH_TEXT_THREADS", "5")
+    assert search.default_text_threads(1) == 5
+
+
 def test_write_records_bytes(tmp_path):
     """csv.writer defaults: \\r\\n terminators, minimal quoting, None -> empty,
     floats by repr (search.py:331-334)."""
