@@ -17,7 +17,9 @@ from tests import util
 pytestmark = pytest.mark.gpu
 
 
-def test_ao3_search_c1(tmp_path, monkeypatch, synth_base, capsys):
+@pytest.mark.parametrize("native_csv", ["1", "0"])      # batch files by fs_csvw_* / by csv.writer in forked workers
+def test_ao3_search_c1(tmp_path, monkeypatch, synth_base, capsys, native_csv):
+    monkeypatch.setenv("FANDOM_SEARCH_NATIVE_CSV", native_csv)
     words, emb = synth_base["words"], synth_base["emb"]
     script = synth.script_tokens(5000)
     fandir = tmp_path / "fanworks"
