@@ -23,7 +23,7 @@ verification, Levenshtein records, per-word dedupe, records left in HBM).
           it is one of the ranks.
 
 The timed region is `--steps` steps between barrier + synchronize on both sides; when
-steps <= 64 it is repeated (7 regions, each primed by the warm-up) and the median region
+steps <= 64 it is repeated (9 regions, each primed by the warm-up) and the median region
 is reported, with every sample in `samples_ms` (a 0.6 ms region is a fragile basis).
 
 Prints ONE JSON line (rank 0): the driver's contract plus
@@ -72,7 +72,7 @@ def parse(argv=None):
                     help="N > 1: rotate (step i's records to rank i mod N, one all_to_all per N steps; default), "
                          "step (the same with one gather per step) or 0 (a gather per step, always to rank 0)")
     ap.add_argument("--reps", type=int, default=0,
-                    help="timed regions of --steps steps (default: 7 when steps <= 64, else 3); "
+                    help="timed regions of --steps steps (default: 9 when steps <= 64, else 3); "
                          "the median is reported")
     ap.add_argument("--master-port", type=int, default=0, help="self-launch: rendezvous port (default: a free one)")
     ap.add_argument("--works", type=int, default=0, help="override works (per rank)")
@@ -689,7 +689,7 @@ def main():
     # the dominant kernel carries timing events on every search of a short run (the driver
     # passes --steps 20), on every 4th of a long one (an event record costs stream time)
     ix.set_scan_timing(args.scan_timing or (1 if args.steps <= 64 else 4))
-    reps = args.reps or (7 if args.steps <= 64 else 3)
+    reps = args.reps or (9 if args.steps <= 64 else 3)
     samples = []
     it = 0
     for rep in range(reps):
