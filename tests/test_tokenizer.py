@@ -219,3 +219,44 @@ def test_differential_against_spacy_where_installed():
     print("tokenizer vs spaCy %s: %d of %d texts differ (%.2f %%)"
           % (spacy.__version__, len(differ), len(sample), 100 * rate), differ[:5])
     assert rate < 0.02
+
+
+def test_affix_shortcut_is_the_long_way():
+    """tokenizer._affix_shortcut (a word with marks around it, decided in one go) against
+    _tokenize_chunk for every word that is part of a special case, single letters, plain,
+    capitalised and upper-case words, under every combination of marks in front, a full stop and
+    marks behind -- including combinations the shortcut must decline."""
+    import re
+    from fandom_search_amd import synth
+    t = tokenizer
+    words = synth.vocab_words()
+    stems = sorted({m for c in t.SPECIAL_CASES for m in re.findall(r"[A-Za-z]+", c)})
+    stems += ["hello", "Hello", "HELLO", "USA", "x", "X", "ok", "OK", "Ok"]
+    sample = [words[i] for i in range(0, len(words), 257)]
+    base = sample + [w.capitalize() for w in sample[:10]] + [w.upper() for w in sample[:5]] + stems
+    fronts = ["", '"', "(", '("', '"(', "((", "(((", "'", "["]
+    backs = ["", ",", "!", "?", ";", ":", '"', ")", ',"', '?")', ").", "!!!", "!!!!", "...", "'", "'s", ",.", ":)", "):", "-", "%"]
+    fired = 0
+    for w in base:
+        for f in fronts:
+            for m in ("", "."):
+                for b in backs:
+                    c = f + w + m + b
+                    sc = t._affix_shortcut(c)
+                    if sc is None:
+                        continue
+                    fired += 1
+                    out = []
+                    t._tokenize_chunk(c, out)
+                    assert tuple(out) == sc, c
+    assert fired > 50000
+    # what it must decline: an abbreviation or an emoticon inside, a capital in front of the full stop
+    abbr = sorted(k for k in t.SPECIAL_CASES if re.fullmatch(r"[A-Za-z]*[a-z]\.", k))
+    assert "Mr." in abbr and "a." in abbr and len(abbr) > 50
+    for k in abbr:
+        for c in (k + ",", '"' + k, k + ")", "(" + k + ")"):
+            assert t._affix_shortcut(c) is None, c
+    for c in ("(o:,", '"(o:', "A.", "USA.", "word...", "don't,", "word"):
+        assert t._affix_shortcut(c) is None, c
+    assert t._affix_shortcut('"word,"') == ('"', "word", ",", '"')
+    assert t._affix_shortcut("cannot.") == ("can", "not", ".")
