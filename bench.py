@@ -235,6 +235,7 @@ def search_companion(ix, corpus, n_works, n_tok, n_fl, reps=24, alone_reps=6):
             best = st.total_ms if best is None else min(best, st.total_ms)
     cap = len(rows) + 64
     bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(n_fl + 1)]
+    torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
     for i in range(2 * n_fl):                                    # (every lane's workspaces grown)
         ix.search_end(ix.search_begin(corpus, bufs[0].data_ptr(), cap, header=True))
     ix.set_scan_timing(1 << 20)
@@ -353,6 +354,7 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     cap = len(rows) + 64
     n_fl = max(2, int(os.environ.get("FS_LANES", "1")))          # searches in flight, as in the timed region
     bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(n_fl + 1)]
+    torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
     reps, tickets = 48, []
     for i in range(8):                                           # (primed pipeline)
         ix.search_end(ix.search_begin(cs, bufs[0].data_ptr(), cap, header=True))
@@ -463,6 +465,7 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
     n_tok = corpora[0].n_tok
     cap = n_tok // 64
     probe = torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
     for c in corpora:
         while True:
             try:
@@ -473,8 +476,10 @@ def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
                     raise
                 cap = int(e.required * 1.05) + 64
                 probe = torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
     del probe
     bufs = [torch.zeros(32 + cap * 32, dtype=torch.uint8, device="cuda") for _ in range(inflight + 1)]
+    torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
 
     def run(n_steps):
         tickets = []
@@ -620,6 +625,7 @@ def main():
     rec_bytes = packed if packed else 32
     cap = 4096
     probe = torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
     rows_per_corpus = []
     for c in corpora:
         while True:
@@ -632,6 +638,7 @@ def main():
                     raise
                 cap = int(e.required * 1.05) + 64
                 probe = torch.zeros(HDR + cap * rec_bytes, dtype=torch.uint8, device="cuda")
+                torch.cuda.synchronize()      # (torch's fill is complete before the library's own streams write the buffer)
     del probe
     NB = inflight + 1
     # the receiver of a step's records goes round (step i to rank i mod N): every pair of GPUs

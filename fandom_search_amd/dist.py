@@ -332,6 +332,9 @@ class RowGather(object):
         src = self.landing[b] if self.world > 1 else self.bufs[b]
         if self.rec_bytes != 32 and src.device.type != "cuda":
             src = src.cuda()                        # the expansion kernels need the records in HBM
+        if self.rec_bytes != 32:
+            from .engine import torch_ready
+            torch_ready()                           # (torch's copy is complete before the library's stream reads it)
         parts = []
         for r in range(self.world):
             n = min(int(cnts[r]), self.cap)
@@ -400,11 +403,14 @@ def unpack_shard(blob, index):
             raise RuntimeError("wire records need the script index to be expanded")
         dev = blob if blob.device.type == "cuda" else blob[:at_words].cuda()
         full = torch.empty(max(1, n) * 32, dtype=torch.uint8, device="cuda")
+        from .engine import torch_ready
         if rec == 8:
             # (uint64 offsets: an 8-byte aligned copy of their own)
             offs = dev[at_off:at_off + 8 * (n_works + 1)].clone()
+            torch_ready()                           # the copy and the clone are torch's, the expansion runs on the library's stream
             index.unpack8_device(dev.data_ptr() + at_rec, n, offs.data_ptr(), n_works, full.data_ptr())
         else:
+            torch_ready()
             index.unpack_device(dev.data_ptr() + at_rec, n, full.data_ptr())
         rows = full[:n * 32].cpu().numpy().view(abi.ROW_DTYPE).copy()
     else:

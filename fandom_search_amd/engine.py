@@ -85,6 +85,21 @@ class Corpus(object):
             pass
 
 
+def torch_ready():
+    """The library launches on streams of its own (hipStreamNonBlocking: no implicit ordering
+    with torch's stream).  Device memory that torch has only just produced -- a zero-filled
+    buffer, a host-to-device copy, a clone -- must be complete before it is handed to a call
+    that reads it or writes into it: otherwise the library's kernel can read what the allocator
+    left there from an earlier batch, or torch's fill can land on top of the library's records.
+    (Round 5: `unpack_shard` read a stale copy of a shard's work offsets once in five runs of the
+    two-rank test and attributed a run of records to the work in front.)  Not for per-step paths:
+    buffers made ahead of time need none of this."""
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
+
+
 class PinnedBuffer(object):
     """Page-locked host memory (hipHostMalloc) viewed as a numpy array."""
 
@@ -341,6 +356,7 @@ class ScriptIndex(object):
         thr = np.ascontiguousarray(thresholds, dtype=np.float64)
         n_script = int(self.info["n_script"])
         out = torch.zeros(max(1, n_script) * (len(thr) + 1), dtype=torch.int32, device="cuda")
+        torch_ready()                       # (the zeros are there before the kernel adds to them)
         _lib.check(_lib.load().fs_reuse_histogram_rows(
             self._h, C.c_void_p(rows_ptr), int(n_rows), abi.ptr(thr, C.c_double), len(thr),
             C.c_void_p(out.data_ptr())), "fs_reuse_histogram_rows")

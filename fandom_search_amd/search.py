@@ -638,6 +638,8 @@ class AnnIndexSearch(object):
         cap = max(1024, len(tok_vec) // 16)
         while True:
             buf = torch.zeros(HDR + cap * rec, dtype=torch.uint8, device="cuda")
+            from .engine import torch_ready
+            torch_ready()                       # (torch's fill is done before the search writes header and records)
             try:
                 n, st = self.engine.search_end(self.engine.search_begin(
                     corpus, buf.data_ptr(), cap, packed=packed, header=True))
