@@ -102,6 +102,7 @@ def test_format_on_search_output(tmp_path, monkeypatch, synth_base):
     corpus = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
     rows, _ = ix.search(corpus)
     buf = torch.zeros(len(rows) * 32 + 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     n, _ = ix.search_device(corpus, buf.data_ptr(), len(rows) + 1)
     counts = ix.reuse_histogram_device(buf.data_ptr(), n, fmt.THRESHOLDS)
     want = fmt.reuse_histogram(rows["orig_ix"], rows["comb"], len(script))

@@ -107,10 +107,12 @@ def test_c2_full_properties_and_pipeline_equality(c2, synth_base, monkeypatch):
     import torch
     cap = len(rows) + 16
     wire = torch.zeros(32 + cap * 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # (as below: the fill is torch's, the search writes on the library's streams)
     n8, _ = ix.search_end(ix.search_begin(corpus, wire.data_ptr(), cap, packed=8, header=True))
     assert n8 == len(rows) and int(wire[:8].cpu().numpy().view(np.uint64)[0]) == n8
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     full = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     ix.unpack8_device(wire.data_ptr() + 32, n8, d_off.data_ptr(), len(off) - 1, full.data_ptr())
     assert full.cpu().numpy()[:n8 * 32].tobytes() == rows.tobytes()
     del wire, full

@@ -191,9 +191,11 @@ def test_packed_wire_rows_round_trip(synth_base):
     want, _ = ix.search(corpus)
     cap = len(want) + 10
     packed = torch.zeros(cap * 16, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # (as below: the fill is torch's, the search writes on the library's streams)
     n, st = ix.search_device(corpus, packed.data_ptr(), cap, packed=True)
     assert n == len(want)
     full = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     ix.unpack_device(packed.data_ptr(), n, full.data_ptr())
     got = full.cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
     assert got.tobytes() == want.tobytes()
@@ -299,6 +301,7 @@ def test_searches_in_flight(synth_base):
         corpora.append(c)
         want.append(ix.search(c)[0])
     bufs = [torch.zeros((len(w) + 8) * 32, dtype=torch.uint8, device="cuda") for w in want]
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     tickets = [ix.search_begin(c, b.data_ptr(), len(w) + 8) for c, b, w in zip(corpora, bufs, want)]
     with pytest.raises(_lib.FsError, match="in flight"):
         ix.search_begin(corpora[0], bufs[0].data_ptr(), 8)
@@ -412,6 +415,7 @@ def test_overlapping_searches_stress(synth_base, mode, lanes, monkeypatch):
         corpora.append(c)
         want.append(ix.search(c)[0])
     bufs = [torch.zeros((len(w) + 8) * 32, dtype=torch.uint8, device="cuda") for w in want]
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     rounds = 25 if mode == abi.FS_MODE_AUTO else 6
     for r in range(rounds):
         order = [(r + j) % 4 for j in range(4)]
@@ -520,10 +524,12 @@ def test_eight_byte_wire_rows_round_trip(synth_base):
     want, _ = ix.search(corpus)
     cap = len(want) + 10
     packed = torch.zeros(cap * 8, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # (as below: the fill is torch's, the search writes on the library's streams)
     n, st = ix.search_device(corpus, packed.data_ptr(), cap, packed=8)
     assert n == len(want)
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     full = torch.empty(cap * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     ix.unpack8_device(packed.data_ptr(), n, d_off.data_ptr(), len(off) - 1, full.data_ptr())
     got = full.cpu().numpy()[:n * 32].view(abi.ROW_DTYPE)
     assert got.tobytes() == want.tobytes()
@@ -547,6 +553,7 @@ def test_rows_header_receives_the_count(synth_base):
     cap = len(want) + 5
     for packed, size in ((False, 32), (True, 16), (8, 8)):
         buf = torch.full((32 + cap * size,), 0xAB, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
         n, st = ix.search_end(ix.search_begin(corpus, buf.data_ptr(), cap, packed=packed, header=True))
         host = buf.cpu().numpy()
         assert n == len(want) and int(host[:8].view(np.uint64)[0]) == n
@@ -709,6 +716,7 @@ def test_scan_rows_and_chain_agree(synth_base, monkeypatch, n):
         cap = len(rows) + 3
         for packed, size in ((True, 16), (8, 8)):
             buf = torch.zeros(32 + cap * size, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
             nw, _ = ix.search_end(ix.search_begin(c, buf.data_ptr(), cap, packed=packed, header=True))
             host = buf.cpu().numpy()
             assert nw == len(rows) and int(host[:8].view(np.uint64)[0]) == nw

@@ -97,6 +97,7 @@ def test_update_of_a_corpus_with_a_search_in_flight_is_refused(synth_base):
     c = ix.corpus(tok, off, synth_base["chars"], synth_base["off"])
     want, _ = ix.search(c)
     buf = torch.zeros(32 + (len(want) + 8) * 32, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()      # torch's fill / copy is complete before the library's own streams touch the buffer (engine.torch_ready)
     t = ix.search_begin(c, buf.data_ptr(), len(want) + 8, header=True)
     with pytest.raises(_lib.FsError) as e:
         c.update_begin(tok2, off2)
