@@ -447,6 +447,26 @@ def companions(ix, corpora, toks, offs, chars, coff, words, script, swords, emb,
     return out
 
 
+def command_companion(works=20000, timeout=180):
+    """The reference's command itself (`ao3.py search <dir> <script>`, a process of its own) on
+    `works` synthetic files of 2000 tokens: wall time from start to the dated CSV, files/s, and
+    where it went (tools/cli_bench.py).  Host work -- reading, tokenising, the batch files -- and
+    start-up: the GPU's share of a 500-work batch is 0.3 ms.  Never fails the bench line."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cli_bench.py"), "--works", str(works)],
+                           capture_output=True, text=True, timeout=timeout)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        return {"value": d["works_per_s"], "unit": "fanworks/s", "works": d["works"],
+                "tokens_per_work": d["tokens_per_work"], "search_command_s": d["search_command_s"],
+                "rows": d["rows"], "csv_files": d["csv_files"], "rc": d["rc"],
+                "where": d["stderr_tail"][-700:],
+                "note": "python ao3.py search (one process: native text encoder, one GPU, native batch writer) on "
+                        "synthetic files written for the run; includes interpreter and HIP start-up"}
+    except Exception as e:          # (diagnostic companion: reported, not raised)
+        return {"value": None, "error": repr(e)[:300]}
+
+
 def c3_companions(ix, script, chars, coff, inflight, shards=8, passes=5):
     """BASELINE.json configs[2] (100k works x 5k tokens) on ONE GPU, as the eight 12.5k-work
     shards an 8-GPU run deals out (the script is configs[1]'s, so the index is the same):
@@ -924,6 +944,7 @@ def main():
                 for c in corpora:
                     c.close()
                 out["companions"].update(c3_companions(ix, script, chars, coff, inflight))
+                out["companions"]["command_end_to_end"] = command_companion()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, script, swords, words, emb, normals, tpw,
                                                chars, coff, args.cpu_seconds)
