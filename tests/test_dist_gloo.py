@@ -89,6 +89,9 @@ WORKER = textwrap.dedent('''
         with open("match-6gram-batch-1.csv", "w") as fh:
             fh.write("stale" + chr(10))
         os.utime("match-6gram-batch-1.csv", (1, 1))
+    if os.environ.get("SCRAMBLE_LISTING") and me > 0:  # a file system that lists for this rank in another order
+        real_listdir = os.listdir
+        os.listdir = lambda d=".": list(reversed(real_listdir(d)))
     if os.environ.get("FAIL_WRITE_RANK") == str(me):
         def full(records, name):
             raise OSError("no space left on rank %%d" %% me)
@@ -150,6 +153,29 @@ def test_gloo_runs_write_identical_csvs(tmp_path):
         assert list(one) == list(many)
         for name in one:
             assert one[name] == many[name], (world, name)
+
+
+@pytest.mark.timeout(900)
+def test_listing_order_os_is_rank_zeros_on_every_rank(tmp_path):
+    """--listing os / FANDOM_SEARCH_LISTING=os: the file system's own listing goes into the
+    seeded shuffle, and under a launcher every rank works on rank 0's list -- also when its own
+    listdir() answers in another order (here: reversed for the ranks > 0)."""
+    fandir, spath = _small_corpus(tmp_path)
+    one = _run(tmp_path, str(tmp_path / "out1"), fandir, spath, 1, FANDOM_SEARCH_LISTING="os")
+    two = _run(tmp_path, str(tmp_path / "out2"), fandir, spath, 2, FANDOM_SEARCH_LISTING="os", SCRAMBLE_LISTING="1")
+    assert list(one) == list(two) and len(one) == 4
+    for name in one:
+        assert one[name] == two[name], name
+    # (and it is the listing's order that went in: the sorted default gives other batches
+    # unless the file system happens to list in sorted order)
+    import random
+    from fandom_search_amd import search
+    names = os.listdir(fandir)
+    want = list(names)
+    random.seed(search.SHUFFLE_SEED)
+    random.shuffle(want)
+    first = one["match-6gram-batch-0.csv"].split(b"\r\n")[0].split(b",")[0].decode()
+    assert os.path.basename(first) in want[:7]
 
 
 def _small_corpus(tmp_path):
