@@ -426,9 +426,10 @@ def default_workers(world=1):
 
 
 def default_text_threads(world=1):
-    """Threads of the native text encoder per rank: FANDOM_SEARCH_TEXT_THREADS, else what
-    FANDOM_SEARCH_WORKERS says, else the half of this rank's share of the cores that
-    default_workers leaves (writers and encoder run at the same time)."""
+    """Threads of one native text encoder (a rank runs FANDOM_SEARCH_TEXT_HANDLES of them, default
+    two, on consecutive batches): FANDOM_SEARCH_TEXT_THREADS, else what FANDOM_SEARCH_WORKERS
+    says, else this rank's share of the cores -- less the half default_workers' forked writers
+    take where they run -- divided among the encoders."""
     env = os.environ.get("FANDOM_SEARCH_TEXT_THREADS")
     if env is not None:
         return max(1, int(env))
@@ -439,6 +440,9 @@ def default_text_threads(world=1):
     share = usable_cpus() // max(1, world)
     if not (csvw.enabled() and world == 1):
         share //= 2                         # (the forked writers take the other half)
+    # (two native encoders work on consecutive batches at the same time, textenc.TextEncoder:
+    # the threads are per encoder)
+    share //= max(1, int(os.environ.get("FANDOM_SEARCH_TEXT_HANDLES", "2")))
     return max(1, min(16, share))
 
 
@@ -871,6 +875,8 @@ def _analyze(args, window_size, number_of_hashes, hash_dimensions, distance_thre
     for i, fan_cluster in enumerate(fan_clusters):
         if pool is not None and i + 1 < len(fan_clusters):
             pool.start(share(fan_clusters[i + 1]))
+            if pool.native is not None and i + 2 < len(fan_clusters):
+                pool.start(share(fan_clusters[i + 2]))      # (the native encoder takes two batches at a time)
         if rank == 0:
             print('Processing cluster {} ({}-{})'.format(i,
                                                          chunk_size * i,

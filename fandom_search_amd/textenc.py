@@ -66,18 +66,25 @@ class TextEncoder(object):
             threads = min(16, usable_cpus())
         self.threads = int(threads)
         self._L = _bind(_lib.load())
-        self._h = C.c_void_p()
-        _lib.check(self._L.fs_textenc_create(C.byref(self._h)), "fs_textenc_create")
-        self._lock = threading.Lock()
+        # native encoders, each with a table of its own (taught alike) and a lock: start() gives
+        # consecutive batches to them in turn, so that one batch's serial parts (its threads'
+        # start, the copies of its results) run beside the other's parallel part
+        # (FANDOM_SEARCH_TEXT_HANDLES, default 2)
+        self._hs = []
+        for _ in range(max(1, int(os.environ.get("FANDOM_SEARCH_TEXT_HANDLES", "2")))):
+            h = C.c_void_p()
+            _lib.check(self._L.fs_textenc_create(C.byref(h)), "fs_textenc_create")
+            self._hs.append((h, threading.Lock()))
+        self._turn = 0
         self._pending = {}
         self._taught = 0
         self.last_vec = None
         self._teach_plain()
 
     def close(self):
-        if self._h:
-            self._L.fs_textenc_destroy(self._h)
-            self._h = C.c_void_p()
+        hs, self._hs = getattr(self, "_hs", []), []
+        for h, _ in hs:
+            self._L.fs_textenc_destroy(h)
 
     def __del__(self):
         try:
@@ -97,11 +104,13 @@ class TextEncoder(object):
         poff = np.zeros(len(raw) + 1, dtype=np.uint64)
         poff[1:] = np.cumsum([len(p) for p in pieces], dtype=np.uint64)
         flat = np.fromiter((s for p in pieces for s in p), dtype=np.uint32, count=int(poff[-1]))
-        with self._lock:
-            _lib.check(self._L.fs_textenc_add(
-                self._h, b"".join(raw), coff.ctypes.data_as(C.POINTER(C.c_uint64)), len(raw),
-                poff.ctypes.data_as(C.POINTER(C.c_uint64)), flat.ctypes.data_as(C.POINTER(C.c_uint32))),
-                "fs_textenc_add")
+        blob = b"".join(raw)
+        for h, lock in self._hs:
+            with lock:
+                _lib.check(self._L.fs_textenc_add(
+                    h, blob, coff.ctypes.data_as(C.POINTER(C.c_uint64)), len(raw),
+                    poff.ctypes.data_as(C.POINTER(C.c_uint64)), flat.ctypes.data_as(C.POINTER(C.c_uint32))),
+                    "fs_textenc_add")
 
     def _teach_plain(self):
         """The vocabulary's words that are their own single token (letters only, no special
@@ -115,7 +124,7 @@ class TextEncoder(object):
 
     # ---- encoding ---------------------------------------------------------------------------
 
-    def _native(self, filenames, made=None):
+    def _native(self, filenames, made=None, turn=0):
         """(tokens, work offsets, status per file, unknown chunks' texts).  `made`: a dict that
         receives "vec" = (vector id per token, OOV tokens, string ids == vector ids) when the
         batch needs nothing more from the host -- no unknown chunk, no work left to the Python
@@ -125,16 +134,17 @@ class TextEncoder(object):
         status, ub, uo = C.POINTER(C.c_int32)(), C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint64)()
         n_tok, n_unk = C.c_uint64(), C.c_uint64()
         vec, n_oov, same = C.POINTER(C.c_uint32)(), C.c_uint64(), C.c_int32()
-        with self._lock:
+        h, lock = self._hs[turn % len(self._hs)]
+        with lock:
             if made is not None:
                 vt = self.vocab.vec_ids()          # (covers every string id the encoder has been taught)
                 _lib.check(self._L.fs_textenc_encode_files_vec(
-                    self._h, paths, len(filenames), self.threads, vt.ctypes.data_as(C.POINTER(C.c_uint32)), len(vt),
+                    h, paths, len(filenames), self.threads, vt.ctypes.data_as(C.POINTER(C.c_uint32)), len(vt),
                     C.byref(tok), C.byref(n_tok), C.byref(woff), C.byref(status), C.byref(ub), C.byref(uo),
                     C.byref(n_unk), C.byref(vec), C.byref(n_oov), C.byref(same)), "fs_textenc_encode_files_vec")
             else:
                 _lib.check(self._L.fs_textenc_encode_files(
-                    self._h, paths, len(filenames), self.threads, C.byref(tok), C.byref(n_tok), C.byref(woff),
+                    h, paths, len(filenames), self.threads, C.byref(tok), C.byref(n_tok), C.byref(woff),
                     C.byref(status), C.byref(ub), C.byref(uo), C.byref(n_unk)), "fs_textenc_encode_files")
             n = len(filenames)
 
@@ -156,13 +166,15 @@ class TextEncoder(object):
         if not key or key in self._pending:
             return
         box = {}
+        turn = self._turn
+        self._turn += 1
 
         def run():
             try:
                 # (a batch the encoder knows every chunk of -- any batch, once the first few have
                 # taught it -- comes with its vector ids, made by the encoding threads: the search
                 # then has no pass of its own to make over the batch's tokens)
-                box["r"] = self._native(key, box)
+                box["r"] = self._native(key, box, turn)
             except BaseException as e:          # (raised again in the caller's thread)
                 box["e"] = e
 

@@ -56,15 +56,17 @@ def test_threads_and_workers_follow_the_cpu_share(monkeypatch):
     threads and the forked workers share it where both run, and a one-rank run whose text and
     batch files are both native forks nobody."""
     for k in ("FANDOM_SEARCH_WORKERS", "FANDOM_SEARCH_TEXT_THREADS", "FANDOM_SEARCH_NATIVE_CSV",
-              "FANDOM_SEARCH_NATIVE_TEXT", "FANDOM_SEARCH_TOKENIZER"):
+              "FANDOM_SEARCH_NATIVE_TEXT", "FANDOM_SEARCH_TOKENIZER", "FANDOM_SEARCH_TEXT_HANDLES"):
         monkeypatch.delenv(k, raising=False)
     cpus = search.usable_cpus()
     assert 1 <= cpus <= len(os.sched_getaffinity(0))
     assert search.default_workers(1) == 0                      # native text + native csv, one rank
-    assert search.default_text_threads(1) == max(1, min(16, cpus))
+    assert search.default_text_threads(1) == max(1, min(16, cpus // 2))         # two encoders share them
     assert search.default_workers(2) == max(1, min(16, (cpus // 2 + 1) // 2))     # ranks write through the pool
     monkeypatch.setenv("FANDOM_SEARCH_NATIVE_CSV", "0")
     assert search.default_workers(1) == max(1, min(16, (cpus + 1) // 2))
+    assert search.default_text_threads(1) == max(1, min(16, cpus // 2 // 2))
+    monkeypatch.setenv("FANDOM_SEARCH_TEXT_HANDLES", "1")
     assert search.default_text_threads(1) == max(1, min(16, cpus // 2))
     monkeypatch.setenv("FANDOM_SEARCH_NATIVE_TEXT", "0")
     assert search.default_workers(1) == max(1, min(16, cpus))
