@@ -787,10 +787,28 @@ def analyze(args,
     pool = None
     _startup_lap("interpreter, imports, arguments")
     if searcher is None:
+        n_workers = default_workers(dist.env_world()[2])
+        if n_workers <= 1 and dist.env_world()[2] == 1 and os.environ.get("FANDOM_SEARCH_EARLY_HIP", "1") != "0":
+            # nobody is forked from here on (text and batch files are native): the HIP runtime's
+            # start-up -- a quarter of a second, most of what `script index on the GPU` is -- runs on
+            # a thread beside the vector table, the encoder's teaching and the script's parse instead of behind them
+            import threading
+            from . import _lib
+            L = _lib.load()                       # (on this thread: one loader)
+
+            def warm():
+                try:
+                    import ctypes as C
+                    p = C.c_void_p()
+                    if L.fs_host_alloc(4096, C.byref(p)) == 0:
+                        L.fs_host_free(p)
+                except Exception:
+                    pass                          # (whatever it is, fs_index_create says it again)
+            threading.Thread(target=warm, daemon=True).start()
         get_vocab()               # (host only) the workers inherit the string table ...
         from . import tokenizer   # noqa: F401  ... and the compiled tokenizer rules
         _startup_lap("vector table")
-        pool = TokenPool(default_workers(dist.env_world()[2]))
+        pool = TokenPool(n_workers)
         _startup_lap("fork the token pool")
         from . import textenc
         if textenc.enabled():
